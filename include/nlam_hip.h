@@ -1,0 +1,144 @@
+/*
+ * nlam_hip.h -- C ABI of libnlam_hip.so, the MI355X (gfx950) message-passing
+ * core that sits behind neural_lam.interaction_net.InteractionNet and the
+ * GraphLAM / Hi-LAM encode-process-decode stack.
+ *
+ * Conventions
+ *   - every device pointer is a raw fp32 (float*) or int32 (int32_t*) HBM
+ *     address owned by the caller (the Python host allocates through torch);
+ *     nothing is allocated, freed or retained by the library;
+ *   - all matrices are row-major; `ld*` is the row pitch in elements;
+ *     `*_bstride` is the pitch between batch items in elements and may be 0
+ *     (the reference's stride-0 `expand_to_batch` views, ar_model.py:204-209);
+ *   - `stream` is a hipStream_t passed as void* (the caller's current stream);
+ *   - return value 0 = success, otherwise an error code; the message is
+ *     available from nlam_last_error() (thread-local);
+ *   - thread-compatible: concurrent calls must use different streams/buffers.
+ *
+ * Each entry point names the reference interface (file:line under
+ * neural_lam/) it replaces.  The reference has no FFI of its own (it is pure
+ * Python over torch / torch_geometric); INTEGRATION.md shows the ctypes
+ * binding a maintainer adds.
+ */
+#ifndef NLAM_HIP_H
+#define NLAM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* nlam_last_error(void);
+/* ABI version of this header; bumped on any signature change. */
+int nlam_abi_version(void);
+
+/* ---------------------------------------------------------------- graph --
+ * Host-side preprocessing, run once per InteractionNet at construction.
+ * Replaces the implicit edge bookkeeping of torch_geometric's
+ * MessagePassing.propagate as configured by interaction_net.py:56-62.
+ *
+ * Input: local edge ids (senders in [0,n_send), receivers in [0,n_rec)),
+ * host memory, original edge order e = 0..M-1.
+ * Output (host, int32):
+ *   csr_rowptr[n_rec+1], csr_eid[M]  : edges grouped by receiver, stable
+ *       (csr_eid[p] = original edge id at CSR position p)
+ *   csr_send[M], csr_rec[M]          : sender / receiver of the edge at p
+ *   csc_colptr[n_send+1], csc_pos[M] : edges grouped by sender, stable; values
+ *       are CSR positions p (so a sender-side reduction reads CSR-ordered rows)
+ *   csc_eid[M]                       : the same lists as original edge ids
+ *   inv_deg[n_rec] (float)           : 1 / max(in_degree, 1)  ("mean" aggr)
+ */
+int nlam_graph_build_host(const int64_t* send, const int64_t* rec, int64_t M,
+                          int64_t n_send, int64_t n_rec, int32_t* csr_rowptr,
+                          int32_t* csr_eid, int32_t* csr_send, int32_t* csr_rec,
+                          int32_t* csc_colptr, int32_t* csc_pos, int32_t* csc_eid,
+                          float* inv_deg);
+
+/* ------------------------------------------------------------ generic ops --
+ * Shape-generic fp32 kernels (any hidden_dim, any number of MLP layers).
+ * They cover every configuration reachable through the reference's public
+ * constructors; the fused kernels further down take over for the shapes the
+ * BASELINE configs use.
+ */
+
+/* C[M x N] = A[M x K] * B[K x N] (+ bias[N]) (+ C if accumulate).
+ * A(i,k) = A[i*sa_i + k*sa_k], B(k,j) = B[k*sb_k + j*sb_j]  (element strides),
+ * C row-major with pitch ldc.  `splitk` > 1 splits K over that many
+ * workgroups per tile; partial tiles go to `workspace`
+ * (splitk*M*N floats) and are summed in a fixed order (deterministic).
+ * Replaces torch.nn.Linear forward / backward GEMMs inside utils.make_mlp
+ * (utils.py:191-214). */
+int nlam_gemm(int64_t M, int64_t N, int64_t K, const float* A, int64_t sa_i,
+              int64_t sa_k, const float* B, int64_t sb_k, int64_t sb_j,
+              const float* bias, float* C, int64_t ldc, int accumulate,
+              int splitk, float* workspace, void* stream);
+
+/* y = x * sigmoid(x) over n elements;  gx = gy * d silu(x)/dx. (utils.py:207) */
+int nlam_silu_fwd(const float* x, float* y, int64_t n, void* stream);
+int nlam_silu_bwd(const float* x, const float* gy, float* gx, int64_t n,
+                  void* stream);
+
+/* Row LayerNorm (eps 1e-5, affine) with optional fused residual:
+ *   y[r] = (res ? res[r] : 0) + gamma * (z[r]-mean)/sqrt(var+eps) + beta.
+ * (utils.py:210-212; residual = interaction_net.py:109,112) */
+int nlam_layernorm_fwd(const float* z, int64_t ldz, const float* gamma,
+                       const float* beta, const float* res, int64_t ldres,
+                       float* y, int64_t ldy, int64_t rows, int64_t d,
+                       void* stream);
+/* gz from gy; per-block partial dgamma/dbeta are written to `partial`
+ * (2 * nblocks * d floats, nblocks = nlam_layernorm_bwd_blocks(rows)) and
+ * reduced in order into dgamma/dbeta (accumulate=1 adds to them). */
+int64_t nlam_layernorm_bwd_blocks(int64_t rows);
+int nlam_layernorm_bwd(const float* z, int64_t ldz, const float* gamma,
+                       const float* gy, int64_t ldgy, float* gz, int64_t ldgz,
+                       float* dgamma, float* dbeta, int accumulate,
+                       float* partial, int64_t rows, int64_t d, void* stream);
+
+/* out[r] += / = sum over rows of x (column sums; bias gradients). `partial`:
+ * nlam_colsum_blocks(rows) * d floats. */
+int64_t nlam_colsum_blocks(int64_t rows);
+int nlam_colsum(const float* x, int64_t ldx, float* out, int accumulate,
+                float* partial, int64_t rows, int64_t d, void* stream);
+
+/* out[b][k][0:d] = s * x[b][idx[k]][0:d]  (row gather along dim -2), with
+ * s = row_scale ? row_scale[idx[k]] : 1 (the 1/deg factor of "mean" backward).
+ * Replaces MessagePassing.__lift__ / index_select (interaction_net.py:103). */
+int nlam_gather_rows(const float* x, int64_t x_bstride, int64_t ldx,
+                     const int32_t* idx, const float* row_scale, float* out,
+                     int64_t out_bstride, int64_t ldout, int64_t B,
+                     int64_t n_out, int64_t d, void* stream);
+
+/* out[b][i][0:d] = scale_i * sum_{p in [rowptr[i], rowptr[i+1])}
+ *                       src[b][pos ? pos[p] : p][0:d]
+ * (+ out if accumulate).  One wavefront walks one segment: no atomics,
+ * fixed summation order.  scale_i = scale ? scale[i] : 1.
+ * Replaces MessagePassing.aggregate / scatter_add_ (interaction_net.py:124-131)
+ * and the index_add_ backward of the gathers. */
+int nlam_segment_sum(const float* src, int64_t src_bstride, int64_t ldsrc,
+                     const int32_t* rowptr, const int32_t* pos,
+                     const float* scale, float* out, int64_t out_bstride,
+                     int64_t ldout, int accumulate, int64_t B, int64_t n_out,
+                     int64_t d, void* stream);
+
+/* out[r][0:d] = a[r][0:d] + b[r][0:d]  (strided 2-D add; cat-slice grads). */
+int nlam_add_rows(const float* a, int64_t lda, const float* b, int64_t ldb,
+                  float* out, int64_t ldout, int64_t rows, int64_t d,
+                  void* stream);
+/* out[r][0:d] = x[r][0:d]  (strided copy into a column slice of a wider row).*/
+int nlam_copy_rows(const float* x, int64_t x_bstride, int64_t ldx, float* out,
+                   int64_t out_bstride, int64_t ldout, int64_t B, int64_t rows,
+                   int64_t d, void* stream);
+/* out[0:n] = sum_b x[b*bstride + 0:n]  (gradient of a stride-0 expand). */
+int nlam_sum_batch(const float* x, int64_t bstride, float* out, int64_t B,
+                   int64_t n, void* stream);
+
+/* Debug / self-test: verifies the MFMA fp32 32x32x2 operand and accumulator
+ * lane maps the fused kernels rely on.  out: 32*32 floats = A(32x64) * B(64x32)
+ * for the integer test pattern documented in csrc/mfma_probe.hip. */
+int nlam_mfma_probe(float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NLAM_HIP_H */

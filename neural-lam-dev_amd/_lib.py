@@ -1,0 +1,71 @@
+"""ctypes binding of libnlam_hip.so (C ABI: include/nlam_hip.h).
+
+The library is the product: there is no CPU or eager-PyTorch fallback.  If the
+shared object is missing or does not export a symbol, importing this module
+raises with the build command to run.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (loads torch's libamdhip64.so.7 first, so that the
+# library binds to the same HIP runtime as the streams/tensors it is handed)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnlam_hip.so")
+
+_i64, _i32, _p = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p
+
+# name -> argtypes  (restype is int unless listed in _RESTYPES)
+SIGNATURES = {
+    "nlam_last_error": [],
+    "nlam_abi_version": [],
+    "nlam_graph_build_host": [_p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p],
+    "nlam_gemm": [_i64, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _p, _p, _i64, _i32, _i32, _p, _p],
+    "nlam_silu_fwd": [_p, _p, _i64, _p],
+    "nlam_silu_bwd": [_p, _p, _p, _i64, _p],
+    "nlam_layernorm_fwd": [_p, _i64, _p, _p, _p, _i64, _p, _i64, _i64, _i64, _p],
+    "nlam_layernorm_bwd_blocks": [_i64],
+    "nlam_layernorm_bwd": [_p, _i64, _p, _p, _i64, _p, _i64, _p, _p, _i32, _p, _i64, _i64, _p],
+    "nlam_colsum_blocks": [_i64],
+    "nlam_colsum": [_p, _i64, _p, _i32, _p, _i64, _i64, _p],
+    "nlam_gather_rows": [_p, _i64, _i64, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p],
+    "nlam_segment_sum": [_p, _i64, _i64, _p, _p, _p, _p, _i64, _i64, _i32, _i64, _i64, _i64, _p],
+    "nlam_add_rows": [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _p],
+    "nlam_copy_rows": [_p, _i64, _i64, _p, _i64, _i64, _i64, _i64, _i64, _p],
+    "nlam_sum_batch": [_p, _i64, _p, _i64, _i64, _p],
+    "nlam_mfma_probe": [_p, _p],
+}
+_RESTYPES = {
+    "nlam_last_error": ctypes.c_char_p,
+    "nlam_layernorm_bwd_blocks": _i64,
+    "nlam_colsum_blocks": _i64,
+}
+
+
+class NlamError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (hipcc --offload-arch=gfx950); there is no fallback path."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise ImportError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, ctypes.c_int)
+    return lib
+
+
+lib = _load()
+
+
+def check(code, what):
+    if code != 0:
+        raise NlamError(f"{what} failed ({code}): {lib.nlam_last_error().decode()}")

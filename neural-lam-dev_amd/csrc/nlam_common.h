@@ -1,0 +1,48 @@
+// Shared helpers for libnlam_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/nlam_hip.h"
+
+void nlam_set_error(const char* fmt, ...);
+
+#define NLAM_REQUIRE(cond, ...)        \
+  do {                                 \
+    if (!(cond)) {                     \
+      nlam_set_error(__VA_ARGS__);     \
+      return 1;                        \
+    }                                  \
+  } while (0)
+
+#define NLAM_CHECK_LAUNCH(name)                                              \
+  do {                                                                       \
+    hipError_t e_ = hipGetLastError();                                       \
+    if (e_ != hipSuccess) {                                                  \
+      nlam_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));  \
+      return 2;                                                              \
+    }                                                                        \
+  } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static inline bool nlam_aligned16(const void* p) {
+  return (reinterpret_cast<uintptr_t>(p) & 15u) == 0;
+}
+
+__device__ __forceinline__ float nlam_sigmoid(float x) {
+  return 1.0f / (1.0f + __expf(-x));
+}
+__device__ __forceinline__ float nlam_silu(float x) { return x * nlam_sigmoid(x); }
+// d/dx [x sigmoid(x)] = s (1 + x (1 - s))
+__device__ __forceinline__ float nlam_silu_grad(float x) {
+  float s = nlam_sigmoid(x);
+  return s * (1.0f + x * (1.0f - s));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}

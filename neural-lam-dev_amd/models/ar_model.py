@@ -1,0 +1,132 @@
+"""Training-path shell of the reference's ARModel (neural_lam/models/ar_model.py:
+__init__ :30-151, configure_optimizers :191-195, expand_to_batch :204-209,
+unroll_prediction :220-267, common_step :269-285, training_step :287-309).
+Validation / test / plotting / W&B stay with the reference (out of scope).
+
+It is a pytorch_lightning.LightningModule when Lightning is installed and a
+plain nn.Module otherwise; the method names and batch layout are Lightning's.
+"""
+import torch
+from torch import nn
+
+from .. import metrics
+
+try:  # pragma: no cover - Lightning is not installed in the build image
+    import pytorch_lightning as pl
+
+    _Base = pl.LightningModule
+except ImportError:
+    _Base = nn.Module
+
+
+def _state_feature_weights(config, datastore):
+    """loss_weighting.py:52-106: manual weights if the config carries them,
+    uniform 1/n otherwise."""
+    n = datastore.get_num_data_vars(category="state")
+    weighting = getattr(getattr(config, "training", None), "state_feature_weighting", None)
+    weights = getattr(weighting, "weights", None)
+    if weights:
+        names = datastore.get_vars_names(category="state")
+        if set(names) != set(weights):
+            raise ValueError("State feature weights must be provided for each state feature")
+        return [weights[k] for k in names]
+    return [1.0 / n] * n
+
+
+class ARModel(_Base):
+    def __init__(self, args, config, datastore):
+        super().__init__()
+        if hasattr(self, "save_hyperparameters") and _Base is not nn.Module:
+            self.save_hyperparameters(ignore=["datastore"])
+        self.args = args
+        self._datastore = datastore
+        num_state_vars = datastore.get_num_data_vars(category="state")
+        num_forcing_vars = datastore.get_num_data_vars(category="forcing")
+        da_static = datastore.get_dataarray(category="static", split=None)
+        da_stats = datastore.get_standardization_dataarray(category="state")
+
+        arr_static = da_static.transpose("grid_index", "static_feature").values
+        self.register_buffer(
+            "grid_static_features", torch.tensor(arr_static, dtype=torch.float32), persistent=False
+        )
+        for key, src in (("state_mean", "state_mean"), ("state_std", "state_std"),
+                         ("diff_mean", "state_diff_mean"), ("diff_std", "state_diff_std")):
+            self.register_buffer(
+                key, torch.tensor(getattr(da_stats, src).values, dtype=torch.float32),
+                persistent=False,
+            )
+        self.feature_weights = torch.tensor(
+            _state_feature_weights(config, datastore), dtype=torch.float32
+        )
+        self.output_std = bool(args.output_std)
+        if self.output_std:
+            self.grid_output_dim = 2 * num_state_vars
+        else:
+            self.grid_output_dim = num_state_vars
+            self.register_buffer(
+                "per_var_std", self.diff_std / torch.sqrt(self.feature_weights), persistent=False
+            )
+        self.num_grid_nodes, grid_static_dim = self.grid_static_features.shape
+        # ar_model.py:111-116 (kept as in the reference, including 2*grid_output_dim)
+        self.grid_dim = (
+            2 * self.grid_output_dim
+            + grid_static_dim
+            + num_forcing_vars
+            * (args.num_past_forcing_steps + args.num_future_forcing_steps + 1)
+        )
+        self.loss = metrics.get_metric(args.loss)
+        boundary_mask = torch.tensor(datastore.boundary_mask.values, dtype=torch.float32).unsqueeze(1)
+        self.register_buffer("boundary_mask", boundary_mask, persistent=False)
+        self.register_buffer("interior_mask", 1.0 - self.boundary_mask, persistent=False)
+        self.restore_opt = getattr(args, "restore_opt", False)
+
+    def configure_optimizers(self):
+        return torch.optim.AdamW(self.parameters(), lr=self.args.lr, betas=(0.9, 0.95))
+
+    @property
+    def interior_mask_bool(self):
+        return self.interior_mask[:, 0].to(torch.bool)
+
+    @staticmethod
+    def expand_to_batch(x, batch_size):
+        return x.unsqueeze(0).expand(batch_size, -1, -1)
+
+    def predict_step(self, prev_state, prev_prev_state, forcing):
+        raise NotImplementedError("No prediction step implemented")
+
+    def unroll_prediction(self, init_states, forcing_features, true_states):
+        """init_states (B,2,N,d_f), forcing (B,T,N,d_forcing), true_states (B,T,N,d_f)."""
+        prev_prev_state = init_states[:, 0]
+        prev_state = init_states[:, 1]
+        prediction_list, pred_std_list = [], []
+        for i in range(forcing_features.shape[1]):
+            pred_state, pred_std = self.predict_step(
+                prev_state, prev_prev_state, forcing_features[:, i]
+            )
+            new_state = self.boundary_mask * true_states[:, i] + self.interior_mask * pred_state
+            prediction_list.append(new_state)
+            if self.output_std:
+                pred_std_list.append(pred_std)
+            prev_prev_state = prev_state
+            prev_state = new_state
+        prediction = torch.stack(prediction_list, dim=1)
+        if self.output_std:
+            pred_std = torch.stack(pred_std_list, dim=1)
+        else:
+            pred_std = self.per_var_std
+        return prediction, pred_std
+
+    def common_step(self, batch):
+        init_states, target_states, forcing_features, batch_times = batch
+        prediction, pred_std = self.unroll_prediction(init_states, forcing_features, target_states)
+        return prediction, target_states, pred_std, batch_times
+
+    def training_step(self, batch):
+        prediction, target, pred_std, _ = self.common_step(batch)
+        batch_loss = torch.mean(
+            self.loss(prediction, target, pred_std, mask=self.interior_mask_bool)
+        )
+        if hasattr(self, "log_dict") and _Base is not nn.Module:
+            self.log_dict({"train_loss": batch_loss}, prog_bar=True, on_step=True, on_epoch=True,
+                          sync_dist=True, batch_size=batch[0].shape[0])
+        return batch_loss

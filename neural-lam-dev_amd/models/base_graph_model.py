@@ -1,0 +1,80 @@
+"""Encode-process-decode base (reference models/base_graph_model.py:12-177):
+same sub-module names, construction order (=> same default-init RNG stream)
+and predict_step contract; the GNN / MLP blocks are the HIP modules."""
+import torch
+
+from .. import utils
+from ..interaction_net import InteractionNet
+from .ar_model import ARModel
+
+
+class BaseGraphModel(ARModel):
+    def __init__(self, args, config, datastore):
+        super().__init__(args, config=config, datastore=datastore)
+        graph_dir_path = datastore.root_path / "graph" / args.graph
+        self.hierarchical, graph_ldict = utils.load_graph(graph_dir_path=graph_dir_path)
+        for name, attr_value in graph_ldict.items():
+            if isinstance(attr_value, torch.Tensor):
+                self.register_buffer(name, attr_value, persistent=False)
+            else:
+                setattr(self, name, attr_value)
+        self.num_mesh_nodes, _ = self.get_num_mesh()
+        self.g2m_edges, g2m_dim = self.g2m_features.shape
+        self.m2g_edges, m2g_dim = self.m2g_features.shape
+
+        self.mlp_blueprint_end = [args.hidden_dim] * (args.hidden_layers + 1)
+        self.grid_embedder = utils.make_mlp([self.grid_dim] + self.mlp_blueprint_end)
+        self.g2m_embedder = utils.make_mlp([g2m_dim] + self.mlp_blueprint_end)
+        self.m2g_embedder = utils.make_mlp([m2g_dim] + self.mlp_blueprint_end)
+        self.g2m_gnn = InteractionNet(
+            self.g2m_edge_index, args.hidden_dim, hidden_layers=args.hidden_layers,
+            update_edges=False,
+        )
+        self.encoding_grid_mlp = utils.make_mlp([args.hidden_dim] + self.mlp_blueprint_end)
+        self.m2g_gnn = InteractionNet(
+            self.m2g_edge_index, args.hidden_dim, hidden_layers=args.hidden_layers,
+            update_edges=False,
+        )
+        self.output_map = utils.make_mlp(
+            [args.hidden_dim] * (args.hidden_layers + 1) + [self.grid_output_dim], layer_norm=False
+        )
+
+    def get_num_mesh(self):
+        raise NotImplementedError("get_num_mesh not implemented")
+
+    def embedd_mesh_nodes(self):
+        raise NotImplementedError("embedd_mesh_nodes not implemented")
+
+    def process_step(self, mesh_rep):
+        raise NotImplementedError("process_step not implemented")
+
+    def predict_step(self, prev_state, prev_prev_state, forcing):
+        """X_{t-1}, X_t, forcing -> X_{t+1}  (base_graph_model.py:106-177)."""
+        batch_size = prev_state.shape[0]
+        grid_features = torch.cat(
+            (prev_state, prev_prev_state, forcing,
+             self.expand_to_batch(self.grid_static_features, batch_size)),
+            dim=-1,
+        )
+        grid_emb = self.grid_embedder(grid_features)
+        g2m_emb = self.g2m_embedder(self.g2m_features)
+        m2g_emb = self.m2g_embedder(self.m2g_features)
+        mesh_emb = self.embedd_mesh_nodes()
+
+        mesh_rep = self.g2m_gnn(
+            grid_emb, self.expand_to_batch(mesh_emb, batch_size),
+            self.expand_to_batch(g2m_emb, batch_size),
+        )
+        # grid_rep = grid_emb + MLP(grid_emb): residual fused into the MLP kernel
+        grid_rep = self.encoding_grid_mlp(grid_emb, res=grid_emb)
+        mesh_rep = self.process_step(mesh_rep)
+        grid_rep = self.m2g_gnn(mesh_rep, grid_rep, self.expand_to_batch(m2g_emb, batch_size))
+        net_output = self.output_map(grid_rep)
+
+        if self.output_std:
+            pred_delta_mean, pred_std_raw = net_output.chunk(2, dim=-1)
+            pred_std = torch.nn.functional.softplus(pred_std_raw)
+        else:
+            pred_delta_mean, pred_std = net_output, None
+        rescaled_delta_mean = pred_delta_mean * self.diff_std + self.diff_mean
+        return prev_state + rescaled_delta_mean, pred_std

@@ -1,0 +1,254 @@
+"""Thin tensor-level wrappers over the C ABI (include/nlam_hip.h).
+
+torch is used for device memory, streams and autograd bookkeeping only; every
+arithmetic operation below is a kernel of libnlam_hip.so launched on torch's
+current stream.  All functions require fp32 HIP-device tensors and raise
+otherwise (no CPU fallback).
+"""
+from collections import namedtuple
+
+import torch
+
+from ._lib import check, lib
+
+# A (B, rows, cols) fp32 matrix stack in device memory with unit column stride.
+# bstride may be 0 (batch-invariant).  `keep` pins the owning tensor.
+Mat = namedtuple("Mat", "ptr B rows cols bstride ld keep")
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _require_dev(t, what="tensor"):
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"neural_lam_amd: {what} is on {t.device}; the MI355X HIP path needs device tensors "
+            "(there is no CPU fallback)"
+        )
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"neural_lam_amd: {what} has dtype {t.dtype}, expected float32")
+
+
+def mat(t, col_off=0, cols=None):
+    """Describe `t` ((rows, c) or (B, rows, c), or more leading dims that
+    flatten) as a Mat, optionally restricted to columns [col_off, col_off+cols)."""
+    _require_dev(t)
+    if t.dim() == 1:
+        t = t.unsqueeze(0)
+    if t.dim() == 2:
+        t = t.unsqueeze(0)
+    if t.dim() > 3:
+        t = t.reshape(-1, t.shape[-2], t.shape[-1])
+    if t.shape[-1] > 1 and t.stride(-1) != 1:
+        t = t.contiguous()
+    B, rows, c = t.shape
+    bs, ld = t.stride(0), t.stride(1)
+    if rows == 1:
+        ld = max(ld, c)
+    if B == 1:
+        bs = 0
+    if ld < c or (bs != 0 and bs < rows * ld):
+        t = t.contiguous()
+        bs, ld = t.stride(0) if B > 1 else 0, t.stride(1)
+    cols = c - col_off if cols is None else cols
+    assert 0 <= col_off and col_off + cols <= c
+    return Mat(t.data_ptr() + 4 * col_off, B, rows, cols, bs, ld, t)
+
+
+def flat(m):
+    """(B, rows) -> one (B*rows)-row matrix if the batch pitch allows it."""
+    if m.B == 1:
+        return m
+    if m.bstride == m.rows * m.ld:
+        return Mat(m.ptr, 1, m.B * m.rows, m.cols, 0, m.ld, m.keep)
+    return None
+
+
+def batch_item(m, b):
+    return Mat(m.ptr + 4 * b * m.bstride, 1, m.rows, m.cols, 0, m.ld, m.keep)
+
+
+def _each_flat(*ms):
+    """Yield tuples of 2-D Mats covering the batch (one tuple if all flatten)."""
+    fl = [flat(m) for m in ms]
+    if all(f is not None for f in fl):
+        yield tuple(fl)
+        return
+    B = max(m.B for m in ms)
+    for b in range(B):
+        yield tuple(batch_item(m, b if m.B > 1 else 0) for m in ms)
+
+
+def _ws(n, device):
+    return torch.empty(max(int(n), 1), dtype=torch.float32, device=device)
+
+
+# ------------------------------------------------------------------ linear
+def _splitk_for(rows):
+    return int(max(1, min(256, rows // 512)))
+
+
+def linear_fwd(x, W, b, out, accumulate=False):
+    """out = x @ W.T (+ b) (+ out).  x: Mat (rows x in), W: (out_f, in) tensor."""
+    of, inf = W.shape
+    assert x.cols == inf and out.cols == of
+    for xm, om in _each_flat(x, out):
+        check(
+            lib.nlam_gemm(
+                xm.rows, of, inf, xm.ptr, xm.ld, 1, W.data_ptr(), 1, W.stride(0),
+                b.data_ptr() if b is not None else None, om.ptr, om.ld, int(accumulate), 1,
+                None, stream(),
+            ),
+            "nlam_gemm(linear_fwd)",
+        )
+
+
+def linear_bwd_data(gy, W, gx, accumulate=False):
+    """gx = gy @ W  (rows x in)."""
+    of, inf = W.shape
+    assert gy.cols == of and gx.cols == inf
+    for gm, xm in _each_flat(gy, gx):
+        check(
+            lib.nlam_gemm(
+                gm.rows, inf, of, gm.ptr, gm.ld, 1, W.data_ptr(), W.stride(0), 1, None, xm.ptr,
+                xm.ld, int(accumulate), 1, None, stream(),
+            ),
+            "nlam_gemm(linear_bwd_data)",
+        )
+
+
+def linear_bwd_weight(gy, x, dW, db):
+    """dW = gy.T @ x (out_f x in), db = column sums of gy; deterministic split-K."""
+    of, inf = dW.shape
+    dev = dW.device
+    first = True
+    for gm, xm in _each_flat(gy, x):
+        sk = _splitk_for(gm.rows)
+        ws = _ws(sk * of * inf, dev) if sk > 1 else None
+        check(
+            lib.nlam_gemm(
+                of, inf, gm.rows, gm.ptr, 1, gm.ld, xm.ptr, xm.ld, 1, None, dW.data_ptr(),
+                dW.stride(0), int(not first), sk, ws.data_ptr() if ws is not None else None,
+                stream(),
+            ),
+            "nlam_gemm(linear_bwd_weight)",
+        )
+        if db is not None:
+            colsum(gm, db, accumulate=not first)
+        first = False
+
+
+def colsum(x, out, accumulate=False):
+    first = not accumulate
+    for (xm,) in _each_flat(x):
+        nb = lib.nlam_colsum_blocks(xm.rows)
+        part = _ws(nb * xm.cols, out.device)
+        check(
+            lib.nlam_colsum(
+                xm.ptr, xm.ld, out.data_ptr(), int(not first), part.data_ptr(), xm.rows, xm.cols,
+                stream(),
+            ),
+            "nlam_colsum",
+        )
+        first = False
+
+
+# -------------------------------------------------------------- elementwise
+def silu_fwd(x, y):
+    """x, y: contiguous tensors of equal numel."""
+    check(lib.nlam_silu_fwd(x.data_ptr(), y.data_ptr(), x.numel(), stream()), "nlam_silu_fwd")
+
+
+def silu_bwd(x, gy, gx):
+    check(
+        lib.nlam_silu_bwd(x.data_ptr(), gy.data_ptr(), gx.data_ptr(), x.numel(), stream()),
+        "nlam_silu_bwd",
+    )
+
+
+def layernorm_fwd(z, gamma, beta, res, y):
+    for parts in _each_flat(*([z, y] + ([res] if res is not None else []))):
+        zm, ym = parts[0], parts[1]
+        rm = parts[2] if res is not None else None
+        check(
+            lib.nlam_layernorm_fwd(
+                zm.ptr, zm.ld, gamma.data_ptr(), beta.data_ptr(),
+                rm.ptr if rm is not None else None, rm.ld if rm is not None else 0, ym.ptr, ym.ld,
+                zm.rows, zm.cols, stream(),
+            ),
+            "nlam_layernorm_fwd",
+        )
+
+
+def layernorm_bwd(z, gamma, gy, gz, dgamma, dbeta):
+    first = True
+    for zm, gm, om in _each_flat(z, gy, gz):
+        nb = lib.nlam_layernorm_bwd_blocks(zm.rows)
+        part = _ws(2 * nb * zm.cols, dgamma.device)
+        check(
+            lib.nlam_layernorm_bwd(
+                zm.ptr, zm.ld, gamma.data_ptr(), gm.ptr, gm.ld, om.ptr, om.ld, dgamma.data_ptr(),
+                dbeta.data_ptr(), int(not first), part.data_ptr(), zm.rows, zm.cols, stream(),
+            ),
+            "nlam_layernorm_bwd",
+        )
+        first = False
+
+
+def add_rows(a, b, out):
+    for am, bm, om in _each_flat(a, b, out):
+        check(
+            lib.nlam_add_rows(am.ptr, am.ld, bm.ptr, bm.ld, om.ptr, om.ld, am.rows, am.cols, stream()),
+            "nlam_add_rows",
+        )
+
+
+def copy_rows(x, out):
+    """out[b] = x[b]; x may be batch-invariant (bstride 0) and is then broadcast."""
+    B = out.B
+    check(
+        lib.nlam_copy_rows(
+            x.ptr, x.bstride, x.ld, out.ptr, out.bstride, out.ld, B, out.rows, out.cols, stream()
+        ),
+        "nlam_copy_rows",
+    )
+
+
+def sum_batch(x, out):
+    """out (n,) = sum over batch of contiguous x (B, n)."""
+    B = x.shape[0]
+    n = x.numel() // B
+    check(lib.nlam_sum_batch(x.data_ptr(), n, out.data_ptr(), B, n, stream()), "nlam_sum_batch")
+
+
+# ---------------------------------------------------------- gather / segment
+def gather_rows(x, idx, out, row_scale=None):
+    """out[b][k] = x[b][idx[k]] (* row_scale[idx[k]])."""
+    check(
+        lib.nlam_gather_rows(
+            x.ptr, x.bstride, x.ld, idx.data_ptr(),
+            row_scale.data_ptr() if row_scale is not None else None, out.ptr, out.bstride, out.ld,
+            out.B, out.rows, out.cols, stream(),
+        ),
+        "nlam_gather_rows",
+    )
+
+
+def segment_sum(src, rowptr, pos, out, scale=None, accumulate=False):
+    """out[b][i] = scale[i] * sum_{p in segment i} src[b][pos[p]]."""
+    check(
+        lib.nlam_segment_sum(
+            src.ptr, src.bstride, src.ld, rowptr.data_ptr(),
+            pos.data_ptr() if pos is not None else None,
+            scale.data_ptr() if scale is not None else None, out.ptr, out.bstride, out.ld,
+            int(accumulate), out.B, out.rows, out.cols, stream(),
+        ),
+        "nlam_segment_sum",
+    )
+
+
+def mfma_probe():
+    out = torch.empty(32, 32, dtype=torch.float32, device="cuda")
+    check(lib.nlam_mfma_probe(out.data_ptr(), stream()), "nlam_mfma_probe")
+    return out

@@ -1,0 +1,99 @@
+"""Parity of the HIP InteractionNet (through the C ABI) with the golden vectors
+captured from the reference's own source (tests/golden/op_*.pt), forward and
+backward.  Tolerances (fp32, relative to max|ref|): forward 1e-4, grads 1e-3
+(SURVEY.md section 8c)."""
+import glob
+import os
+
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+OP_FILES = sorted(glob.glob(os.path.join(GOLDEN, "op_*.pt")))
+
+
+def rel(a, b):
+    return float((a.detach().cpu() - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def run_case(fx, force_generic):
+    from neural_lam_amd import fused
+    from neural_lam_amd.interaction_net import InteractionNet
+
+    old = fused.FORCE_GENERIC
+    fused.FORCE_GENERIC = force_generic
+    try:
+        kw, shared = fx["kwargs"], fx["shared"]
+        net = InteractionNet(fx["edge_index"], fx["d"], **kw)
+        missing = net.load_state_dict(fx["state_dict"], strict=True)
+        assert not missing.missing_keys and not missing.unexpected_keys
+        net = net.cuda()
+        s = fx["send"].cuda().requires_grad_(True)
+        r = s if shared else fx["rec"].cuda().requires_grad_(True)
+        e = fx["edge"].cuda().requires_grad_(True)
+        out = net(s, r, e)
+        if kw.get("update_edges", True):
+            o_rec, o_edge = out
+            loss = (o_rec * fx["cot_rec"].cuda()).sum() + (o_edge * fx["cot_edge"].cuda()).sum()
+            assert rel(o_edge, fx["out_edge"]) < 1e-4
+        else:
+            o_rec = out
+            loss = (o_rec * fx["cot_rec"].cuda()).sum()
+        assert rel(o_rec, fx["out_rec"]) < 1e-4
+        loss.backward()
+        assert rel(s.grad, fx["grad_send"]) < 1e-3
+        assert rel(e.grad, fx["grad_edge"]) < 1e-3
+        if not shared:
+            assert rel(r.grad, fx["grad_rec"]) < 1e-3
+        for k, p in net.named_parameters():
+            assert rel(p.grad, fx["grad_params"][k]) < 1e-3, k
+    finally:
+        fused.FORCE_GENERIC = old
+
+
+@pytest.mark.parametrize("path", OP_FILES, ids=[os.path.basename(p)[:-3] for p in OP_FILES])
+def test_generic_path_vs_reference_golden(path):
+    run_case(torch.load(path, weights_only=False), force_generic=True)
+
+
+@pytest.mark.parametrize("path", OP_FILES, ids=[os.path.basename(p)[:-3] for p in OP_FILES])
+def test_default_path_vs_reference_golden(path):
+    run_case(torch.load(path, weights_only=False), force_generic=False)
+
+
+def test_stride0_batch_inputs_match_oracle():
+    """g2m-style call: receiver and edge reps are stride-0 expands."""
+    import nlam_oracle as orc
+    from neural_lam_amd.interaction_net import InteractionNet
+
+    gen = torch.Generator().manual_seed(11)
+    d, B, n_s, n_r, M = 32, 3, 60, 20, 150
+    ei = torch.stack((torch.randint(0, n_s, (M,), generator=gen) + n_r, torch.randint(0, n_r, (M,), generator=gen)))
+    ei[0, 0], ei[1, 0], ei[1, 1] = n_r, 0, n_r - 1
+    torch.manual_seed(3)
+    net = InteractionNet(ei, d, update_edges=False)
+    sd = {f"n.{k}": v.clone() for k, v in net.state_dict().items()}
+    net = net.cuda()
+    send = torch.randn(B, n_s, d, generator=gen)
+    rec1 = torch.randn(n_r, d, generator=gen)
+    edge1 = torch.randn(M, d, generator=gen)
+    sc, rc, ec = (t.clone().requires_grad_(True) for t in (send, rec1, edge1))
+    want = orc.interaction_net(sd, "n", ei, sc, rc.unsqueeze(0).expand(B, -1, -1),
+                               ec.unsqueeze(0).expand(B, -1, -1), update_edges=False)
+    (want ** 2).sum().backward()
+    sg, rg, eg = (t.cuda().requires_grad_(True) for t in (send, rec1, edge1))
+    got = net(sg, rg.unsqueeze(0).expand(B, -1, -1), eg.unsqueeze(0).expand(B, -1, -1))
+    (got ** 2).sum().backward()
+    assert rel(got, want) < 1e-4
+    assert rel(sg.grad, sc.grad) < 1e-3 and rel(rg.grad, rc.grad) < 1e-3 and rel(eg.grad, ec.grad) < 1e-3
+
+
+def test_cpu_tensors_fail_loudly():
+    from neural_lam_amd.interaction_net import InteractionNet
+
+    ei = torch.tensor([[3, 4, 5, 3], [0, 1, 2, 2]])
+    net = InteractionNet(ei, 8)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        net(torch.randn(1, 3, 8), torch.randn(1, 3, 8), torch.randn(1, 4, 8))
