@@ -133,6 +133,15 @@ int nlam_copy_rows(const float* x, int64_t x_bstride, int64_t ldx, float* out,
 int nlam_sum_batch(const float* x, int64_t bstride, float* out, int64_t B,
                    int64_t n, void* stream);
 
+/* One AdamW step over a flat fp32 parameter buffer (decoupled weight decay,
+ * bias correction; torch.optim.AdamW semantics, ar_model.py:191-195).
+ * g is multiplied by grad_scale first (1/world after a SUM all-reduce).
+ * `step` is the 1-based step count. */
+int nlam_adamw_step(float* p, const float* g, float* m, float* v, int64_t n,
+                    float lr, float beta1, float beta2, float eps,
+                    float weight_decay, int64_t step, float grad_scale,
+                    void* stream);
+
 /* Debug / self-test: verifies the MFMA fp32 32x32x2 operand and accumulator
  * lane maps the fused kernels rely on.  out: 32*32 floats = A(32x64) * B(64x32)
  * for the integer test pattern documented in csrc/mfma_probe.hip. */

@@ -13,7 +13,7 @@ import torch  # noqa: F401  (loads torch's libamdhip64.so.7 first, so that the
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnlam_hip.so")
 
-_i64, _i32, _p = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p
+_i64, _i32, _p, _f = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_float
 
 # name -> argtypes  (restype is int unless listed in _RESTYPES)
 SIGNATURES = {
@@ -33,6 +33,7 @@ SIGNATURES = {
     "nlam_add_rows": [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _p],
     "nlam_copy_rows": [_p, _i64, _i64, _p, _i64, _i64, _i64, _i64, _i64, _p],
     "nlam_sum_batch": [_p, _i64, _p, _i64, _i64, _p],
+    "nlam_adamw_step": [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _i64, _f, _p],
     "nlam_mfma_probe": [_p, _p],
 }
 _RESTYPES = {

@@ -152,6 +152,19 @@ class InteractionNetGenericFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, send_rep, rec_rep, edge_rep, g, update_edges, mean, edge_blocks,
                 aggr_blocks, *params):
+        with ops.tag(g.tag):
+            return InteractionNetGenericFunction._forward(
+                ctx, send_rep, rec_rep, edge_rep, g, update_edges, mean, edge_blocks,
+                aggr_blocks, *params)
+
+    @staticmethod
+    def backward(ctx, g_rec_out, g_edge_out=None):
+        with ops.tag(ctx.g.tag):
+            return InteractionNetGenericFunction._backward(ctx, g_rec_out, g_edge_out)
+
+    @staticmethod
+    def _forward(ctx, send_rep, rec_rep, edge_rep, g, update_edges, mean, edge_blocks,
+                 aggr_blocks, *params):
         dev = edge_rep.device
         B = max(send_rep.shape[0], rec_rep.shape[0], edge_rep.shape[0])
         M, d = edge_rep.shape[-2], edge_rep.shape[-1]
@@ -206,7 +219,7 @@ class InteractionNetGenericFunction(torch.autograd.Function):
         return rec_out
 
     @staticmethod
-    def backward(ctx, g_rec_out, g_edge_out=None):
+    def _backward(ctx, g_rec_out, g_edge_out=None):
         params = ctx.saved_tensors
         g = ctx.g
         cat, cat2, saved_e, saved_a = ctx.bufs
@@ -251,8 +264,13 @@ class InteractionNetGenericFunction(torch.autograd.Function):
             ops.add_rows(mat(g_cat, 0, d), mat(g_edge_out), mat(g_edge))
         else:
             g_edge = g_cat[:, :, :d]
-        g_send = _empty(B, n_send, d, dev)
-        ops.segment_sum(mat(g_cat, d, d), g.csc_colptr, g.csc_eid, mat(g_send))
+        # the sender table spans g.n_send rows (max - min + 1 of the sender ids,
+        # interaction_net.py:56); send_rep may have more rows, whose grad is zero
+        if n_send > g.n_send:
+            g_send = torch.zeros(B, n_send, d, dtype=torch.float32, device=dev)
+        else:
+            g_send = _empty(B, n_send, d, dev)
+        ops.segment_sum(mat(g_cat, d, d), g.csc_colptr, g.csc_eid, mat(g_send[:, : g.n_send]))
         ops.segment_sum(mat(g_cat, 2 * d, d), g.csr_rowptr, g.csr_eid, mat(g_rec), accumulate=True)
 
         def fit(gr, shape):

@@ -32,6 +32,7 @@ class EdgeTables(torch.nn.Module):
         super().__init__()
         M = int(send.shape[0])
         self.M, self.n_send, self.n_rec = M, int(n_send), int(n_rec)
+        self.tag = "inet"  # profiler label; models set g2m / m2m / m2g / ...
         s = np.ascontiguousarray(send.numpy(), dtype=np.int64)
         r = np.ascontiguousarray(rec.numpy(), dtype=np.int64)
         out = {

@@ -35,6 +35,7 @@ class BaseGraphModel(ARModel):
             self.m2g_edge_index, args.hidden_dim, hidden_layers=args.hidden_layers,
             update_edges=False,
         )
+        self.g2m_gnn.tables.tag, self.m2g_gnn.tables.tag = "g2m", "m2g"
         self.output_map = utils.make_mlp(
             [args.hidden_dim] * (args.hidden_layers + 1) + [self.grid_output_dim], layer_norm=False
         )

@@ -46,6 +46,9 @@ class GraphLAM(BaseGraphModel):
             ]
         )
 
+        for net in self.processor:
+            net.tables.tag = "m2m"
+
     def get_num_mesh(self):
         return self.mesh_static_features.shape[0], 0
 

@@ -5,6 +5,8 @@ arithmetic operation below is a kernel of libnlam_hip.so launched on torch's
 current stream.  All functions require fp32 HIP-device tensors and raise
 otherwise (no CPU fallback).
 """
+import os
+import sys
 from collections import namedtuple
 
 import torch
@@ -18,6 +20,71 @@ Mat = namedtuple("Mat", "ptr B rows cols bstride ld keep")
 
 def stream():
     return torch.cuda.current_stream().cuda_stream
+
+
+class KernelProfiler:
+    """Brackets every C-ABI launch with HIP events on the launch stream (torch's
+    current stream is the stream the kernels are launched on) and accumulates
+    per-entry-point time, algorithmic flops and algorithmic bytes.  Used by
+    bench.py for the live `roofline` numbers; off (None) otherwise."""
+
+    def __init__(self):
+        self.pending = []  # (name, start, end, flops, bytes)
+        self.stats = {}
+
+    def add(self, name, start, end, flops, nbytes):
+        self.pending.append((name, start, end, flops, nbytes))
+
+    def collect(self):
+        torch.cuda.synchronize()
+        for name, s, e, flops, nbytes in self.pending:
+            st = self.stats.setdefault(name, {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            st["calls"] += 1
+            st["ms"] += s.elapsed_time(e)
+            st["flops"] += flops
+            st["bytes"] += nbytes
+        self.pending = []
+        return self.stats
+
+
+PROFILER = None
+_TAG = []
+
+
+class tag:
+    """with ops.tag("m2m"): launches inside are accounted as "<entry>@m2m"."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        _TAG.append(self.name)
+
+    def __exit__(self, *a):
+        _TAG.pop()
+
+
+_DEBUG_SYNC = os.environ.get("NLAM_DEBUG_SYNC", "0") == "1"
+
+
+def _launch(name, fn, args, flops=0.0, nbytes=0.0):
+    if _DEBUG_SYNC:  # print-before-launch + sync-after: the last line names a faulting kernel
+        print(f"[nlam] {name} {args}", file=sys.stderr, flush=True)
+        check(fn(*args), name)
+        torch.cuda.synchronize()
+        return
+    prof = PROFILER
+    if prof is None:
+        check(fn(*args), name)
+        return
+    if _TAG:
+        name = f"{name}@{_TAG[-1]}"
+    s = torch.cuda.Event(enable_timing=True)
+    e = torch.cuda.Event(enable_timing=True)
+    s.record()
+    check(fn(*args), name)
+    e.record()
+    prof.add(name, s, e, flops, nbytes)
 
 
 def _require_dev(t, what="tensor"):
@@ -94,13 +161,12 @@ def linear_fwd(x, W, b, out, accumulate=False):
     of, inf = W.shape
     assert x.cols == inf and out.cols == of
     for xm, om in _each_flat(x, out):
-        check(
-            lib.nlam_gemm(
-                xm.rows, of, inf, xm.ptr, xm.ld, 1, W.data_ptr(), 1, W.stride(0),
-                b.data_ptr() if b is not None else None, om.ptr, om.ld, int(accumulate), 1,
-                None, stream(),
-            ),
-            "nlam_gemm(linear_fwd)",
+        _launch(
+            "nlam_gemm", lib.nlam_gemm,
+            (xm.rows, of, inf, xm.ptr, xm.ld, 1, W.data_ptr(), 1, W.stride(0),
+             b.data_ptr() if b is not None else None, om.ptr, om.ld, int(accumulate), 1,
+             None, stream()),
+            flops=2.0 * xm.rows * of * inf, nbytes=4.0 * (xm.rows * (of + inf) + of * inf),
         )
 
 
@@ -109,12 +175,11 @@ def linear_bwd_data(gy, W, gx, accumulate=False):
     of, inf = W.shape
     assert gy.cols == of and gx.cols == inf
     for gm, xm in _each_flat(gy, gx):
-        check(
-            lib.nlam_gemm(
-                gm.rows, inf, of, gm.ptr, gm.ld, 1, W.data_ptr(), W.stride(0), 1, None, xm.ptr,
-                xm.ld, int(accumulate), 1, None, stream(),
-            ),
-            "nlam_gemm(linear_bwd_data)",
+        _launch(
+            "nlam_gemm", lib.nlam_gemm,
+            (gm.rows, inf, of, gm.ptr, gm.ld, 1, W.data_ptr(), W.stride(0), 1, None, xm.ptr,
+             xm.ld, int(accumulate), 1, None, stream()),
+            flops=2.0 * gm.rows * of * inf, nbytes=4.0 * (gm.rows * (of + inf) + of * inf),
         )
 
 
@@ -126,13 +191,12 @@ def linear_bwd_weight(gy, x, dW, db):
     for gm, xm in _each_flat(gy, x):
         sk = _splitk_for(gm.rows)
         ws = _ws(sk * of * inf, dev) if sk > 1 else None
-        check(
-            lib.nlam_gemm(
-                of, inf, gm.rows, gm.ptr, 1, gm.ld, xm.ptr, xm.ld, 1, None, dW.data_ptr(),
-                dW.stride(0), int(not first), sk, ws.data_ptr() if ws is not None else None,
-                stream(),
-            ),
-            "nlam_gemm(linear_bwd_weight)",
+        _launch(
+            "nlam_gemm", lib.nlam_gemm,
+            (of, inf, gm.rows, gm.ptr, 1, gm.ld, xm.ptr, xm.ld, 1, None, dW.data_ptr(),
+             dW.stride(0), int(not first), sk, ws.data_ptr() if ws is not None else None,
+             stream()),
+            flops=2.0 * gm.rows * of * inf, nbytes=4.0 * (gm.rows * (of + inf) + of * inf),
         )
         if db is not None:
             colsum(gm, db, accumulate=not first)
@@ -144,12 +208,11 @@ def colsum(x, out, accumulate=False):
     for (xm,) in _each_flat(x):
         nb = lib.nlam_colsum_blocks(xm.rows)
         part = _ws(nb * xm.cols, out.device)
-        check(
-            lib.nlam_colsum(
-                xm.ptr, xm.ld, out.data_ptr(), int(not first), part.data_ptr(), xm.rows, xm.cols,
-                stream(),
-            ),
-            "nlam_colsum",
+        _launch(
+            "nlam_colsum", lib.nlam_colsum,
+            (xm.ptr, xm.ld, out.data_ptr(), int(not first), part.data_ptr(), xm.rows, xm.cols,
+             stream()),
+            nbytes=4.0 * xm.rows * xm.cols,
         )
         first = False
 
@@ -157,27 +220,26 @@ def colsum(x, out, accumulate=False):
 # -------------------------------------------------------------- elementwise
 def silu_fwd(x, y):
     """x, y: contiguous tensors of equal numel."""
-    check(lib.nlam_silu_fwd(x.data_ptr(), y.data_ptr(), x.numel(), stream()), "nlam_silu_fwd")
+    _launch("nlam_silu_fwd", lib.nlam_silu_fwd, (x.data_ptr(), y.data_ptr(), x.numel(), stream()),
+            nbytes=8.0 * x.numel())
 
 
 def silu_bwd(x, gy, gx):
-    check(
-        lib.nlam_silu_bwd(x.data_ptr(), gy.data_ptr(), gx.data_ptr(), x.numel(), stream()),
-        "nlam_silu_bwd",
-    )
+    _launch("nlam_silu_bwd", lib.nlam_silu_bwd,
+            (x.data_ptr(), gy.data_ptr(), gx.data_ptr(), x.numel(), stream()),
+            nbytes=12.0 * x.numel())
 
 
 def layernorm_fwd(z, gamma, beta, res, y):
     for parts in _each_flat(*([z, y] + ([res] if res is not None else []))):
         zm, ym = parts[0], parts[1]
         rm = parts[2] if res is not None else None
-        check(
-            lib.nlam_layernorm_fwd(
-                zm.ptr, zm.ld, gamma.data_ptr(), beta.data_ptr(),
-                rm.ptr if rm is not None else None, rm.ld if rm is not None else 0, ym.ptr, ym.ld,
-                zm.rows, zm.cols, stream(),
-            ),
-            "nlam_layernorm_fwd",
+        _launch(
+            "nlam_layernorm_fwd", lib.nlam_layernorm_fwd,
+            (zm.ptr, zm.ld, gamma.data_ptr(), beta.data_ptr(),
+             rm.ptr if rm is not None else None, rm.ld if rm is not None else 0, ym.ptr, ym.ld,
+             zm.rows, zm.cols, stream()),
+            nbytes=4.0 * zm.rows * zm.cols * (3 if rm is not None else 2),
         )
 
 
@@ -186,32 +248,31 @@ def layernorm_bwd(z, gamma, gy, gz, dgamma, dbeta):
     for zm, gm, om in _each_flat(z, gy, gz):
         nb = lib.nlam_layernorm_bwd_blocks(zm.rows)
         part = _ws(2 * nb * zm.cols, dgamma.device)
-        check(
-            lib.nlam_layernorm_bwd(
-                zm.ptr, zm.ld, gamma.data_ptr(), gm.ptr, gm.ld, om.ptr, om.ld, dgamma.data_ptr(),
-                dbeta.data_ptr(), int(not first), part.data_ptr(), zm.rows, zm.cols, stream(),
-            ),
-            "nlam_layernorm_bwd",
+        _launch(
+            "nlam_layernorm_bwd", lib.nlam_layernorm_bwd,
+            (zm.ptr, zm.ld, gamma.data_ptr(), gm.ptr, gm.ld, om.ptr, om.ld, dgamma.data_ptr(),
+             dbeta.data_ptr(), int(not first), part.data_ptr(), zm.rows, zm.cols, stream()),
+            nbytes=12.0 * zm.rows * zm.cols,
         )
         first = False
 
 
 def add_rows(a, b, out):
     for am, bm, om in _each_flat(a, b, out):
-        check(
-            lib.nlam_add_rows(am.ptr, am.ld, bm.ptr, bm.ld, om.ptr, om.ld, am.rows, am.cols, stream()),
-            "nlam_add_rows",
+        _launch(
+            "nlam_add_rows", lib.nlam_add_rows,
+            (am.ptr, am.ld, bm.ptr, bm.ld, om.ptr, om.ld, am.rows, am.cols, stream()),
+            nbytes=12.0 * am.rows * am.cols,
         )
 
 
 def copy_rows(x, out):
     """out[b] = x[b]; x may be batch-invariant (bstride 0) and is then broadcast."""
     B = out.B
-    check(
-        lib.nlam_copy_rows(
-            x.ptr, x.bstride, x.ld, out.ptr, out.bstride, out.ld, B, out.rows, out.cols, stream()
-        ),
-        "nlam_copy_rows",
+    _launch(
+        "nlam_copy_rows", lib.nlam_copy_rows,
+        (x.ptr, x.bstride, x.ld, out.ptr, out.bstride, out.ld, B, out.rows, out.cols, stream()),
+        nbytes=8.0 * B * out.rows * out.cols,
     )
 
 
@@ -219,32 +280,42 @@ def sum_batch(x, out):
     """out (n,) = sum over batch of contiguous x (B, n)."""
     B = x.shape[0]
     n = x.numel() // B
-    check(lib.nlam_sum_batch(x.data_ptr(), n, out.data_ptr(), B, n, stream()), "nlam_sum_batch")
+    _launch("nlam_sum_batch", lib.nlam_sum_batch, (x.data_ptr(), n, out.data_ptr(), B, n, stream()),
+            nbytes=4.0 * n * (B + 1))
 
 
 # ---------------------------------------------------------- gather / segment
 def gather_rows(x, idx, out, row_scale=None):
     """out[b][k] = x[b][idx[k]] (* row_scale[idx[k]])."""
-    check(
-        lib.nlam_gather_rows(
-            x.ptr, x.bstride, x.ld, idx.data_ptr(),
-            row_scale.data_ptr() if row_scale is not None else None, out.ptr, out.bstride, out.ld,
-            out.B, out.rows, out.cols, stream(),
-        ),
-        "nlam_gather_rows",
+    if idx.numel() != out.rows or idx.dtype != torch.int32:
+        raise ValueError(f"gather_rows: idx has {idx.numel()} entries for {out.rows} output rows")
+    _launch(
+        "nlam_gather_rows", lib.nlam_gather_rows,
+        (x.ptr, x.bstride, x.ld, idx.data_ptr(),
+         row_scale.data_ptr() if row_scale is not None else None, out.ptr, out.bstride, out.ld,
+         out.B, out.rows, out.cols, stream()),
+        nbytes=out.B * (4.0 * out.cols * (out.rows + x.rows) + 4.0 * out.rows),
     )
 
 
 def segment_sum(src, rowptr, pos, out, scale=None, accumulate=False):
     """out[b][i] = scale[i] * sum_{p in segment i} src[b][pos[p]]."""
-    check(
-        lib.nlam_segment_sum(
-            src.ptr, src.bstride, src.ld, rowptr.data_ptr(),
-            pos.data_ptr() if pos is not None else None,
-            scale.data_ptr() if scale is not None else None, out.ptr, out.bstride, out.ld,
-            int(accumulate), out.B, out.rows, out.cols, stream(),
-        ),
-        "nlam_segment_sum",
+    if rowptr.numel() != out.rows + 1 or rowptr.dtype != torch.int32:
+        raise ValueError(
+            f"segment_sum: rowptr has {rowptr.numel()} entries for {out.rows} output rows"
+        )
+    if scale is not None and scale.numel() != out.rows:
+        raise ValueError("segment_sum: scale length does not match the output rows")
+    # algorithmic bytes (SURVEY.md 8d): read src rows 4dM + write 4dN + int32
+    # indices 4M + 4(N+1), per batch item
+    _launch(
+        "nlam_segment_sum", lib.nlam_segment_sum,
+        (src.ptr, src.bstride, src.ld, rowptr.data_ptr(),
+         pos.data_ptr() if pos is not None else None,
+         scale.data_ptr() if scale is not None else None, out.ptr, out.bstride, out.ld,
+         int(accumulate), out.B, out.rows, out.cols, stream()),
+        nbytes=out.B * (4.0 * out.cols * (src.rows + out.rows) + 4.0 * src.rows
+                        + 4.0 * (out.rows + 1)),
     )
 
 

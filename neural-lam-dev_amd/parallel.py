@@ -1,0 +1,130 @@
+"""Pure data parallelism for the hot path: one process per GPU, the full graph
+and model replicated, samples sharded, ONE exchange per step -- the gradient
+all-reduce (the reference's Lightning `strategy="ddp"`, train_model.py:279).
+
+MI355X-first choices:
+  * parameters live in one flat fp32 buffer (FlatParams); gradients are packed
+    into one flat buffer, so the exchange is a single RCCL all-reduce (GraphLAM:
+    0.86 MB, latency-bound) or a few large buckets (Hi-LAM: 22-89 MB) rather
+    than per-parameter messages; xGMI is point-to-point, so fewer and larger
+    collectives win;
+  * buckets are reduced asynchronously in reverse parameter order while the
+    packing of earlier buckets proceeds;
+  * the optimiser is one fused AdamW kernel over the flat buffers
+    (nlam_adamw_step), with the 1/world scale folded in.
+Works unchanged on CPU with the gloo backend for the collective part (tests).
+"""
+import torch
+import torch.distributed as dist
+
+
+class FlatParams:
+    """Re-homes every parameter of `module` into one contiguous fp32 buffer
+    (views keep names/shapes, so state_dict is unchanged)."""
+
+    def __init__(self, module):
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        self.numel = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = torch.empty(self.numel, dtype=torch.float32, device=dev)
+        self.offsets = []
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            self.flat[off : off + n].copy_(p.data.reshape(-1))
+            p.data = self.flat[off : off + n].view(p.shape)
+            self.offsets.append(off)
+            off += n
+        self.grad = torch.zeros_like(self.flat)
+
+    def pack_grads(self, lo=0, hi=None):
+        """Copy p.grad of params[lo:hi] into their slice of the flat grad buffer."""
+        hi = len(self.params) if hi is None else hi
+        if hi <= lo:
+            return
+        parts = []
+        for p in self.params[lo:hi]:
+            parts.append(p.grad.reshape(-1) if p.grad is not None else
+                         torch.zeros(p.numel(), dtype=torch.float32, device=self.flat.device))
+        a = self.offsets[lo]
+        b = self.offsets[hi - 1] + self.params[hi - 1].numel()
+        torch.cat(parts, out=self.grad[a:b])
+
+    def zero_grad(self):
+        for p in self.params:
+            p.grad = None
+
+
+def bucket_ranges(sizes, bucket_numel):
+    """Split parameter indices [0, n) into contiguous ranges of about
+    bucket_numel elements, returned in REVERSE order (last layers first, the
+    order backward produces them)."""
+    ranges, start, acc = [], 0, 0
+    for i, s in enumerate(sizes):
+        acc += s
+        if acc >= bucket_numel:
+            ranges.append((start, i + 1))
+            start, acc = i + 1, 0
+    if start < len(sizes):
+        ranges.append((start, len(sizes)))
+    return ranges[::-1]
+
+
+class GradAllReduce:
+    """Bucketed flat-buffer gradient all-reduce (SUM; the 1/world factor is
+    applied by the optimiser)."""
+
+    def __init__(self, flat, bucket_bytes=32 << 20, group=None):
+        self.flat = flat
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        sizes = [p.numel() for p in flat.params]
+        self.ranges = bucket_ranges(sizes, max(1, bucket_bytes // 4))
+
+    def broadcast_params(self, src=0):
+        if self.world > 1:
+            dist.broadcast(self.flat.flat, src=src, group=self.group)
+
+    def reduce(self):
+        """Pack + all-reduce every bucket; returns when all are complete on the
+        current stream."""
+        f = self.flat
+        if self.world == 1:
+            f.pack_grads()
+            return
+        handles = []
+        for lo, hi in self.ranges:
+            f.pack_grads(lo, hi)
+            a = f.offsets[lo]
+            b = f.offsets[hi - 1] + f.params[hi - 1].numel()
+            handles.append(dist.all_reduce(f.grad[a:b], op=dist.ReduceOp.SUM, group=self.group,
+                                           async_op=True))
+        for h in handles:
+            h.wait()
+
+
+class FlatAdamW:
+    """AdamW(lr, betas=(0.9, 0.95)) of ar_model.py:191-195 as one kernel over the
+    flat parameter buffer."""
+
+    def __init__(self, flat, lr=1e-3, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.01):
+        self.flat, self.lr, self.betas, self.eps, self.wd = flat, lr, betas, eps, weight_decay
+        self.m = torch.zeros_like(flat.flat)
+        self.v = torch.zeros_like(flat.flat)
+        self.t = 0
+
+    def step(self, grad_scale=1.0):
+        from . import ops
+        from ._lib import check, lib
+
+        self.t += 1
+        f = self.flat
+        ops._require_dev(f.flat, "flat parameter buffer")
+        check(
+            lib.nlam_adamw_step(
+                f.flat.data_ptr(), f.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+                f.numel, self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.t,
+                grad_scale, ops.stream(),
+            ),
+            "nlam_adamw_step",
+        )

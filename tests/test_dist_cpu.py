@@ -1,0 +1,77 @@
+"""world_size-2 gloo tests (CPU) of the data-parallel exchange: bucketed flat
+gradient all-reduce and parameter broadcast."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, bucket_bytes, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from neural_lam_amd import parallel
+
+    torch.manual_seed(rank)  # different init per rank: broadcast must fix it
+    net = torch.nn.Sequential(torch.nn.Linear(5, 9), torch.nn.SiLU(), torch.nn.Linear(9, 4),
+                              torch.nn.LayerNorm(4))
+    flat = parallel.FlatParams(net)
+    red = parallel.GradAllReduce(flat, bucket_bytes=bucket_bytes)
+    red.broadcast_params()
+    p0 = flat.flat.clone()
+    gen = torch.Generator().manual_seed(100 + rank)
+    x = torch.randn(6, 5, generator=gen)
+    net(x).pow(2).sum().backward()
+    local = torch.cat([p.grad.reshape(-1) for p in flat.params])
+    red.reduce()
+    # plain lists: tensors in an mp.Queue travel as fds that die with the sender
+    q.put((rank, p0.tolist(), local.tolist(), flat.grad.tolist(), len(red.ranges)))
+    dist.destroy_process_group()
+
+
+def _run(bucket_bytes):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, bucket_bytes, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, p0a, la, ga, nb), (_, p0b, lb, gb, _) = [
+        (r, torch.tensor(a), torch.tensor(b), torch.tensor(c), n) for r, a, b, c, n in res
+    ]
+    assert torch.equal(p0a, p0b), "parameters differ after broadcast"
+    assert torch.allclose(ga, la + lb, atol=1e-6) and torch.equal(ga, gb)
+    return nb
+
+
+def test_single_bucket_allreduce():
+    assert _run(bucket_bytes=1 << 20) == 1
+
+
+def test_multi_bucket_allreduce():
+    assert _run(bucket_bytes=64) > 2
+
+
+def test_bucket_ranges_cover_all_params_in_reverse():
+    from neural_lam_amd.parallel import bucket_ranges
+
+    sizes = [10, 3, 50, 7, 7, 100, 1]
+    r = bucket_ranges(sizes, 40)
+    flat = sorted(i for lo, hi in r for i in range(lo, hi))
+    assert flat == list(range(len(sizes)))
+    assert r[0][1] == len(sizes) and r[-1][0] == 0

@@ -1,0 +1,95 @@
+"""CPU tests of the host side: C-ABI library loads and exports every declared
+symbol, graph tables, module/state_dict layout vs the golden state_dicts,
+loud failure on CPU tensors."""
+import glob
+import os
+import re
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, ROOT
+
+
+def test_library_exports_every_declared_symbol():
+    from neural_lam_amd import _lib
+
+    hdr = open(os.path.join(ROOT, "include", "nlam_hip.h")).read()
+    declared = set(re.findall(r"\b(nlam_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(_lib.lib, name), f"libnlam_hip.so does not export {name}"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert _lib.lib.nlam_abi_version() >= 1
+
+
+def test_graph_tables_match_numpy():
+    from neural_lam_amd.graph import EdgeTables, normalise_edge_index
+
+    gen = torch.Generator().manual_seed(0)
+    M, n_s, n_r = 500, 37, 23
+    ei = torch.stack((torch.randint(0, n_s, (M,), generator=gen) + 100,
+                      torch.randint(0, n_r, (M,), generator=gen) + 5))
+    ei[0, 0], ei[1, 0], ei[1, 1], ei[0, 1] = 100, 5, 5 + n_r - 1, 100 + n_s - 1
+    send, rec, num_rec, num_send = normalise_edge_index(ei)
+    assert num_rec == n_r and num_send == n_s
+    t = EdgeTables(send, rec, num_send, num_rec)
+    s, r = send.numpy(), rec.numpy()
+    order = np.argsort(r, kind="stable")
+    assert np.array_equal(t.csr_eid.numpy(), order)
+    assert np.array_equal(t.csr_send.numpy(), s[order])
+    assert np.array_equal(t.csr_rec.numpy(), r[order])
+    assert np.array_equal(np.diff(t.csr_rowptr.numpy()), np.bincount(r, minlength=n_r))
+    # CSC lists hold CSR positions, ascending, grouped by sender
+    pos = t.csc_pos.numpy()
+    colptr = t.csc_colptr.numpy()
+    assert np.array_equal(np.diff(colptr), np.bincount(s, minlength=n_s))
+    for j in range(n_s):
+        seg = pos[colptr[j]:colptr[j + 1]]
+        assert np.all(t.csr_send.numpy()[seg] == j) and np.all(np.diff(seg) > 0)
+    assert np.array_equal(t.csc_eid.numpy(), t.csr_eid.numpy()[pos])
+    deg = np.maximum(np.bincount(r, minlength=n_r), 1)
+    assert np.allclose(t.inv_deg.numpy(), 1.0 / deg)
+
+
+def test_graph_build_rejects_bad_input():
+    from neural_lam_amd._lib import NlamError
+    from neural_lam_amd.graph import EdgeTables
+
+    with pytest.raises(NlamError, match="out of"):
+        EdgeTables(torch.tensor([0, 5]), torch.tensor([0, 1]), 3, 2)
+    with pytest.raises(ValueError):
+        from neural_lam_amd.graph import normalise_edge_index
+
+        normalise_edge_index(torch.zeros(2, 0, dtype=torch.int64))
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "model_*.pt"))),
+                         ids=lambda p: os.path.basename(p)[:-3])
+def test_model_state_dict_layout_matches_reference(path):
+    """Same parameter names / shapes as the reference's checkpoint, and -- with
+    the same seed -- the same default-init values (construction order)."""
+    from test_gpu_models import build_model
+
+    fx = torch.load(path, weights_only=False)
+    with tempfile.TemporaryDirectory() as tmp:
+        torch.manual_seed(42)  # the seed make_golden.py constructs the reference model with
+        model = build_model(fx, tmp, load_weights=False)
+    sd = model.state_dict()
+    assert list(sd.keys()) == list(fx["state_dict"].keys())
+    for k, v in sd.items():
+        assert v.shape == fx["state_dict"][k].shape, k
+        assert torch.equal(v, fx["state_dict"][k]), f"default init differs at {k}"
+
+
+def test_cpu_tensors_fail_loudly():
+    from neural_lam_amd.interaction_net import InteractionNet
+
+    net = InteractionNet(torch.tensor([[3, 4, 5, 3], [0, 1, 2, 2]]), 8)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        net(torch.randn(1, 3, 8), torch.randn(1, 3, 8), torch.randn(1, 4, 8))
+    mlp = __import__("neural_lam_amd").make_mlp([3, 8, 8])
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        mlp(torch.randn(5, 3))
