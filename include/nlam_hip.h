@@ -55,6 +55,15 @@ int nlam_graph_build_host(const int64_t* send, const int64_t* rec, int64_t M,
                           int32_t* csc_colptr, int32_t* csc_pos, int32_t* csc_eid,
                           float* inv_deg);
 
+/* Receiver-aligned edge tiles for the fused edge kernels: tile = CSR positions
+ * [p0, p1), p1 - p0 <= max_edges, covering the complete in-edge segments of
+ * receivers [r0, r1), r1 - r0 <= max_recs.  tiles: host int32[4 * capacity].
+ * Returns the tile count, -1 if a receiver has more than max_edges in-edges,
+ * -2 if capacity is too small. */
+int64_t nlam_graph_tiles_host(const int32_t* csr_rowptr, int64_t n_rec,
+                              int32_t max_edges, int32_t max_recs,
+                              int32_t* tiles, int64_t capacity);
+
 /* ------------------------------------------------------------ generic ops --
  * Shape-generic fp32 kernels (any hidden_dim, any number of MLP layers).
  * They cover every configuration reachable through the reference's public
@@ -132,6 +141,58 @@ int nlam_copy_rows(const float* x, int64_t x_bstride, int64_t ldx, float* out,
 /* out[0:n] = sum_b x[b*bstride + 0:n]  (gradient of a stride-0 expand). */
 int nlam_sum_batch(const float* x, int64_t bstride, float* out, int64_t B,
                    int64_t n, void* stream);
+
+/* ------------------------------------------------------------- fused ops --
+ * gfx950 kernels for hidden_layers == 1 and hidden width in {64, 128}: one
+ * wavefront owns 32 rows, features live in MFMA accumulator layout, weights in
+ * LDS, workgroups persistent.  Forward saves nothing (backward recomputes).
+ */
+
+/* y = [res +] [LayerNorm](W2 silu(W1 [xa | xb] + b1) + b2)
+ * = utils.make_mlp([k_in, hid, n_out]) applied to rows (utils.py:191-214);
+ * the two-source form is the node update aggr_mlp([x_r, agg]) with residual
+ * (interaction_net.py:106-109).  xb may be NULL.  gamma/beta NULL = no LN.
+ * W1: (hid x k_in) pitch ldW1, W2: (n_out x hid) pitch ldW2. */
+int nlam_mlp_fwd(const float* xa, int64_t xa_bstride, int64_t xa_ld, int xa_width,
+                 const float* xb, int64_t xb_bstride, int64_t xb_ld, int xb_width,
+                 const float* W1, int64_t ldW1, const float* b1,
+                 const float* W2, int64_t ldW2, const float* b2,
+                 const float* gamma, const float* beta,
+                 const float* res, int64_t res_bstride, int64_t res_ld,
+                 float* out, int64_t out_bstride, int64_t out_ld,
+                 int64_t B, int64_t rows, int hid, int n_out, void* stream);
+
+/* out[:, 0:nA] = x WA^T + bA, out[:, nA:nA+nB] = x WB^T + bB (WB may be NULL):
+ * the node-side projections Ps = W1s x_s, Pr = W1r x_r + b1 of the edge MLP's
+ * first Linear (edge_mlp.0, interaction_net.py:65,121) after splitting
+ * W1 [e; x_s; x_r] = W1e e + W1s x_s + W1r x_r.  nA, nB multiples of 32. */
+int nlam_lin_fwd(const float* x, int64_t x_bstride, int64_t x_ld, int k_in,
+                 const float* WA, int64_t ldWA, const float* bA, int nA,
+                 const float* WB, int64_t ldWB, const float* bB, int nB,
+                 float* out, int64_t out_bstride, int64_t out_ld,
+                 int64_t B, int64_t rows, void* stream);
+
+/* Fused edge update + aggregation of one InteractionNet layer
+ * (interaction_net.py:102-105,117-131):
+ *   h_k = (has_egemm ? W1e e_k : e_k) + ps[send(k)] + pr[rec(k)]
+ *   m_k = LN(W2 silu(h_k) + b2);  agg_i = inv_deg_i * sum_{rec(k)=i} m_k;
+ *   e_out_k = e_k + m_k (has_egemm only).
+ * With has_egemm = 0, `e` holds the pre-projected edge term Pe = W1e e (+0),
+ * typically batch-invariant (e_bstride = 0).  Edge rows are addressed in the
+ * ORIGINAL edge order through csr_eid; tiles from nlam_graph_tiles_host. */
+int nlam_edge_fwd(const int32_t* tiles, int64_t ntiles,
+                  const int32_t* csr_rowptr, const int32_t* csr_eid,
+                  const int32_t* csr_send, const int32_t* csr_rec,
+                  const float* inv_deg,
+                  const float* e, int64_t e_bstride, int64_t e_ld, int has_egemm,
+                  const float* ps, int64_t ps_bstride, int64_t ps_ld,
+                  const float* pr, int64_t pr_bstride, int64_t pr_ld,
+                  const float* W1e, int64_t ldW1e,
+                  const float* W2, int64_t ldW2, const float* b2,
+                  const float* gamma, const float* beta,
+                  float* agg, int64_t agg_bstride, int64_t agg_ld,
+                  float* e_out, int64_t eo_bstride, int64_t eo_ld,
+                  int64_t B, int d, void* stream);
 
 /* One AdamW step over a flat fp32 parameter buffer (decoupled weight decay,
  * bias correction; torch.optim.AdamW semantics, ar_model.py:191-195).

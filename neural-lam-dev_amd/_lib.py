@@ -33,6 +33,14 @@ SIGNATURES = {
     "nlam_add_rows": [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _p],
     "nlam_copy_rows": [_p, _i64, _i64, _p, _i64, _i64, _i64, _i64, _i64, _p],
     "nlam_sum_batch": [_p, _i64, _p, _i64, _i64, _p],
+    "nlam_mlp_fwd": [_p, _i64, _i64, _i32, _p, _i64, _i64, _i32, _p, _i64, _p, _p, _i64, _p, _p, _p,
+                     _p, _i64, _i64, _p, _i64, _i64, _i64, _i64, _i32, _i32, _p],
+    "nlam_lin_fwd": [_p, _i64, _i64, _i32, _p, _i64, _p, _i32, _p, _i64, _p, _i32, _p, _i64, _i64,
+                     _i64, _i64, _p],
+    "nlam_edge_fwd": [_p, _i64, _p, _p, _p, _p, _p, _p, _i64, _i64, _i32, _p, _i64, _i64, _p, _i64,
+                      _i64, _p, _i64, _p, _i64, _p, _p, _p, _p, _i64, _i64, _p, _i64, _i64, _i64,
+                      _i32, _p],
+    "nlam_graph_tiles_host": [_p, _i64, _i32, _i32, _p, _i64],
     "nlam_adamw_step": [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _i64, _f, _p],
     "nlam_mfma_probe": [_p, _p],
 }
@@ -40,6 +48,7 @@ _RESTYPES = {
     "nlam_last_error": ctypes.c_char_p,
     "nlam_layernorm_bwd_blocks": _i64,
     "nlam_colsum_blocks": _i64,
+    "nlam_graph_tiles_host": _i64,
 }
 
 

@@ -1,0 +1,416 @@
+// Wave-level building blocks of the fused gfx950 kernels.
+//
+// Layout convention ("row-on-lane"): a wavefront owns a tile of 32 rows (edges
+// or nodes).  Lane l = (t, h) with t = l & 31 the row and h = l >> 5.  A row's
+// D features live in accumulator blocks acc[nb][r] (nb = feature block of 32,
+// r in [0,16)):   feature f = 32 nb + 8 (r >> 2) + 4 h + (r & 3).
+// This is exactly the C/D map of v_mfma_f32_32x32x2_f32 when the GEMM is
+// computed transposed (D^T[f][t] = W[f][:] . X[t][:]), so
+//   * the result of one GEMM is directly the B operand of the next one
+//     (no LDS round trip, no lane movement), and
+//   * LayerNorm over the features is a per-lane sum plus one xor-32 shuffle.
+// The k index of a K=2 MFMA step is permuted consistently on both operands:
+// step (c, j) multiplies k_a = 8c + j (lanes h = 0) and k_b = 8c + 4 + j
+// (lanes h = 1); any pairing is valid as long as A and B agree.
+//
+// LDS row tiles are [32][LD] floats with LD = K + 4 (K a multiple of 8): the
+// pad makes the float4 operand reads (16-lane groups, distinct rows) and the
+// float4 tile writes conflict-free.
+#pragma once
+#include "nlam_common.h"
+
+#define NLAM_TILE 32
+
+struct RowView {        // (B, rows, width) fp32 with unit column stride
+  const float* ptr;
+  int64_t bstride;      // elements between batch items (0 = batch-invariant)
+  int64_t ld;           // elements between rows
+  int width;            // columns taken from this view
+};
+
+static inline bool view_vec_ok(const float* ptr, int64_t bstride, int64_t ld, int width) {
+  return ptr != nullptr && nlam_aligned16(ptr) && (bstride % 4 == 0) && (ld % 4 == 0) &&
+         (width % 4 == 0) && width >= 4 && width <= 256;
+}
+
+static inline unsigned persistent_grid(int64_t ntiles, size_t lds_bytes) {
+  // 256 CUs; as many workgroups per CU as the LDS footprint admits (<= 2)
+  int per_cu = lds_bytes * 2 <= 160 * 1024 ? 2 : 1;
+  int64_t g = (ntiles + 3) / 4;
+  const int64_t cap = 256 * per_cu;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+
+// Orders this wavefront's LDS traffic: tile data written by some lanes is read by
+// other lanes of the SAME wave (DS ops of one wave execute in order; the fence
+// keeps the compiler from reordering across it).  No workgroup barrier needed.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// ---- weights global -> LDS ---------------------------------------------------
+// W is (n_out x k_in) row-major in global memory; the LDS image is
+// [n_pad][k_pad + 4] with zero fill (n_pad multiple of 32, k_pad multiple of 8).
+__device__ __forceinline__ void load_weight_lds(float* __restrict__ Ws, const float* __restrict__ W,
+                                                int64_t ldW, int n_out, int k_in, int n_pad,
+                                                int k_pad, int tid, int nthreads) {
+  const int ld = k_pad + 4;
+  for (int idx = tid; idx < n_pad * k_pad; idx += nthreads) {
+    const int i = idx / k_pad, k = idx - i * k_pad;
+    Ws[i * ld + k] = (i < n_out && k < k_in) ? W[(int64_t)i * ldW + k] : 0.f;
+  }
+}
+// per-feature vector -> LDS, zero padded to n_pad
+__device__ __forceinline__ void load_vec_lds(float* __restrict__ vs, const float* __restrict__ v,
+                                             int n, int n_pad, int tid, int nthreads) {
+  for (int i = tid; i < n_pad; i += nthreads) vs[i] = (v != nullptr && i < n) ? v[i] : 0.f;
+}
+
+// ---- row staging: global rows -> LDS tile ------------------------------------
+// Tile row t (< nrows) comes from src + row_off(t); `width` floats are copied to
+// columns [col0, col0 + width); vectorised when width % 4 == 0 and the source
+// rows are 16-byte aligned (VEC = true), scalar otherwise.  With ADD the values
+// are added to what the tile already holds.  Rows >= nrows are zero-filled
+// (ADD = false) so that padded slots contribute nothing downstream.
+template <bool VEC, bool ADD, typename RowPtr>
+__device__ __forceinline__ void stage_rows(float* __restrict__ tile, int ld, int col0, int width,
+                                           int nrows, int lane, RowPtr row_ptr) {
+  if (VEC) {
+    const int lpr = width >> 2;                 // lanes per row (float4 each)
+    const int rpi = 64 / lpr;                   // rows per wave-instruction
+    const int sub = lane / lpr, c4 = lane - sub * lpr;
+    // row_ptr may shuffle indices across lanes (gathers): it is evaluated by all
+    // lanes, outside the divergent parts (lanes 0..31 hold the slot indices and
+    // are never masked here because rpi * lpr > 32).
+    for (int k = 0; k * rpi < NLAM_TILE; ++k) {
+      const int t = sub + k * rpi;
+      const float* src = row_ptr(t < NLAM_TILE ? t : 0);
+      if (sub < rpi && t < NLAM_TILE) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (t < nrows) v = reinterpret_cast<const f32x4*>(src)[c4];
+        f32x4* dst = reinterpret_cast<f32x4*>(tile + t * ld + col0) + c4;
+        if (ADD) v += *dst;
+        *dst = v;
+      }
+    }
+  } else {
+    for (int idx = lane; idx < NLAM_TILE * width; idx += 64) {
+      const int t = idx / width, c = idx - t * width;
+      float v = (t < nrows) ? row_ptr(t)[c] : 0.f;
+      float* dst = tile + t * ld + col0 + c;
+      if (ADD) v += *dst;
+      *dst = v;
+    }
+  }
+}
+
+// zero columns [col0, col0+width) of the tile (K padding)
+__device__ __forceinline__ void zero_cols(float* __restrict__ tile, int ld, int col0, int width,
+                                          int lane) {
+  for (int idx = lane; idx < NLAM_TILE * width; idx += 64) {
+    const int t = idx / width, c = idx - t * width;
+    tile[t * ld + col0 + c] = 0.f;
+  }
+}
+
+// ---- LDS tile <-> accumulator layout -----------------------------------------
+// acc[nb][4q..4q+3] <-> tile[t][32 nb + 8 q + 4 h .. +3]
+template <int NB>
+__device__ __forceinline__ void tile_to_acc(f32x16 (&acc)[NB], const float* __restrict__ tile,
+                                            int ld, int lane) {
+  const int t = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(tile + t * ld + 32 * nb + 8 * q + 4 * h);
+      acc[nb][4 * q + 0] = v[0];
+      acc[nb][4 * q + 1] = v[1];
+      acc[nb][4 * q + 2] = v[2];
+      acc[nb][4 * q + 3] = v[3];
+    }
+  }
+}
+template <int NB>
+__device__ __forceinline__ void acc_to_tile(const f32x16 (&acc)[NB], float* __restrict__ tile,
+                                            int ld, int lane) {
+  const int t = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 v = {acc[nb][4 * q + 0], acc[nb][4 * q + 1], acc[nb][4 * q + 2], acc[nb][4 * q + 3]};
+      *reinterpret_cast<f32x4*>(tile + t * ld + 32 * nb + 8 * q + 4 * h) = v;
+    }
+  }
+}
+
+// per-feature vector (bias / gamma / beta) in accumulator layout: v[nb][r] = p[f(nb,r,h)]
+template <int NB>
+__device__ __forceinline__ void vec_to_acc(f32x16 (&v)[NB], const float* __restrict__ p, int lane) {
+  const int h = lane >> 5;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 x = *reinterpret_cast<const f32x4*>(p + 32 * nb + 8 * q + 4 * h);
+      v[nb][4 * q + 0] = x[0];
+      v[nb][4 * q + 1] = x[1];
+      v[nb][4 * q + 2] = x[2];
+      v[nb][4 * q + 3] = x[3];
+    }
+  }
+}
+
+// ---- GEMMs -------------------------------------------------------------------
+// out[nb] += W[32 nb .. +31][0 .. 8*kc) . X^T, X read from an LDS row tile.
+// Ws: LDS weight image, row stride ldw (= k_pad + 4), rows = output features.
+template <int NB>
+__device__ __forceinline__ void gemm_tile(f32x16 (&out)[NB], const float* __restrict__ Ws, int ldw,
+                                          const float* __restrict__ tile, int ld, int kc,
+                                          int lane) {
+  const int t = lane & 31, h = lane >> 5;
+  for (int c = 0; c < kc; ++c) {
+    const f32x4 b = *reinterpret_cast<const f32x4*>(tile + t * ld + 8 * c + 4 * h);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(Ws + (32 * nb + t) * ldw + 8 * c + 4 * h);
+      out[nb] = mfma32(a[0], b[0], out[nb]);
+      out[nb] = mfma32(a[1], b[1], out[nb]);
+      out[nb] = mfma32(a[2], b[2], out[nb]);
+      out[nb] = mfma32(a[3], b[3], out[nb]);
+    }
+  }
+}
+
+// out[nb] += W[32 nb ..][k0 .. k0 + 32 KB) . IN, with IN (KB feature blocks) in
+// accumulator layout used directly as the B operand.
+template <int NB, int KB>
+__device__ __forceinline__ void gemm_acc(f32x16 (&out)[NB], const float* __restrict__ Ws, int ldw,
+                                         int k0, const f32x16 (&in)[KB], int lane) {
+  const int t = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(Ws + (32 * nb + t) * ldw + k0 + 32 * kb +
+                                                        8 * q + 4 * h);
+        out[nb] = mfma32(a[0], in[kb][4 * q + 0], out[nb]);
+        out[nb] = mfma32(a[1], in[kb][4 * q + 1], out[nb]);
+        out[nb] = mfma32(a[2], in[kb][4 * q + 2], out[nb]);
+        out[nb] = mfma32(a[3], in[kb][4 * q + 3], out[nb]);
+      }
+    }
+  }
+}
+
+// out[nb] += W^T . IN : out feature i = column i of W, summed over W's rows k
+// (the data-gradient GEMM g_in = W^T g_out).  Ws rows = k (KB blocks of 32),
+// columns = i.  A operand element (i, k): Ws[k][i] -> 4 scalar LDS reads per
+// 4 MFMAs, consecutive lanes consecutive i (conflict-free).
+template <int NB, int KB>
+__device__ __forceinline__ void gemm_acc_wt(f32x16 (&out)[NB], const float* __restrict__ Ws,
+                                            int ldw, int i0, const f32x16 (&in)[KB], int lane) {
+  const int t = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int kbase = 32 * kb + 8 * q + 4 * h;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const float* col = Ws + i0 + 32 * nb + t;
+        out[nb] = mfma32(col[(kbase + 0) * ldw], in[kb][4 * q + 0], out[nb]);
+        out[nb] = mfma32(col[(kbase + 1) * ldw], in[kb][4 * q + 1], out[nb]);
+        out[nb] = mfma32(col[(kbase + 2) * ldw], in[kb][4 * q + 2], out[nb]);
+        out[nb] = mfma32(col[(kbase + 3) * ldw], in[kb][4 * q + 3], out[nb]);
+      }
+    }
+  }
+}
+
+// dW[ib][jb] += sum_t G[t][32 ib + .] (x) X[t][32 jb + .] over the 32 tile rows:
+// the weight-gradient outer product.  G and X are LDS row tiles.  Result block
+// layout: row i = 32 ib + 8 (r >> 2) + 4 h + (r & 3), column j = 32 jb + (lane & 31).
+template <int NI, int NJ>
+__device__ __forceinline__ void outer_accum(f32x16 (&dW)[NI][NJ], const float* __restrict__ G,
+                                            int ldg, int gcol0, const float* __restrict__ X,
+                                            int ldx, int xcol0, int lane) {
+  const int i = lane & 31, h = lane >> 5;
+#pragma unroll 4
+  for (int s = 0; s < NLAM_TILE / 2; ++s) {
+    const int t = 2 * s + h;
+    float a[NI], b[NJ];
+#pragma unroll
+    for (int ib = 0; ib < NI; ++ib) a[ib] = G[t * ldg + gcol0 + 32 * ib + i];
+#pragma unroll
+    for (int jb = 0; jb < NJ; ++jb) b[jb] = X[t * ldx + xcol0 + 32 * jb + i];
+#pragma unroll
+    for (int ib = 0; ib < NI; ++ib)
+#pragma unroll
+      for (int jb = 0; jb < NJ; ++jb) dW[ib][jb] = mfma32(a[ib], b[jb], dW[ib][jb]);
+  }
+}
+
+// ---- LayerNorm in accumulator layout -----------------------------------------
+template <int NB>
+__device__ __forceinline__ void ln_stats(const f32x16 (&z)[NB], float& mean, float& rstd) {
+  constexpr float inv_d = 1.0f / (32.0f * NB);
+  float s = 0.f;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += z[nb][r];
+  s += __shfl_xor(s, 32, 64);
+  mean = s * inv_d;
+  float v = 0.f;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float d = z[nb][r] - mean;
+      v += d * d;
+    }
+  v += __shfl_xor(v, 32, 64);
+  rstd = rsqrtf(v * inv_d + 1e-5f);
+}
+
+// y = (z - mean) rstd gamma + beta, in place
+template <int NB>
+__device__ __forceinline__ void ln_apply(f32x16 (&z)[NB], const float* __restrict__ gamma,
+                                         const float* __restrict__ beta, int lane) {
+  float mean, rstd;
+  ln_stats<NB>(z, mean, rstd);
+  const int h = lane >> 5;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + 32 * nb + 8 * q + 4 * h);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(beta + 32 * nb + 8 * q + 4 * h);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        z[nb][4 * q + j] = (z[nb][4 * q + j] - mean) * rstd * g[j] + b[j];
+    }
+  }
+}
+
+// LayerNorm backward in place: z (pre-LN) -> xhat is consumed, gy -> gz.
+// Accumulates per-lane partial dgamma/dbeta (acc layout; rows with valid=false
+// contribute nothing).
+template <int NB>
+__device__ __forceinline__ void ln_backward(const f32x16 (&z)[NB], f32x16 (&gy)[NB],
+                                            const float* __restrict__ gamma, f32x16 (&dgam)[NB],
+                                            f32x16 (&dbet)[NB], bool valid, int lane) {
+  constexpr float inv_d = 1.0f / (32.0f * NB);
+  float mean, rstd;
+  ln_stats<NB>(z, mean, rstd);
+  const int h = lane >> 5;
+  float s1 = 0.f, s2 = 0.f;
+  f32x16 gg[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + 32 * nb + 8 * q + 4 * h);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = 4 * q + j;
+        const float xh = (z[nb][r] - mean) * rstd;
+        const float go = valid ? gy[nb][r] : 0.f;
+        dgam[nb][r] += go * xh;
+        dbet[nb][r] += go;
+        const float gv = go * g[j];
+        gg[nb][r] = gv;
+        s1 += gv;
+        s2 += gv * xh;
+      }
+    }
+  }
+  s1 += __shfl_xor(s1, 32, 64);
+  s2 += __shfl_xor(s2, 32, 64);
+  const float m1 = s1 * inv_d, m2 = s2 * inv_d;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float xh = (z[nb][r] - mean) * rstd;
+      gy[nb][r] = rstd * (gg[nb][r] - m1 - xh * m2);
+    }
+}
+
+// ---- coalesced tile -> global row stores -------------------------------------
+template <bool VEC, typename RowPtr>
+__device__ __forceinline__ void store_rows(const float* __restrict__ tile, int ld, int col0,
+                                           int width, int nrows, int lane, RowPtr row_ptr) {
+  if (VEC) {
+    const int lpr = width >> 2;
+    const int rpi = 64 / lpr;
+    const int sub = lane / lpr, c4 = lane - sub * lpr;
+    for (int k = 0; k * rpi < NLAM_TILE; ++k) {   // uniform trip count (see stage_rows)
+      const int t = sub + k * rpi;
+      float* dst = row_ptr(t < NLAM_TILE ? t : 0);
+      if (sub < rpi && t < nrows)
+        reinterpret_cast<f32x4*>(dst)[c4] =
+            *(reinterpret_cast<const f32x4*>(tile + t * ld + col0) + c4);
+    }
+  } else {
+    for (int idx = lane; idx < nrows * width; idx += 64) {
+      const int t = idx / width, c = idx - t * width;
+      row_ptr(t)[c] = tile[t * ld + col0 + c];
+    }
+  }
+}
+
+// out[t][c] = tile[t][c] + res[t][c]
+template <bool VEC, typename RowPtr, typename ResPtr>
+__device__ __forceinline__ void store_rows_res(const float* __restrict__ tile, int ld, int col0,
+                                               int width, int nrows, int lane, RowPtr row_ptr,
+                                               ResPtr res_ptr) {
+  if (VEC) {
+    const int lpr = width >> 2;
+    const int rpi = 64 / lpr;
+    const int sub = lane / lpr, c4 = lane - sub * lpr;
+    for (int k = 0; k * rpi < NLAM_TILE; ++k) {
+      const int t = sub + k * rpi;
+      const int ts = t < NLAM_TILE ? t : 0;
+      float* dst = row_ptr(ts);
+      const float* rsrc = res_ptr(ts);
+      if (sub < rpi && t < nrows) {
+        const f32x4 r = reinterpret_cast<const f32x4*>(rsrc)[c4];
+        reinterpret_cast<f32x4*>(dst)[c4] =
+            *(reinterpret_cast<const f32x4*>(tile + t * ld + col0) + c4) + r;
+      }
+    }
+  } else {
+    for (int idx = lane; idx < nrows * width; idx += 64) {
+      const int t = idx / width, c = idx - t * width;
+      row_ptr(t)[c] = tile[t * ld + col0 + c] + res_ptr(t)[c];
+    }
+  }
+}
+
+// column sums over the 32 lanes t of per-lane partials in acc layout, through an
+// LDS tile: out[f] (+)= sum_t v(t, f).  Used to fold dgamma/dbeta/bias partials.
+template <int NB>
+__device__ __forceinline__ void acc_colsum_to(const f32x16 (&v)[NB], float* __restrict__ tile,
+                                              int ld, float* __restrict__ out, int lane) {
+  acc_to_tile<NB>(v, tile, ld, lane);
+  wave_sync();
+  for (int f = lane; f < 32 * NB; f += 64) {
+    float s = 0.f;
+#pragma unroll 8
+    for (int t = 0; t < NLAM_TILE; ++t) s += tile[t * ld + f];
+    out[f] = s;
+  }
+}

@@ -49,3 +49,38 @@ extern "C" int nlam_graph_build_host(const int64_t* send, const int64_t* rec, in
   }
   return 0;
 }
+
+// Receiver-aligned edge tiles for the fused edge kernels: consecutive CSR
+// positions [p0, p1) with p1 - p0 <= max_edges covering the whole in-edge
+// segments of consecutive receivers [r0, r1), r1 - r0 <= max_recs.  A tile never
+// splits a receiver's segment, so per-tile reductions need no cross-tile carry
+// (deterministic, no atomics).  tiles: int32[4 * capacity] = (p0, p1, r0, r1).
+// Returns the number of tiles, or -1 (a receiver has more than max_edges
+// in-edges) / -2 (capacity too small).
+extern "C" int64_t nlam_graph_tiles_host(const int32_t* csr_rowptr, int64_t n_rec,
+                                         int32_t max_edges, int32_t max_recs, int32_t* tiles,
+                                         int64_t capacity) {
+  int64_t nt = 0;
+  int64_t r = 0;
+  while (r < n_rec) {
+    const int32_t p0 = csr_rowptr[r];
+    int64_t r1 = r;
+    while (r1 < n_rec && (r1 - r) < max_recs && (csr_rowptr[r1 + 1] - p0) <= max_edges) ++r1;
+    if (r1 == r) {
+      nlam_set_error("graph_tiles: receiver %ld has %d in-edges (> %d)", (long)r,
+                     csr_rowptr[r + 1] - p0, max_edges);
+      return -1;
+    }
+    if (nt >= capacity) {
+      nlam_set_error("graph_tiles: capacity %ld too small", (long)capacity);
+      return -2;
+    }
+    tiles[4 * nt + 0] = p0;
+    tiles[4 * nt + 1] = csr_rowptr[r1];
+    tiles[4 * nt + 2] = (int32_t)r;
+    tiles[4 * nt + 3] = (int32_t)r1;
+    ++nt;
+    r = r1;
+  }
+  return nt;
+}

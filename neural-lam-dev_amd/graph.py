@@ -56,3 +56,18 @@ class EdgeTables(torch.nn.Module):
             self.register_buffer(k, torch.from_numpy(out[k]), persistent=False)
         deg = np.diff(out["csr_rowptr"])
         self.max_in_degree = int(deg.max())
+        # receiver-aligned 32-edge tiles for the fused edge kernels (None if a
+        # receiver has more than 32 in-edges: such graphs take the generic path)
+        self.ntiles = 0
+        if self.max_in_degree <= 32:
+            cap = n_rec + M // 32 + 2
+            tiles = np.empty(4 * cap, np.int32)
+            nt = lib.nlam_graph_tiles_host(p(out["csr_rowptr"]), n_rec, 32, 32, p(tiles), cap)
+            if nt < 0:
+                raise RuntimeError(lib.nlam_last_error().decode())
+            self.ntiles = int(nt)
+            self.register_buffer(
+                "tiles", torch.from_numpy(tiles[: 4 * nt].copy()).view(nt, 4), persistent=False
+            )
+        else:
+            self.tiles = None

@@ -323,3 +323,65 @@ def mfma_probe():
     out = torch.empty(32, 32, dtype=torch.float32, device="cuda")
     check(lib.nlam_mfma_probe(out.data_ptr(), stream()), "nlam_mfma_probe")
     return out
+
+
+# ------------------------------------------------------------------- fused
+def _p(t):
+    return t.data_ptr() if t is not None else None
+
+
+def fused_mlp_fwd(xa, xb, W1, b1, W2, b2, gamma, beta, res, out, hid, n_out):
+    """xa/xb/res/out: Mat (xb, res may be None); W1 (hid, k_in) and W2 (n_out, hid)
+    tensors (any row pitch, unit column stride)."""
+    B = out.B
+    k_in = xa.cols + (xb.cols if xb is not None else 0)
+    _launch(
+        "nlam_mlp_fwd", lib.nlam_mlp_fwd,
+        (xa.ptr, xa.bstride, xa.ld, xa.cols,
+         xb.ptr if xb is not None else None, xb.bstride if xb is not None else 0,
+         xb.ld if xb is not None else 0, xb.cols if xb is not None else 0,
+         W1.data_ptr(), W1.stride(0), _p(b1), W2.data_ptr(), W2.stride(0), _p(b2),
+         _p(gamma), _p(beta),
+         res.ptr if res is not None else None, res.bstride if res is not None else 0,
+         res.ld if res is not None else 0,
+         out.ptr, out.bstride, out.ld, B, out.rows, hid, n_out, stream()),
+        flops=2.0 * B * out.rows * hid * (k_in + n_out),
+        nbytes=4.0 * B * out.rows * (k_in + n_out * (2 if res is not None else 1)),
+    )
+
+
+def fused_lin_fwd(x, WA, bA, WB, bB, out):
+    """out[:, :nA] = x WA^T + bA ; out[:, nA:] = x WB^T + bB.  WA/WB: 2-D weight
+    views (any row pitch)."""
+    nA = WA.shape[0]
+    nB = WB.shape[0] if WB is not None else 0
+    _launch(
+        "nlam_lin_fwd", lib.nlam_lin_fwd,
+        (x.ptr, x.bstride, x.ld, x.cols, WA.data_ptr(), WA.stride(0), _p(bA), nA,
+         _p(WB), WB.stride(0) if WB is not None else 0, _p(bB), nB,
+         out.ptr, out.bstride, out.ld, out.B, out.rows, stream()),
+        flops=2.0 * out.B * out.rows * x.cols * (nA + nB),
+        nbytes=4.0 * out.B * out.rows * (x.cols + nA + nB),
+    )
+
+
+def fused_edge_fwd(g, e, has_egemm, ps, pr, W1e, W2, b2, gamma, beta, agg, e_out, mean, d):
+    """g: EdgeTables (with tiles); e/ps/pr/agg/e_out: Mat."""
+    B = agg.B
+    M = g.M
+    units = 2 if has_egemm else 1
+    _launch(
+        "nlam_edge_fwd", lib.nlam_edge_fwd,
+        (g.tiles.data_ptr(), g.ntiles, g.csr_rowptr.data_ptr(), g.csr_eid.data_ptr(),
+         g.csr_send.data_ptr(), g.csr_rec.data_ptr(), g.inv_deg.data_ptr() if mean else None,
+         e.ptr, e.bstride, e.ld, int(has_egemm), ps.ptr, ps.bstride, ps.ld, pr.ptr, pr.bstride,
+         pr.ld, _p(W1e), W1e.stride(0) if W1e is not None else 0, W2.data_ptr(), W2.stride(0),
+         b2.data_ptr(), gamma.data_ptr(), beta.data_ptr(), agg.ptr, agg.bstride, agg.ld,
+         e_out.ptr if e_out is not None else None, e_out.bstride if e_out is not None else 0,
+         e_out.ld if e_out is not None else 0, B, d, stream()),
+        flops=2.0 * B * M * d * d * units,
+        # algorithmic bytes (SURVEY.md 8d): read e (per batch item if it varies), write e',
+        # read the projected node rows once, write agg, int32 indices
+        nbytes=4.0 * d * ((B if e.bstride else 1) * M + (B * M if has_egemm else 0)
+                          + B * (ps.rows + pr.rows) + B * agg.rows) + 16.0 * M,
+    )

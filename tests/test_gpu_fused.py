@@ -1,0 +1,144 @@
+"""GPU tests of the fused gfx950 kernels (C ABI) against plain torch fp32."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return float((a.detach().cpu() - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+@pytest.mark.parametrize(
+    "hid,ka,kb,n_out,ln,res,B,rows",
+    [
+        (64, 64, 0, 64, True, False, 1, 100),
+        (64, 64, 64, 64, True, True, 3, 77),     # node update [x_r | agg] + residual
+        (64, 3, 0, 64, True, False, 1, 1000),    # edge-feature embedder
+        (64, 2, 0, 64, True, False, 1, 33),
+        (64, 56, 0, 64, True, False, 2, 250),    # grid embedder
+        (64, 64, 0, 17, False, False, 2, 129),   # output map
+        (64, 64, 0, 64, True, True, 2, 64),      # encoding_grid_mlp with residual
+        (128, 3, 0, 128, True, False, 1, 45),
+        (128, 128, 0, 17, False, False, 1, 40),
+    ],
+)
+def test_fused_mlp_fwd(hid, ka, kb, n_out, ln, res, B, rows):
+    from neural_lam_amd import ops
+
+    gen = torch.Generator().manual_seed(hid + ka + kb + n_out + rows)
+    k_in = ka + kb
+    xa = torch.randn(B, rows, ka, generator=gen)
+    xb = torch.randn(B, rows, kb, generator=gen) if kb else None
+    W1 = torch.randn(hid, k_in, generator=gen) / k_in ** 0.5
+    b1 = torch.randn(hid, generator=gen)
+    W2 = torch.randn(n_out, hid, generator=gen) / hid ** 0.5
+    b2 = torch.randn(n_out, generator=gen)
+    gam = 1 + 0.1 * torch.randn(n_out, generator=gen)
+    bet = 0.1 * torch.randn(n_out, generator=gen)
+    r = torch.randn(B, rows, n_out, generator=gen) if res else None
+    x = torch.cat((xa, xb), -1) if kb else xa
+    want = F.linear(F.silu(F.linear(x, W1, b1)), W2, b2)
+    if ln:
+        want = F.layer_norm(want, (n_out,), gam, bet, 1e-5)
+    if res:
+        want = want + r
+    dev = "cuda"
+    out = torch.full((B, rows, n_out), float("nan"), device=dev)
+    ops.fused_mlp_fwd(
+        ops.mat(xa.to(dev)), ops.mat(xb.to(dev)) if kb else None, W1.to(dev), b1.to(dev),
+        W2.to(dev), b2.to(dev), gam.to(dev) if ln else None, bet.to(dev) if ln else None,
+        ops.mat(r.to(dev)) if res else None, ops.mat(out), hid, n_out,
+    )
+    assert rel(out, want) < 1e-5
+
+
+def test_fused_mlp_fwd_strided_views_and_broadcast():
+    """sources that are column slices of wider buffers, a batch-invariant
+    (stride-0) first source, and a large row count (persistent loop)."""
+    from neural_lam_amd import ops
+
+    gen = torch.Generator().manual_seed(9)
+    B, rows, d = 3, 20000, 64
+    wide = torch.randn(rows, 3 * d, generator=gen)          # batch-invariant
+    agg = torch.randn(B, rows, d, generator=gen)
+    Wfull = torch.randn(d, 2 * d, generator=gen) / 11.0
+    b1, b2 = torch.randn(d, generator=gen), torch.randn(d, generator=gen)
+    W2 = torch.randn(d, d, generator=gen) / 8.0
+    gam, bet = torch.rand(d, generator=gen) + 0.5, torch.randn(d, generator=gen)
+    xr = wide[:, d : 2 * d]
+    x = torch.cat((xr.unsqueeze(0).expand(B, -1, -1), agg), -1)
+    want = xr + F.layer_norm(F.linear(F.silu(F.linear(x, Wfull, b1)), W2, b2), (d,), gam, bet, 1e-5)
+    wd = wide.cuda()
+    out = torch.empty(B, rows, d, device="cuda")
+    xm = ops.mat(wd.unsqueeze(0).expand(B, -1, -1), d, d)
+    ops.fused_mlp_fwd(xm, ops.mat(agg.cuda()), Wfull.cuda(), b1.cuda(), W2.cuda(), b2.cuda(),
+                      gam.cuda(), bet.cuda(), xm, ops.mat(out), d, d)
+    assert rel(out, want) < 1e-5
+
+
+@pytest.mark.parametrize("k_in,nA,nB,B,rows", [(64, 64, 64, 2, 333), (64, 64, 0, 1, 50),
+                                               (128, 128, 0, 2, 100), (3, 64, 0, 1, 70)])
+def test_fused_lin_fwd(k_in, nA, nB, B, rows):
+    from neural_lam_amd import ops
+
+    gen = torch.Generator().manual_seed(k_in + nA + nB)
+    x = torch.randn(B, rows, k_in, generator=gen)
+    Wfull = torch.randn(nA, 3 * k_in, generator=gen) / k_in ** 0.5   # column slices as weights
+    WA, WB = Wfull[:, k_in : 2 * k_in], Wfull[:, 2 * k_in :]
+    bB = torch.randn(max(nB, 1), generator=gen)
+    want = [x @ WA.T]
+    if nB:
+        want.append(x @ WB.T + bB)
+    want = torch.cat(want, -1)
+    Wd = Wfull.cuda()
+    out = torch.empty(B, rows, nA + nB, device="cuda")
+    ops.fused_lin_fwd(ops.mat(x.cuda()), Wd[:, k_in : 2 * k_in], None,
+                      Wd[:, 2 * k_in :] if nB else None, bB.cuda() if nB else None, ops.mat(out))
+    assert rel(out, want) < 1e-5
+
+
+def _edge_ref(e_term, ps, pr, send, rec, W2, b2, gam, bet, n_rec, mean):
+    h = e_term + ps[:, send] + pr[:, rec]
+    m = F.layer_norm(F.linear(F.silu(h), W2, b2), (h.shape[-1],), gam, bet, 1e-5)
+    agg = torch.zeros(h.shape[0], n_rec, h.shape[-1]).index_add_(1, rec, m)
+    if mean:
+        deg = torch.zeros(n_rec).index_add_(0, rec, torch.ones(rec.shape[0])).clamp(min=1)
+        agg = agg / deg.view(1, -1, 1)
+    return m, agg
+
+
+@pytest.mark.parametrize("d,egemm,mean,B,n_s,n_r,M", [
+    (64, True, False, 2, 50, 50, 400), (64, False, True, 3, 80, 30, 333),
+    (64, True, True, 1, 20, 700, 900),
+    (128, False, False, 2, 30, 60, 250),
+])
+def test_fused_edge_fwd(d, egemm, mean, B, n_s, n_r, M):
+    from neural_lam_amd import ops
+    from neural_lam_amd.graph import EdgeTables
+
+    gen = torch.Generator().manual_seed(d + M)
+    send = torch.randint(0, n_s, (M,), generator=gen)
+    rec = torch.randint(0, n_r, (M,), generator=gen)
+    rec[rec == 3] = 4                      # an empty receiver
+    g = EdgeTables(send, rec, n_s, n_r).cuda()
+    assert g.ntiles > 0
+    e = torch.randn(B if egemm else 1, M, d, generator=gen)
+    ps = torch.randn(B, n_s, d, generator=gen)
+    pr = torch.randn(1 if not egemm else B, n_r, d, generator=gen)   # batch-invariant in (b)
+    W1e = torch.randn(d, d, generator=gen) / d ** 0.5
+    W2 = torch.randn(d, d, generator=gen) / d ** 0.5
+    b2, gam, bet = (torch.randn(d, generator=gen) for _ in range(3))
+    e_term = e @ W1e.T if egemm else e
+    m, agg = _edge_ref(e_term, ps, pr.expand(B, -1, -1), send, rec, W2, b2, gam, bet, n_r, mean)
+    agg_d = torch.full((B, n_r, d), float("nan"), device="cuda")
+    eo_d = torch.full((B, M, d), float("nan"), device="cuda") if egemm else None
+    ed, psd, prd = e.cuda(), ps.cuda(), pr.cuda()
+    ops.fused_edge_fwd(
+        g, ops.mat(ed if egemm else ed.expand(B, -1, -1)), egemm, ops.mat(psd),
+        ops.mat(prd.expand(B, -1, -1)), W1e.cuda() if egemm else None, W2.cuda(), b2.cuda(),
+        gam.cuda(), bet.cuda(), ops.mat(agg_d), ops.mat(eo_d) if egemm else None, mean, d)
+    assert rel(agg_d, agg) < 2e-5
+    if egemm:
+        assert rel(eo_d, e + m) < 2e-5
