@@ -162,6 +162,29 @@ int nlam_mlp_fwd(const float* xa, int64_t xa_bstride, int64_t xa_ld, int xa_widt
                  float* out, int64_t out_bstride, int64_t out_ld,
                  int64_t B, int64_t rows, int hid, int n_out, void* stream);
 
+/* Backward of nlam_mlp_fwd with recomputation (nothing is saved in forward).
+ * gy: gradient of the output (B, rows, n_out).  gxa / gxb (optional) receive
+ * the gradients of the two sources; add_gy_to_gxa adds gy to gxa (the residual
+ * was source a).  Parameter gradients are written as per-workgroup partial
+ * slabs  [dW1 (hid x KP32) | db1 | dW2 (NO32 x hid) | db2 | dgamma | dbeta]
+ * (KP32 / NO32 = k_in / n_out rounded up to 32) with pitch slab_stride >=
+ * nlam_mlp_bwd_slab_stride(); the number of slabs is nlam_bwd_grid(B *
+ * ceil(rows/32)); nlam_reduce_slabs sums them in a fixed order. */
+int64_t nlam_bwd_grid(int64_t ntiles);
+int64_t nlam_mlp_bwd_slab_stride(int k_in, int hid, int n_out);
+int nlam_mlp_bwd(const float* xa, int64_t xa_bstride, int64_t xa_ld, int xa_width,
+                 const float* xb, int64_t xb_bstride, int64_t xb_ld, int xb_width,
+                 const float* W1, int64_t ldW1, const float* b1,
+                 const float* W2, int64_t ldW2, const float* b2, const float* gamma,
+                 const float* gy, int64_t gy_bstride, int64_t gy_ld,
+                 float* gxa, int64_t gxa_bstride, int64_t gxa_ld,
+                 float* gxb, int64_t gxb_bstride, int64_t gxb_ld, int add_gy_to_gxa,
+                 float* slab, int64_t slab_stride,
+                 int64_t B, int64_t rows, int hid, int n_out, void* stream);
+/* out[i] (+)= sum_s slab[s * stride + i], i < n (deterministic order). */
+int nlam_reduce_slabs(const float* slab, int64_t nslabs, int64_t stride, int64_t n,
+                      float* out, int accumulate, void* stream);
+
 /* out[:, 0:nA] = x WA^T + bA, out[:, nA:nA+nB] = x WB^T + bB (WB may be NULL):
  * the node-side projections Ps = W1s x_s, Pr = W1r x_r + b1 of the edge MLP's
  * first Linear (edge_mlp.0, interaction_net.py:65,121) after splitting
@@ -193,6 +216,44 @@ int nlam_edge_fwd(const int32_t* tiles, int64_t ntiles,
                   float* agg, int64_t agg_bstride, int64_t agg_ld,
                   float* e_out, int64_t eo_bstride, int64_t eo_ld,
                   int64_t B, int d, void* stream);
+
+/* Backward of nlam_lin_fwd: gx = gy [WA; WB] (optional), per-workgroup slabs
+ * [dW ((nA+nB) x KP32) | db (nA+nB)], KP32 = k_in rounded up to 32; number of
+ * slabs = nlam_bwd_grid(B * ceil(rows/32)). */
+int64_t nlam_lin_bwd_slab_stride(int k_in, int n_out);
+int nlam_lin_bwd(const float* x, int64_t x_bstride, int64_t x_ld, int k_in,
+                 const float* gy, int64_t gy_bstride, int64_t gy_ld,
+                 const float* WA, int64_t ldWA, int nA,
+                 const float* WB, int64_t ldWB, int nB,
+                 float* gx, int64_t gx_bstride, int64_t gx_ld,
+                 float* slab, int64_t slab_stride, int64_t B, int64_t rows,
+                 void* stream);
+
+/* Backward of nlam_edge_fwd with recomputation.  Inputs as in forward plus
+ *   g_agg (B, N_r, d): gradient of the aggregate; g_eout (B, M, d, original
+ *   order, may be NULL): gradient of e_out (has_egemm).
+ * Outputs: gh_out (B, M, d) = gradient of h in CSR order (pitch d) -- the caller
+ * reduces it per sender (nlam_segment_sum over csc_pos) and, for a batch-
+ * invariant Pe, over the batch; gpr (B, N_r, d) = per-receiver sum of gh;
+ * g_e (B, M, d, original order; has_egemm) = g_eout + W1e^T gh; per-workgroup
+ * slabs [dW1e (d x d) | dW2 (d x d) | db2 | dgamma | dbeta], count =
+ * nlam_bwd_grid(B * ntiles). */
+int64_t nlam_edge_bwd_slab_stride(int d);
+int nlam_edge_bwd(const int32_t* tiles, int64_t ntiles,
+                  const int32_t* csr_rowptr, const int32_t* csr_eid,
+                  const int32_t* csr_send, const int32_t* csr_rec,
+                  const float* inv_deg,
+                  const float* e, int64_t e_bstride, int64_t e_ld, int has_egemm,
+                  const float* ps, int64_t ps_bstride, int64_t ps_ld,
+                  const float* pr, int64_t pr_bstride, int64_t pr_ld,
+                  const float* W1e, int64_t ldW1e,
+                  const float* W2, int64_t ldW2, const float* b2, const float* gamma,
+                  const float* g_agg, int64_t gagg_bstride, int64_t gagg_ld,
+                  const float* g_eout, int64_t geo_bstride, int64_t geo_ld,
+                  float* gh_out, int64_t gh_bstride,
+                  float* gpr, int64_t gpr_bstride, int64_t gpr_ld,
+                  float* g_e, int64_t ge_bstride, int64_t ge_ld,
+                  float* slab, int64_t slab_stride, int64_t B, int d, void* stream);
 
 /* One AdamW step over a flat fp32 parameter buffer (decoupled weight decay,
  * bias correction; torch.optim.AdamW semantics, ar_model.py:191-195).

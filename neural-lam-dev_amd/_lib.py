@@ -35,12 +35,25 @@ SIGNATURES = {
     "nlam_sum_batch": [_p, _i64, _p, _i64, _i64, _p],
     "nlam_mlp_fwd": [_p, _i64, _i64, _i32, _p, _i64, _i64, _i32, _p, _i64, _p, _p, _i64, _p, _p, _p,
                      _p, _i64, _i64, _p, _i64, _i64, _i64, _i64, _i32, _i32, _p],
+    "nlam_bwd_grid": [_i64],
+    "nlam_mlp_bwd_slab_stride": [_i32, _i32, _i32],
+    "nlam_mlp_bwd": [_p, _i64, _i64, _i32, _p, _i64, _i64, _i32, _p, _i64, _p, _p, _i64, _p, _p,
+                     _p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _i32, _p, _i64,
+                     _i64, _i64, _i32, _i32, _p],
+    "nlam_reduce_slabs": [_p, _i64, _i64, _i64, _p, _i32, _p],
     "nlam_lin_fwd": [_p, _i64, _i64, _i32, _p, _i64, _p, _i32, _p, _i64, _p, _i32, _p, _i64, _i64,
                      _i64, _i64, _p],
     "nlam_edge_fwd": [_p, _i64, _p, _p, _p, _p, _p, _p, _i64, _i64, _i32, _p, _i64, _i64, _p, _i64,
                       _i64, _p, _i64, _p, _i64, _p, _p, _p, _p, _i64, _i64, _p, _i64, _i64, _i64,
                       _i32, _p],
     "nlam_graph_tiles_host": [_p, _i64, _i32, _i32, _p, _i64],
+    "nlam_lin_bwd_slab_stride": [_i32, _i32],
+    "nlam_lin_bwd": [_p, _i64, _i64, _i32, _p, _i64, _i64, _p, _i64, _i32, _p, _i64, _i32, _p, _i64,
+                     _i64, _p, _i64, _i64, _i64, _p],
+    "nlam_edge_bwd_slab_stride": [_i32],
+    "nlam_edge_bwd": [_p, _i64, _p, _p, _p, _p, _p, _p, _i64, _i64, _i32, _p, _i64, _i64, _p, _i64,
+                      _i64, _p, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _p, _i64, _i64, _p, _i64,
+                      _p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _i32, _p],
     "nlam_adamw_step": [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _i64, _f, _p],
     "nlam_mfma_probe": [_p, _p],
 }
@@ -49,6 +62,10 @@ _RESTYPES = {
     "nlam_layernorm_bwd_blocks": _i64,
     "nlam_colsum_blocks": _i64,
     "nlam_graph_tiles_host": _i64,
+    "nlam_bwd_grid": _i64,
+    "nlam_lin_bwd_slab_stride": _i64,
+    "nlam_edge_bwd_slab_stride": _i64,
+    "nlam_mlp_bwd_slab_stride": _i64,
 }
 
 

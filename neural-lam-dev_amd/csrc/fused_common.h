@@ -414,3 +414,56 @@ __device__ __forceinline__ void acc_colsum_to(const f32x16 (&v)[NB], float* __re
     out[f] = s;
   }
 }
+
+// ---- gradient helpers ----------------------------------------------------------
+// lanes = features: acc[j] += sum_t tile[t][col0 + 64 j + lane]  (j < NV), the
+// per-feature (bias / gamma / beta) gradient contribution of one tile.
+template <int NV>
+__device__ __forceinline__ void tile_colsum(float (&acc)[NV], const float* __restrict__ tile,
+                                            int ld, int col0, int nrows, int lane) {
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    float s = 0.f;
+    for (int t = 0; t < nrows; ++t) s += tile[t * ld + col0 + 64 * j + lane];
+    acc[j] += s;
+  }
+}
+
+// Workgroup-level fold of per-wave weight-gradient blocks into an LDS image
+// [rows][ldimg] (row-major, rows = 32 NI, cols = 32 NJ), wave after wave (fixed
+// order => deterministic).  Must be called by all 256 threads.
+template <int NI, int NJ>
+__device__ __forceinline__ void fold_blocks_lds(const f32x16 (&dW)[NI][NJ], float* __restrict__ img,
+                                                int ldimg, int wave, int lane) {
+  const int h = lane >> 5, j = lane & 31;
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int ib = 0; ib < NI; ++ib)
+#pragma unroll
+        for (int jb = 0; jb < NJ; ++jb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int i = 32 * ib + 8 * (r >> 2) + 4 * h + (r & 3);
+            float* dst = img + i * ldimg + 32 * jb + j;
+            *dst = (w == 0) ? dW[ib][jb][r] : (*dst + dW[ib][jb][r]);
+          }
+    }
+    __syncthreads();
+  }
+}
+// same for per-feature vectors held as lanes = features (NV values per lane)
+template <int NV>
+__device__ __forceinline__ void fold_vec_lds(const float (&v)[NV], float* __restrict__ img, int wave,
+                                             int lane) {
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        float* dst = img + 64 * j + lane;
+        *dst = (w == 0) ? v[j] : (*dst + v[j]);
+      }
+    }
+    __syncthreads();
+  }
+}

@@ -194,3 +194,313 @@ extern "C" int nlam_edge_fwd(
   if (d == 64) return has_egemm ? launch_edge_fwd<64, true>(p, s) : launch_edge_fwd<64, false>(p, s);
   return has_egemm ? launch_edge_fwd<128, true>(p, s) : launch_edge_fwd<128, false>(p, s);
 }
+
+// =============================================================== backward ===
+// Recomputes h, s = silu(h), z = W2 s + b2 from the inputs, then
+//   gm_k = scale * g_agg[rec(k)] + g_eout_k
+//   gz   = LN'(z; gm),   dW2 += gz (x) s,  db2 += gz,  dgamma, dbeta
+//   gh   = (W2^T gz) * silu'(h)       -> gh_out (CSR order), gPr_i = sum_{rec=i} gh
+//   dW1e += gh (x) e ;  g_e = g_eout + W1e^T gh                 (has_egemm)
+// Slab per workgroup: [dW1e (D x D) | dW2 (D x D) | db2 | dgamma | dbeta].
+struct EdgeBwdParams {
+  EdgeFwdParams f;              // forward operands (agg / e_out unused)
+  RowView g_agg;                // (B, N_r, d)
+  const float* g_eout; int64_t geo_bstride; int64_t geo_ld;   // (B, M, d) original order, may be NULL
+  float* gh_out; int64_t gh_bstride;                          // (B, M, d) CSR order, pitch d
+  float* gpr; int64_t gpr_bstride; int64_t gpr_ld;            // (B, N_r, d)
+  float* g_e; int64_t ge_bstride; int64_t ge_ld;              // (B, M, d) original order (has_egemm)
+  float* slab; int64_t slab_stride;
+};
+
+template <int D, bool HAS_EGEMM>
+__global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NB = D / 32, NV = D / 64;
+  constexpr int LDW = D + 4, LDT = D + 4;
+  const EdgeFwdParams& p = q.f;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* W1s = smem;
+  float* W2s = W1s + (HAS_EGEMM ? D * LDW : 0);
+  float* b2s = W2s + D * LDW;
+  float* gs = b2s + D;
+  float* T0 = gs + D + wave * (3 * NLAM_TILE * LDT);
+  float* T1 = T0 + NLAM_TILE * LDT;
+  float* T2 = T1 + NLAM_TILE * LDT;
+  if (HAS_EGEMM) load_weight_lds(W1s, p.W1e, p.ldW1e, D, D, D, D, tid, 256);
+  load_weight_lds(W2s, p.W2, p.ldW2, D, D, D, D, tid, 256);
+  load_vec_lds(b2s, p.b2, D, D, tid, 256);
+  load_vec_lds(gs, p.gamma, D, D, tid, 256);
+  __syncthreads();
+
+  f32x16 dW1[NB][NB], dW2[NB][NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dW1[i][j][r] = dW2[i][j][r] = 0.f;
+  float db2[NV], dgam[NV], dbet[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) db2[j] = dgam[j] = dbet[j] = 0.f;
+
+  const int64_t total = p.ntiles * p.B;
+  const int t = lane & 31, hh = lane >> 5;
+  for (int64_t tt = (int64_t)blockIdx.x * 4 + wave; tt < total; tt += (int64_t)gridDim.x * 4) {
+    const int64_t b = tt / p.ntiles;
+    const int64_t ti = tt - b * p.ntiles;
+    const int4 tl = reinterpret_cast<const int4*>(p.tiles)[ti];
+    const int p0 = tl.x, ne = tl.y - tl.x, r0 = tl.z, nr = tl.w - tl.z;
+    int eid = 0, snd = 0, rcv = 0;
+    if (t < ne) {
+      eid = p.csr_eid[p0 + t];
+      snd = p.csr_send[p0 + t];
+      rcv = p.csr_rec[p0 + t];
+    }
+    const float* eb = p.e.ptr + b * p.e.bstride;
+    const float* psb = p.ps.ptr + b * p.ps.bstride;
+    const float* prb = p.pr.ptr + b * p.pr.bstride;
+    auto e_row = [&](int s) { return eb + (int64_t)__shfl(eid, s, 64) * p.e.ld; };
+    auto ps_row = [&](int s) { return psb + (int64_t)__shfl(snd, s, 64) * p.ps.ld; };
+    auto pr_row = [&](int s) { return prb + (int64_t)__shfl(rcv, s, 64) * p.pr.ld; };
+
+    // ---- recompute forward: hpre, sact, xhat
+    f32x16 hpre[NB];
+    if (HAS_EGEMM) {
+      stage_rows<true, false>(T0, LDT, 0, D, ne, lane, e_row);        // E stays in T0
+      stage_rows<true, false>(T1, LDT, 0, D, ne, lane, ps_row);
+    } else {
+      stage_rows<true, false>(T1, LDT, 0, D, ne, lane, e_row);        // Pe rows
+      wave_sync();
+      stage_rows<true, true>(T1, LDT, 0, D, ne, lane, ps_row);
+    }
+    wave_sync();
+    stage_rows<true, true>(T1, LDT, 0, D, ne, lane, pr_row);
+    wave_sync();
+    tile_to_acc<NB>(hpre, T1, LDT, lane);
+    if (HAS_EGEMM) gemm_tile<NB>(hpre, W1s, LDW, T0, LDT, D / 8, lane);
+    f32x16 sact[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sact[nb][r] = nlam_silu(hpre[nb][r]);
+    f32x16 z[NB];
+    vec_to_acc<NB>(z, b2s, lane);
+    gemm_acc<NB, NB>(z, W2s, LDW, 0, sact, lane);
+    float mean, rstd;
+    ln_stats<NB>(z, mean, rstd);
+
+    // ---- message gradient gm = scale * g_agg[rec] (+ g_eout)
+    const float* gab = q.g_agg.ptr + b * q.g_agg.bstride;
+    auto ga_row = [&](int s) { return gab + (int64_t)__shfl(rcv, s, 64) * q.g_agg.ld; };
+    wave_sync();
+    stage_rows<true, false>(T1, LDT, 0, D, ne, lane, ga_row);
+    wave_sync();
+    f32x16 g[NB];
+    tile_to_acc<NB>(g, T1, LDT, lane);
+    if (p.inv_deg != nullptr) {
+      const float sc = (t < ne) ? p.inv_deg[rcv] : 0.f;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g[nb][r] *= sc;
+    }
+    f32x16 geo[NB];
+    const bool has_geo = HAS_EGEMM && q.g_eout != nullptr;
+    if (has_geo) {
+      const float* gob = q.g_eout + b * q.geo_bstride;
+      auto go_row = [&](int s) { return gob + (int64_t)__shfl(eid, s, 64) * q.geo_ld; };
+      stage_rows<true, false>(T2, LDT, 0, D, ne, lane, go_row);
+      wave_sync();
+      tile_to_acc<NB>(geo, T2, LDT, lane);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g[nb][r] += geo[nb][r];
+    }
+    // dbeta from the final gm tile
+    wave_sync();
+    acc_to_tile<NB>(g, T1, LDT, lane);
+    wave_sync();
+    tile_colsum<NV>(dbet, T1, LDT, 0, ne, lane);
+    // LN backward
+    constexpr float inv_d = 1.0f / (float)D;
+    float s1 = 0.f, s2 = 0.f;
+    {
+      f32x16 prod[NB];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+          const f32x4 gm = *reinterpret_cast<const f32x4*>(gs + 32 * nb + 8 * qq + 4 * hh);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int r = 4 * qq + j;
+            const float xh = (z[nb][r] - mean) * rstd;
+            z[nb][r] = xh;
+            prod[nb][r] = g[nb][r] * xh;
+            const float gv = g[nb][r] * gm[j];
+            g[nb][r] = gv;
+            s1 += gv;
+            s2 += gv * xh;
+          }
+        }
+      wave_sync();
+      acc_to_tile<NB>(prod, T2, LDT, lane);
+    }
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    const float m1 = s1 * inv_d, m2 = s2 * inv_d;
+    wave_sync();
+    tile_colsum<NV>(dgam, T2, LDT, 0, ne, lane);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) g[nb][r] = rstd * (g[nb][r] - m1 - z[nb][r] * m2);
+    // g = gz (zero on padded slots: their gm rows were staged as zeros)
+    wave_sync();
+    acc_to_tile<NB>(g, T1, LDT, lane);        // GZ
+    acc_to_tile<NB>(sact, T2, LDT, lane);     // S
+    wave_sync();
+    tile_colsum<NV>(db2, T1, LDT, 0, ne, lane);
+    outer_accum<NB, NB>(dW2, T1, LDT, 0, T2, LDT, 0, lane);
+    // gh = (W2^T gz) * silu'(h)
+    f32x16 gh[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) gh[nb][r] = 0.f;
+    gemm_acc_wt<NB, NB>(gh, W2s, LDW, 0, g, lane);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) gh[nb][r] *= nlam_silu_grad(hpre[nb][r]);
+    wave_sync();
+    acc_to_tile<NB>(gh, T1, LDT, lane);       // GH
+    wave_sync();
+    {
+      float* ghb = q.gh_out + b * q.gh_bstride + (int64_t)p0 * D;
+      auto gh_row = [&](int s) { return ghb + (int64_t)s * D; };
+      store_rows<true>(T1, LDT, 0, D, ne, lane, gh_row);
+      // receiver-side sum of gh (segments are tile-local)
+      int rp = 0;
+      if (lane <= nr) rp = p.csr_rowptr[r0 + lane] - p0;
+      float* gb = q.gpr + b * q.gpr_bstride;
+      for (int i = 0; i < nr; ++i) {
+        const int beg = __shfl(rp, i, 64), end = __shfl(rp, i + 1, 64);
+#pragma unroll
+        for (int f0 = 0; f0 < D; f0 += 64) {
+          float acc = 0.f;
+          for (int s = beg; s < end; ++s) acc += T1[s * LDT + f0 + lane];
+          gb[(int64_t)(r0 + i) * q.gpr_ld + f0 + lane] = acc;
+        }
+      }
+    }
+    if (HAS_EGEMM) {
+      outer_accum<NB, NB>(dW1, T1, LDT, 0, T0, LDT, 0, lane);
+      f32x16 ge[NB];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ge[nb][r] = has_geo ? geo[nb][r] : 0.f;
+      gemm_acc_wt<NB, NB>(ge, W1s, LDW, 0, gh, lane);
+      wave_sync();
+      acc_to_tile<NB>(ge, T2, LDT, lane);
+      wave_sync();
+      float* ob = q.g_e + b * q.ge_bstride;
+      auto o_row = [&](int s) { return ob + (int64_t)__shfl(eid, s, 64) * q.ge_ld; };
+      store_rows<true>(T2, LDT, 0, D, ne, lane, o_row);
+    }
+    wave_sync();
+  }
+
+  __syncthreads();
+  float* img = smem;
+  float* slab = q.slab + (int64_t)blockIdx.x * q.slab_stride;
+  constexpr int nW = D * D;
+  if (HAS_EGEMM) {
+    fold_blocks_lds<NB, NB>(dW1, img, D, wave, lane);
+    for (int i = tid; i < nW; i += 256) slab[i] = img[i];
+    __syncthreads();
+  }
+  fold_blocks_lds<NB, NB>(dW2, img, D, wave, lane);
+  for (int i = tid; i < nW; i += 256) slab[nW + i] = img[i];
+  __syncthreads();
+  fold_vec_lds<NV>(db2, img, wave, lane);
+  for (int i = tid; i < D; i += 256) slab[2 * nW + i] = img[i];
+  __syncthreads();
+  fold_vec_lds<NV>(dgam, img, wave, lane);
+  for (int i = tid; i < D; i += 256) slab[2 * nW + D + i] = img[i];
+  __syncthreads();
+  fold_vec_lds<NV>(dbet, img, wave, lane);
+  for (int i = tid; i < D; i += 256) slab[2 * nW + 2 * D + i] = img[i];
+}
+
+template <int D, bool HAS_EGEMM>
+static int launch_edge_bwd(const EdgeBwdParams& q, hipStream_t s) {
+  const size_t lds = ((size_t)(HAS_EGEMM ? 2 : 1) * D * (D + 4) + 2 * D +
+                      (size_t)4 * 3 * NLAM_TILE * (D + 4)) * sizeof(float);
+  NLAM_REQUIRE(lds <= 160 * 1024, "edge_bwd: LDS footprint %zu B exceeds 160 KiB", lds);
+  auto kern = edge_bwd_kernel<D, HAS_EGEMM>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  int64_t g = (q.f.ntiles * q.f.B + 3) / 4;
+  if (g > 256) g = 256;
+  kern<<<(unsigned)g, 256, lds, s>>>(q);
+  NLAM_CHECK_LAUNCH("edge_bwd_kernel");
+  return 0;
+}
+
+extern "C" int64_t nlam_edge_bwd_slab_stride(int d) { return 2 * (int64_t)d * d + 3 * d; }
+
+extern "C" int nlam_edge_bwd(
+    const int32_t* tiles, int64_t ntiles, const int32_t* csr_rowptr, const int32_t* csr_eid,
+    const int32_t* csr_send, const int32_t* csr_rec, const float* inv_deg,
+    const float* e, int64_t e_bstride, int64_t e_ld, int has_egemm,
+    const float* ps, int64_t ps_bstride, int64_t ps_ld,
+    const float* pr, int64_t pr_bstride, int64_t pr_ld,
+    const float* W1e, int64_t ldW1e, const float* W2, int64_t ldW2, const float* b2,
+    const float* gamma,
+    const float* g_agg, int64_t gagg_bstride, int64_t gagg_ld,
+    const float* g_eout, int64_t geo_bstride, int64_t geo_ld,
+    float* gh_out, int64_t gh_bstride,
+    float* gpr, int64_t gpr_bstride, int64_t gpr_ld,
+    float* g_e, int64_t ge_bstride, int64_t ge_ld,
+    float* slab, int64_t slab_stride, int64_t B, int d, void* stream) {
+  if (B <= 0 || ntiles <= 0) return 0;
+  NLAM_REQUIRE(d == 64, "nlam_edge_bwd: d=%d not supported (64 only)", d);
+  NLAM_REQUIRE(view_vec_ok(e, e_bstride, e_ld, d) && view_vec_ok(ps, ps_bstride, ps_ld, d) &&
+                   view_vec_ok(pr, pr_bstride, pr_ld, d) &&
+                   view_vec_ok(g_agg, gagg_bstride, gagg_ld, d) &&
+                   view_vec_ok(gh_out, gh_bstride, d, d),
+               "nlam_edge_bwd: operand rows must be 16-byte aligned with pitch %% 4 == 0");
+  NLAM_REQUIRE(g_eout == nullptr || view_vec_ok(g_eout, geo_bstride, geo_ld, d),
+               "nlam_edge_bwd: bad g_eout view");
+  NLAM_REQUIRE(gpr != nullptr && gpr_ld >= d, "nlam_edge_bwd: bad gpr view");
+  NLAM_REQUIRE(slab != nullptr && slab_stride >= nlam_edge_bwd_slab_stride(d),
+               "nlam_edge_bwd: slab too small");
+  if (has_egemm)
+    NLAM_REQUIRE(W1e != nullptr && g_e != nullptr && view_vec_ok(g_e, ge_bstride, ge_ld, d),
+                 "nlam_edge_bwd: update_edges needs W1e and a 16-byte aligned g_e");
+  EdgeBwdParams q;
+  EdgeFwdParams& p = q.f;
+  p.tiles = tiles; p.ntiles = ntiles; p.csr_rowptr = csr_rowptr; p.csr_eid = csr_eid;
+  p.csr_send = csr_send; p.csr_rec = csr_rec; p.inv_deg = inv_deg;
+  p.e = RowView{e, e_bstride, e_ld, d};
+  p.ps = RowView{ps, ps_bstride, ps_ld, d};
+  p.pr = RowView{pr, pr_bstride, pr_ld, d};
+  p.W1e = W1e; p.ldW1e = ldW1e; p.W2 = W2; p.ldW2 = ldW2; p.b2 = b2;
+  p.gamma = gamma; p.beta = nullptr;
+  p.agg = nullptr; p.agg_bstride = 0; p.agg_ld = 0; p.e_out = nullptr; p.eo_bstride = 0; p.eo_ld = 0;
+  p.B = (int)B;
+  q.g_agg = RowView{g_agg, gagg_bstride, gagg_ld, d};
+  q.g_eout = g_eout; q.geo_bstride = geo_bstride; q.geo_ld = geo_ld;
+  q.gh_out = gh_out; q.gh_bstride = gh_bstride;
+  q.gpr = gpr; q.gpr_bstride = gpr_bstride; q.gpr_ld = gpr_ld;
+  q.g_e = g_e; q.ge_bstride = ge_bstride; q.ge_ld = ge_ld;
+  q.slab = slab; q.slab_stride = slab_stride;
+  hipStream_t s = (hipStream_t)stream;
+  return has_egemm ? launch_edge_bwd<64, true>(q, s) : launch_edge_bwd<64, false>(q, s);
+}

@@ -297,3 +297,512 @@ extern "C" int nlam_lin_fwd(const float* x, int64_t x_bstride, int64_t x_ld, int
       return 1;
   }
 }
+
+// =============================================================== backward ===
+// Per-workgroup partial parameter gradients go to a slab
+//   [dW1 (HID x KP32) | db1 (HID) | dW2 (32 NOUTB x HID) | db2 | dgamma | dbeta]
+// (KP32 = k_in rounded up to 32); nlam_reduce_slabs sums the slabs in a fixed
+// order.  Activations are recomputed from the inputs (nothing saved in forward).
+struct MlpBwdParams {
+  MlpParams f;                 // forward operands (out/res unused)
+  RowView gy;                  // (B, rows, n_out)
+  float* gxa; int64_t gxa_bstride; int64_t gxa_ld;   // optional grads of the sources
+  float* gxb; int64_t gxb_bstride; int64_t gxb_ld;
+  int add_gy_to_gxa;           // residual taken from source a: gxa += gy
+  float* slab; int64_t slab_stride;
+  int vec_gy, vec_gxa, vec_gxb;
+};
+
+template <int HID, int NOUTB, int KB, bool HAS_LN>
+__global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpBwdParams q) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NBH = HID / 32;
+  constexpr int KP32 = 32 * KB;
+  constexpr int NV_H = (HID + 63) / 64, NV_O = (32 * NOUTB + 63) / 64;
+  const MlpParams& p = q.f;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int ldw1 = KP32 + 4, ldw2 = HID + 4;
+  constexpr int ldt0 = (KP32 > HID ? KP32 : HID) + 4;            // X / S / GX tile
+  constexpr int ldt1 = (HID > 32 * NOUTB ? HID : 32 * NOUTB) + 4;  // GY / GZ / GA tile
+  float* W1s = smem;
+  float* W2s = W1s + HID * ldw1;
+  float* b1s = W2s + 32 * NOUTB * ldw2;
+  float* b2s = b1s + HID;
+  float* gs = b2s + 32 * NOUTB;
+  float* T0 = gs + 32 * NOUTB + wave * (NLAM_TILE * (ldt0 + ldt1));
+  float* T1 = T0 + NLAM_TILE * ldt0;
+
+  load_weight_lds(W1s, p.W1, p.ldW1, HID, p.k_in, HID, KP32, tid, 256);
+  load_weight_lds(W2s, p.W2, p.ldW2, p.n_out, HID, 32 * NOUTB, HID, tid, 256);
+  load_vec_lds(b1s, p.b1, HID, HID, tid, 256);
+  load_vec_lds(b2s, p.b2, p.n_out, 32 * NOUTB, tid, 256);
+  load_vec_lds(gs, p.gamma, p.n_out, 32 * NOUTB, tid, 256);
+  __syncthreads();
+
+  f32x16 dW1[NBH][KB], dW2[NOUTB][NBH];
+#pragma unroll
+  for (int i = 0; i < NBH; ++i)
+#pragma unroll
+    for (int j = 0; j < KB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dW1[i][j][r] = 0.f;
+#pragma unroll
+  for (int i = 0; i < NOUTB; ++i)
+#pragma unroll
+    for (int j = 0; j < NBH; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dW2[i][j][r] = 0.f;
+  float db1[NV_H], db2[NV_O], dgam[NV_O], dbet[NV_O];
+#pragma unroll
+  for (int j = 0; j < NV_H; ++j) db1[j] = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV_O; ++j) db2[j] = dgam[j] = dbet[j] = 0.f;
+
+  auto stage_x = [&](int64_t b, int64_t r0, int nrows) {
+    int col = 0;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      if (s < p.nsrc) {
+        const RowView v = p.src[s];
+        const float* base = v.ptr + b * v.bstride + r0 * v.ld;
+        auto rp = [&](int t) { return base + (int64_t)t * v.ld; };
+        if ((p.vec_mask >> s) & 1)
+          stage_rows<true, false>(T0, ldt0, col, v.width, nrows, lane, rp);
+        else
+          stage_rows<false, false>(T0, ldt0, col, v.width, nrows, lane, rp);
+        col += v.width;
+      }
+    }
+    if (KP32 > col) zero_cols(T0, ldt0, col, KP32 - col, lane);
+  };
+
+  const int64_t tiles_per_b = (p.rows + NLAM_TILE - 1) / NLAM_TILE;
+  const int64_t ntiles = tiles_per_b * p.B;
+  for (int64_t tt = (int64_t)blockIdx.x * 4 + wave; tt < ntiles; tt += (int64_t)gridDim.x * 4) {
+    const int64_t b = tt / tiles_per_b;
+    const int64_t r0 = (tt - b * tiles_per_b) * NLAM_TILE;
+    const int nrows = (int)((p.rows - r0) < NLAM_TILE ? (p.rows - r0) : NLAM_TILE);
+    // ---- recompute forward
+    stage_x(b, r0, nrows);
+    wave_sync();
+    f32x16 hpre[NBH];
+    vec_to_acc<NBH>(hpre, b1s, lane);
+    gemm_tile<NBH>(hpre, W1s, ldw1, T0, ldt0, p.k_pad >> 3, lane);
+    f32x16 sact[NBH];
+#pragma unroll
+    for (int nb = 0; nb < NBH; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sact[nb][r] = nlam_silu(hpre[nb][r]);
+    // ---- output gradient
+    const float* gyb = q.gy.ptr + b * q.gy.bstride + r0 * q.gy.ld;
+    auto gyp = [&](int t) { return gyb + (int64_t)t * q.gy.ld; };
+    if (q.vec_gy)
+      stage_rows<true, false>(T1, ldt1, 0, p.n_out, nrows, lane, gyp);
+    else
+      stage_rows<false, false>(T1, ldt1, 0, p.n_out, nrows, lane, gyp);
+    if (32 * NOUTB > p.n_out) zero_cols(T1, ldt1, p.n_out, 32 * NOUTB - p.n_out, lane);
+    wave_sync();
+    f32x16 g[NOUTB];
+    tile_to_acc<NOUTB>(g, T1, ldt1, lane);
+    if (HAS_LN) {
+      tile_colsum<NV_O>(dbet, T1, ldt1, 0, nrows, lane);
+      f32x16 z[NOUTB];
+      vec_to_acc<NOUTB>(z, b2s, lane);
+      gemm_acc<NOUTB, NBH>(z, W2s, ldw2, 0, sact, lane);
+      // LayerNorm backward: z -> xhat in place; g (= gy) -> gz
+      constexpr float inv_d = 1.0f / (32.0f * NOUTB);
+      float mean, rstd;
+      ln_stats<NOUTB>(z, mean, rstd);
+      const int hh = lane >> 5;
+      float s1 = 0.f, s2 = 0.f;
+      f32x16 prod[NOUTB];
+#pragma unroll
+      for (int nb = 0; nb < NOUTB; ++nb)
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+          const f32x4 gm = *reinterpret_cast<const f32x4*>(gs + 32 * nb + 8 * qq + 4 * hh);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int r = 4 * qq + j;
+            const float xh = (z[nb][r] - mean) * rstd;
+            z[nb][r] = xh;
+            prod[nb][r] = g[nb][r] * xh;         // gy * xhat -> dgamma
+            const float gv = g[nb][r] * gm[j];
+            g[nb][r] = gv;
+            s1 += gv;
+            s2 += gv * xh;
+          }
+        }
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      const float m1 = s1 * inv_d, m2 = s2 * inv_d;
+      wave_sync();
+      acc_to_tile<NOUTB>(prod, T1, ldt1, lane);
+      wave_sync();
+      tile_colsum<NV_O>(dgam, T1, ldt1, 0, nrows, lane);
+#pragma unroll
+      for (int nb = 0; nb < NOUTB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g[nb][r] = rstd * (g[nb][r] - m1 - z[nb][r] * m2);
+      wave_sync();
+    }
+    // g is now gz.  Padded rows (t >= nrows) carry gy = 0 => gz = 0 there only
+    // without LN; with LN gz of a zero gy row is 0 as well (g gamma = 0, m1 = m2 = 0).
+    acc_to_tile<NOUTB>(g, T1, ldt1, lane);          // GZ
+    wave_sync();
+    tile_colsum<NV_O>(db2, T1, ldt1, 0, nrows, lane);
+    wave_sync();
+    acc_to_tile<NBH>(sact, T0, ldt0, lane);         // S (X no longer needed)
+    wave_sync();
+    outer_accum<NOUTB, NBH>(dW2, T1, ldt1, 0, T0, ldt0, 0, lane);
+    // gs = W2^T gz ; ga = gs * silu'(h)
+    f32x16 ga[NBH];
+#pragma unroll
+    for (int nb = 0; nb < NBH; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ga[nb][r] = 0.f;
+    gemm_acc_wt<NBH, NOUTB>(ga, W2s, ldw2, 0, g, lane);
+#pragma unroll
+    for (int nb = 0; nb < NBH; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ga[nb][r] *= nlam_silu_grad(hpre[nb][r]);
+    wave_sync();
+    acc_to_tile<NBH>(ga, T1, ldt1, lane);           // GA
+    stage_x(b, r0, nrows);                          // X again (S consumed)
+    wave_sync();
+    tile_colsum<NV_H>(db1, T1, ldt1, 0, nrows, lane);
+    outer_accum<NBH, KB>(dW1, T1, ldt1, 0, T0, ldt0, 0, lane);
+    // gx = W1^T ga
+    if (q.gxa != nullptr || q.gxb != nullptr) {
+      f32x16 gx[KB];
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gx[kb][r] = 0.f;
+      gemm_acc_wt<KB, NBH>(gx, W1s, ldw1, 0, ga, lane);
+      wave_sync();
+      acc_to_tile<KB>(gx, T0, ldt0, lane);
+      wave_sync();
+      if (q.gxa != nullptr) {
+        float* ob = q.gxa + b * q.gxa_bstride + r0 * q.gxa_ld;
+        auto op = [&](int t) { return ob + (int64_t)t * q.gxa_ld; };
+        const int w = p.src[0].width;
+        if (q.add_gy_to_gxa) {
+          if (q.vec_gxa && q.vec_gy)
+            store_rows_res<true>(T0, ldt0, 0, w, nrows, lane, op, gyp);
+          else
+            store_rows_res<false>(T0, ldt0, 0, w, nrows, lane, op, gyp);
+        } else {
+          if (q.vec_gxa)
+            store_rows<true>(T0, ldt0, 0, w, nrows, lane, op);
+          else
+            store_rows<false>(T0, ldt0, 0, w, nrows, lane, op);
+        }
+      }
+      if (q.gxb != nullptr) {
+        float* ob = q.gxb + b * q.gxb_bstride + r0 * q.gxb_ld;
+        auto op = [&](int t) { return ob + (int64_t)t * q.gxb_ld; };
+        if (q.vec_gxb)
+          store_rows<true>(T0, ldt0, p.src[0].width, p.src[1].width, nrows, lane, op);
+        else
+          store_rows<false>(T0, ldt0, p.src[0].width, p.src[1].width, nrows, lane, op);
+      }
+    }
+    wave_sync();
+  }
+
+  // ---- fold the 4 waves' partials in LDS (fixed order) and write the slab
+  __syncthreads();
+  float* img = smem;  // weights are dead: reuse the front of LDS
+  float* slab = q.slab + (int64_t)blockIdx.x * q.slab_stride;
+  constexpr int n1 = HID * KP32, n2 = 32 * NOUTB * HID;
+  fold_blocks_lds<NBH, KB>(dW1, img, KP32, wave, lane);
+  for (int i = tid; i < n1; i += 256) slab[i] = img[i];
+  __syncthreads();
+  fold_vec_lds<NV_H>(db1, img, wave, lane);
+  for (int i = tid; i < HID; i += 256) slab[n1 + i] = img[i];
+  __syncthreads();
+  fold_blocks_lds<NOUTB, NBH>(dW2, img, HID, wave, lane);
+  for (int i = tid; i < n2; i += 256) slab[n1 + HID + i] = img[i];
+  __syncthreads();
+  float* vbase = slab + n1 + HID + n2;
+  fold_vec_lds<NV_O>(db2, img, wave, lane);
+  for (int i = tid; i < 32 * NOUTB; i += 256) vbase[i] = img[i];
+  __syncthreads();
+  fold_vec_lds<NV_O>(dgam, img, wave, lane);
+  for (int i = tid; i < 32 * NOUTB; i += 256) vbase[32 * NOUTB + i] = img[i];
+  __syncthreads();
+  fold_vec_lds<NV_O>(dbet, img, wave, lane);
+  for (int i = tid; i < 32 * NOUTB; i += 256) vbase[2 * 32 * NOUTB + i] = img[i];
+}
+
+extern "C" int64_t nlam_bwd_grid(int64_t ntiles) {
+  int64_t g = (ntiles + 3) / 4;
+  if (g > 256) g = 256;
+  if (g < 1) g = 1;
+  return g;
+}
+
+// out[i] (+)= sum_s slab[s * stride + i], i < n: 64 elements x 4 slab subsets per
+// workgroup, combined in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slab,
+                                                           int64_t nslabs, int64_t stride,
+                                                           int64_t n, float* __restrict__ out,
+                                                           int accumulate) {
+  __shared__ float red[4][64];
+  const int e = threadIdx.x & 63, gsub = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + e;
+  float s = 0.f;
+  if (i < n)
+    for (int64_t k = gsub; k < nslabs; k += 4) s += slab[k * stride + i];
+  red[gsub][e] = s;
+  __syncthreads();
+  if (gsub == 0 && i < n) {
+    float v = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    if (accumulate) v += out[i];
+    out[i] = v;
+  }
+}
+extern "C" int nlam_reduce_slabs(const float* slab, int64_t nslabs, int64_t stride, int64_t n,
+                                 float* out, int accumulate, void* stream) {
+  if (n <= 0) return 0;
+  reduce_slabs_kernel<<<(unsigned)((n + 63) / 64), 256, 0, (hipStream_t)stream>>>(
+      slab, nslabs, stride, n, out, accumulate);
+  NLAM_CHECK_LAUNCH("reduce_slabs");
+  return 0;
+}
+
+template <int HID, int NOUTB, int KB, bool HAS_LN>
+static int launch_mlp_bwd(const MlpBwdParams& q, hipStream_t s) {
+  constexpr int KP32 = 32 * KB;
+  constexpr int ldt0 = (KP32 > HID ? KP32 : HID) + 4;
+  constexpr int ldt1 = (HID > 32 * NOUTB ? HID : 32 * NOUTB) + 4;
+  const size_t lds = ((size_t)HID * (KP32 + 4) + (size_t)32 * NOUTB * (HID + 4) + HID +
+                      2 * 32 * NOUTB + (size_t)4 * NLAM_TILE * (ldt0 + ldt1)) * sizeof(float);
+  NLAM_REQUIRE(lds <= 160 * 1024, "mlp_bwd: LDS footprint %zu B exceeds 160 KiB", lds);
+  auto kern = mlp_bwd_kernel<HID, NOUTB, KB, HAS_LN>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  const int64_t ntiles = ((q.f.rows + NLAM_TILE - 1) / NLAM_TILE) * q.f.B;
+  kern<<<(unsigned)nlam_bwd_grid(ntiles), 256, lds, s>>>(q);
+  NLAM_CHECK_LAUNCH("mlp_bwd_kernel");
+  return 0;
+}
+
+/* slab floats per workgroup for nlam_mlp_bwd */
+extern "C" int64_t nlam_mlp_bwd_slab_stride(int k_in, int hid, int n_out) {
+  const int kp32 = (k_in + 31) & ~31, no32 = (n_out + 31) & ~31;
+  return (int64_t)hid * kp32 + hid + (int64_t)no32 * hid + 3 * no32;
+}
+
+extern "C" int nlam_mlp_bwd(
+    const float* xa, int64_t xa_bstride, int64_t xa_ld, int xa_width,
+    const float* xb, int64_t xb_bstride, int64_t xb_ld, int xb_width,
+    const float* W1, int64_t ldW1, const float* b1, const float* W2, int64_t ldW2,
+    const float* b2, const float* gamma,
+    const float* gy, int64_t gy_bstride, int64_t gy_ld,
+    float* gxa, int64_t gxa_bstride, int64_t gxa_ld,
+    float* gxb, int64_t gxb_bstride, int64_t gxb_ld, int add_gy_to_gxa,
+    float* slab, int64_t slab_stride,
+    int64_t B, int64_t rows, int hid, int n_out, void* stream) {
+  if (B <= 0 || rows <= 0) return 0;
+  NLAM_REQUIRE(hid == 64 || hid == 128, "nlam_mlp_bwd: hidden width %d not in {64,128}", hid);
+  NLAM_REQUIRE(n_out >= 1 && n_out <= hid, "nlam_mlp_bwd: n_out out of range");
+  NLAM_REQUIRE(gamma == nullptr || n_out == hid, "nlam_mlp_bwd: LayerNorm needs n_out == hid");
+  NLAM_REQUIRE(slab != nullptr && slab_stride >= nlam_mlp_bwd_slab_stride(
+                   xa_width + (xb ? xb_width : 0), hid, n_out), "nlam_mlp_bwd: slab too small");
+  NLAM_REQUIRE(!add_gy_to_gxa || xa_width == n_out, "nlam_mlp_bwd: residual width mismatch");
+  MlpBwdParams q;
+  MlpParams& p = q.f;
+  p.src[0] = RowView{xa, xa_bstride, xa_ld, xa_width};
+  p.src[1] = RowView{xb, xb_bstride, xb_ld, xb ? xb_width : 0};
+  p.nsrc = xb ? 2 : 1;
+  p.k_in = xa_width + (xb ? xb_width : 0);
+  p.k_pad = (p.k_in + 7) & ~7;
+  p.n_out = n_out;
+  p.W1 = W1; p.ldW1 = ldW1; p.b1 = b1; p.W2 = W2; p.ldW2 = ldW2; p.b2 = b2;
+  p.gamma = gamma; p.beta = nullptr;
+  p.res = nullptr; p.res_bstride = 0; p.res_ld = 0; p.out = nullptr; p.out_bstride = 0; p.out_ld = 0;
+  p.rows = rows; p.B = (int)B;
+  p.vec_mask = 0;
+  if (view_vec_ok(xa, xa_bstride, xa_ld, xa_width)) p.vec_mask |= 1;
+  if (xb && view_vec_ok(xb, xb_bstride, xb_ld, xb_width) && (xa_width % 4 == 0)) p.vec_mask |= 2;
+  q.gy = RowView{gy, gy_bstride, gy_ld, n_out};
+  q.gxa = gxa; q.gxa_bstride = gxa_bstride; q.gxa_ld = gxa_ld;
+  q.gxb = gxb; q.gxb_bstride = gxb_bstride; q.gxb_ld = gxb_ld;
+  q.add_gy_to_gxa = add_gy_to_gxa;
+  q.slab = slab; q.slab_stride = slab_stride;
+  q.vec_gy = view_vec_ok(gy, gy_bstride, gy_ld, n_out);
+  q.vec_gxa = gxa && view_vec_ok(gxa, gxa_bstride, gxa_ld, xa_width);
+  q.vec_gxb = gxb && view_vec_ok(gxb, gxb_bstride, gxb_ld, xb_width) && (xa_width % 4 == 0);
+  hipStream_t s = (hipStream_t)stream;
+  const bool ln = gamma != nullptr;
+  const int kb = (p.k_in + 31) / 32;
+  const int noutb = (n_out + 31) / 32;
+#define MLP_BWD_CASE(H, NO, K, L) return launch_mlp_bwd<H, NO, K, L>(q, s)
+  if (hid == 64) {
+    if (ln) {
+      if (kb == 1) MLP_BWD_CASE(64, 2, 1, true);
+      if (kb == 2) MLP_BWD_CASE(64, 2, 2, true);
+      if (kb == 4) MLP_BWD_CASE(64, 2, 4, true);
+    } else if (noutb == 1 && kb == 2) {
+      MLP_BWD_CASE(64, 1, 2, false);
+    }
+  }
+#undef MLP_BWD_CASE
+  nlam_set_error("nlam_mlp_bwd: unsupported shape hid=%d k_in=%d n_out=%d ln=%d", hid, p.k_in,
+                 n_out, (int)ln);
+  return 1;
+}
+
+// ---------------------------------------------------- projection backward
+// y = x [WA; WB]^T + [bA; bB]:  gx = gy [WA; WB],  dW = gy^T x,  db = colsum(gy).
+// Slab per workgroup: [dW (32 NOUTB x KP32) | db (32 NOUTB)].
+struct LinBwdParams {
+  RowView x;                   // (B, rows, k_in)
+  RowView gy;                  // (B, rows, n_out)
+  const float* WA; int64_t ldWA; int nA;
+  const float* WB; int64_t ldWB; int nB;
+  float* gx; int64_t gx_bstride; int64_t gx_ld;   // optional
+  float* slab; int64_t slab_stride;
+  int64_t rows; int B;
+  int vec_x, vec_gy, vec_gx;
+};
+
+template <int NOUTB, int KB>
+__global__ __launch_bounds__(256) void lin_bwd_kernel(LinBwdParams q) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int KP32 = 32 * KB, NO = 32 * NOUTB;
+  constexpr int NV = (NO + 63) / 64;
+  constexpr int ldw = KP32 + 4, ldt0 = KP32 + 4, ldt1 = NO + 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* Ws = smem;
+  float* T0 = Ws + NO * ldw + wave * (NLAM_TILE * (ldt0 + ldt1));
+  float* T1 = T0 + NLAM_TILE * ldt0;
+  load_weight_lds(Ws, q.WA, q.ldWA, q.nA, q.x.width, q.nA, KP32, tid, 256);
+  if (q.nB > 0)
+    load_weight_lds(Ws + q.nA * ldw, q.WB, q.ldWB, q.nB, q.x.width, NO - q.nA, KP32, tid, 256);
+  __syncthreads();
+  f32x16 dW[NOUTB][KB];
+#pragma unroll
+  for (int i = 0; i < NOUTB; ++i)
+#pragma unroll
+    for (int j = 0; j < KB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dW[i][j][r] = 0.f;
+  float db[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) db[j] = 0.f;
+
+  const int n_out = q.nA + q.nB;
+  const int64_t tiles_per_b = (q.rows + NLAM_TILE - 1) / NLAM_TILE;
+  const int64_t ntiles = tiles_per_b * q.B;
+  for (int64_t tt = (int64_t)blockIdx.x * 4 + wave; tt < ntiles; tt += (int64_t)gridDim.x * 4) {
+    const int64_t b = tt / tiles_per_b;
+    const int64_t r0 = (tt - b * tiles_per_b) * NLAM_TILE;
+    const int nrows = (int)((q.rows - r0) < NLAM_TILE ? (q.rows - r0) : NLAM_TILE);
+    const float* xb = q.x.ptr + b * q.x.bstride + r0 * q.x.ld;
+    auto xp = [&](int t) { return xb + (int64_t)t * q.x.ld; };
+    if (q.vec_x)
+      stage_rows<true, false>(T0, ldt0, 0, q.x.width, nrows, lane, xp);
+    else
+      stage_rows<false, false>(T0, ldt0, 0, q.x.width, nrows, lane, xp);
+    if (KP32 > q.x.width) zero_cols(T0, ldt0, q.x.width, KP32 - q.x.width, lane);
+    const float* gb = q.gy.ptr + b * q.gy.bstride + r0 * q.gy.ld;
+    auto gp = [&](int t) { return gb + (int64_t)t * q.gy.ld; };
+    if (q.vec_gy)
+      stage_rows<true, false>(T1, ldt1, 0, n_out, nrows, lane, gp);
+    else
+      stage_rows<false, false>(T1, ldt1, 0, n_out, nrows, lane, gp);
+    if (NO > n_out) zero_cols(T1, ldt1, n_out, NO - n_out, lane);
+    wave_sync();
+    tile_colsum<NV>(db, T1, ldt1, 0, nrows, lane);
+    outer_accum<NOUTB, KB>(dW, T1, ldt1, 0, T0, ldt0, 0, lane);
+    if (q.gx != nullptr) {
+      f32x16 g[NOUTB], gx[KB];
+      tile_to_acc<NOUTB>(g, T1, ldt1, lane);
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gx[kb][r] = 0.f;
+      gemm_acc_wt<KB, NOUTB>(gx, Ws, ldw, 0, g, lane);
+      wave_sync();
+      acc_to_tile<KB>(gx, T0, ldt0, lane);
+      wave_sync();
+      float* ob = q.gx + b * q.gx_bstride + r0 * q.gx_ld;
+      auto op = [&](int t) { return ob + (int64_t)t * q.gx_ld; };
+      if (q.vec_gx)
+        store_rows<true>(T0, ldt0, 0, q.x.width, nrows, lane, op);
+      else
+        store_rows<false>(T0, ldt0, 0, q.x.width, nrows, lane, op);
+    }
+    wave_sync();
+  }
+  __syncthreads();
+  float* img = smem;
+  float* slab = q.slab + (int64_t)blockIdx.x * q.slab_stride;
+  fold_blocks_lds<NOUTB, KB>(dW, img, KP32, wave, lane);
+  for (int i = tid; i < NO * KP32; i += 256) slab[i] = img[i];
+  __syncthreads();
+  fold_vec_lds<NV>(db, img, wave, lane);
+  for (int i = tid; i < NO; i += 256) slab[NO * KP32 + i] = img[i];
+}
+
+template <int NOUTB, int KB>
+static int launch_lin_bwd(const LinBwdParams& q, hipStream_t s) {
+  constexpr int KP32 = 32 * KB, NO = 32 * NOUTB;
+  const size_t lds = ((size_t)NO * (KP32 + 4) + (size_t)4 * NLAM_TILE * (KP32 + 4 + NO + 4)) *
+                     sizeof(float);
+  NLAM_REQUIRE(lds <= 160 * 1024, "lin_bwd: LDS footprint %zu B exceeds 160 KiB", lds);
+  auto kern = lin_bwd_kernel<NOUTB, KB>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  const int64_t ntiles = ((q.rows + NLAM_TILE - 1) / NLAM_TILE) * q.B;
+  kern<<<(unsigned)nlam_bwd_grid(ntiles), 256, lds, s>>>(q);
+  NLAM_CHECK_LAUNCH("lin_bwd_kernel");
+  return 0;
+}
+
+extern "C" int64_t nlam_lin_bwd_slab_stride(int k_in, int n_out) {
+  const int kp32 = (k_in + 31) & ~31;
+  return (int64_t)n_out * kp32 + n_out;
+}
+
+extern "C" int nlam_lin_bwd(const float* x, int64_t x_bstride, int64_t x_ld, int k_in,
+                            const float* gy, int64_t gy_bstride, int64_t gy_ld,
+                            const float* WA, int64_t ldWA, int nA,
+                            const float* WB, int64_t ldWB, int nB,
+                            float* gx, int64_t gx_bstride, int64_t gx_ld,
+                            float* slab, int64_t slab_stride, int64_t B, int64_t rows,
+                            void* stream) {
+  if (B <= 0 || rows <= 0) return 0;
+  NLAM_REQUIRE(nA > 0 && nA % 32 == 0 && nB >= 0 && nB % 32 == 0,
+               "nlam_lin_bwd: output block widths must be multiples of 32");
+  LinBwdParams q;
+  q.x = RowView{x, x_bstride, x_ld, k_in};
+  q.nA = nA; q.nB = WB ? nB : 0;
+  q.gy = RowView{gy, gy_bstride, gy_ld, q.nA + q.nB};
+  q.WA = WA; q.ldWA = ldWA; q.WB = WB; q.ldWB = ldWB;
+  q.gx = gx; q.gx_bstride = gx_bstride; q.gx_ld = gx_ld;
+  q.slab = slab; q.slab_stride = slab_stride;
+  q.rows = rows; q.B = (int)B;
+  NLAM_REQUIRE(slab != nullptr && slab_stride >= nlam_lin_bwd_slab_stride(k_in, q.nA + q.nB),
+               "nlam_lin_bwd: slab too small");
+  q.vec_x = view_vec_ok(x, x_bstride, x_ld, k_in);
+  q.vec_gy = view_vec_ok(gy, gy_bstride, gy_ld, q.nA + q.nB);
+  q.vec_gx = gx && view_vec_ok(gx, gx_bstride, gx_ld, k_in);
+  hipStream_t s = (hipStream_t)stream;
+  const int noutb = (q.nA + q.nB) / 32, kb = (k_in + 31) / 32;
+  if (noutb == 2 && kb == 2) return launch_lin_bwd<2, 2>(q, s);
+  if (noutb == 4 && kb == 2) return launch_lin_bwd<4, 2>(q, s);
+  if (noutb == 2 && kb == 1) return launch_lin_bwd<2, 1>(q, s);
+  if (noutb == 4 && kb == 4) return launch_lin_bwd<4, 4>(q, s);
+  nlam_set_error("nlam_lin_bwd: unsupported shape k_in=%d n_out=%d", k_in, q.nA + q.nB);
+  return 1;
+}

@@ -1,14 +1,294 @@
-"""Fused gfx950 kernels for the BASELINE shapes (hidden_layers == 1,
-hidden_dim in {64, 128}).  Until a shape is covered the callers use the generic
-kernel sequences (generic.py); both are HIP."""
+"""Fused gfx950 path for the BASELINE shapes: hidden_layers == 1, hidden width 64,
+single (non-split) MLPs, in-degree <= 32.  Everything else takes the generic
+kernel sequences (generic.py); both are HIP, there is no eager fallback.
+
+One InteractionNet layer (interaction_net.py:86-131) runs as
+  forward : nlam_lin_fwd (node-side projections of edge_mlp.0)
+            nlam_edge_fwd (edge MLP + LN + segmented aggregation [+ e' = e + m])
+            nlam_mlp_fwd  (node update [x_r | agg] + residual)
+  backward: nlam_mlp_bwd, nlam_edge_bwd, nlam_segment_sum (sender side),
+            nlam_lin_bwd, nlam_reduce_slabs
+Forward keeps only the layer inputs, the (small) node projections and the
+aggregate; edge-sized activations are recomputed in backward.
+"""
 import os
 
+import torch
+
+from . import ops
+from .ops import mat
+
 FORCE_GENERIC = os.environ.get("NLAM_FORCE_GENERIC", "0") == "1"
+SUPPORTED_HIDDEN = (64,)
+
+
+def _empty(*shape, device):
+    return torch.empty(*shape, dtype=torch.float32, device=device)
+
+
+def _mlp_parts(seq):
+    lin = [m for m in seq if isinstance(m, torch.nn.Linear)]
+    lns = [m for m in seq if isinstance(m, torch.nn.LayerNorm)]
+    return lin, (lns[0] if lns else None)
+
+
+def _bwd_shape_ok(k_in, n_out, has_ln):
+    kb = (k_in + 31) // 32
+    if has_ln:
+        return kb in (1, 2, 4)
+    return n_out <= 32 and kb == 2
 
 
 def mlp_eligible(seq, x):
-    return False
+    if FORCE_GENERIC or not x.is_cuda or x.dtype != torch.float32:
+        return False
+    lin, ln = _mlp_parts(seq)
+    if len(lin) != 2:
+        return False
+    hid, k_in = lin[0].weight.shape
+    n_out = lin[1].weight.shape[0]
+    if hid not in SUPPORTED_HIDDEN or lin[1].weight.shape[1] != hid or k_in > 128:
+        return False
+    if ln is not None and n_out != hid:
+        return False
+    if n_out > hid:
+        return False
+    return _bwd_shape_ok(k_in, n_out, ln is not None)
 
 
+# --------------------------------------------------------------------- MLP
+class FusedMLPFunction(torch.autograd.Function):
+    """y = [res +] [LN](W2 silu(W1 x + b1) + b2), x: (..., rows, k_in)."""
+
+    @staticmethod
+    def forward(ctx, x, res, W1, b1, W2, b2, gamma, beta):
+        hid, n_out = W1.shape[0], W2.shape[0]
+        xm = mat(x.detach())
+        res_is_x = res is x
+        rm = xm if res_is_x else (mat(res.detach()) if res is not None else None)
+        out = _empty(xm.B, xm.rows, n_out, device=x.device)
+        ops.fused_mlp_fwd(xm, None, W1, b1, W2, b2, gamma, beta, rm, mat(out), hid, n_out)
+        ctx.save_for_backward(W1, b1, W2, b2, gamma)
+        ctx.xm, ctx.x_shape = xm, x.shape
+        ctx.res_mode = 0 if res is None else (1 if res_is_x else 2)
+        ctx.has_ln = gamma is not None
+        return out.reshape(*x.shape[:-1], n_out)
+
+    @staticmethod
+    def backward(ctx, gy):
+        W1, b1, W2, b2, gamma = ctx.saved_tensors
+        hid, k_in = W1.shape
+        n_out = W2.shape[0]
+        xm = ctx.xm
+        gy = gy.contiguous()
+        gym = mat(gy.reshape(xm.B, xm.rows, n_out))
+        need_gx = ctx.needs_input_grad[0]
+        gx = _empty(xm.B, xm.rows, k_in, device=gy.device) if need_gx else None
+        red, kp32, no32 = ops.fused_mlp_bwd(
+            xm, None, W1, b1, W2, b2, gamma, gym, mat(gx) if need_gx else None, None,
+            ctx.res_mode == 1 and need_gx, hid, n_out)
+        dW1, db1, dW2, db2, dg, dbt = ops.split_mlp_grads(red, k_in, hid, n_out, kp32, no32,
+                                                          ctx.has_ln)
+        gres = gy if ctx.res_mode == 2 else None
+        if ctx.res_mode == 1 and not need_gx:
+            gres = None
+        return (gx.reshape(ctx.x_shape) if need_gx else None, gres, dW1, db1, dW2, db2, dg, dbt)
+
+
+def apply_mlp(seq, x, res=None):
+    lin, ln = _mlp_parts(seq)
+    return FusedMLPFunction.apply(
+        x, res, lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias,
+        ln.weight if ln is not None else None, ln.bias if ln is not None else None)
+
+
+# ---------------------------------------------------------- InteractionNet
 def inet_eligible(net, send_rep, rec_rep, edge_rep):
-    return False
+    if FORCE_GENERIC or not edge_rep.is_cuda:
+        return False
+    from .interaction_net import SplitMLPs
+
+    if isinstance(net.edge_mlp, SplitMLPs) or isinstance(net.aggr_mlp, SplitMLPs):
+        return False
+    if net.hidden_layers != 1 or net.input_dim != net.hidden_dim:
+        return False
+    if net.hidden_dim not in SUPPORTED_HIDDEN:
+        return False
+    return net.tables.ntiles > 0
+
+
+def _base(t):
+    """(B, N, d) view with B == 1 for batch-invariant inputs (2-D, leading dim 1,
+    or a stride-0 expand as the reference's expand_to_batch produces)."""
+    if t.dim() == 2:
+        return t.unsqueeze(0)
+    if t.dim() == 3 and t.shape[0] > 1 and t.stride(0) == 0:
+        return t[:1]
+    return t
+
+
+class FusedInteractionNetFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, send_rep, rec_rep, edge_rep, same, g, update_edges, mean,
+                W1, b1, W2, b2, gam, bet, V1, c1, V2, c2, gam2, bet2):
+        with ops.tag(g.tag):
+            dev = edge_rep.device
+            d = W2.shape[0]
+            B = max(send_rep.shape[0], rec_rep.shape[0], edge_rep.shape[0])
+            N_s, N_r, M = send_rep.shape[1], rec_rep.shape[1], edge_rep.shape[1]
+            sm, rm, em = mat(send_rep.detach()), mat(rec_rep.detach()), mat(edge_rep.detach())
+            W1e, W1s, W1r = W1[:, :d], W1[:, d : 2 * d], W1[:, 2 * d :]
+            # node-side projections of edge_mlp.0 (Pr carries the bias)
+            if same:
+                P = _empty(sm.B, N_s, 2 * d, device=dev)
+                ops.fused_lin_fwd(sm, W1s, None, W1r, b1, mat(P))
+                psm, prm = mat(P, 0, d), mat(P, d, d)
+                saved_proj = (P,)
+            else:
+                Ps = _empty(sm.B, N_s, d, device=dev)
+                Pr = _empty(rm.B, N_r, d, device=dev)
+                ops.fused_lin_fwd(sm, W1s, None, None, None, mat(Ps))
+                ops.fused_lin_fwd(rm, W1r, b1, None, None, mat(Pr))
+                psm, prm = mat(Ps), mat(Pr)
+                saved_proj = (Ps, Pr)
+            agg = _empty(B, N_r, d, device=dev)
+            if update_edges:
+                e_out = _empty(B, M, d, device=dev)
+                ops.fused_edge_fwd(g, em, True, psm, prm, W1e, W2, b2, gam, bet, mat(agg),
+                                   mat(e_out), mean, d)
+                Pe = None
+            else:
+                e_out = None
+                Pe = _empty(em.B, M, d, device=dev)
+                ops.fused_lin_fwd(em, W1e, None, None, None, mat(Pe))
+                ops.fused_edge_fwd(g, mat(Pe), False, psm, prm, None, W2, b2, gam, bet, mat(agg),
+                                   None, mean, d)
+            rec_out = _empty(B, N_r, d, device=dev)
+            ops.fused_mlp_fwd(rm, mat(agg), V1, c1, V2, c2, gam2, bet2, rm, mat(rec_out), d, d)
+            ctx.save_for_backward(W1, b1, W2, b2, gam, V1, c1, V2, c2, gam2)
+            ctx.g, ctx.same, ctx.update_edges, ctx.mean = g, same, update_edges, mean
+            ctx.mats = (sm, rm, em)
+            ctx.bufs = (saved_proj, Pe, agg)
+            ctx.dims = (B, N_s, N_r, M, d)
+        if update_edges:
+            return rec_out, e_out
+        return rec_out
+
+    @staticmethod
+    def backward(ctx, g_rec_out, g_edge_out=None):
+        with ops.tag(ctx.g.tag):
+            W1, b1, W2, b2, gam, V1, c1, V2, c2, gam2 = ctx.saved_tensors
+            g = ctx.g
+            sm, rm, em = ctx.mats
+            saved_proj, Pe, agg = ctx.bufs
+            ctx.bufs = None
+            B, N_s, N_r, M, d = ctx.dims
+            dev = W1.device
+            W1e, W1s, W1r = W1[:, :d], W1[:, d : 2 * d], W1[:, 2 * d :]
+            same = ctx.same
+            # 1. node update backward: g_rec (incl. residual), g_agg
+            g_rec_out = g_rec_out.contiguous()
+            g_rec = _empty(B, N_r, d, device=dev)
+            g_agg = _empty(B, N_r, d, device=dev)
+            red, kp32, no32 = ops.fused_mlp_bwd(rm, mat(agg), V1, c1, V2, c2, gam2, mat(g_rec_out),
+                                                mat(g_rec), mat(g_agg), True, d, d)
+            dV1, dc1, dV2, dc2, dg2, db2n = ops.split_mlp_grads(red, 2 * d, d, d, kp32, no32, True)
+            if rm.B == 1 and B > 1:   # batch-invariant receivers: their grad sums over the batch
+                t3 = _empty(1, N_r, d, device=dev)
+                ops.sum_batch(g_rec, t3)
+                g_rec = t3
+            # 2. edge backward
+            gh = _empty(B, M, d, device=dev)
+            if same:
+                gP = _empty(B, N_r, 2 * d, device=dev)
+                gpr_m = mat(gP, d, d)
+                psm, prm = mat(saved_proj[0], 0, d), mat(saved_proj[0], d, d)
+            else:
+                gPr = _empty(B, N_r, d, device=dev)
+                gpr_m = mat(gPr)
+                psm, prm = mat(saved_proj[0]), mat(saved_proj[1])
+            if ctx.update_edges:
+                g_e = _empty(B, M, d, device=dev)
+                geo = mat(g_edge_out.contiguous()) if g_edge_out is not None else None
+                dW1e, dW2, db2, dgam, dbet = ops.fused_edge_bwd(
+                    g, em, True, psm, prm, W1e, W2, b2, gam, mat(g_agg), geo, mat(gh), gpr_m,
+                    mat(g_e), ctx.mean, d)
+            else:
+                g_e = None
+                _, dW2, db2, dgam, dbet = ops.fused_edge_bwd(
+                    g, mat(Pe), False, psm, prm, None, W2, b2, gam, mat(g_agg), None, mat(gh),
+                    gpr_m, None, ctx.mean, d)
+            # 3. sender-side reduction of gh (CSR-ordered rows, sender lists of CSR positions)
+            dW1 = _empty(d, 3 * d, device=dev)
+            if same:
+                if N_s > g.n_send:
+                    gP[:, g.n_send :, :d].zero_()
+                ops.segment_sum(mat(gh), g.csc_colptr, g.csc_pos, mat(gP[:, : g.n_send], 0, d))
+                # 4. projections backward (x W1s^T | x W1r^T + b1)
+                gx_p = _empty(sm.B, N_s, d, device=dev)
+                gpm = mat(gP)
+                if sm.B == 1 and B > 1:
+                    gP1 = _empty(1, N_s, 2 * d, device=dev)
+                    ops.sum_batch(gP, gP1)
+                    gpm = mat(gP1)
+                dWp, dbp = ops.fused_lin_bwd(sm, gpm, W1s, W1r, mat(gx_p))
+                ops.copy_rows(mat(dWp[:d]), mat(dW1, d, d))
+                ops.copy_rows(mat(dWp[d:]), mat(dW1, 2 * d, d))
+                db1 = dbp[d:]
+                g_send, g_rec_total = gx_p, g_rec
+            else:
+                gPs = (torch.zeros if N_s > g.n_send else torch.empty)(
+                    B, N_s, d, dtype=torch.float32, device=dev)
+                ops.segment_sum(mat(gh), g.csc_colptr, g.csc_pos, mat(gPs[:, : g.n_send]))
+                gps_m, gpr_in = mat(gPs), mat(gPr)
+                if sm.B == 1 and B > 1:
+                    t1 = _empty(1, N_s, d, device=dev)
+                    ops.sum_batch(gPs, t1)
+                    gps_m = mat(t1)
+                if rm.B == 1 and B > 1:
+                    t2 = _empty(1, N_r, d, device=dev)
+                    ops.sum_batch(gPr, t2)
+                    gpr_in = mat(t2)
+                g_send = _empty(sm.B, N_s, d, device=dev)
+                dWs, _ = ops.fused_lin_bwd(sm, gps_m, W1s, None, mat(g_send))
+                gx_r = _empty(rm.B, N_r, d, device=dev)
+                dWr, db1 = ops.fused_lin_bwd(rm, gpr_in, W1r, None, mat(gx_r))
+                ops.copy_rows(mat(dWs), mat(dW1, d, d))
+                ops.copy_rows(mat(dWr), mat(dW1, 2 * d, d))
+                # receiver gradient: node-update part (+ residual) + projection part
+                ops.add_rows(mat(g_rec), mat(gx_r), mat(g_rec))
+                g_rec_total = g_rec
+            # 5. edge-side first-layer weights
+            if ctx.update_edges:
+                ops.copy_rows(mat(dW1e), mat(dW1, 0, d))
+                g_edge = g_e
+                if em.B == 1 and B > 1:
+                    t4 = _empty(1, M, d, device=dev)
+                    ops.sum_batch(g_e, t4)
+                    g_edge = t4
+            else:
+                dPe = gh
+                if em.B == 1 and B > 1:
+                    dPe = _empty(1, M, d, device=dev)
+                    ops.sum_batch(gh, dPe)
+                dPe_o = _empty(em.B, M, d, device=dev)
+                ops.gather_rows(mat(dPe), g.pos_of_eid, mat(dPe_o))   # CSR -> original order
+                g_edge = _empty(em.B, M, d, device=dev)
+                dWe, _ = ops.fused_lin_bwd(em, mat(dPe_o), W1e, None, mat(g_edge))
+                ops.copy_rows(mat(dWe), mat(dW1, 0, d))
+        return (g_send, g_rec_total, g_edge, None, None, None, None,
+                dW1, db1, dW2, db2, dgam, dbet, dV1, dc1, dV2, dc2, dg2, db2n)
+
+
+def apply_inet(net, send_rep, rec_rep, edge_rep):
+    same = send_rep is rec_rep
+    s, e = _base(send_rep), _base(edge_rep)
+    r = s if same else _base(rec_rep)
+    if net.update_edges and e.shape[0] == 1 and max(s.shape[0], r.shape[0]) > 1:
+        pass  # batch-invariant e with per-sample nodes: e' is per-sample, the kernel broadcasts e
+    el, al = _mlp_parts(net.edge_mlp), _mlp_parts(net.aggr_mlp)
+    out = FusedInteractionNetFunction.apply(
+        s, r, e, same, net.tables, net.update_edges, net.aggr == "mean",
+        el[0][0].weight, el[0][0].bias, el[0][1].weight, el[0][1].bias, el[1].weight, el[1].bias,
+        al[0][0].weight, al[0][0].bias, al[0][1].weight, al[0][1].bias, al[1].weight, al[1].bias)
+    return out

@@ -26,7 +26,7 @@ class EdgeTables(torch.nn.Module):
     edge_index buffer, interaction_net.py:62)."""
 
     NAMES = ("send", "rec", "csr_rowptr", "csr_eid", "csr_send", "csr_rec", "csc_colptr",
-             "csc_pos", "csc_eid", "inv_deg")
+             "csc_pos", "csc_eid", "inv_deg", "pos_of_eid")
 
     def __init__(self, send, rec, n_send, n_rec):
         super().__init__()
@@ -50,6 +50,9 @@ class EdgeTables(torch.nn.Module):
             ),
             "nlam_graph_build_host",
         )
+        inv = np.empty(M, np.int32)
+        inv[out["csr_eid"]] = np.arange(M, dtype=np.int32)
+        out["pos_of_eid"] = inv
         out["send"] = s.astype(np.int32)
         out["rec"] = r.astype(np.int32)
         for k in self.NAMES:

@@ -385,3 +385,121 @@ def fused_edge_fwd(g, e, has_egemm, ps, pr, W1e, W2, b2, gamma, beta, agg, e_out
         nbytes=4.0 * d * ((B if e.bstride else 1) * M + (B * M if has_egemm else 0)
                           + B * (ps.rows + pr.rows) + B * agg.rows) + 16.0 * M,
     )
+
+
+def _ntiles(B, rows):
+    return B * ((rows + 31) // 32)
+
+
+def reduce_slabs(slab, nslabs, stride, n, out, accumulate=False):
+    _launch("nlam_reduce_slabs", lib.nlam_reduce_slabs,
+            (slab.data_ptr(), nslabs, stride, n, out.data_ptr(), int(accumulate), stream()),
+            nbytes=4.0 * nslabs * n)
+
+
+def fused_mlp_bwd(xa, xb, W1, b1, W2, b2, gamma, gy, gxa, gxb, add_gy_to_gxa, hid, n_out):
+    """Returns the reduced parameter-gradient buffer laid out as
+    [dW1 (hid x KP32) | db1 | dW2 (NO32 x hid) | db2 | dgamma | dbeta] and (KP32, NO32)."""
+    B, rows = gy.B, gy.rows
+    k_in = xa.cols + (xb.cols if xb is not None else 0)
+    stride = lib.nlam_mlp_bwd_slab_stride(k_in, hid, n_out)
+    nslabs = lib.nlam_bwd_grid(_ntiles(B, rows))
+    dev = W1.device
+    slab = torch.empty(nslabs * stride, dtype=torch.float32, device=dev)
+    _launch(
+        "nlam_mlp_bwd", lib.nlam_mlp_bwd,
+        (xa.ptr, xa.bstride, xa.ld, xa.cols,
+         xb.ptr if xb is not None else None, xb.bstride if xb is not None else 0,
+         xb.ld if xb is not None else 0, xb.cols if xb is not None else 0,
+         W1.data_ptr(), W1.stride(0), _p(b1), W2.data_ptr(), W2.stride(0), _p(b2), _p(gamma),
+         gy.ptr, gy.bstride, gy.ld,
+         gxa.ptr if gxa is not None else None, gxa.bstride if gxa is not None else 0,
+         gxa.ld if gxa is not None else 0,
+         gxb.ptr if gxb is not None else None, gxb.bstride if gxb is not None else 0,
+         gxb.ld if gxb is not None else 0, int(add_gy_to_gxa),
+         slab.data_ptr(), stride, B, rows, hid, n_out, stream()),
+        flops=2.0 * B * rows * hid * ((3 if (gxa is not None or gxb is not None) else 2) * k_in
+                                       + 4 * n_out),
+        nbytes=4.0 * B * rows * (2 * k_in + n_out),
+    )
+    red = torch.empty(stride, dtype=torch.float32, device=dev)
+    reduce_slabs(slab, nslabs, stride, stride, red)
+    return red, (k_in + 31) // 32 * 32, (n_out + 31) // 32 * 32
+
+
+def split_mlp_grads(red, k_in, hid, n_out, kp32, no32, has_ln):
+    """Views of the reduced buffer as (dW1, db1, dW2, db2, dgamma, dbeta)."""
+    o = 0
+    dW1 = red[o : o + hid * kp32].view(hid, kp32)[:, :k_in]
+    o += hid * kp32
+    db1 = red[o : o + hid]
+    o += hid
+    dW2 = red[o : o + no32 * hid].view(no32, hid)[:n_out]
+    o += no32 * hid
+    db2 = red[o : o + n_out]
+    o += no32
+    dg = red[o : o + n_out] if has_ln else None
+    o += no32
+    dbt = red[o : o + n_out] if has_ln else None
+    return dW1, db1, dW2, db2, dg, dbt
+
+
+def fused_lin_bwd(x, gy, WA, WB, gx):
+    """Returns the reduced [dW ((nA+nB) x KP32) | db] buffer and KP32."""
+    nA = WA.shape[0]
+    nB = WB.shape[0] if WB is not None else 0
+    B, rows, k_in = gy.B, gy.rows, x.cols
+    stride = lib.nlam_lin_bwd_slab_stride(k_in, nA + nB)
+    nslabs = lib.nlam_bwd_grid(_ntiles(B, rows))
+    dev = WA.device
+    slab = torch.empty(nslabs * stride, dtype=torch.float32, device=dev)
+    _launch(
+        "nlam_lin_bwd", lib.nlam_lin_bwd,
+        (x.ptr, x.bstride, x.ld, k_in, gy.ptr, gy.bstride, gy.ld, WA.data_ptr(), WA.stride(0), nA,
+         _p(WB), WB.stride(0) if WB is not None else 0, nB,
+         gx.ptr if gx is not None else None, gx.bstride if gx is not None else 0,
+         gx.ld if gx is not None else 0, slab.data_ptr(), stride, B, rows, stream()),
+        flops=2.0 * B * rows * k_in * (nA + nB) * (2 if gx is not None else 1),
+        nbytes=4.0 * B * rows * (k_in * (2 if gx is not None else 1) + nA + nB),
+    )
+    red = torch.empty(stride, dtype=torch.float32, device=dev)
+    reduce_slabs(slab, nslabs, stride, stride, red)
+    kp32 = (k_in + 31) // 32 * 32
+    n = nA + nB
+    return red[: n * kp32].view(n, kp32)[:, :k_in], red[n * kp32 : n * kp32 + n]
+
+
+def fused_edge_bwd(g, e, has_egemm, ps, pr, W1e, W2, b2, gamma, g_agg, g_eout, gh_out, gpr, g_e,
+                   mean, d):
+    """Returns (dW1e or None, dW2, db2, dgamma, dbeta) views of the reduced slab."""
+    B = g_agg.B
+    stride = lib.nlam_edge_bwd_slab_stride(d)
+    nslabs = lib.nlam_bwd_grid(B * g.ntiles)
+    dev = W2.device
+    slab = torch.empty(nslabs * stride, dtype=torch.float32, device=dev)
+    units = 6 if has_egemm else 3
+    _launch(
+        "nlam_edge_bwd", lib.nlam_edge_bwd,
+        (g.tiles.data_ptr(), g.ntiles, g.csr_rowptr.data_ptr(), g.csr_eid.data_ptr(),
+         g.csr_send.data_ptr(), g.csr_rec.data_ptr(), g.inv_deg.data_ptr() if mean else None,
+         e.ptr, e.bstride, e.ld, int(has_egemm), ps.ptr, ps.bstride, ps.ld, pr.ptr, pr.bstride,
+         pr.ld, _p(W1e), W1e.stride(0) if W1e is not None else 0, W2.data_ptr(), W2.stride(0),
+         b2.data_ptr(), gamma.data_ptr(), g_agg.ptr, g_agg.bstride, g_agg.ld,
+         g_eout.ptr if g_eout is not None else None,
+         g_eout.bstride if g_eout is not None else 0, g_eout.ld if g_eout is not None else 0,
+         gh_out.ptr, gh_out.bstride, gpr.ptr, gpr.bstride, gpr.ld,
+         g_e.ptr if g_e is not None else None, g_e.bstride if g_e is not None else 0,
+         g_e.ld if g_e is not None else 0, slab.data_ptr(), stride, B, d, stream()),
+        flops=2.0 * B * g.M * d * d * units,
+        # algorithmic bytes (SURVEY.md 8d): read e, g_e', write g_e (has_egemm) / gh;
+        # node-side rows (ps, pr, g_agg, gpr) once; indices
+        nbytes=4.0 * d * ((B if e.bstride else 1) * g.M
+                          + (2 * B * g.M if has_egemm else 0) + B * g.M
+                          + B * (ps.rows + 3 * pr.rows)) + 16.0 * g.M,
+    )
+    red = torch.empty(stride, dtype=torch.float32, device=dev)
+    reduce_slabs(slab, nslabs, stride, stride, red)
+    dd = d * d
+    dW1e = red[:dd].view(d, d) if has_egemm else None
+    return (dW1e, red[dd : 2 * dd].view(d, d), red[2 * dd : 2 * dd + d],
+            red[2 * dd + d : 2 * dd + 2 * d], red[2 * dd + 2 * d : 2 * dd + 3 * d])

@@ -142,3 +142,84 @@ def test_fused_edge_fwd(d, egemm, mean, B, n_s, n_r, M):
     assert rel(agg_d, agg) < 2e-5
     if egemm:
         assert rel(eo_d, e + m) < 2e-5
+
+
+@pytest.mark.parametrize(
+    "ka,kb,n_out,ln,res_a,B,rows,need_gx",
+    [
+        (64, 0, 64, True, True, 2, 300, True),      # encoding_grid_mlp (+residual from x)
+        (64, 64, 64, True, True, 3, 77, True),      # node update [x_r | agg]
+        (3, 0, 64, True, False, 1, 1000, False),    # feature embedder (no input grad)
+        (56, 0, 64, True, False, 2, 250, False),    # grid embedder
+        (64, 0, 17, False, False, 2, 129, True),    # output map
+    ],
+)
+def test_fused_mlp_bwd(ka, kb, n_out, ln, res_a, B, rows, need_gx):
+    from neural_lam_amd import ops
+
+    hid = 64
+    gen = torch.Generator().manual_seed(ka + kb + n_out + rows)
+    k_in = ka + kb
+    xa = torch.randn(B, rows, ka, generator=gen, requires_grad=True)
+    xb = torch.randn(B, rows, kb, generator=gen, requires_grad=True) if kb else None
+    W1 = (torch.randn(hid, k_in, generator=gen) / k_in ** 0.5).requires_grad_(True)
+    b1 = torch.randn(hid, generator=gen, requires_grad=True)
+    W2 = (torch.randn(n_out, hid, generator=gen) / hid ** 0.5).requires_grad_(True)
+    b2 = torch.randn(n_out, generator=gen, requires_grad=True)
+    gam = (1 + 0.1 * torch.randn(n_out, generator=gen)).requires_grad_(True)
+    bet = (0.1 * torch.randn(n_out, generator=gen)).requires_grad_(True)
+    gy = torch.randn(B, rows, n_out, generator=gen)
+    x = torch.cat((xa, xb), -1) if kb else xa
+    y = F.linear(F.silu(F.linear(x, W1, b1)), W2, b2)
+    if ln:
+        y = F.layer_norm(y, (n_out,), gam, bet, 1e-5)
+    if res_a:
+        y = y + xa[..., :n_out]
+    y.backward(gy)
+    dev = "cuda"
+    gxa = torch.full((B, rows, ka), float("nan"), device=dev) if need_gx else None
+    gxb = torch.full((B, rows, kb), float("nan"), device=dev) if (need_gx and kb) else None
+    red, kp32, no32 = ops.fused_mlp_bwd(
+        ops.mat(xa.detach().to(dev)), ops.mat(xb.detach().to(dev)) if kb else None,
+        W1.detach().to(dev), b1.detach().to(dev), W2.detach().to(dev), b2.detach().to(dev),
+        gam.detach().to(dev) if ln else None, ops.mat(gy.to(dev)),
+        ops.mat(gxa) if need_gx else None, ops.mat(gxb) if gxb is not None else None,
+        res_a, hid, n_out)
+    dW1, db1, dW2, db2, dg, dbt = ops.split_mlp_grads(red, k_in, hid, n_out, kp32, no32, ln)
+    tol = 2e-5 * max(1.0, (B * rows) ** 0.5 / 8)
+    assert rel(dW1, W1.grad) < tol and rel(db1, b1.grad) < tol
+    assert rel(dW2, W2.grad) < tol and rel(db2, b2.grad) < tol
+    if ln:
+        assert rel(dg, gam.grad) < tol and rel(dbt, bet.grad) < tol
+    if need_gx:
+        assert rel(gxa, xa.grad) < 2e-5
+        if kb:
+            assert rel(gxb, xb.grad) < 2e-5
+
+
+def test_fused_paths_are_taken_for_baseline_shapes():
+    """d=64, hidden_layers=1: the fused kernels must be the ones that run."""
+    from neural_lam_amd import fused, ops, utils
+    from neural_lam_amd.interaction_net import InteractionNet
+
+    gen = torch.Generator().manual_seed(0)
+    ei = torch.stack((torch.randint(0, 30, (200,), generator=gen),
+                      torch.randint(0, 30, (200,), generator=gen)))
+    ei[0, 0], ei[1, 0], ei[1, 1] = 0, 0, 29
+    net = InteractionNet(ei, 64).cuda()
+    x = torch.randn(2, 30, 64, device="cuda", requires_grad=True)
+    e = torch.randn(2, 200, 64, device="cuda", requires_grad=True)
+    assert fused.inet_eligible(net, x, x, e)
+    ops.PROFILER = ops.KernelProfiler()
+    try:
+        o_x, o_e = net(x, x, e)
+        (o_x.sum() + o_e.sum()).backward()
+        mlp = utils.make_mlp([3, 64, 64]).cuda()
+        mlp(torch.randn(50, 3, device="cuda")).sum().backward()
+        stats = ops.PROFILER.collect()
+    finally:
+        ops.PROFILER = None
+    names = {k.split("@")[0] for k in stats}
+    assert {"nlam_edge_fwd", "nlam_edge_bwd", "nlam_mlp_fwd", "nlam_mlp_bwd", "nlam_lin_fwd",
+            "nlam_lin_bwd"} <= names
+    assert "nlam_gemm" not in names
