@@ -51,6 +51,7 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
 }
+__device__ __forceinline__ void phase_fence() { __builtin_amdgcn_sched_barrier(0); }
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
@@ -110,6 +111,91 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ tile, int ld, int
       *dst = v;
     }
   }
+}
+
+// ---- two-phase staging: issue every row load of a source first (they stay in
+// flight together), write the LDS tile afterwards.  Loads are unconditional --
+// slots >= nrows read a valid row (their index is clamped by the caller's
+// row_ptr) and are zeroed when written -- so the compiler emits no branches and
+// no per-load waits.  NV = number of float4 (or floats) per lane that covers the
+// 32 rows: NV >= ceil(32 / (64 / (width/4))) for the vector form.
+template <int NV, typename RowPtr>
+__device__ __forceinline__ void load_rows_v(f32x4 (&v)[NV], int width, int lane, RowPtr row_ptr) {
+  const int lpr = width >> 2;
+  const int rpi = 64 / lpr;
+  const int sub = lane / lpr, c4 = lane - sub * lpr;
+  const bool on = sub < rpi;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    if (k * rpi < NLAM_TILE) {   // wave-uniform
+      const int t = sub + k * rpi;
+      const float* src = row_ptr((on && t < NLAM_TILE) ? t : 0);
+      v[k] = reinterpret_cast<const f32x4*>(src)[on ? c4 : 0];
+    }
+  }
+}
+template <int NV, bool ADD>
+__device__ __forceinline__ void put_rows_v(float* __restrict__ tile, int ld, int col0, int width,
+                                           int nrows, int lane, const f32x4 (&v)[NV]) {
+  const int lpr = width >> 2;
+  const int rpi = 64 / lpr;
+  const int sub = lane / lpr, c4 = lane - sub * lpr;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int t = sub + k * rpi;
+    if (sub < rpi && t < NLAM_TILE) {
+      f32x4 x = v[k];
+      if (t >= nrows) x = f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4* dst = reinterpret_cast<f32x4*>(tile + t * ld + col0) + c4;
+      if (ADD) x += *dst;
+      *dst = x;
+    }
+  }
+}
+// scalar form for narrow / unaligned sources (width <= 2 NS)
+template <int NS, typename RowPtr>
+__device__ __forceinline__ void load_rows_s(float (&v)[NS], int width, int lane, RowPtr row_ptr) {
+  const int total = NLAM_TILE * width;
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    const int idx = lane + 64 * k;
+    const bool on = idx < total;
+    const int t = on ? idx / width : 0, c = on ? idx - t * width : 0;
+    v[k] = row_ptr(t)[c];
+  }
+}
+template <int NS>
+__device__ __forceinline__ void put_rows_s(float* __restrict__ tile, int ld, int col0, int width,
+                                           int nrows, int lane, const float (&v)[NS]) {
+  const int total = NLAM_TILE * width;
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    const int idx = lane + 64 * k;
+    if (idx < total) {
+      const int t = idx / width, c = idx - t * width;
+      tile[t * ld + col0 + c] = (t < nrows) ? v[k] : 0.f;
+    }
+  }
+}
+
+// Contiguous-row views (rows r0 .. r0+nrows of batch item b).  Vector-capable
+// views are staged in two phases (view_load_v: issue all loads; view_put_v: write
+// the tile) so that several sources overlap their latency; narrow / unaligned
+// views (feature embedders, 17-wide outputs) use the simple scalar stager.
+template <int NV>
+__device__ __forceinline__ void view_load_v(f32x4 (&v)[NV], const RowView& src, int64_t b,
+                                            int64_t r0, int nrows, int lane) {
+  const float* base = src.ptr + b * src.bstride + r0 * src.ld;
+  const int last = nrows - 1;
+  auto rp = [&](int t) { return base + (int64_t)(t < last ? t : last) * src.ld; };
+  load_rows_v<NV>(v, src.width, lane, rp);
+}
+__device__ __forceinline__ void view_stage_s(float* __restrict__ tile, int ld, int col0,
+                                             const RowView& src, int64_t b, int64_t r0, int nrows,
+                                             int lane) {
+  const float* base = src.ptr + b * src.bstride + r0 * src.ld;
+  auto rp = [&](int t) { return base + (int64_t)t * src.ld; };
+  stage_rows<false, false>(tile, ld, col0, src.width, nrows, lane, rp);
 }
 
 // zero columns [col0, col0+width) of the tile (K padding)
@@ -429,6 +515,56 @@ __device__ __forceinline__ void tile_colsum(float (&acc)[NV], const float* __res
   }
 }
 
+// Segmented sum of a message tile over receiver segments with lanes = features:
+// out_row(i)[f] = scale_i * sum_{s in [rp_i, rp_{i+1})} tile[s][f], i < nr.  `rp` /
+// `scale` are held by lane i (lane i <= nr for rp).  Slot values are read from LDS
+// eight at a time (static, pipelined); the walk over the segments is wave-uniform.
+__device__ __forceinline__ int lane_i(int v, int i) {
+  return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(i));
+}
+__device__ __forceinline__ float lane_f(float v, int i) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), __builtin_amdgcn_readfirstlane(i)));
+}
+template <int D, typename OutRow>
+__device__ __forceinline__ void segment_reduce_tile(const float* __restrict__ tile, int ld, int ne,
+                                                    int nr, int rp, float scale, int lane,
+                                                    OutRow out_row) {
+#pragma unroll
+  for (int f0 = 0; f0 < D; f0 += 64) {
+    int i = 0;
+    int end = lane_i(rp, 1);
+    float acc = 0.f;
+    while (i < nr && end == lane_i(rp, i)) {   // receivers without in-edges at the front
+      out_row(i)[f0 + lane] = 0.f;
+      ++i;
+      end = lane_i(rp, i + 1);
+    }
+    for (int s0 = 0; s0 < ne; s0 += 8) {
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = tile[(s0 + k) * ld + f0 + lane];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int s = s0 + k;
+        if (s < ne) {
+          acc += v[k];
+          if (s + 1 == end) {
+            out_row(i)[f0 + lane] = acc * lane_f(scale, i);
+            acc = 0.f;
+            ++i;
+            end = lane_i(rp, i + 1);
+            while (i < nr && end == s + 1) {   // empty receivers in between / at the end
+              out_row(i)[f0 + lane] = 0.f;
+              ++i;
+              end = lane_i(rp, i + 1);
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
 // Workgroup-level fold of per-wave weight-gradient blocks into an LDS image
 // [rows][ldimg] (row-major, rows = 32 NI, cols = 32 NJ), wave after wave (fixed
 // order => deterministic).  Must be called by all 256 threads.
@@ -462,6 +598,81 @@ __device__ __forceinline__ void fold_vec_lds(const float (&v)[NV], float* __rest
       for (int j = 0; j < NV; ++j) {
         float* dst = img + 64 * j + lane;
         *dst = (w == 0) ? v[j] : (*dst + v[j]);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+
+// ---- workgroup-distributed weight gradients -------------------------------------
+// dW (32 NI x 32 NJ) = sum over rows of G (x) X.  Instead of every wave holding all
+// NI*NJ accumulator blocks for its own tile (128+ registers), the 4 waves of the
+// workgroup run in lockstep: each wave publishes its G / X tiles in LDS, then
+// accumulates only ITS blocks over all four tiles.  With fewer than 4 blocks the
+// tiles are split between the waves that share a block.  MAXB = max(1, NI*NJ/4).
+template <int NI, int NJ>
+struct DwMap {
+  static constexpr int NBLK = NI * NJ;
+  static constexpr int MAXB = NBLK >= 4 ? NBLK / 4 : 1;
+  static_assert(NBLK == 1 || NBLK == 2 || NBLK % 4 == 0, "unsupported block count");
+  __device__ static __forceinline__ int block(int wave, int m) {
+    return NBLK >= 4 ? wave + 4 * m : (NBLK == 2 ? (wave & 1) : 0);
+  }
+  __device__ static __forceinline__ int tile_first(int wave) {
+    return NBLK >= 4 ? 0 : (NBLK == 2 ? (wave >> 1) : wave);
+  }
+  __device__ static __forceinline__ int tile_step() { return NBLK >= 4 ? 1 : (NBLK == 2 ? 2 : 4); }
+};
+
+// Gbase / Xbase: tile of wave 0; wave w2's tile is at + w2 * wstride floats.
+// Call between two __syncthreads() (tiles published / tiles free again).
+template <int NI, int NJ, int MAXB>
+__device__ __forceinline__ void dw_accumulate(f32x16 (&acc)[MAXB],
+                                              const float* __restrict__ Gbase, int ldg,
+                                              const float* __restrict__ Xbase, int ldx,
+                                              int wstride, int wave, int lane) {
+  using M = DwMap<NI, NJ>;
+  static_assert(MAXB == M::MAXB, "accumulator array size");
+  const int i = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int m = 0; m < M::MAXB; ++m) {
+    const int bid = M::block(wave, m);
+    const int gcol = 32 * (bid / NJ) + i, xcol = 32 * (bid % NJ) + i;
+    for (int w2 = M::tile_first(wave); w2 < 4; w2 += M::tile_step()) {
+      const float* G = Gbase + w2 * wstride;
+      const float* X = Xbase + w2 * wstride;
+#pragma unroll
+      for (int s = 0; s < NLAM_TILE / 2; ++s) {
+        const int t = 2 * s + h;
+        acc[m] = mfma32(G[t * ldg + gcol], X[t * ldx + xcol], acc[m]);
+      }
+    }
+  }
+}
+
+// Sum the waves' blocks into an LDS image [32 NI][ldimg] in wave order (fixed order
+// => deterministic).  All 256 threads; img must not alias live data.
+template <int NI, int NJ, int MAXB>
+__device__ __forceinline__ void dw_fold(const f32x16 (&acc)[MAXB],
+                                        float* __restrict__ img, int ldimg, int tid, int wave,
+                                        int lane) {
+  using M = DwMap<NI, NJ>;
+  static_assert(MAXB == M::MAXB, "accumulator array size");
+  for (int idx = tid; idx < 32 * NI * ldimg; idx += 256) img[idx] = 0.f;
+  __syncthreads();
+  const int h = lane >> 5, j = lane & 31;
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int m = 0; m < M::MAXB; ++m) {
+        const int bid = M::block(wave, m);
+        const int ib = bid / NJ, jb = bid % NJ;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = 32 * ib + 8 * (r >> 2) + 4 * h + (r & 3);
+          img[i * ldimg + 32 * jb + j] += acc[m][r];
+        }
       }
     }
     __syncthreads();

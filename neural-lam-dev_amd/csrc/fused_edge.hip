@@ -37,8 +37,35 @@ struct EdgeFwdParams {
   int B;
 };
 
+
+// Per-tile indices, loaded unconditionally (padded slots use CSR position 0, whose
+// rows exist) so that the loads of the NEXT tile can be issued one iteration ahead.
+struct TileCtx {
+  int p0, ne, r0, nr;   // wave-uniform
+  int eid, snd, rcv;    // slot t = lane & 31
+  int rp;               // lane i <= nr: csr_rowptr[r0 + i] - p0
+  float invd;           // lane i <  nr: inv_deg[r0 + i] (1 if unused)
+};
+__device__ __forceinline__ TileCtx load_tile_ctx(const EdgeFwdParams& p, int4 hdr, int lane) {
+  TileCtx c;
+  c.p0 = hdr.x; c.ne = hdr.y - hdr.x; c.r0 = hdr.z; c.nr = hdr.w - hdr.z;
+  const int t = lane & 31;
+  const int pos = (t < c.ne) ? c.p0 + t : 0;
+  c.eid = p.csr_eid[pos];
+  c.snd = p.csr_send[pos];
+  c.rcv = p.csr_rec[pos];
+  const int ri = c.r0 + (lane < c.nr ? lane : c.nr);
+  c.rp = p.csr_rowptr[ri] - c.p0;
+  c.invd = p.inv_deg ? p.inv_deg[c.r0 + (lane < c.nr ? lane : 0)] : 1.0f;
+  return c;
+}
+__device__ __forceinline__ int4 load_tile_hdr(const EdgeFwdParams& p, unsigned tt, unsigned total) {
+  const unsigned q = tt < total ? tt : total - 1;
+  return reinterpret_cast<const int4*>(p.tiles)[q % (unsigned)p.ntiles];
+}
+
 template <int D, bool HAS_EGEMM>
-__global__ __launch_bounds__(256) void edge_fwd_kernel(EdgeFwdParams p) {
+__global__ __launch_bounds__(256, 2) void edge_fwd_kernel(EdgeFwdParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NB = D / 32;
   constexpr int LDW = D + 4, LDT = D + 4;
@@ -56,41 +83,44 @@ __global__ __launch_bounds__(256) void edge_fwd_kernel(EdgeFwdParams p) {
   load_vec_lds(bs, p.beta, D, D, tid, 256);
   __syncthreads();
 
-  const int64_t total = p.ntiles * p.B;
-  const int t = lane & 31;
-  for (int64_t tt = (int64_t)blockIdx.x * 4 + wave; tt < total; tt += (int64_t)gridDim.x * 4) {
-    const int64_t b = tt / p.ntiles;
-    const int64_t ti = tt - b * p.ntiles;
-    const int4 tl = reinterpret_cast<const int4*>(p.tiles)[ti];
-    const int p0 = tl.x, ne = tl.y - tl.x, r0 = tl.z, nr = tl.w - tl.z;
-    // per-slot indices: lane (t, *) holds those of slot t
-    int eid = 0, snd = 0, rcv = 0;
-    if (t < ne) {
-      eid = p.csr_eid[p0 + t];
-      snd = p.csr_send[p0 + t];
-      rcv = p.csr_rec[p0 + t];
-    }
-    const float* eb = p.e.ptr + b * p.e.bstride;
-    const float* psb = p.ps.ptr + b * p.ps.bstride;
-    const float* prb = p.pr.ptr + b * p.pr.bstride;
+  constexpr int NV = D / 8;
+  const unsigned total = (unsigned)(p.ntiles * p.B);
+  const unsigned stride = gridDim.x * 4;
+  unsigned tt = blockIdx.x * 4 + wave;
+  if (tt >= total) return;
+  TileCtx cur = load_tile_ctx(p, load_tile_hdr(p, tt, total), lane);
+  int4 hdr_n = load_tile_hdr(p, tt + stride, total);
+  for (; tt < total; tt += stride) {
+    const unsigned b = tt / (unsigned)p.ntiles;
+    const int p0 = cur.p0, ne = cur.ne, r0 = cur.r0, nr = cur.nr;
+    const int eid = cur.eid, snd = cur.snd, rcv = cur.rcv;
+    const float* eb = p.e.ptr + (int64_t)b * p.e.bstride;
+    const float* psb = p.ps.ptr + (int64_t)b * p.ps.bstride;
+    const float* prb = p.pr.ptr + (int64_t)b * p.pr.bstride;
     auto e_row = [&](int s) { return eb + (int64_t)__shfl(eid, s, 64) * p.e.ld; };
     auto ps_row = [&](int s) { return psb + (int64_t)__shfl(snd, s, 64) * p.ps.ld; };
     auto pr_row = [&](int s) { return prb + (int64_t)__shfl(rcv, s, 64) * p.pr.ld; };
+    // all row gathers of this tile in flight together, then the next tile's indices
+    f32x4 vE[NV], vS[NV], vR[NV];
+    load_rows_v<NV>(vE, D, lane, e_row);
+    load_rows_v<NV>(vS, D, lane, ps_row);
+    load_rows_v<NV>(vR, D, lane, pr_row);
+    const TileCtx nxt = load_tile_ctx(p, hdr_n, lane);
+    const int4 hdr_nn = load_tile_hdr(p, tt + 2 * stride, total);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) vS[k] += vR[k];
 
     f32x16 a1[NB], ebuf[NB];
     if (HAS_EGEMM) {
-      stage_rows<true, false>(tile, LDT, 0, D, ne, lane, e_row);
+      put_rows_v<NV, false>(tile, LDT, 0, D, ne, lane, vE);
       wave_sync();
       tile_to_acc<NB>(ebuf, tile, LDT, lane);
       wave_sync();
-      stage_rows<true, false>(tile, LDT, 0, D, ne, lane, ps_row);
     } else {
-      stage_rows<true, false>(tile, LDT, 0, D, ne, lane, e_row);   // Pe rows
-      wave_sync();
-      stage_rows<true, true>(tile, LDT, 0, D, ne, lane, ps_row);
+#pragma unroll
+      for (int k = 0; k < NV; ++k) vS[k] += vE[k];     // Pe + Ps + Pr
     }
-    wave_sync();
-    stage_rows<true, true>(tile, LDT, 0, D, ne, lane, pr_row);
+    put_rows_v<NV, false>(tile, LDT, 0, D, ne, lane, vS);
     wave_sync();
     tile_to_acc<NB>(a1, tile, LDT, lane);
     if (HAS_EGEMM) gemm_acc<NB, NB>(a1, W1s, LDW, 0, ebuf, lane);
@@ -108,12 +138,10 @@ __global__ __launch_bounds__(256) void edge_fwd_kernel(EdgeFwdParams p) {
     acc_to_tile<NB>(m, tile, LDT, lane);
     wave_sync();
     {
-      int rp = 0;
-      if (lane <= nr) rp = p.csr_rowptr[r0 + lane] - p0;
-      float* ab = p.agg + b * p.agg_bstride;
+      float* ab = p.agg + (int64_t)b * p.agg_bstride;
       for (int i = 0; i < nr; ++i) {
-        const int beg = __shfl(rp, i, 64), end = __shfl(rp, i + 1, 64);
-        const float sc = p.inv_deg ? p.inv_deg[r0 + i] : 1.0f;
+        const int beg = __shfl(cur.rp, i, 64), end = __shfl(cur.rp, i + 1, 64);
+        const float sc = __shfl(cur.invd, i, 64);
 #pragma unroll
         for (int f0 = 0; f0 < D; f0 += 64) {
           float acc = 0.f;
@@ -130,11 +158,13 @@ __global__ __launch_bounds__(256) void edge_fwd_kernel(EdgeFwdParams p) {
       wave_sync();
       acc_to_tile<NB>(ebuf, tile, LDT, lane);
       wave_sync();
-      float* ob = p.e_out + b * p.eo_bstride;
+      float* ob = p.e_out + (int64_t)b * p.eo_bstride;
       auto o_row = [&](int s) { return ob + (int64_t)__shfl(eid, s, 64) * p.eo_ld; };
       store_rows<true>(tile, LDT, 0, D, ne, lane, o_row);
     }
     wave_sync();
+    cur = nxt;
+    hdr_n = hdr_nn;
   }
 }
 
@@ -217,15 +247,20 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NB = D / 32, NV = D / 64;
   constexpr int LDW = D + 4, LDT = D + 4;
+  constexpr int NVR = D / 8;
+  constexpr int WSTRIDE = 3 * NLAM_TILE * LDT;
   const EdgeFwdParams& p = q.f;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float* W1s = smem;
   float* W2s = W1s + (HAS_EGEMM ? D * LDW : 0);
   float* b2s = W2s + D * LDW;
   float* gs = b2s + D;
-  float* T0 = gs + D + wave * (3 * NLAM_TILE * LDT);
-  float* T1 = T0 + NLAM_TILE * LDT;
-  float* T2 = T1 + NLAM_TILE * LDT;
+  float* T0base = gs + D;
+  float* T1base = T0base + NLAM_TILE * LDT;
+  float* T2base = T1base + NLAM_TILE * LDT;
+  float* T0 = T0base + wave * WSTRIDE;
+  float* T1 = T1base + wave * WSTRIDE;
+  float* T2 = T2base + wave * WSTRIDE;
   if (HAS_EGEMM) load_weight_lds(W1s, p.W1e, p.ldW1e, D, D, D, D, tid, 256);
   load_weight_lds(W2s, p.W2, p.ldW2, D, D, D, D, tid, 256);
   load_vec_lds(b2s, p.b2, D, D, tid, 256);
@@ -243,40 +278,73 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
 #pragma unroll
   for (int j = 0; j < NV; ++j) db2[j] = dgam[j] = dbet[j] = 0.f;
 
-  const int64_t total = p.ntiles * p.B;
+  const unsigned total = (unsigned)(p.ntiles * p.B);
+  const unsigned stride = gridDim.x * 4;
   const int t = lane & 31, hh = lane >> 5;
-  for (int64_t tt = (int64_t)blockIdx.x * 4 + wave; tt < total; tt += (int64_t)gridDim.x * 4) {
-    const int64_t b = tt / p.ntiles;
-    const int64_t ti = tt - b * p.ntiles;
-    const int4 tl = reinterpret_cast<const int4*>(p.tiles)[ti];
-    const int p0 = tl.x, ne = tl.y - tl.x, r0 = tl.z, nr = tl.w - tl.z;
-    int eid = 0, snd = 0, rcv = 0;
-    if (t < ne) {
-      eid = p.csr_eid[p0 + t];
-      snd = p.csr_send[p0 + t];
-      rcv = p.csr_rec[p0 + t];
-    }
-    const float* eb = p.e.ptr + b * p.e.bstride;
-    const float* psb = p.ps.ptr + b * p.ps.bstride;
-    const float* prb = p.pr.ptr + b * p.pr.bstride;
+  const bool has_geo = HAS_EGEMM && q.g_eout != nullptr;
+  unsigned tt = blockIdx.x * 4 + wave;
+  TileCtx cur = load_tile_ctx(p, load_tile_hdr(p, tt, total), lane);
+  int4 hdr_n = load_tile_hdr(p, tt + stride, total);
+  for (; tt < total; tt += stride) {
+    const unsigned b = tt / (unsigned)p.ntiles;
+    const int p0 = cur.p0, r0 = cur.r0;
+    const int ne = cur.ne, nr = cur.nr;
+    const int eid = cur.eid, snd = cur.snd, rcv = cur.rcv;
+    const float* eb = p.e.ptr + (int64_t)b * p.e.bstride;
+    const float* psb = p.ps.ptr + (int64_t)b * p.ps.bstride;
+    const float* prb = p.pr.ptr + (int64_t)b * p.pr.bstride;
+    const float* gab = q.g_agg.ptr + (int64_t)b * q.g_agg.bstride;
+    const float* gob = has_geo ? q.g_eout + (int64_t)b * q.geo_bstride : eb;
+    const int64_t gold = has_geo ? q.geo_ld : p.e.ld;
     auto e_row = [&](int s) { return eb + (int64_t)__shfl(eid, s, 64) * p.e.ld; };
     auto ps_row = [&](int s) { return psb + (int64_t)__shfl(snd, s, 64) * p.ps.ld; };
     auto pr_row = [&](int s) { return prb + (int64_t)__shfl(rcv, s, 64) * p.pr.ld; };
+    auto ga_row = [&](int s) { return gab + (int64_t)__shfl(rcv, s, 64) * q.g_agg.ld; };
+    auto go_row = [&](int s) { return gob + (int64_t)__shfl(eid, s, 64) * gold; };
+    // every gather of this tile in flight together; then the next tile's indices
+    f32x4 vE[NVR], vS[NVR], vR[NVR], vG[NVR], vO[NVR];
+    load_rows_v<NVR>(vE, D, lane, e_row);
+    load_rows_v<NVR>(vS, D, lane, ps_row);
+    load_rows_v<NVR>(vR, D, lane, pr_row);
+    load_rows_v<NVR>(vG, D, lane, ga_row);
+    if (has_geo) load_rows_v<NVR>(vO, D, lane, go_row);
+    const TileCtx nxt = load_tile_ctx(p, hdr_n, lane);
+    const int4 hdr_nn = load_tile_hdr(p, tt + 2 * stride, total);
 
     // ---- recompute forward: hpre, sact, xhat
+#pragma unroll
+    for (int k = 0; k < NVR; ++k) vS[k] += vR[k];
     f32x16 hpre[NB];
     if (HAS_EGEMM) {
-      stage_rows<true, false>(T0, LDT, 0, D, ne, lane, e_row);        // E stays in T0
-      stage_rows<true, false>(T1, LDT, 0, D, ne, lane, ps_row);
+      put_rows_v<NVR, false>(T0, LDT, 0, D, ne, lane, vE);       // E stays in T0
     } else {
-      stage_rows<true, false>(T1, LDT, 0, D, ne, lane, e_row);        // Pe rows
-      wave_sync();
-      stage_rows<true, true>(T1, LDT, 0, D, ne, lane, ps_row);
+#pragma unroll
+      for (int k = 0; k < NVR; ++k) vS[k] += vE[k];              // Pe + Ps + Pr
     }
-    wave_sync();
-    stage_rows<true, true>(T1, LDT, 0, D, ne, lane, pr_row);
+    put_rows_v<NVR, false>(T1, LDT, 0, D, ne, lane, vS);
+    put_rows_v<NVR, false>(T2, LDT, 0, D, ne, lane, vG);         // g_agg rows
     wave_sync();
     tile_to_acc<NB>(hpre, T1, LDT, lane);
+    f32x16 g[NB];
+    tile_to_acc<NB>(g, T2, LDT, lane);
+    if (p.inv_deg != nullptr) {
+      const float sc = (t < ne) ? p.inv_deg[rcv] : 0.f;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g[nb][r] *= sc;
+    }
+    f32x16 geo[NB];
+    if (has_geo) {
+      wave_sync();
+      put_rows_v<NVR, false>(T2, LDT, 0, D, ne, lane, vO);
+      wave_sync();
+      tile_to_acc<NB>(geo, T2, LDT, lane);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g[nb][r] += geo[nb][r];
+    }
     if (HAS_EGEMM) gemm_tile<NB>(hpre, W1s, LDW, T0, LDT, D / 8, lane);
     f32x16 sact[NB];
 #pragma unroll
@@ -288,35 +356,6 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
     gemm_acc<NB, NB>(z, W2s, LDW, 0, sact, lane);
     float mean, rstd;
     ln_stats<NB>(z, mean, rstd);
-
-    // ---- message gradient gm = scale * g_agg[rec] (+ g_eout)
-    const float* gab = q.g_agg.ptr + b * q.g_agg.bstride;
-    auto ga_row = [&](int s) { return gab + (int64_t)__shfl(rcv, s, 64) * q.g_agg.ld; };
-    wave_sync();
-    stage_rows<true, false>(T1, LDT, 0, D, ne, lane, ga_row);
-    wave_sync();
-    f32x16 g[NB];
-    tile_to_acc<NB>(g, T1, LDT, lane);
-    if (p.inv_deg != nullptr) {
-      const float sc = (t < ne) ? p.inv_deg[rcv] : 0.f;
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) g[nb][r] *= sc;
-    }
-    f32x16 geo[NB];
-    const bool has_geo = HAS_EGEMM && q.g_eout != nullptr;
-    if (has_geo) {
-      const float* gob = q.g_eout + b * q.geo_bstride;
-      auto go_row = [&](int s) { return gob + (int64_t)__shfl(eid, s, 64) * q.geo_ld; };
-      stage_rows<true, false>(T2, LDT, 0, D, ne, lane, go_row);
-      wave_sync();
-      tile_to_acc<NB>(geo, T2, LDT, lane);
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) g[nb][r] += geo[nb][r];
-    }
     // dbeta from the final gm tile
     wave_sync();
     acc_to_tile<NB>(g, T1, LDT, lane);
@@ -344,7 +383,6 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
             s2 += gv * xh;
           }
         }
-      wave_sync();
       acc_to_tile<NB>(prod, T2, LDT, lane);
     }
     s1 += __shfl_xor(s1, 32, 64);
@@ -356,14 +394,14 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) g[nb][r] = rstd * (g[nb][r] - m1 - z[nb][r] * m2);
-    // g = gz (zero on padded slots: their gm rows were staged as zeros)
+    // g = gz (zero on padded slots).  Publish GZ (T1) and S (T2) for the dW2 blocks.
     wave_sync();
-    acc_to_tile<NB>(g, T1, LDT, lane);        // GZ
-    acc_to_tile<NB>(sact, T2, LDT, lane);     // S
+    acc_to_tile<NB>(g, T1, LDT, lane);
+    acc_to_tile<NB>(sact, T2, LDT, lane);
     wave_sync();
     tile_colsum<NV>(db2, T1, LDT, 0, ne, lane);
     outer_accum<NB, NB>(dW2, T1, LDT, 0, T2, LDT, 0, lane);
-    // gh = (W2^T gz) * silu'(h)
+    // gh = (W2^T gz) * silu'(h)   (registers + weights only)
     f32x16 gh[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
@@ -378,15 +416,13 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
     acc_to_tile<NB>(gh, T1, LDT, lane);       // GH
     wave_sync();
     {
-      float* ghb = q.gh_out + b * q.gh_bstride + (int64_t)p0 * D;
+      float* ghb = q.gh_out + (int64_t)b * q.gh_bstride + (int64_t)p0 * D;
       auto gh_row = [&](int s) { return ghb + (int64_t)s * D; };
       store_rows<true>(T1, LDT, 0, D, ne, lane, gh_row);
       // receiver-side sum of gh (segments are tile-local)
-      int rp = 0;
-      if (lane <= nr) rp = p.csr_rowptr[r0 + lane] - p0;
-      float* gb = q.gpr + b * q.gpr_bstride;
+      float* gb = q.gpr + (int64_t)b * q.gpr_bstride;
       for (int i = 0; i < nr; ++i) {
-        const int beg = __shfl(rp, i, 64), end = __shfl(rp, i + 1, 64);
+        const int beg = __shfl(cur.rp, i, 64), end = __shfl(cur.rp, i + 1, 64);
 #pragma unroll
         for (int f0 = 0; f0 < D; f0 += 64) {
           float acc = 0.f;
@@ -406,11 +442,13 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
       wave_sync();
       acc_to_tile<NB>(ge, T2, LDT, lane);
       wave_sync();
-      float* ob = q.g_e + b * q.ge_bstride;
+      float* ob = q.g_e + (int64_t)b * q.ge_bstride;
       auto o_row = [&](int s) { return ob + (int64_t)__shfl(eid, s, 64) * q.ge_ld; };
       store_rows<true>(T2, LDT, 0, D, ne, lane, o_row);
     }
     wave_sync();
+    cur = nxt;
+    hdr_n = hdr_nn;
   }
 
   __syncthreads();

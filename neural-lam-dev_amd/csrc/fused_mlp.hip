@@ -36,10 +36,12 @@ __device__ __forceinline__ int mlp_ldt(int k_pad) {
 }
 
 template <int HID, int NOUTB, bool HAS_LN>
-__global__ __launch_bounds__(256) void mlp_fwd_kernel(MlpParams p) {
+__global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(MlpParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NBH = HID / 32;
+  constexpr int NVS = HID / 8;   // float4 per lane per source (source width <= HID)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool fast_stage = (p.vec_mask & 1) && (p.nsrc == 1 || ((p.vec_mask >> 1) & 1));
   const int ldw1 = p.k_pad + 4, ldw2 = HID + 4;
   const int ldt = mlp_ldt<HID, NOUTB>(p.k_pad);
   float* W1s = smem;
@@ -64,22 +66,19 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(MlpParams p) {
     const int64_t b = tt / tiles_per_b;
     const int64_t r0 = (tt - b * tiles_per_b) * NLAM_TILE;
     const int nrows = (int)((p.rows - r0) < NLAM_TILE ? (p.rows - r0) : NLAM_TILE);
-    // stage [x_a | x_b] rows
-    int col = 0;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      if (s < p.nsrc) {
-        const RowView v = p.src[s];
-        const float* base = v.ptr + b * v.bstride + r0 * v.ld;
-        auto rp = [&](int t) { return base + (int64_t)t * v.ld; };
-        if ((p.vec_mask >> s) & 1)
-          stage_rows<true, false>(tile, ldt, col, v.width, nrows, lane, rp);
-        else
-          stage_rows<false, false>(tile, ldt, col, v.width, nrows, lane, rp);
-        col += v.width;
-      }
+    // stage [x_a | x_b] rows: both sources' loads in flight before the LDS writes
+    if (fast_stage) {
+      f32x4 va[NVS], vb[NVS];
+      view_load_v<NVS>(va, p.src[0], b, r0, nrows, lane);
+      if (p.nsrc > 1) view_load_v<NVS>(vb, p.src[1], b, r0, nrows, lane);
+      put_rows_v<NVS, false>(tile, ldt, 0, p.src[0].width, nrows, lane, va);
+      if (p.nsrc > 1)
+        put_rows_v<NVS, false>(tile, ldt, p.src[0].width, p.src[1].width, nrows, lane, vb);
+    } else {
+      view_stage_s(tile, ldt, 0, p.src[0], b, r0, nrows, lane);
+      if (p.nsrc > 1) view_stage_s(tile, ldt, p.src[0].width, p.src[1], b, r0, nrows, lane);
     }
-    if (p.k_pad > col) zero_cols(tile, ldt, col, p.k_pad - col, lane);
+    if (p.k_pad > p.k_in) zero_cols(tile, ldt, p.k_in, p.k_pad - p.k_in, lane);
     wave_sync();
 
     f32x16 a1[NBH];
@@ -203,7 +202,7 @@ struct LinParams {
 };
 
 template <int NOUTB>
-__global__ __launch_bounds__(256) void lin_fwd_kernel(LinParams p) {
+__global__ __launch_bounds__(256, 2) void lin_fwd_kernel(LinParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ldw = p.k_pad + 4;
@@ -226,12 +225,13 @@ __global__ __launch_bounds__(256) void lin_fwd_kernel(LinParams p) {
     const int64_t b = tt / tiles_per_b;
     const int64_t r0 = (tt - b * tiles_per_b) * NLAM_TILE;
     const int nrows = (int)((p.rows - r0) < NLAM_TILE ? (p.rows - r0) : NLAM_TILE);
-    const float* base = p.x.ptr + b * p.x.bstride + r0 * p.x.ld;
-    auto rp = [&](int t) { return base + (int64_t)t * p.x.ld; };
-    if (p.vec_mask & 1)
-      stage_rows<true, false>(tile, ldt, 0, p.x.width, nrows, lane, rp);
-    else
-      stage_rows<false, false>(tile, ldt, 0, p.x.width, nrows, lane, rp);
+    if (p.vec_mask & 1) {
+      f32x4 vx[16];
+      view_load_v<16>(vx, p.x, b, r0, nrows, lane);
+      put_rows_v<16, false>(tile, ldt, 0, p.x.width, nrows, lane, vx);
+    } else {
+      view_stage_s(tile, ldt, 0, p.x, b, r0, nrows, lane);
+    }
     if (p.k_pad > p.x.width) zero_cols(tile, ldt, p.x.width, p.k_pad - p.x.width, lane);
     wave_sync();
     f32x16 a[NOUTB];
@@ -319,18 +319,22 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpBwdParams q) {
   constexpr int NBH = HID / 32;
   constexpr int KP32 = 32 * KB;
   constexpr int NV_H = (HID + 63) / 64, NV_O = (32 * NOUTB + 63) / 64;
+  constexpr int NVS = HID / 8;
   const MlpParams& p = q.f;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int ldw1 = KP32 + 4, ldw2 = HID + 4;
-  constexpr int ldt0 = (KP32 > HID ? KP32 : HID) + 4;            // X / S / GX tile
+  constexpr int ldt0 = (KP32 > HID ? KP32 : HID) + 4;              // X / S / GX tile
   constexpr int ldt1 = (HID > 32 * NOUTB ? HID : 32 * NOUTB) + 4;  // GY / GZ / GA tile
+  constexpr int WSTRIDE = NLAM_TILE * (ldt0 + ldt1);
   float* W1s = smem;
   float* W2s = W1s + HID * ldw1;
   float* b1s = W2s + 32 * NOUTB * ldw2;
   float* b2s = b1s + HID;
   float* gs = b2s + 32 * NOUTB;
-  float* T0 = gs + 32 * NOUTB + wave * (NLAM_TILE * (ldt0 + ldt1));
-  float* T1 = T0 + NLAM_TILE * ldt0;
+  float* T0base = gs + 32 * NOUTB;
+  float* T1base = T0base + NLAM_TILE * ldt0;
+  float* T0 = T0base + wave * WSTRIDE;
+  float* T1 = T1base + wave * WSTRIDE;
 
   load_weight_lds(W1s, p.W1, p.ldW1, HID, p.k_in, HID, KP32, tid, 256);
   load_weight_lds(W2s, p.W2, p.ldW2, p.n_out, HID, 32 * NOUTB, HID, tid, 256);
@@ -358,22 +362,20 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpBwdParams q) {
 #pragma unroll
   for (int j = 0; j < NV_O; ++j) db2[j] = dgam[j] = dbet[j] = 0.f;
 
+  const bool fast_stage = (p.vec_mask & 1) && (p.nsrc == 1 || ((p.vec_mask >> 1) & 1));
   auto stage_x = [&](int64_t b, int64_t r0, int nrows) {
-    int col = 0;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      if (s < p.nsrc) {
-        const RowView v = p.src[s];
-        const float* base = v.ptr + b * v.bstride + r0 * v.ld;
-        auto rp = [&](int t) { return base + (int64_t)t * v.ld; };
-        if ((p.vec_mask >> s) & 1)
-          stage_rows<true, false>(T0, ldt0, col, v.width, nrows, lane, rp);
-        else
-          stage_rows<false, false>(T0, ldt0, col, v.width, nrows, lane, rp);
-        col += v.width;
-      }
+    if (fast_stage) {
+      f32x4 va[NVS], vb[NVS];
+      view_load_v<NVS>(va, p.src[0], b, r0, nrows, lane);
+      if (p.nsrc > 1) view_load_v<NVS>(vb, p.src[1], b, r0, nrows, lane);
+      put_rows_v<NVS, false>(T0, ldt0, 0, p.src[0].width, nrows, lane, va);
+      if (p.nsrc > 1)
+        put_rows_v<NVS, false>(T0, ldt0, p.src[0].width, p.src[1].width, nrows, lane, vb);
+    } else {
+      view_stage_s(T0, ldt0, 0, p.src[0], b, r0, nrows, lane);
+      if (p.nsrc > 1) view_stage_s(T0, ldt0, p.src[0].width, p.src[1], b, r0, nrows, lane);
     }
-    if (KP32 > col) zero_cols(T0, ldt0, col, KP32 - col, lane);
+    if (KP32 > p.k_in) zero_cols(T0, ldt0, p.k_in, KP32 - p.k_in, lane);
   };
 
   const int64_t tiles_per_b = (p.rows + NLAM_TILE - 1) / NLAM_TILE;
@@ -381,9 +383,18 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpBwdParams q) {
   for (int64_t tt = (int64_t)blockIdx.x * 4 + wave; tt < ntiles; tt += (int64_t)gridDim.x * 4) {
     const int64_t b = tt / tiles_per_b;
     const int64_t r0 = (tt - b * tiles_per_b) * NLAM_TILE;
-    const int nrows = (int)((p.rows - r0) < NLAM_TILE ? (p.rows - r0) : NLAM_TILE);
-    // ---- recompute forward
+    const int nfull = (int)((p.rows - r0) < NLAM_TILE ? (p.rows - r0) : NLAM_TILE);
+    const int nrows = nfull;
+    // ---- recompute forward; gy rows go to T1 right away (latencies overlap)
     stage_x(b, r0, nrows);
+    if (q.vec_gy) {
+      f32x4 vg[NVS];
+      view_load_v<NVS>(vg, q.gy, b, r0, nfull, lane);
+      put_rows_v<NVS, false>(T1, ldt1, 0, p.n_out, nrows, lane, vg);
+    } else {
+      view_stage_s(T1, ldt1, 0, q.gy, b, r0, nrows, lane);
+    }
+    if (32 * NOUTB > p.n_out) zero_cols(T1, ldt1, p.n_out, 32 * NOUTB - p.n_out, lane);
     wave_sync();
     f32x16 hpre[NBH];
     vec_to_acc<NBH>(hpre, b1s, lane);
@@ -393,15 +404,6 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpBwdParams q) {
     for (int nb = 0; nb < NBH; ++nb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) sact[nb][r] = nlam_silu(hpre[nb][r]);
-    // ---- output gradient
-    const float* gyb = q.gy.ptr + b * q.gy.bstride + r0 * q.gy.ld;
-    auto gyp = [&](int t) { return gyb + (int64_t)t * q.gy.ld; };
-    if (q.vec_gy)
-      stage_rows<true, false>(T1, ldt1, 0, p.n_out, nrows, lane, gyp);
-    else
-      stage_rows<false, false>(T1, ldt1, 0, p.n_out, nrows, lane, gyp);
-    if (32 * NOUTB > p.n_out) zero_cols(T1, ldt1, p.n_out, 32 * NOUTB - p.n_out, lane);
-    wave_sync();
     f32x16 g[NOUTB];
     tile_to_acc<NOUTB>(g, T1, ldt1, lane);
     if (HAS_LN) {
@@ -444,18 +446,15 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpBwdParams q) {
       for (int nb = 0; nb < NOUTB; ++nb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) g[nb][r] = rstd * (g[nb][r] - m1 - z[nb][r] * m2);
-      wave_sync();
     }
-    // g is now gz.  Padded rows (t >= nrows) carry gy = 0 => gz = 0 there only
-    // without LN; with LN gz of a zero gy row is 0 as well (g gamma = 0, m1 = m2 = 0).
-    acc_to_tile<NOUTB>(g, T1, ldt1, lane);          // GZ
+    // g is gz (zero on padded rows).  Publish GZ (T1) and S (T0) for the dW2 blocks.
+    wave_sync();
+    acc_to_tile<NOUTB>(g, T1, ldt1, lane);
+    acc_to_tile<NBH>(sact, T0, ldt0, lane);
     wave_sync();
     tile_colsum<NV_O>(db2, T1, ldt1, 0, nrows, lane);
-    wave_sync();
-    acc_to_tile<NBH>(sact, T0, ldt0, lane);         // S (X no longer needed)
-    wave_sync();
     outer_accum<NOUTB, NBH>(dW2, T1, ldt1, 0, T0, ldt0, 0, lane);
-    // gs = W2^T gz ; ga = gs * silu'(h)
+    // ga = (W2^T gz) * silu'(h)   (registers + weights only)
     f32x16 ga[NBH];
 #pragma unroll
     for (int nb = 0; nb < NBH; ++nb)
@@ -468,21 +467,25 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpBwdParams q) {
       for (int r = 0; r < 16; ++r) ga[nb][r] *= nlam_silu_grad(hpre[nb][r]);
     wave_sync();
     acc_to_tile<NBH>(ga, T1, ldt1, lane);           // GA
-    stage_x(b, r0, nrows);                          // X again (S consumed)
+    stage_x(b, r0, nrows);                          // X again
     wave_sync();
     tile_colsum<NV_H>(db1, T1, ldt1, 0, nrows, lane);
     outer_accum<NBH, KB>(dW1, T1, ldt1, 0, T0, ldt0, 0, lane);
-    // gx = W1^T ga
-    if (q.gxa != nullptr || q.gxb != nullptr) {
-      f32x16 gx[KB];
+    const bool want_gx = q.gxa != nullptr || q.gxb != nullptr;
+    f32x16 gx[KB];
+    if (want_gx) {
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) gx[kb][r] = 0.f;
       gemm_acc_wt<KB, NBH>(gx, W1s, ldw1, 0, ga, lane);
+    }
+    if (want_gx) {
       wave_sync();
       acc_to_tile<KB>(gx, T0, ldt0, lane);
       wave_sync();
+      const float* gyb = q.gy.ptr + b * q.gy.bstride + r0 * q.gy.ld;
+      auto gyp = [&](int t) { return gyb + (int64_t)t * q.gy.ld; };
       if (q.gxa != nullptr) {
         float* ob = q.gxa + b * q.gxa_bstride + r0 * q.gxa_ld;
         auto op = [&](int t) { return ob + (int64_t)t * q.gxa_ld; };
@@ -507,11 +510,11 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpBwdParams q) {
         else
           store_rows<false>(T0, ldt0, p.src[0].width, p.src[1].width, nrows, lane, op);
       }
+      wave_sync();
     }
-    wave_sync();
   }
 
-  // ---- fold the 4 waves' partials in LDS (fixed order) and write the slab
+  // ---- fold the waves' partials in LDS (fixed order) and write the slab
   __syncthreads();
   float* img = smem;  // weights are dead: reuse the front of LDS
   float* slab = q.slab + (int64_t)blockIdx.x * q.slab_stride;
@@ -678,10 +681,13 @@ __global__ __launch_bounds__(256) void lin_bwd_kernel(LinBwdParams q) {
   constexpr int KP32 = 32 * KB, NO = 32 * NOUTB;
   constexpr int NV = (NO + 63) / 64;
   constexpr int ldw = KP32 + 4, ldt0 = KP32 + 4, ldt1 = NO + 4;
+  constexpr int WSTRIDE = NLAM_TILE * (ldt0 + ldt1);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float* Ws = smem;
-  float* T0 = Ws + NO * ldw + wave * (NLAM_TILE * (ldt0 + ldt1));
-  float* T1 = T0 + NLAM_TILE * ldt0;
+  float* T0base = Ws + NO * ldw;
+  float* T1base = T0base + NLAM_TILE * ldt0;
+  float* T0 = T0base + wave * WSTRIDE;
+  float* T1 = T1base + wave * WSTRIDE;
   load_weight_lds(Ws, q.WA, q.ldWA, q.nA, q.x.width, q.nA, KP32, tid, 256);
   if (q.nB > 0)
     load_weight_lds(Ws + q.nA * ldw, q.WB, q.ldWB, q.nB, q.x.width, NO - q.nA, KP32, tid, 256);
@@ -703,32 +709,34 @@ __global__ __launch_bounds__(256) void lin_bwd_kernel(LinBwdParams q) {
   for (int64_t tt = (int64_t)blockIdx.x * 4 + wave; tt < ntiles; tt += (int64_t)gridDim.x * 4) {
     const int64_t b = tt / tiles_per_b;
     const int64_t r0 = (tt - b * tiles_per_b) * NLAM_TILE;
-    const int nrows = (int)((q.rows - r0) < NLAM_TILE ? (q.rows - r0) : NLAM_TILE);
-    const float* xb = q.x.ptr + b * q.x.bstride + r0 * q.x.ld;
-    auto xp = [&](int t) { return xb + (int64_t)t * q.x.ld; };
-    if (q.vec_x)
-      stage_rows<true, false>(T0, ldt0, 0, q.x.width, nrows, lane, xp);
-    else
-      stage_rows<false, false>(T0, ldt0, 0, q.x.width, nrows, lane, xp);
+    const int nfull = (int)((q.rows - r0) < NLAM_TILE ? (q.rows - r0) : NLAM_TILE);
+    const int nrows = nfull;
+    if (q.vec_x && q.vec_gy) {
+      f32x4 vx[4 * KB], vg[4 * NOUTB];
+      view_load_v<4 * KB>(vx, q.x, b, r0, nfull, lane);
+      view_load_v<4 * NOUTB>(vg, q.gy, b, r0, nfull, lane);
+      put_rows_v<4 * KB, false>(T0, ldt0, 0, q.x.width, nrows, lane, vx);
+      put_rows_v<4 * NOUTB, false>(T1, ldt1, 0, n_out, nrows, lane, vg);
+    } else {
+      view_stage_s(T0, ldt0, 0, q.x, b, r0, nrows, lane);
+      view_stage_s(T1, ldt1, 0, q.gy, b, r0, nrows, lane);
+    }
     if (KP32 > q.x.width) zero_cols(T0, ldt0, q.x.width, KP32 - q.x.width, lane);
-    const float* gb = q.gy.ptr + b * q.gy.bstride + r0 * q.gy.ld;
-    auto gp = [&](int t) { return gb + (int64_t)t * q.gy.ld; };
-    if (q.vec_gy)
-      stage_rows<true, false>(T1, ldt1, 0, n_out, nrows, lane, gp);
-    else
-      stage_rows<false, false>(T1, ldt1, 0, n_out, nrows, lane, gp);
     if (NO > n_out) zero_cols(T1, ldt1, n_out, NO - n_out, lane);
     wave_sync();
     tile_colsum<NV>(db, T1, ldt1, 0, nrows, lane);
     outer_accum<NOUTB, KB>(dW, T1, ldt1, 0, T0, ldt0, 0, lane);
+    f32x16 gx[KB];
     if (q.gx != nullptr) {
-      f32x16 g[NOUTB], gx[KB];
+      f32x16 g[NOUTB];
       tile_to_acc<NOUTB>(g, T1, ldt1, lane);
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) gx[kb][r] = 0.f;
       gemm_acc_wt<KB, NOUTB>(gx, Ws, ldw, 0, g, lane);
+    }
+    if (q.gx != nullptr) {
       wave_sync();
       acc_to_tile<KB>(gx, T0, ldt0, lane);
       wave_sync();
@@ -738,8 +746,8 @@ __global__ __launch_bounds__(256) void lin_bwd_kernel(LinBwdParams q) {
         store_rows<true>(T0, ldt0, 0, q.x.width, nrows, lane, op);
       else
         store_rows<false>(T0, ldt0, 0, q.x.width, nrows, lane, op);
+      wave_sync();
     }
-    wave_sync();
   }
   __syncthreads();
   float* img = smem;

@@ -184,6 +184,10 @@ MODEL_CASES = {
     "model_graphlam_multiscale": ("graph_lam", 30, 28, None, False, 16, 2, 2, 3, "wmse", "mean"),
     "model_hilam_3level": ("hi_lam", 81, 83, 3, True, 8, 2, 1, 2, "wmse", "sum"),
     "model_hilam_parallel_2level": ("hi_lam_parallel", 30, 28, 2, True, 8, 2, 1, 2, "mse", "sum"),
+    # hidden_dim 64: the shapes the fused gfx950 kernels take
+    "model_graphlam_d64": ("graph_lam", 30, 28, None, False, 64, 2, 2, 2, "wmse", "sum"),
+    "model_graphlam_d64_mean": ("graph_lam", 27, 31, None, False, 64, 1, 1, 1, "mse", "mean"),
+    "model_hilam_d64": ("hi_lam", 30, 28, 2, True, 64, 1, 2, 1, "wmse", "sum"),
 }
 
 
@@ -253,10 +257,13 @@ def make_model_case(ns, name):
 def main():
     ns = ref_shim.load()
     torch.set_num_threads(4)
+    only = set(sys.argv[1:])
     for name in OP_CASES:
-        make_op_case(ns, name)
+        if not only or name in only:
+            make_op_case(ns, name)
     for name in MODEL_CASES:
-        make_model_case(ns, name)
+        if not only or name in only:
+            make_model_case(ns, name)
 
 
 if __name__ == "__main__":
