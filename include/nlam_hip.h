@@ -264,6 +264,34 @@ int nlam_adamw_step(float* p, const float* g, float* m, float* v, int64_t n,
                     float weight_decay, int64_t step, float grad_scale,
                     void* stream);
 
+/* ------------------------------------------------------------ rollout glue --
+ * y = a + x * scale[f] + shift[f] over (rows, F): the state residual
+ * prev_state + net_out * diff_std + diff_mean (base_graph_model.py:174-177). */
+int nlam_affine_residual(const float* a, const float* x, const float* scale,
+                         const float* shift, float* y, int64_t rows, int F,
+                         void* stream);
+/* gx = g * scale[f] (its backward w.r.t. x). */
+int nlam_scale_cols(const float* g, const float* scale, float* gx, int64_t rows,
+                    int F, void* stream);
+/* out[b][n][:] = mask[n] * truth[b][n][:] + (1 - mask[n]) * pred[b][n][:], the
+ * boundary overwrite of ar_model.py:244-247; truth == NULL gives the backward
+ * g_pred = (1 - mask) * g_out. */
+int nlam_boundary_mix(const float* pred, const float* truth, const float* mask,
+                      float* out, int64_t B, int64_t N, int F, void* stream);
+/* out[0] = scale * sum_{r,f} keep[r % N] * w[f] * (pred - target)^2 over
+ * (rows, F): torch.mean over (B,T) of the masked, grid-averaged, variable-summed
+ * wmse/mse (metrics.py:21-108, ar_model.py:294-298) with keep = interior mask,
+ * w = 1/std^2, scale = 1/(n_interior * B * T).  partial: nlam_wmse_blocks()
+ * floats.  Deterministic two-stage reduction. */
+int64_t nlam_wmse_blocks(void);
+int nlam_wmse_fwd(const float* pred, const float* target, const float* keep,
+                  const float* w, float* partial, float* out, int64_t rows,
+                  int64_t N, int F, float scale, void* stream);
+/* g_pred = gloss[0] * 2 * scale * keep * w * (pred - target). */
+int nlam_wmse_bwd(const float* pred, const float* target, const float* keep,
+                  const float* w, const float* gloss, float scale, float* g_pred,
+                  int64_t rows, int64_t N, int F, void* stream);
+
 /* Debug / self-test: verifies the MFMA fp32 32x32x2 operand and accumulator
  * lane maps the fused kernels rely on.  out: 32*32 floats = A(32x64) * B(64x32)
  * for the integer test pattern documented in csrc/mfma_probe.hip. */

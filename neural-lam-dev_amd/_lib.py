@@ -55,6 +55,12 @@ SIGNATURES = {
                       _i64, _p, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _p, _i64, _i64, _p, _i64,
                       _p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _i32, _p],
     "nlam_adamw_step": [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _i64, _f, _p],
+    "nlam_affine_residual": [_p, _p, _p, _p, _p, _i64, _i32, _p],
+    "nlam_scale_cols": [_p, _p, _p, _i64, _i32, _p],
+    "nlam_boundary_mix": [_p, _p, _p, _p, _i64, _i64, _i32, _p],
+    "nlam_wmse_blocks": [],
+    "nlam_wmse_fwd": [_p, _p, _p, _p, _p, _p, _i64, _i64, _i32, _f, _p],
+    "nlam_wmse_bwd": [_p, _p, _p, _p, _p, _f, _p, _i64, _i64, _i32, _p],
     "nlam_mfma_probe": [_p, _p],
 }
 _RESTYPES = {
@@ -65,6 +71,7 @@ _RESTYPES = {
     "nlam_bwd_grid": _i64,
     "nlam_lin_bwd_slab_stride": _i64,
     "nlam_edge_bwd_slab_stride": _i64,
+    "nlam_wmse_blocks": _i64,
     "nlam_mlp_bwd_slab_stride": _i64,
 }
 

@@ -36,3 +36,145 @@ extern "C" int nlam_adamw_step(float* p, const float* g, float* m, float* v, int
   NLAM_CHECK_LAUNCH("adamw");
   return 0;
 }
+
+// ---------------------------------------------------------------- rollout glue
+// y[b][n][f] = a[b][n][f] + x[b][n][f] * scale[f] + shift[f]
+//   (state = prev_state + net_out * diff_std + diff_mean, base_graph_model.py:174-177)
+__global__ void affine_residual_kernel(const float* __restrict__ a, const float* __restrict__ x,
+                                       const float* __restrict__ scale,
+                                       const float* __restrict__ shift, float* __restrict__ y,
+                                       int64_t n, int F) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int f = (int)(i % F);
+    y[i] = a[i] + x[i] * scale[f] + shift[f];
+  }
+}
+extern "C" int nlam_affine_residual(const float* a, const float* x, const float* scale,
+                                    const float* shift, float* y, int64_t rows, int F,
+                                    void* stream) {
+  const int64_t n = rows * F;
+  if (n <= 0) return 0;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  affine_residual_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(a, x, scale, shift, y,
+                                                                           n, F);
+  NLAM_CHECK_LAUNCH("affine_residual");
+  return 0;
+}
+// gx[i] = g[i] * scale[f]
+__global__ void scale_cols_kernel(const float* __restrict__ g, const float* __restrict__ scale,
+                                  float* __restrict__ gx, int64_t n, int F) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    gx[i] = g[i] * scale[(int)(i % F)];
+}
+extern "C" int nlam_scale_cols(const float* g, const float* scale, float* gx, int64_t rows, int F,
+                               void* stream) {
+  const int64_t n = rows * F;
+  if (n <= 0) return 0;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  scale_cols_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(g, scale, gx, n, F);
+  NLAM_CHECK_LAUNCH("scale_cols");
+  return 0;
+}
+
+// new[b][n][:] = mask[n] ? truth[b][n][:] : pred[b][n][:]   (mask in {0,1};
+// boundary overwrite of ar_model.py:244-247);  backward: g_pred = (1 - mask) g_new
+__global__ void boundary_mix_kernel(const float* __restrict__ pred, const float* __restrict__ truth,
+                                    const float* __restrict__ mask, float* __restrict__ out,
+                                    int64_t B, int64_t N, int F) {
+  const int64_t total = B * N * F;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t node = (i / F) % N;
+    const float m = mask[node];
+    out[i] = truth ? (m * truth[i] + (1.0f - m) * pred[i]) : (1.0f - m) * pred[i];
+  }
+}
+extern "C" int nlam_boundary_mix(const float* pred, const float* truth, const float* mask,
+                                 float* out, int64_t B, int64_t N, int F, void* stream) {
+  const int64_t n = B * N * F;
+  if (n <= 0) return 0;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  boundary_mix_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(pred, truth, mask, out, B,
+                                                                        N, F);
+  NLAM_CHECK_LAUNCH("boundary_mix");
+  return 0;
+}
+
+// ------------------------------------------------------------------------ loss
+// loss = scale * sum_{r < rows, f} w[f] * keep[r % N] * (pred - target)^2
+//   = torch.mean over (B, T) of  sum_f mean_{interior n} (pred - target)^2 / std_f^2
+// (metrics.py:21-84, ar_model.py:294-298) with keep = interior mask,
+// w = 1/std^2 and scale = 1 / (n_interior * B * T).  Two-stage fixed-order reduce.
+__global__ __launch_bounds__(256) void wmse_partial_kernel(
+    const float* __restrict__ pred, const float* __restrict__ target,
+    const float* __restrict__ keep, const float* __restrict__ w, float* __restrict__ partial,
+    int64_t rows, int64_t N, int F) {
+  __shared__ float red[256];
+  const int64_t total = rows * F;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  float s = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t r = i / F;
+    const int f = (int)(i - r * F);
+    const float d = pred[i] - target[i];
+    s += keep[r % N] * w[f] * d * d;
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+__global__ void wmse_final_kernel(const float* __restrict__ partial, int n, float scale,
+                                  float* __restrict__ out) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < n; ++i) s += partial[i];
+    out[0] = s * scale;
+  }
+}
+extern "C" int64_t nlam_wmse_blocks(void) { return 1024; }
+extern "C" int nlam_wmse_fwd(const float* pred, const float* target, const float* keep,
+                             const float* w, float* partial, float* out, int64_t rows, int64_t N,
+                             int F, float scale, void* stream) {
+  NLAM_REQUIRE(rows > 0 && N > 0 && F > 0, "wmse_fwd: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  wmse_partial_kernel<<<1024, 256, 0, s>>>(pred, target, keep, w, partial, rows, N, F);
+  NLAM_CHECK_LAUNCH("wmse_partial");
+  wmse_final_kernel<<<1, 64, 0, s>>>(partial, 1024, scale, out);
+  NLAM_CHECK_LAUNCH("wmse_final");
+  return 0;
+}
+// g_pred = gloss[0] * 2 scale keep w (pred - target)
+__global__ void wmse_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                const float* __restrict__ keep, const float* __restrict__ w,
+                                const float* __restrict__ gloss, float scale,
+                                float* __restrict__ g_pred, int64_t rows, int64_t N, int F) {
+  const int64_t total = rows * F;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const float c = 2.0f * scale * gloss[0];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t r = i / F;
+    const int f = (int)(i - r * F);
+    g_pred[i] = c * keep[r % N] * w[f] * (pred[i] - target[i]);
+  }
+}
+extern "C" int nlam_wmse_bwd(const float* pred, const float* target, const float* keep,
+                             const float* w, const float* gloss, float scale, float* g_pred,
+                             int64_t rows, int64_t N, int F, void* stream) {
+  const int64_t n = rows * F;
+  if (n <= 0) return 0;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  wmse_bwd_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(pred, target, keep, w, gloss,
+                                                                    scale, g_pred, rows, N, F);
+  NLAM_CHECK_LAUNCH("wmse_bwd");
+  return 0;
+}

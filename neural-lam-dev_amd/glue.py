@@ -1,0 +1,98 @@
+"""Device-side rollout glue of the training path as HIP kernels with autograd:
+state residual (base_graph_model.py:174-177), boundary overwrite
+(ar_model.py:244-247) and the masked wmse/mse training loss (metrics.py:21-108,
+ar_model.py:294-298).  They replace ~15 eager elementwise / indexing launches
+per AR step, including a boolean-mask gather that synchronises the host."""
+import torch
+
+from . import ops
+from ._lib import lib
+
+
+class StateResidual(torch.autograd.Function):
+    """prev_state + net_out * diff_std + diff_mean."""
+
+    @staticmethod
+    def forward(ctx, prev_state, net_out, diff_std, diff_mean):
+        prev_state, net_out = prev_state.contiguous(), net_out.contiguous()
+        ops._require_dev(net_out, "net_out")
+        y = torch.empty_like(net_out)
+        F = net_out.shape[-1]
+        ops._launch("nlam_affine_residual", lib.nlam_affine_residual,
+                    (prev_state.data_ptr(), net_out.data_ptr(), diff_std.data_ptr(),
+                     diff_mean.data_ptr(), y.data_ptr(), net_out.numel() // F, F, ops.stream()),
+                    nbytes=12.0 * net_out.numel())
+        ctx.save_for_backward(diff_std)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (diff_std,) = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = None
+        if ctx.needs_input_grad[1]:
+            gx = torch.empty_like(gy)
+            F = gy.shape[-1]
+            ops._launch("nlam_scale_cols", lib.nlam_scale_cols,
+                        (gy.data_ptr(), diff_std.data_ptr(), gx.data_ptr(), gy.numel() // F, F,
+                         ops.stream()), nbytes=8.0 * gy.numel())
+        return (gy if ctx.needs_input_grad[0] else None), gx, None, None
+
+
+class BoundaryMix(torch.autograd.Function):
+    """boundary_mask * true_state + interior_mask * pred_state (mask (N,1) in {0,1})."""
+
+    @staticmethod
+    def forward(ctx, pred, truth, mask):
+        pred, truth = pred.contiguous(), truth.contiguous()
+        ops._require_dev(pred, "pred")
+        B, N, F = pred.shape
+        out = torch.empty_like(pred)
+        ops._launch("nlam_boundary_mix", lib.nlam_boundary_mix,
+                    (pred.data_ptr(), truth.data_ptr(), mask.data_ptr(), out.data_ptr(), B, N, F,
+                     ops.stream()), nbytes=12.0 * pred.numel())
+        ctx.save_for_backward(mask)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (mask,) = ctx.saved_tensors
+        g = g.contiguous()
+        B, N, F = g.shape
+        gp = torch.empty_like(g)
+        ops._launch("nlam_boundary_mix", lib.nlam_boundary_mix,
+                    (g.data_ptr(), None, mask.data_ptr(), gp.data_ptr(), B, N, F, ops.stream()),
+                    nbytes=8.0 * g.numel())
+        return gp, None, None
+
+
+class MaskedWMSE(torch.autograd.Function):
+    """mean over the leading dims of sum_f mean_{kept n} (pred - target)^2 * w_f."""
+
+    @staticmethod
+    def forward(ctx, pred, target, keep, w, scale):
+        pred, target = pred.contiguous(), target.contiguous()
+        ops._require_dev(pred, "pred")
+        N, F = pred.shape[-2], pred.shape[-1]
+        rows = pred.numel() // F
+        partial = torch.empty(lib.nlam_wmse_blocks(), dtype=torch.float32, device=pred.device)
+        out = torch.empty(1, dtype=torch.float32, device=pred.device)
+        ops._launch("nlam_wmse_fwd", lib.nlam_wmse_fwd,
+                    (pred.data_ptr(), target.data_ptr(), keep.data_ptr(), w.data_ptr(),
+                     partial.data_ptr(), out.data_ptr(), rows, N, F, scale, ops.stream()),
+                    nbytes=8.0 * pred.numel())
+        ctx.save_for_backward(pred, target, keep, w)
+        ctx.scale = scale
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, gloss):
+        pred, target, keep, w = ctx.saved_tensors
+        N, F = pred.shape[-2], pred.shape[-1]
+        g = torch.empty_like(pred)
+        gl = gloss.reshape(1).contiguous()
+        ops._launch("nlam_wmse_bwd", lib.nlam_wmse_bwd,
+                    (pred.data_ptr(), target.data_ptr(), keep.data_ptr(), w.data_ptr(),
+                     gl.data_ptr(), ctx.scale, g.data_ptr(), pred.numel() // F, N, F,
+                     ops.stream()), nbytes=12.0 * pred.numel())
+        return g, None, None, None, None

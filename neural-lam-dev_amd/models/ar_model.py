@@ -9,7 +9,7 @@ plain nn.Module otherwise; the method names and batch layout are Lightning's.
 import torch
 from torch import nn
 
-from .. import metrics
+from .. import glue, metrics
 
 try:  # pragma: no cover - Lightning is not installed in the build image
     import pytorch_lightning as pl
@@ -103,7 +103,7 @@ class ARModel(_Base):
             pred_state, pred_std = self.predict_step(
                 prev_state, prev_prev_state, forcing_features[:, i]
             )
-            new_state = self.boundary_mask * true_states[:, i] + self.interior_mask * pred_state
+            new_state = glue.BoundaryMix.apply(pred_state, true_states[:, i], self.boundary_mask)
             prediction_list.append(new_state)
             if self.output_std:
                 pred_std_list.append(pred_std)
@@ -123,9 +123,22 @@ class ARModel(_Base):
 
     def training_step(self, batch):
         prediction, target, pred_std, _ = self.common_step(batch)
-        batch_loss = torch.mean(
-            self.loss(prediction, target, pred_std, mask=self.interior_mask_bool)
-        )
+        if not self.output_std and self.loss in (metrics.wmse, metrics.mse):
+            # fused masked loss kernel (no boolean-mask gather, no host sync)
+            if not hasattr(self, "_loss_consts") or self._loss_consts[0].device != prediction.device:
+                keep = self.interior_mask[:, 0].contiguous()
+                w = (
+                    1.0 / self.per_var_std**2 if self.loss is metrics.wmse
+                    else torch.ones_like(self.per_var_std)
+                ).contiguous()
+                self._loss_consts = (keep, w, float(keep.sum().item()))
+            keep, w, n_keep = self._loss_consts
+            lead = prediction.numel() // (prediction.shape[-1] * prediction.shape[-2])
+            batch_loss = glue.MaskedWMSE.apply(prediction, target, keep, w, 1.0 / (n_keep * lead))
+        else:
+            batch_loss = torch.mean(
+                self.loss(prediction, target, pred_std, mask=self.interior_mask_bool)
+            )
         if hasattr(self, "log_dict") and _Base is not nn.Module:
             self.log_dict({"train_loss": batch_loss}, prog_bar=True, on_step=True, on_epoch=True,
                           sync_dist=True, batch_size=batch[0].shape[0])

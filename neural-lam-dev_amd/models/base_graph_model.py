@@ -3,7 +3,7 @@ same sub-module names, construction order (=> same default-init RNG stream)
 and predict_step contract; the GNN / MLP blocks are the HIP modules."""
 import torch
 
-from .. import utils
+from .. import glue, utils
 from ..interaction_net import InteractionNet
 from .ar_model import ARModel
 
@@ -77,5 +77,7 @@ class BaseGraphModel(ARModel):
             pred_std = torch.nn.functional.softplus(pred_std_raw)
         else:
             pred_delta_mean, pred_std = net_output, None
-        rescaled_delta_mean = pred_delta_mean * self.diff_std + self.diff_mean
-        return prev_state + rescaled_delta_mean, pred_std
+        new_state = glue.StateResidual.apply(
+            prev_state, pred_delta_mean, self.diff_std, self.diff_mean
+        )
+        return new_state, pred_std
