@@ -48,14 +48,23 @@ def setup_dist(args):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = max(1, torch.cuda.device_count())
+    dev_index = local % ndev   # one rank per GPU; rehearsals may stack ranks on one card
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local))
+        torch.cuda.set_device(dev_index)
+        # RCCL ("nccl") over xGMI is the product path; NLAM_BENCH_BACKEND=gloo only exists
+        # to rehearse the multi-rank control flow on a 1-GPU box
+        backend = os.environ.get("NLAM_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
+    local = dev_index
     assert world == args.gpus or world == 1, (
         f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     )
@@ -193,9 +202,14 @@ def main():
     # launch stream); kept out of the timed region above so `value` is unperturbed
     roofline = None
     kernels = None
+    scatter = None
+    nprof = max(1, min(3, args.steps))
+    if not args.no_kernel_timing and rank != 0:
+        for _ in range(nprof):   # every rank takes part in the steps' collective
+            step()
+        torch.cuda.synchronize()
     if not args.no_kernel_timing and rank == 0:
         ops.PROFILER = ops.KernelProfiler()
-        nprof = max(1, min(3, args.steps))
         for _ in range(nprof):
             step()
         stats = ops.PROFILER.collect()
@@ -230,14 +244,11 @@ def main():
                         "avg_launch_us": st["ms"] * 1e3 / st["calls"]}
         # the scatter-add the north star names: m2m aggregate (segment-sum) launches
         agg = stats.get("nlam_segment_sum@m2m")
-        scatter = None
         if agg and agg["ms"] > 0:
             g = agg["bytes"] / (agg["ms"] / 1e3) / 1e9
             scatter = {"kernel": "nlam_segment_sum@m2m", "bound": "hbm", "achieved": g,
                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g / HBM_PEAK_GBS,
                        "avg_launch_us": agg["ms"] * 1e3 / agg["calls"]}
-    else:
-        scatter = None
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
