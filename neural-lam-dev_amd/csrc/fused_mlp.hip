@@ -546,22 +546,26 @@ extern "C" int64_t nlam_bwd_grid(int64_t ntiles) {
   return g;
 }
 
-// out[i] (+)= sum_s slab[s * stride + i], i < n: 64 elements x 4 slab subsets per
-// workgroup, combined in a fixed order (deterministic).
-__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slab,
-                                                           int64_t nslabs, int64_t stride,
-                                                           int64_t n, float* __restrict__ out,
-                                                           int accumulate) {
-  __shared__ float red[4][64];
-  const int e = threadIdx.x & 63, gsub = threadIdx.x >> 6;
-  const int64_t i = (int64_t)blockIdx.x * 64 + e;
+// out[i] (+)= sum_s slab[s * stride + i], i < n: a workgroup owns 32 consecutive
+// elements and splits the slabs over its 32 sub-groups (1024 threads keep enough
+// loads in flight for these latency-bound 10-30 MB reductions); partial sums are
+// combined in a fixed order (deterministic).
+__global__ __launch_bounds__(1024) void reduce_slabs_kernel(const float* __restrict__ slab,
+                                                            int64_t nslabs, int64_t stride,
+                                                            int64_t n, float* __restrict__ out,
+                                                            int accumulate) {
+  __shared__ float red[32][33];
+  const int e = threadIdx.x & 31, gsub = threadIdx.x >> 5;
+  const int64_t i = (int64_t)blockIdx.x * 32 + e;
   float s = 0.f;
   if (i < n)
-    for (int64_t k = gsub; k < nslabs; k += 4) s += slab[k * stride + i];
+    for (int64_t k = gsub; k < nslabs; k += 32) s += slab[k * stride + i];
   red[gsub][e] = s;
   __syncthreads();
   if (gsub == 0 && i < n) {
-    float v = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    float v = 0.f;
+#pragma unroll
+    for (int g = 0; g < 32; ++g) v += red[g][e];
     if (accumulate) v += out[i];
     out[i] = v;
   }
@@ -569,7 +573,7 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
 extern "C" int nlam_reduce_slabs(const float* slab, int64_t nslabs, int64_t stride, int64_t n,
                                  float* out, int accumulate, void* stream) {
   if (n <= 0) return 0;
-  reduce_slabs_kernel<<<(unsigned)((n + 63) / 64), 256, 0, (hipStream_t)stream>>>(
+  reduce_slabs_kernel<<<(unsigned)((n + 31) / 32), 1024, 0, (hipStream_t)stream>>>(
       slab, nslabs, stride, n, out, accumulate);
   NLAM_CHECK_LAUNCH("reduce_slabs");
   return 0;
