@@ -40,7 +40,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="skip the per-kernel HIP-event pass (roofline = null)")
-    ap.add_argument("--micro", action="store_true", help="also run the m2m layer micro-benchmarks")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="eager launches instead of replaying the captured HIP graph")
     return ap.parse_args()
 
 
@@ -176,18 +177,30 @@ def main():
         opt.step(grad_scale=gscale)
         return loss
 
+    graphed = None
+    if not args.no_graph:
+        graphed = parallel.GraphedTrainStep(model, flat, batch)
+
+        def gstep():
+            loss = graphed()
+            reducer.reduce(packed=True)
+            opt.step(grad_scale=gscale)
+            return loss
+
+    timed_step = gstep if (graphed is not None and graphed.graph is not None) else step
+
     def barrier():
         if world > 1:
             dist.barrier()
 
     for _ in range(args.warmup):
-        step()
+        timed_step()
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = step()
+        loss = timed_step()
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -274,6 +287,7 @@ def main():
                 "parallelism": f"dp{world}",
             },
             "steps_per_s": 1e3 / ms, "loss": loss_val,
+            "hip_graph": bool(graphed is not None and graphed.graph is not None),
             "roofline": roofline, "scatter_add_roofline": scatter, "cpu_baseline": cpu,
             "kernels": kernels,
         }

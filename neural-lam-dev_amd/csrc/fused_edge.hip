@@ -356,8 +356,10 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
     gemm_acc<NB, NB>(z, W2s, LDW, 0, sact, lane);
     float mean, rstd;
     ln_stats<NB>(z, mean, rstd);
-    // dbeta from the final gm tile
+    // S is published right away (T2's g_agg / g_eout rows are already in registers):
+    // sact's registers are free during the LayerNorm backward.  dbeta from the gm tile.
     wave_sync();
+    acc_to_tile<NB>(sact, T2, LDT, lane);
     acc_to_tile<NB>(g, T1, LDT, lane);
     wave_sync();
     tile_colsum<NV>(dbet, T1, LDT, 0, ne, lane);
@@ -383,13 +385,14 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
             s2 += gv * xh;
           }
         }
-      acc_to_tile<NB>(prod, T2, LDT, lane);
+      wave_sync();
+      acc_to_tile<NB>(prod, T1, LDT, lane);
     }
     s1 += __shfl_xor(s1, 32, 64);
     s2 += __shfl_xor(s2, 32, 64);
     const float m1 = s1 * inv_d, m2 = s2 * inv_d;
     wave_sync();
-    tile_colsum<NV>(dgam, T2, LDT, 0, ne, lane);
+    tile_colsum<NV>(dgam, T1, LDT, 0, ne, lane);
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -397,7 +400,6 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
     // g = gz (zero on padded slots).  Publish GZ (T1) and S (T2) for the dW2 blocks.
     wave_sync();
     acc_to_tile<NB>(g, T1, LDT, lane);
-    acc_to_tile<NB>(sact, T2, LDT, lane);
     wave_sync();
     tile_colsum<NV>(db2, T1, LDT, 0, ne, lane);
     outer_accum<NB, NB>(dW2, T1, LDT, 0, T2, LDT, 0, lane);

@@ -411,6 +411,10 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpBwdParams q) {
       f32x16 z[NOUTB];
       vec_to_acc<NOUTB>(z, b2s, lane);
       gemm_acc<NOUTB, NBH>(z, W2s, ldw2, 0, sact, lane);
+      // S goes to T0 right away (X was consumed by the first GEMM): sact's
+      // registers are free during the LayerNorm backward
+      wave_sync();
+      acc_to_tile<NBH>(sact, T0, ldt0, lane);
       // LayerNorm backward: z -> xhat in place; g (= gy) -> gz
       constexpr float inv_d = 1.0f / (32.0f * NOUTB);
       float mean, rstd;
@@ -447,10 +451,10 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpBwdParams q) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) g[nb][r] = rstd * (g[nb][r] - m1 - z[nb][r] * m2);
     }
-    // g is gz (zero on padded rows).  Publish GZ (T1) and S (T0) for the dW2 blocks.
+    // g is gz (zero on padded rows).  Publish GZ (T1); S is in T0.
     wave_sync();
     acc_to_tile<NOUTB>(g, T1, ldt1, lane);
-    acc_to_tile<NBH>(sact, T0, ldt0, lane);
+    if (!HAS_LN) acc_to_tile<NBH>(sact, T0, ldt0, lane);
     wave_sync();
     tile_colsum<NV_O>(db2, T1, ldt1, 0, nrows, lane);
     outer_accum<NOUTB, NBH>(dW2, T1, ldt1, 0, T0, ldt0, 0, lane);
@@ -472,17 +476,20 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpBwdParams q) {
     tile_colsum<NV_H>(db1, T1, ldt1, 0, nrows, lane);
     outer_accum<NBH, KB>(dW1, T1, ldt1, 0, T0, ldt0, 0, lane);
     const bool want_gx = q.gxa != nullptr || q.gxb != nullptr;
-    f32x16 gx[KB];
     if (want_gx) {
-#pragma unroll
-      for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) gx[kb][r] = 0.f;
-      gemm_acc_wt<KB, NBH>(gx, W1s, ldw1, 0, ga, lane);
-    }
-    if (want_gx) {
+      // gx = W1^T ga, 64 input columns (2 blocks) at a time to bound the registers
       wave_sync();
-      acc_to_tile<KB>(gx, T0, ldt0, lane);
+      constexpr int GXB = KB >= 2 ? 2 : 1;
+#pragma unroll
+      for (int kb0 = 0; kb0 < KB; kb0 += GXB) {
+        f32x16 gx[GXB];
+#pragma unroll
+        for (int kb = 0; kb < GXB; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) gx[kb][r] = 0.f;
+        gemm_acc_wt<GXB, NBH>(gx, W1s, ldw1, 32 * kb0, ga, lane);
+        acc_to_tile<GXB>(gx, T0 + 32 * kb0, ldt0, lane);
+      }
       wave_sync();
       const float* gyb = q.gy.ptr + b * q.gy.bstride + r0 * q.gy.ld;
       auto gyp = [&](int t) { return gyb + (int64_t)t * q.gy.ld; };

@@ -85,16 +85,18 @@ class GradAllReduce:
         if self.world > 1:
             dist.broadcast(self.flat.flat, src=src, group=self.group)
 
-    def reduce(self):
-        """Pack + all-reduce every bucket; returns when all are complete on the
-        current stream."""
+    def reduce(self, packed=False):
+        """Pack (unless the caller already did) + all-reduce every bucket; returns
+        when all are complete on the current stream."""
         f = self.flat
         if self.world == 1:
-            f.pack_grads()
+            if not packed:
+                f.pack_grads()
             return
         handles = []
         for lo, hi in self.ranges:
-            f.pack_grads(lo, hi)
+            if not packed:
+                f.pack_grads(lo, hi)
             a = f.offsets[lo]
             b = f.offsets[hi - 1] + f.params[hi - 1].numel()
             handles.append(dist.all_reduce(f.grad[a:b], op=dist.ReduceOp.SUM, group=self.group,
@@ -128,3 +130,51 @@ class FlatAdamW:
             ),
             "nlam_adamw_step",
         )
+
+
+class GraphedTrainStep:
+    """forward + loss + backward + gradient packing of one training step captured
+    into a HIP graph (torch.cuda.CUDAGraph over the launch stream) and replayed:
+    the step is ~150 short launches, so eager dispatch leaves gaps between kernels.
+    The batch tensors are static (copy new data into them between replays); the
+    collective and the AdamW kernel (whose bias correction depends on the step
+    count) stay outside the graph.  Falls back to eager if capture is refused."""
+
+    def __init__(self, model, flat, batch, warmup=3):
+        self.model, self.flat, self.batch = model, flat, batch
+        self.graph = None
+        self.loss = None
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(warmup):
+                    self._eager()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            flat.zero_grad()
+            with torch.cuda.graph(g):
+                loss = model.training_step(batch)
+                loss.backward()
+                flat.pack_grads()
+            self.graph, self.loss = g, loss
+        except Exception as e:  # pragma: no cover - depends on the runtime
+            import warnings
+
+            warnings.warn(f"HIP graph capture failed ({e!r}); running the step eagerly")
+            self.graph = None
+            torch.cuda.synchronize()
+
+    def _eager(self):
+        self.flat.zero_grad()
+        loss = self.model.training_step(self.batch)
+        loss.backward()
+        self.flat.pack_grads()
+        return loss
+
+    def __call__(self):
+        if self.graph is None:
+            return self._eager()
+        self.graph.replay()
+        return self.loss
