@@ -64,9 +64,36 @@ __device__ __forceinline__ void load_weight_lds(float* __restrict__ Ws, const fl
                                                 int64_t ldW, int n_out, int k_in, int n_pad,
                                                 int k_pad, int tid, int nthreads) {
   const int ld = k_pad + 4;
-  for (int idx = tid; idx < n_pad * k_pad; idx += nthreads) {
-    const int i = idx / k_pad, k = idx - i * k_pad;
-    Ws[i * ld + k] = (i < n_out && k < k_in) ? W[(int64_t)i * ldW + k] : 0.f;
+  const bool vec = (k_in % 4 == 0) && (ldW % 4 == 0) && ((reinterpret_cast<uintptr_t>(W) & 15u) == 0);
+  if (vec) {
+    // float4 chunks, 8 loads in flight per thread (this prologue dominates the
+    // small mesh-sized launches, so it must not be a load->store chain)
+    const int cpr = k_pad >> 2;              // chunks per row
+    const int total = n_pad * cpr;
+    for (int base = 0; base < total; base += 8 * nthreads) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = base + u * nthreads + tid;
+        const int i = idx / cpr, c = idx - i * cpr;
+        const bool ok = idx < total && i < n_out && 4 * c < k_in;
+        v[u] = ok ? *reinterpret_cast<const f32x4*>(W + (int64_t)i * ldW + 4 * c)
+                  : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = base + u * nthreads + tid;
+        if (idx < total) {
+          const int i = idx / cpr, c = idx - i * cpr;
+          *reinterpret_cast<f32x4*>(Ws + i * ld + 4 * c) = v[u];
+        }
+      }
+    }
+  } else {
+    for (int idx = tid; idx < n_pad * k_pad; idx += nthreads) {
+      const int i = idx / k_pad, k = idx - i * k_pad;
+      Ws[i * ld + k] = (i < n_out && k < k_in) ? W[(int64_t)i * ldW + k] : 0.f;
+    }
   }
 }
 // per-feature vector -> LDS, zero padded to n_pad
@@ -565,28 +592,32 @@ __device__ __forceinline__ void segment_reduce_tile(const float* __restrict__ ti
   }
 }
 
-// Workgroup-level fold of per-wave weight-gradient blocks into an LDS image
-// [rows][ldimg] (row-major, rows = 32 NI, cols = 32 NJ), wave after wave (fixed
-// order => deterministic).  Must be called by all 256 threads.
+// Workgroup-level fold of per-wave weight-gradient blocks: every wave writes its
+// blocks to its own LDS image (all four in parallel), then all 256 threads add the
+// four images in wave order (fixed => deterministic) straight into the slab.
+// img must hold 4 * (32 NI) * ldimg floats of dead LDS.  Call from all threads,
+// after a __syncthreads() that retires the tiles / weights.
 template <int NI, int NJ>
-__device__ __forceinline__ void fold_blocks_lds(const f32x16 (&dW)[NI][NJ], float* __restrict__ img,
-                                                int ldimg, int wave, int lane) {
+__device__ __forceinline__ void fold_blocks_to_slab(const f32x16 (&dW)[NI][NJ],
+                                                    float* __restrict__ img, int ldimg,
+                                                    float* __restrict__ slab, int tid, int wave,
+                                                    int lane) {
   const int h = lane >> 5, j = lane & 31;
-  for (int w = 0; w < 4; ++w) {
-    if (wave == w) {
+  const int n = 32 * NI * ldimg;
+  float* mine = img + wave * n;
 #pragma unroll
-      for (int ib = 0; ib < NI; ++ib)
+  for (int ib = 0; ib < NI; ++ib)
 #pragma unroll
-        for (int jb = 0; jb < NJ; ++jb)
+    for (int jb = 0; jb < NJ; ++jb)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int i = 32 * ib + 8 * (r >> 2) + 4 * h + (r & 3);
-            float* dst = img + i * ldimg + 32 * jb + j;
-            *dst = (w == 0) ? dW[ib][jb][r] : (*dst + dW[ib][jb][r]);
-          }
-    }
-    __syncthreads();
-  }
+      for (int r = 0; r < 16; ++r) {
+        const int i = 32 * ib + 8 * (r >> 2) + 4 * h + (r & 3);
+        mine[i * ldimg + 32 * jb + j] = dW[ib][jb][r];
+      }
+  __syncthreads();
+  for (int i = tid; i < n; i += 256)
+    slab[i] = ((img[i] + img[n + i]) + img[2 * n + i]) + img[3 * n + i];
+  __syncthreads();
 }
 // same for per-feature vectors held as lanes = features (NV values per lane)
 template <int NV>

@@ -457,14 +457,8 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
   float* img = smem;
   float* slab = q.slab + (int64_t)blockIdx.x * q.slab_stride;
   constexpr int nW = D * D;
-  if (HAS_EGEMM) {
-    fold_blocks_lds<NB, NB>(dW1, img, D, wave, lane);
-    for (int i = tid; i < nW; i += 256) slab[i] = img[i];
-    __syncthreads();
-  }
-  fold_blocks_lds<NB, NB>(dW2, img, D, wave, lane);
-  for (int i = tid; i < nW; i += 256) slab[nW + i] = img[i];
-  __syncthreads();
+  if (HAS_EGEMM) fold_blocks_to_slab<NB, NB>(dW1, img, D, slab, tid, wave, lane);
+  fold_blocks_to_slab<NB, NB>(dW2, img, D, slab + nW, tid, wave, lane);
   fold_vec_lds<NV>(db2, img, wave, lane);
   for (int i = tid; i < D; i += 256) slab[2 * nW + i] = img[i];
   __syncthreads();

@@ -526,15 +526,11 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpBwdParams q) {
   float* img = smem;  // weights are dead: reuse the front of LDS
   float* slab = q.slab + (int64_t)blockIdx.x * q.slab_stride;
   constexpr int n1 = HID * KP32, n2 = 32 * NOUTB * HID;
-  fold_blocks_lds<NBH, KB>(dW1, img, KP32, wave, lane);
-  for (int i = tid; i < n1; i += 256) slab[i] = img[i];
-  __syncthreads();
+  fold_blocks_to_slab<NBH, KB>(dW1, img, KP32, slab, tid, wave, lane);
   fold_vec_lds<NV_H>(db1, img, wave, lane);
   for (int i = tid; i < HID; i += 256) slab[n1 + i] = img[i];
   __syncthreads();
-  fold_blocks_lds<NOUTB, NBH>(dW2, img, HID, wave, lane);
-  for (int i = tid; i < n2; i += 256) slab[n1 + HID + i] = img[i];
-  __syncthreads();
+  fold_blocks_to_slab<NOUTB, NBH>(dW2, img, HID, slab + n1 + HID, tid, wave, lane);
   float* vbase = slab + n1 + HID + n2;
   fold_vec_lds<NV_O>(db2, img, wave, lane);
   for (int i = tid; i < 32 * NOUTB; i += 256) vbase[i] = img[i];
@@ -594,6 +590,9 @@ static int launch_mlp_bwd(const MlpBwdParams& q, hipStream_t s) {
   const size_t lds = ((size_t)HID * (KP32 + 4) + (size_t)32 * NOUTB * (HID + 4) + HID +
                       2 * 32 * NOUTB + (size_t)4 * NLAM_TILE * (ldt0 + ldt1)) * sizeof(float);
   NLAM_REQUIRE(lds <= 160 * 1024, "mlp_bwd: LDS footprint %zu B exceeds 160 KiB", lds);
+  static_assert((size_t)4 * HID * KP32 * 4 <= 160 * 1024, "fold images exceed LDS");
+  const size_t fold_bytes = (size_t)4 * HID * KP32 * sizeof(float);
+  const size_t lds_alloc = lds > fold_bytes ? lds : fold_bytes;
   auto kern = mlp_bwd_kernel<HID, NOUTB, KB, HAS_LN>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -601,7 +600,7 @@ static int launch_mlp_bwd(const MlpBwdParams& q, hipStream_t s) {
     attr_set = true;
   }
   const int64_t ntiles = ((q.f.rows + NLAM_TILE - 1) / NLAM_TILE) * q.f.B;
-  kern<<<(unsigned)nlam_bwd_grid(ntiles), 256, lds, s>>>(q);
+  kern<<<(unsigned)nlam_bwd_grid(ntiles), 256, lds_alloc, s>>>(q);
   NLAM_CHECK_LAUNCH("mlp_bwd_kernel");
   return 0;
 }
@@ -763,9 +762,7 @@ __global__ __launch_bounds__(256) void lin_bwd_kernel(LinBwdParams q) {
   __syncthreads();
   float* img = smem;
   float* slab = q.slab + (int64_t)blockIdx.x * q.slab_stride;
-  fold_blocks_lds<NOUTB, KB>(dW, img, KP32, wave, lane);
-  for (int i = tid; i < NO * KP32; i += 256) slab[i] = img[i];
-  __syncthreads();
+  fold_blocks_to_slab<NOUTB, KB>(dW, img, KP32, slab, tid, wave, lane);
   fold_vec_lds<NV>(db, img, wave, lane);
   for (int i = tid; i < NO; i += 256) slab[NO * KP32 + i] = img[i];
 }
@@ -776,6 +773,9 @@ static int launch_lin_bwd(const LinBwdParams& q, hipStream_t s) {
   const size_t lds = ((size_t)NO * (KP32 + 4) + (size_t)4 * NLAM_TILE * (KP32 + 4 + NO + 4)) *
                      sizeof(float);
   NLAM_REQUIRE(lds <= 160 * 1024, "lin_bwd: LDS footprint %zu B exceeds 160 KiB", lds);
+  const size_t fold_bytes = (size_t)4 * NO * KP32 * sizeof(float);
+  NLAM_REQUIRE(fold_bytes <= 160 * 1024, "lin_bwd: fold images exceed LDS");
+  const size_t lds_alloc = lds > fold_bytes ? lds : fold_bytes;
   auto kern = lin_bwd_kernel<NOUTB, KB>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -783,7 +783,7 @@ static int launch_lin_bwd(const LinBwdParams& q, hipStream_t s) {
     attr_set = true;
   }
   const int64_t ntiles = ((q.rows + NLAM_TILE - 1) / NLAM_TILE) * q.B;
-  kern<<<(unsigned)nlam_bwd_grid(ntiles), 256, lds, s>>>(q);
+  kern<<<(unsigned)nlam_bwd_grid(ntiles), 256, lds_alloc, s>>>(q);
   NLAM_CHECK_LAUNCH("lin_bwd_kernel");
   return 0;
 }
