@@ -179,8 +179,21 @@ int nlam_mlp_bwd(const float* xa, int64_t xa_bstride, int64_t xa_ld, int xa_widt
                  const float* gy, int64_t gy_bstride, int64_t gy_ld,
                  float* gxa, int64_t gxa_bstride, int64_t gxa_ld,
                  float* gxb, int64_t gxb_bstride, int64_t gxb_ld, int add_gy_to_gxa,
-                 float* slab, int64_t slab_stride,
+                 float* slab, int64_t slab_stride, float* ga_out,
                  int64_t B, int64_t rows, int hid, int n_out, void* stream);
+/* Deferred weight gradient of a first layer: with ga_out != NULL nlam_mlp_bwd
+ * stores ga = dL/d(pre-activation) (B, rows, hid; contiguous) instead of forming
+ * dW1 / db1 (their slab ranges are left untouched); this pass computes
+ *   dW (ng x KX32) = sum_rows g[r]^T (x) [xa | xb][x_index ? x_index[r] : r],
+ *   db (ng) = column sums of g
+ * as per-workgroup slabs [dW | db] (count nlam_bwd_grid(B*ceil(rows/32)), pitch >=
+ * nlam_outer_bwd_slab_stride).  Also usable for W1e's gradient from (gh, e). */
+int64_t nlam_outer_bwd_slab_stride(int ng, int kx);
+int nlam_outer_bwd(const float* g, int64_t g_bstride, int64_t g_ld, int ng,
+                   const float* xa, int64_t xa_bstride, int64_t xa_ld, int xa_width,
+                   const float* xb, int64_t xb_bstride, int64_t xb_ld, int xb_width,
+                   const int32_t* x_index, float* slab, int64_t slab_stride,
+                   int64_t B, int64_t rows, void* stream);
 /* out[i] (+)= sum_s slab[s * stride + i], i < n (deterministic order). */
 int nlam_reduce_slabs(const float* slab, int64_t nslabs, int64_t stride, int64_t n,
                       float* out, int accumulate, void* stream);

@@ -38,8 +38,11 @@ SIGNATURES = {
     "nlam_bwd_grid": [_i64],
     "nlam_mlp_bwd_slab_stride": [_i32, _i32, _i32],
     "nlam_mlp_bwd": [_p, _i64, _i64, _i32, _p, _i64, _i64, _i32, _p, _i64, _p, _p, _i64, _p, _p,
-                     _p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _i32, _p, _i64,
+                     _p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _i32, _p, _i64, _p,
                      _i64, _i64, _i32, _i32, _p],
+    "nlam_outer_bwd_slab_stride": [_i32, _i32],
+    "nlam_outer_bwd": [_p, _i64, _i64, _i32, _p, _i64, _i64, _i32, _p, _i64, _i64, _i32, _p, _p,
+                       _i64, _i64, _i64, _p],
     "nlam_reduce_slabs": [_p, _i64, _i64, _i64, _p, _i32, _p],
     "nlam_lin_fwd": [_p, _i64, _i64, _i32, _p, _i64, _p, _i32, _p, _i64, _p, _i32, _p, _i64, _i64,
                      _i64, _i64, _p],
@@ -73,6 +76,7 @@ _RESTYPES = {
     "nlam_edge_bwd_slab_stride": _i64,
     "nlam_wmse_blocks": _i64,
     "nlam_mlp_bwd_slab_stride": _i64,
+    "nlam_outer_bwd_slab_stride": _i64,
 }
 
 

@@ -310,10 +310,15 @@ struct MlpBwdParams {
   float* gxb; int64_t gxb_bstride; int64_t gxb_ld;
   int add_gy_to_gxa;           // residual taken from source a: gxa += gy
   float* slab; int64_t slab_stride;
+  float* ga_out;               // DEFER_DW1: (B, rows, HID) gradient of the hidden pre-activation
   int vec_gy, vec_gxa, vec_gxb;
 };
 
-template <int HID, int NOUTB, int KB, bool HAS_LN>
+// DEFER_DW1: the first layer's weight gradient (HID x KP32 = up to 128 accumulator
+// registers per wave) is not formed here; the kernel stores ga = dL/d(pre-activation)
+// and nlam_outer_bwd computes dW1 = ga^T [x_a | x_b], db1 = colsum(ga) in a lean second
+// pass.  Used for the K = 128 node update, where the in-kernel form spilled.
+template <int HID, int NOUTB, int KB, bool HAS_LN, bool DEFER_DW1>
 __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpBwdParams q) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NBH = HID / 32;
@@ -343,11 +348,12 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpBwdParams q) {
   load_vec_lds(gs, p.gamma, p.n_out, 32 * NOUTB, tid, 256);
   __syncthreads();
 
-  f32x16 dW1[NBH][KB], dW2[NOUTB][NBH];
+  constexpr int KBA = DEFER_DW1 ? 1 : KB;   // no dW1 accumulators when deferred
+  f32x16 dW1[NBH][KBA], dW2[NOUTB][NBH];
 #pragma unroll
   for (int i = 0; i < NBH; ++i)
 #pragma unroll
-    for (int j = 0; j < KB; ++j)
+    for (int j = 0; j < KBA; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) dW1[i][j][r] = 0.f;
 #pragma unroll
@@ -471,10 +477,17 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpBwdParams q) {
       for (int r = 0; r < 16; ++r) ga[nb][r] *= nlam_silu_grad(hpre[nb][r]);
     wave_sync();
     acc_to_tile<NBH>(ga, T1, ldt1, lane);           // GA
-    stage_x(b, r0, nrows);                          // X again
-    wave_sync();
-    tile_colsum<NV_H>(db1, T1, ldt1, 0, nrows, lane);
-    outer_accum<NBH, KB>(dW1, T1, ldt1, 0, T0, ldt0, 0, lane);
+    if constexpr (DEFER_DW1) {
+      wave_sync();
+      float* gb = q.ga_out + (b * p.rows + r0) * HID;
+      auto gp = [&](int t) { return gb + (int64_t)t * HID; };
+      store_rows<true>(T1, ldt1, 0, HID, nrows, lane, gp);
+    } else {
+      stage_x(b, r0, nrows);                        // X again
+      wave_sync();
+      tile_colsum<NV_H>(db1, T1, ldt1, 0, nrows, lane);
+      outer_accum<NBH, KB>(dW1, T1, ldt1, 0, T0, ldt0, 0, lane);
+    }
     const bool want_gx = q.gxa != nullptr || q.gxb != nullptr;
     if (want_gx) {
       // gx = W1^T ga, 64 input columns (2 blocks) at a time to bound the registers
@@ -526,10 +539,12 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpBwdParams q) {
   float* img = smem;  // weights are dead: reuse the front of LDS
   float* slab = q.slab + (int64_t)blockIdx.x * q.slab_stride;
   constexpr int n1 = HID * KP32, n2 = 32 * NOUTB * HID;
-  fold_blocks_to_slab<NBH, KB>(dW1, img, KP32, slab, tid, wave, lane);
-  fold_vec_lds<NV_H>(db1, img, wave, lane);
-  for (int i = tid; i < HID; i += 256) slab[n1 + i] = img[i];
-  __syncthreads();
+  if constexpr (!DEFER_DW1) {
+    fold_blocks_to_slab<NBH, KBA>(dW1, img, KP32, slab, tid, wave, lane);
+    fold_vec_lds<NV_H>(db1, img, wave, lane);
+    for (int i = tid; i < HID; i += 256) slab[n1 + i] = img[i];
+    __syncthreads();
+  }
   fold_blocks_to_slab<NOUTB, NBH>(dW2, img, HID, slab + n1 + HID, tid, wave, lane);
   float* vbase = slab + n1 + HID + n2;
   fold_vec_lds<NV_O>(db2, img, wave, lane);
@@ -582,7 +597,7 @@ extern "C" int nlam_reduce_slabs(const float* slab, int64_t nslabs, int64_t stri
   return 0;
 }
 
-template <int HID, int NOUTB, int KB, bool HAS_LN>
+template <int HID, int NOUTB, int KB, bool HAS_LN, bool DEFER_DW1 = false>
 static int launch_mlp_bwd(const MlpBwdParams& q, hipStream_t s) {
   constexpr int KP32 = 32 * KB;
   constexpr int ldt0 = (KP32 > HID ? KP32 : HID) + 4;
@@ -593,7 +608,7 @@ static int launch_mlp_bwd(const MlpBwdParams& q, hipStream_t s) {
   static_assert((size_t)4 * HID * KP32 * 4 <= 160 * 1024, "fold images exceed LDS");
   const size_t fold_bytes = (size_t)4 * HID * KP32 * sizeof(float);
   const size_t lds_alloc = lds > fold_bytes ? lds : fold_bytes;
-  auto kern = mlp_bwd_kernel<HID, NOUTB, KB, HAS_LN>;
+  auto kern = mlp_bwd_kernel<HID, NOUTB, KB, HAS_LN, DEFER_DW1>;
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -619,7 +634,7 @@ extern "C" int nlam_mlp_bwd(
     const float* gy, int64_t gy_bstride, int64_t gy_ld,
     float* gxa, int64_t gxa_bstride, int64_t gxa_ld,
     float* gxb, int64_t gxb_bstride, int64_t gxb_ld, int add_gy_to_gxa,
-    float* slab, int64_t slab_stride,
+    float* slab, int64_t slab_stride, float* ga_out,
     int64_t B, int64_t rows, int hid, int n_out, void* stream) {
   if (B <= 0 || rows <= 0) return 0;
   NLAM_REQUIRE(hid == 64 || hid == 128, "nlam_mlp_bwd: hidden width %d not in {64,128}", hid);
@@ -648,6 +663,8 @@ extern "C" int nlam_mlp_bwd(
   q.gxb = gxb; q.gxb_bstride = gxb_bstride; q.gxb_ld = gxb_ld;
   q.add_gy_to_gxa = add_gy_to_gxa;
   q.slab = slab; q.slab_stride = slab_stride;
+  q.ga_out = ga_out;
+  NLAM_REQUIRE(ga_out == nullptr || nlam_aligned16(ga_out), "nlam_mlp_bwd: ga_out misaligned");
   q.vec_gy = view_vec_ok(gy, gy_bstride, gy_ld, n_out);
   q.vec_gxa = gxa && view_vec_ok(gxa, gxa_bstride, gxa_ld, xa_width);
   q.vec_gxb = gxb && view_vec_ok(gxb, gxb_bstride, gxb_ld, xb_width) && (xa_width % 4 == 0);
@@ -660,6 +677,7 @@ extern "C" int nlam_mlp_bwd(
     if (ln) {
       if (kb == 1) MLP_BWD_CASE(64, 2, 1, true);
       if (kb == 2) MLP_BWD_CASE(64, 2, 2, true);
+      if (kb == 4 && ga_out != nullptr) return launch_mlp_bwd<64, 2, 4, true, true>(q, s);
       if (kb == 4) MLP_BWD_CASE(64, 2, 4, true);
     } else if (noutb == 1 && kb == 2) {
       MLP_BWD_CASE(64, 1, 2, false);
@@ -823,5 +841,132 @@ extern "C" int nlam_lin_bwd(const float* x, int64_t x_bstride, int64_t x_ld, int
   if (noutb == 2 && kb == 1) return launch_lin_bwd<2, 1>(q, s);
   if (noutb == 4 && kb == 4) return launch_lin_bwd<4, 4>(q, s);
   nlam_set_error("nlam_lin_bwd: unsupported shape k_in=%d n_out=%d", k_in, q.nA + q.nB);
+  return 1;
+}
+
+
+// ------------------------------------------------ deferred weight gradients
+// dW (32 NGB x 32 NXB) = sum_rows G[r]^T (x) [xa | xb][r],  db = colsum(G).
+// A lean streaming pass: no weights in LDS, every register for the accumulators.
+// Slab per workgroup: [dW (32 NGB x 32 NXB) | db (32 NGB)].
+struct OuterParams {
+  RowView g;                   // (B, rows, 32 NGB)
+  RowView xa, xb;              // widths sum to <= 32 NXB; xb.ptr may be NULL
+  const int32_t* x_index;      // optional: x row of (batch-local) row r is x_index[r]
+  float* slab; int64_t slab_stride;
+  int64_t rows; int B;
+};
+
+template <int NGB, int NXB>
+__global__ __launch_bounds__(256) void outer_bwd_kernel(OuterParams q) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NG = 32 * NGB, NX = 32 * NXB;
+  constexpr int NV = (NG + 63) / 64;
+  constexpr int ldg = NG + 4, ldx = NX + 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* TG = smem + wave * (NLAM_TILE * (ldg + ldx));
+  float* TX = TG + NLAM_TILE * ldg;
+  f32x16 dW[NGB][NXB];
+#pragma unroll
+  for (int i = 0; i < NGB; ++i)
+#pragma unroll
+    for (int j = 0; j < NXB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dW[i][j][r] = 0.f;
+  float db[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) db[j] = 0.f;
+  const int kx = q.xa.width + (q.xb.ptr ? q.xb.width : 0);
+  const int64_t tiles_per_b = (q.rows + NLAM_TILE - 1) / NLAM_TILE;
+  const int64_t ntiles = tiles_per_b * q.B;
+  for (int64_t tt = (int64_t)blockIdx.x * 4 + wave; tt < ntiles; tt += (int64_t)gridDim.x * 4) {
+    const int64_t b = tt / tiles_per_b;
+    const int64_t r0 = (tt - b * tiles_per_b) * NLAM_TILE;
+    const int nrows = (int)((q.rows - r0) < NLAM_TILE ? (q.rows - r0) : NLAM_TILE);
+    const int t = lane & 31;
+    int xi = 0;
+    if (q.x_index) xi = q.x_index[r0 + (t < nrows ? t : nrows - 1)];
+    const float* gb = q.g.ptr + b * q.g.bstride + r0 * q.g.ld;
+    const float* xab = q.xa.ptr + b * q.xa.bstride + (q.x_index ? 0 : r0 * q.xa.ld);
+    const float* xbb = q.xb.ptr ? q.xb.ptr + b * q.xb.bstride + (q.x_index ? 0 : r0 * q.xb.ld)
+                                : nullptr;
+    const int last = nrows - 1;
+    auto g_row = [&](int s) { return gb + (int64_t)(s < last ? s : last) * q.g.ld; };
+    auto xa_row = [&](int s) {
+      const int64_t r = q.x_index ? (int64_t)__shfl(xi, s, 64) : (int64_t)(s < last ? s : last);
+      return xab + r * q.xa.ld;
+    };
+    auto xb_row = [&](int s) {
+      const int64_t r = q.x_index ? (int64_t)__shfl(xi, s, 64) : (int64_t)(s < last ? s : last);
+      return xbb + r * q.xb.ld;
+    };
+    f32x4 vg[4 * NGB], va[8], vb[8];
+    load_rows_v<4 * NGB>(vg, NG, lane, g_row);
+    load_rows_v<8>(va, q.xa.width, lane, xa_row);
+    if (xbb) load_rows_v<8>(vb, q.xb.width, lane, xb_row);
+    put_rows_v<4 * NGB, false>(TG, ldg, 0, NG, nrows, lane, vg);
+    put_rows_v<8, false>(TX, ldx, 0, q.xa.width, nrows, lane, va);
+    if (xbb) put_rows_v<8, false>(TX, ldx, q.xa.width, q.xb.width, nrows, lane, vb);
+    if (NX > kx) zero_cols(TX, ldx, kx, NX - kx, lane);
+    wave_sync();
+    tile_colsum<NV>(db, TG, ldg, 0, nrows, lane);
+    outer_accum<NGB, NXB>(dW, TG, ldg, 0, TX, ldx, 0, lane);
+    wave_sync();
+  }
+  __syncthreads();
+  float* slab = q.slab + (int64_t)blockIdx.x * q.slab_stride;
+  fold_blocks_to_slab<NGB, NXB>(dW, smem, NX, slab, tid, wave, lane);
+  fold_vec_lds<NV>(db, smem, wave, lane);
+  for (int i = tid; i < NG; i += 256) slab[NG * NX + i] = smem[i];
+}
+
+template <int NGB, int NXB>
+static int launch_outer_bwd(const OuterParams& q, hipStream_t s) {
+  constexpr int NG = 32 * NGB, NX = 32 * NXB;
+  size_t lds = (size_t)4 * NLAM_TILE * (NG + 4 + NX + 4) * sizeof(float);
+  const size_t fold = (size_t)4 * NG * NX * sizeof(float);
+  if (fold > lds) lds = fold;
+  NLAM_REQUIRE(lds <= 160 * 1024, "outer_bwd: LDS footprint %zu B exceeds 160 KiB", lds);
+  auto kern = outer_bwd_kernel<NGB, NXB>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  const int64_t ntiles = ((q.rows + NLAM_TILE - 1) / NLAM_TILE) * q.B;
+  kern<<<(unsigned)nlam_bwd_grid(ntiles), 256, lds, s>>>(q);
+  NLAM_CHECK_LAUNCH("outer_bwd_kernel");
+  return 0;
+}
+
+extern "C" int64_t nlam_outer_bwd_slab_stride(int ng, int kx) {
+  const int nx = (kx + 31) & ~31;
+  return (int64_t)ng * nx + ng;
+}
+
+extern "C" int nlam_outer_bwd(const float* g, int64_t g_bstride, int64_t g_ld, int ng,
+                              const float* xa, int64_t xa_bstride, int64_t xa_ld, int xa_width,
+                              const float* xb, int64_t xb_bstride, int64_t xb_ld, int xb_width,
+                              const int32_t* x_index, float* slab, int64_t slab_stride,
+                              int64_t B, int64_t rows, void* stream) {
+  if (B <= 0 || rows <= 0) return 0;
+  NLAM_REQUIRE(ng == 64, "nlam_outer_bwd: G width %d unsupported (64)", ng);
+  const int kx = xa_width + (xb ? xb_width : 0);
+  NLAM_REQUIRE(view_vec_ok(g, g_bstride, g_ld, ng) && view_vec_ok(xa, xa_bstride, xa_ld, xa_width) &&
+                   xa_width <= 64 && (!xb || (view_vec_ok(xb, xb_bstride, xb_ld, xb_width) &&
+                                              xb_width <= 64 && xa_width % 4 == 0)),
+               "nlam_outer_bwd: operands must be 16-byte aligned rows of width <= 64, %% 4 == 0");
+  NLAM_REQUIRE(slab != nullptr && slab_stride >= nlam_outer_bwd_slab_stride(ng, kx),
+               "nlam_outer_bwd: slab too small");
+  OuterParams q;
+  q.g = RowView{g, g_bstride, g_ld, ng};
+  q.xa = RowView{xa, xa_bstride, xa_ld, xa_width};
+  q.xb = RowView{xb, xb_bstride, xb_ld, xb ? xb_width : 0};
+  q.x_index = x_index; q.slab = slab; q.slab_stride = slab_stride; q.rows = rows; q.B = (int)B;
+  hipStream_t s = (hipStream_t)stream;
+  const int nxb = (kx + 31) / 32;
+  if (nxb <= 2) return launch_outer_bwd<2, 2>(q, s);
+  if (nxb <= 4) return launch_outer_bwd<2, 4>(q, s);
+  nlam_set_error("nlam_outer_bwd: X width %d unsupported", kx);
   return 1;
 }

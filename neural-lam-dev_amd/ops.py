@@ -406,6 +406,10 @@ def fused_mlp_bwd(xa, xb, W1, b1, W2, b2, gamma, gy, gxa, gxb, add_gy_to_gxa, hi
     nslabs = lib.nlam_bwd_grid(_ntiles(B, rows))
     dev = W1.device
     slab = torch.empty(nslabs * stride, dtype=torch.float32, device=dev)
+    # K = 128 (node update [x_r | agg]): the first layer's weight gradient is formed by a
+    # lean second pass (nlam_outer_bwd) from the stored hidden-pre-activation gradient
+    defer = hid == 64 and k_in == 128 and gamma is not None and xb is not None
+    ga = torch.empty(B, rows, hid, dtype=torch.float32, device=dev) if defer else None
     _launch(
         "nlam_mlp_bwd", lib.nlam_mlp_bwd,
         (xa.ptr, xa.bstride, xa.ld, xa.cols,
@@ -417,14 +421,45 @@ def fused_mlp_bwd(xa, xb, W1, b1, W2, b2, gamma, gy, gxa, gxb, add_gy_to_gxa, hi
          gxa.ld if gxa is not None else 0,
          gxb.ptr if gxb is not None else None, gxb.bstride if gxb is not None else 0,
          gxb.ld if gxb is not None else 0, int(add_gy_to_gxa),
-         slab.data_ptr(), stride, B, rows, hid, n_out, stream()),
+         slab.data_ptr(), stride, _p(ga), B, rows, hid, n_out, stream()),
         flops=2.0 * B * rows * hid * ((3 if (gxa is not None or gxb is not None) else 2) * k_in
                                        + 4 * n_out),
         nbytes=4.0 * B * rows * (2 * k_in + n_out),
     )
     red = torch.empty(stride, dtype=torch.float32, device=dev)
+    kp32 = (k_in + 31) // 32 * 32
+    if defer:
+        n1 = hid * kp32 + hid
+        reduce_slabs(slab[n1:], nslabs, stride, stride - n1, red[n1:])
+        dW1, db1 = fused_outer_bwd(mat(ga), xa, xb, None)
+        copy_rows(mat(dW1), mat(red[: hid * kp32].view(hid, kp32)))
+        copy_rows(mat(db1), mat(red[hid * kp32 : n1]))
+    else:
+        reduce_slabs(slab, nslabs, stride, stride, red)
+    return red, kp32, (n_out + 31) // 32 * 32
+
+
+def fused_outer_bwd(g, xa, xb, x_index):
+    """dW = sum_rows g^T (x) [xa | xb] (rows of x optionally gathered by x_index),
+    db = colsum(g).  Returns (dW (ng, kx) view, db (ng,))."""
+    B, rows, ng = g.B, g.rows, g.cols
+    kx = xa.cols + (xb.cols if xb is not None else 0)
+    stride = lib.nlam_outer_bwd_slab_stride(ng, kx)
+    nslabs = lib.nlam_bwd_grid(_ntiles(B, rows))
+    dev = g.keep.device
+    slab = torch.empty(nslabs * stride, dtype=torch.float32, device=dev)
+    _launch(
+        "nlam_outer_bwd", lib.nlam_outer_bwd,
+        (g.ptr, g.bstride, g.ld, ng, xa.ptr, xa.bstride, xa.ld, xa.cols,
+         xb.ptr if xb is not None else None, xb.bstride if xb is not None else 0,
+         xb.ld if xb is not None else 0, xb.cols if xb is not None else 0,
+         _p(x_index), slab.data_ptr(), stride, B, rows, stream()),
+        flops=2.0 * B * rows * ng * kx, nbytes=4.0 * B * rows * (ng + kx),
+    )
+    red = torch.empty(stride, dtype=torch.float32, device=dev)
     reduce_slabs(slab, nslabs, stride, stride, red)
-    return red, (k_in + 31) // 32 * 32, (n_out + 31) // 32 * 32
+    kx32 = (kx + 31) // 32 * 32
+    return red[: ng * kx32].view(ng, kx32)[:, :kx], red[ng * kx32 : ng * kx32 + ng]
 
 
 def split_mlp_grads(red, k_in, hid, n_out, kp32, no32, has_ln):
