@@ -970,3 +970,69 @@ extern "C" int nlam_outer_bwd(const float* g, int64_t g_bstride, int64_t g_ld, i
   nlam_set_error("nlam_outer_bwd: X width %d unsupported", kx);
   return 1;
 }
+
+
+// ------------------------------------------------------- multi-segment reduce
+// One launch sums up to 8 matrix segments of the per-workgroup slabs straight into
+// their (possibly strided) destinations, e.g. the three column blocks of
+// edge_mlp.0.weight's gradient that come from three different kernels:
+//   dst_k[r * dst_ld_k + c] = sum_s slab[s * stride + src_off_k + r * src_ld_k + c]
+struct ReduceSegs {
+  int nseg;
+  int64_t src_off[8];
+  int32_t rows[8], cols[8];
+  int64_t src_ld[8], dst_ld[8];
+  float* dst[8];
+  int64_t first[9];   // prefix sums of rows*cols
+};
+
+__global__ __launch_bounds__(1024) void reduce_slabs_multi_kernel(const float* __restrict__ slab,
+                                                                  int64_t nslabs, int64_t stride,
+                                                                  ReduceSegs q) {
+  __shared__ float red[32][33];
+  const int e = threadIdx.x & 31, gsub = threadIdx.x >> 5;
+  const int64_t i = (int64_t)blockIdx.x * 32 + e;
+  const int64_t n = q.first[q.nseg];
+  int k = 0;
+  while (k + 1 < q.nseg && i >= q.first[k + 1]) ++k;
+  const int64_t local = i - q.first[k];
+  const int cols = q.cols[k] > 0 ? q.cols[k] : 1;
+  const int64_t r = local / cols, c = local - r * cols;
+  const int64_t src = q.src_off[k] + r * q.src_ld[k] + c;
+  float s = 0.f;
+  if (i < n)
+    for (int64_t sl = gsub; sl < nslabs; sl += 32) s += slab[sl * stride + src];
+  red[gsub][e] = s;
+  __syncthreads();
+  if (gsub == 0 && i < n) {
+    float v = 0.f;
+#pragma unroll
+    for (int g = 0; g < 32; ++g) v += red[g][e];
+    q.dst[k][r * q.dst_ld[k] + c] = v;
+  }
+}
+
+extern "C" int nlam_reduce_slabs_multi(const float* slab, int64_t nslabs, int64_t stride, int nseg,
+                                       const int64_t* src_off, const int32_t* rows,
+                                       const int32_t* cols, const int64_t* src_ld,
+                                       float* const* dst, const int64_t* dst_ld, void* stream) {
+  NLAM_REQUIRE(nseg >= 1 && nseg <= 8, "reduce_slabs_multi: nseg %d out of [1,8]", nseg);
+  ReduceSegs q;
+  q.nseg = nseg;
+  q.first[0] = 0;
+  for (int k = 0; k < nseg; ++k) {
+    NLAM_REQUIRE(rows[k] >= 1 && cols[k] >= 1 && dst[k] != nullptr, "reduce_slabs_multi: bad segment");
+    q.src_off[k] = src_off[k]; q.rows[k] = rows[k]; q.cols[k] = cols[k];
+    q.src_ld[k] = src_ld[k]; q.dst_ld[k] = dst_ld[k]; q.dst[k] = dst[k];
+    q.first[k + 1] = q.first[k] + (int64_t)rows[k] * cols[k];
+  }
+  for (int k = nseg; k < 8; ++k) {
+    q.src_off[k] = 0; q.rows[k] = 0; q.cols[k] = 0; q.src_ld[k] = 0; q.dst_ld[k] = 0;
+    q.dst[k] = nullptr; q.first[k + 1] = q.first[nseg];
+  }
+  const int64_t n = q.first[nseg];
+  reduce_slabs_multi_kernel<<<(unsigned)((n + 31) / 32), 1024, 0, (hipStream_t)stream>>>(
+      slab, nslabs, stride, q);
+  NLAM_CHECK_LAUNCH("reduce_slabs_multi");
+  return 0;
+}

@@ -84,15 +84,26 @@ class FusedMLPFunction(torch.autograd.Function):
         gym = mat(gy.reshape(xm.B, xm.rows, n_out))
         need_gx = ctx.needs_input_grad[0]
         gx = _empty(xm.B, xm.rows, k_in, device=gy.device) if need_gx else None
-        red, kp32, no32 = ops.fused_mlp_bwd(
+        dst = _mlp_grad_dst(W1, W2, ctx.has_ln)
+        ops.fused_mlp_bwd(
             xm, None, W1, b1, W2, b2, gamma, gym, mat(gx) if need_gx else None, None,
-            ctx.res_mode == 1 and need_gx, hid, n_out)
-        dW1, db1, dW2, db2, dg, dbt = ops.split_mlp_grads(red, k_in, hid, n_out, kp32, no32,
-                                                          ctx.has_ln)
+            ctx.res_mode == 1 and need_gx, hid, n_out, dst)
+        dW1, db1, dW2, db2 = dst["dW1"], dst["db1"], dst["dW2"], dst["db2"]
+        dg, dbt = dst.get("dgamma"), dst.get("dbeta")
         gres = gy if ctx.res_mode == 2 else None
         if ctx.res_mode == 1 and not need_gx:
             gres = None
         return (gx.reshape(ctx.x_shape) if need_gx else None, gres, dW1, db1, dW2, db2, dg, dbt)
+
+
+def _mlp_grad_dst(W1, W2, has_ln):
+    dev = W1.device
+    dst = {"dW1": torch.empty_like(W1), "db1": _empty(W1.shape[0], device=dev),
+           "dW2": torch.empty_like(W2), "db2": _empty(W2.shape[0], device=dev)}
+    if has_ln:
+        dst["dgamma"] = _empty(W2.shape[0], device=dev)
+        dst["dbeta"] = _empty(W2.shape[0], device=dev)
+    return dst
 
 
 def apply_mlp(seq, x, res=None):
@@ -190,13 +201,20 @@ class FusedInteractionNetFunction(torch.autograd.Function):
             g_rec_out = g_rec_out.contiguous()
             g_rec = _empty(B, N_r, d, device=dev)
             g_agg = _empty(B, N_r, d, device=dev)
-            red, kp32, no32 = ops.fused_mlp_bwd(rm, mat(agg), V1, c1, V2, c2, gam2, mat(g_rec_out),
-                                                mat(g_rec), mat(g_agg), True, d, d)
-            dV1, dc1, dV2, dc2, dg2, db2n = ops.split_mlp_grads(red, 2 * d, d, d, kp32, no32, True)
+            nd = _mlp_grad_dst(V1, V2, True)
+            ops.fused_mlp_bwd(rm, mat(agg), V1, c1, V2, c2, gam2, mat(g_rec_out),
+                              mat(g_rec), mat(g_agg), True, d, d, nd)
+            dV1, dc1, dV2, dc2, dg2, db2n = (nd["dW1"], nd["db1"], nd["dW2"], nd["db2"],
+                                             nd["dgamma"], nd["dbeta"])
             if rm.B == 1 and B > 1:   # batch-invariant receivers: their grad sums over the batch
                 t3 = _empty(1, N_r, d, device=dev)
                 ops.sum_batch(g_rec, t3)
                 g_rec = t3
+            # edge-MLP parameter gradients, written in place by the reductions below
+            dW1 = _empty(d, 3 * d, device=dev)
+            db1 = _empty(d, device=dev)
+            dW2, db2 = torch.empty_like(W2), _empty(d, device=dev)
+            dgam, dbet = _empty(d, device=dev), _empty(d, device=dev)
             # 2. edge backward
             gh = _empty(B, M, d, device=dev)
             if same:
@@ -210,16 +228,15 @@ class FusedInteractionNetFunction(torch.autograd.Function):
             if ctx.update_edges:
                 g_e = _empty(B, M, d, device=dev)
                 geo = mat(g_edge_out.contiguous()) if g_edge_out is not None else None
-                dW1e, dW2, db2, dgam, dbet = ops.fused_edge_bwd(
+                ops.fused_edge_bwd(
                     g, em, True, psm, prm, W1e, W2, b2, gam, mat(g_agg), geo, mat(gh), gpr_m,
-                    mat(g_e), ctx.mean, d)
+                    mat(g_e), ctx.mean, d, dW1[:, :d], dW2, db2, dgam, dbet)
             else:
                 g_e = None
-                _, dW2, db2, dgam, dbet = ops.fused_edge_bwd(
+                ops.fused_edge_bwd(
                     g, mat(Pe), False, psm, prm, None, W2, b2, gam, mat(g_agg), None, mat(gh),
-                    gpr_m, None, ctx.mean, d)
+                    gpr_m, None, ctx.mean, d, None, dW2, db2, dgam, dbet)
             # 3. sender-side reduction of gh (CSR-ordered rows, sender lists of CSR positions)
-            dW1 = _empty(d, 3 * d, device=dev)
             if same:
                 if N_s > g.n_send:
                     gP[:, g.n_send :, :d].zero_()
@@ -231,10 +248,8 @@ class FusedInteractionNetFunction(torch.autograd.Function):
                     gP1 = _empty(1, N_s, 2 * d, device=dev)
                     ops.sum_batch(gP, gP1)
                     gpm = mat(gP1)
-                dWp, dbp = ops.fused_lin_bwd(sm, gpm, W1s, W1r, mat(gx_p))
-                ops.copy_rows(mat(dWp[:d]), mat(dW1, d, d))
-                ops.copy_rows(mat(dWp[d:]), mat(dW1, 2 * d, d))
-                db1 = dbp[d:]
+                ops.fused_lin_bwd(sm, gpm, W1s, W1r, mat(gx_p), dW1[:, d : 2 * d], None,
+                                  dW1[:, 2 * d :], db1)
                 g_send, g_rec_total = gx_p, g_rec
             else:
                 gPs = (torch.zeros if N_s > g.n_send else torch.empty)(
@@ -250,17 +265,16 @@ class FusedInteractionNetFunction(torch.autograd.Function):
                     ops.sum_batch(gPr, t2)
                     gpr_in = mat(t2)
                 g_send = _empty(sm.B, N_s, d, device=dev)
-                dWs, _ = ops.fused_lin_bwd(sm, gps_m, W1s, None, mat(g_send))
+                ops.fused_lin_bwd(sm, gps_m, W1s, None, mat(g_send), dW1[:, d : 2 * d], None,
+                                  None, None)
                 gx_r = _empty(rm.B, N_r, d, device=dev)
-                dWr, db1 = ops.fused_lin_bwd(rm, gpr_in, W1r, None, mat(gx_r))
-                ops.copy_rows(mat(dWs), mat(dW1, d, d))
-                ops.copy_rows(mat(dWr), mat(dW1, 2 * d, d))
+                ops.fused_lin_bwd(rm, gpr_in, W1r, None, mat(gx_r), dW1[:, 2 * d :], db1,
+                                  None, None)
                 # receiver gradient: node-update part (+ residual) + projection part
                 ops.add_rows(mat(g_rec), mat(gx_r), mat(g_rec))
                 g_rec_total = g_rec
             # 5. edge-side first-layer weights
             if ctx.update_edges:
-                ops.copy_rows(mat(dW1e), mat(dW1, 0, d))
                 g_edge = g_e
                 if em.B == 1 and B > 1:
                     t4 = _empty(1, M, d, device=dev)
@@ -274,8 +288,8 @@ class FusedInteractionNetFunction(torch.autograd.Function):
                 dPe_o = _empty(em.B, M, d, device=dev)
                 ops.gather_rows(mat(dPe), g.pos_of_eid, mat(dPe_o))   # CSR -> original order
                 g_edge = _empty(em.B, M, d, device=dev)
-                dWe, _ = ops.fused_lin_bwd(em, mat(dPe_o), W1e, None, mat(g_edge))
-                ops.copy_rows(mat(dWe), mat(dW1, 0, d))
+                ops.fused_lin_bwd(em, mat(dPe_o), W1e, None, mat(g_edge), dW1[:, :d], None,
+                                  None, None)
         return (g_send, g_rec_total, g_edge, None, None, None, None,
                 dW1, db1, dW2, db2, dgam, dbet, dV1, dc1, dV2, dc2, dg2, db2n)
 

@@ -5,6 +5,7 @@ arithmetic operation below is a kernel of libnlam_hip.so launched on torch's
 current stream.  All functions require fp32 HIP-device tensors and raise
 otherwise (no CPU fallback).
 """
+import ctypes
 import os
 import sys
 from collections import namedtuple
@@ -397,9 +398,32 @@ def reduce_slabs(slab, nslabs, stride, n, out, accumulate=False):
             nbytes=4.0 * nslabs * n)
 
 
-def fused_mlp_bwd(xa, xb, W1, b1, W2, b2, gamma, gy, gxa, gxb, add_gy_to_gxa, hid, n_out):
-    """Returns the reduced parameter-gradient buffer laid out as
-    [dW1 (hid x KP32) | db1 | dW2 (NO32 x hid) | db2 | dgamma | dbeta] and (KP32, NO32)."""
+def reduce_segments(slab, nslabs, stride, segs):
+    """One launch: for every (src_off, rows, cols, src_ld, dst) sum that matrix segment
+    of the per-workgroup slabs into dst (a 1-D or 2-D fp32 view with unit column
+    stride).  Deterministic."""
+    segs = [sg for sg in segs if sg[4] is not None]
+    for i in range(0, len(segs), 8):
+        part = segs[i : i + 8]
+        n = len(part)
+        I64, I32, P = ctypes.c_int64 * n, ctypes.c_int32 * n, ctypes.c_void_p * n
+        dst_ld = [d.stride(0) if d.dim() == 2 else d.numel() for (_, _, _, _, d) in part]
+        for (_, r, c, _, d) in part:
+            assert d.dtype == torch.float32 and (d.dim() == 1 or d.stride(1) == 1)
+            assert d.numel() == r * c, (tuple(d.shape), r, c)
+        _launch(
+            "nlam_reduce_slabs_multi", lib.nlam_reduce_slabs_multi,
+            (slab.data_ptr(), nslabs, stride, n, I64(*[sg[0] for sg in part]),
+             I32(*[sg[1] for sg in part]), I32(*[sg[2] for sg in part]),
+             I64(*[sg[3] for sg in part]), P(*[sg[4].data_ptr() for sg in part]), I64(*dst_ld),
+             stream()),
+            nbytes=4.0 * nslabs * sum(sg[1] * sg[2] for sg in part),
+        )
+
+
+def fused_mlp_bwd(xa, xb, W1, b1, W2, b2, gamma, gy, gxa, gxb, add_gy_to_gxa, hid, n_out, dst):
+    """dst: dict with the gradient tensors to fill: dW1 (hid, k_in), db1 (hid,),
+    dW2 (n_out, hid), db2 (n_out,), dgamma / dbeta (n_out,) (views allowed)."""
     B, rows = gy.B, gy.rows
     k_in = xa.cols + (xb.cols if xb is not None else 0)
     stride = lib.nlam_mlp_bwd_slab_stride(k_in, hid, n_out)
@@ -422,31 +446,34 @@ def fused_mlp_bwd(xa, xb, W1, b1, W2, b2, gamma, gy, gxa, gxb, add_gy_to_gxa, hi
          gxb.ptr if gxb is not None else None, gxb.bstride if gxb is not None else 0,
          gxb.ld if gxb is not None else 0, int(add_gy_to_gxa),
          slab.data_ptr(), stride, _p(ga), B, rows, hid, n_out, stream()),
-        flops=2.0 * B * rows * hid * ((3 if (gxa is not None or gxb is not None) else 2) * k_in
-                                       + 4 * n_out),
+        flops=2.0 * B * rows * hid * ((2 if (gxa is not None or gxb is not None) else 1) * k_in
+                                       + (0 if defer else k_in) + 4 * n_out),
         nbytes=4.0 * B * rows * (2 * k_in + n_out),
     )
-    red = torch.empty(stride, dtype=torch.float32, device=dev)
     kp32 = (k_in + 31) // 32 * 32
+    no32 = (n_out + 31) // 32 * 32
+    o1 = hid * kp32
+    o2 = o1 + hid
+    ov = o2 + no32 * hid
+    segs = [(o2, n_out, hid, hid, dst["dW2"]), (ov, 1, n_out, n_out, dst["db2"])]
+    if gamma is not None:
+        segs += [(ov + no32, 1, n_out, n_out, dst["dgamma"]),
+                 (ov + 2 * no32, 1, n_out, n_out, dst["dbeta"])]
     if defer:
-        n1 = hid * kp32 + hid
-        reduce_slabs(slab[n1:], nslabs, stride, stride - n1, red[n1:])
-        dW1, db1 = fused_outer_bwd(mat(ga), xa, xb, None)
-        copy_rows(mat(dW1), mat(red[: hid * kp32].view(hid, kp32)))
-        copy_rows(mat(db1), mat(red[hid * kp32 : n1]))
+        fused_outer_bwd(mat(ga), xa, xb, None, dst["dW1"], dst["db1"])
     else:
-        reduce_slabs(slab, nslabs, stride, stride, red)
-    return red, kp32, (n_out + 31) // 32 * 32
+        segs += [(0, hid, k_in, kp32, dst["dW1"]), (o1, 1, hid, hid, dst["db1"])]
+    reduce_segments(slab, nslabs, stride, segs)
 
 
-def fused_outer_bwd(g, xa, xb, x_index):
-    """dW = sum_rows g^T (x) [xa | xb] (rows of x optionally gathered by x_index),
-    db = colsum(g).  Returns (dW (ng, kx) view, db (ng,))."""
+def fused_outer_bwd(g, xa, xb, x_index, dW_dst, db_dst):
+    """dW_dst (ng, kx) = sum_rows g^T (x) [xa | xb] (x rows optionally gathered by
+    x_index), db_dst (ng,) = colsum(g) (db_dst may be None)."""
     B, rows, ng = g.B, g.rows, g.cols
     kx = xa.cols + (xb.cols if xb is not None else 0)
     stride = lib.nlam_outer_bwd_slab_stride(ng, kx)
     nslabs = lib.nlam_bwd_grid(_ntiles(B, rows))
-    dev = g.keep.device
+    dev = dW_dst.device
     slab = torch.empty(nslabs * stride, dtype=torch.float32, device=dev)
     _launch(
         "nlam_outer_bwd", lib.nlam_outer_bwd,
@@ -456,31 +483,14 @@ def fused_outer_bwd(g, xa, xb, x_index):
          _p(x_index), slab.data_ptr(), stride, B, rows, stream()),
         flops=2.0 * B * rows * ng * kx, nbytes=4.0 * B * rows * (ng + kx),
     )
-    red = torch.empty(stride, dtype=torch.float32, device=dev)
-    reduce_slabs(slab, nslabs, stride, stride, red)
     kx32 = (kx + 31) // 32 * 32
-    return red[: ng * kx32].view(ng, kx32)[:, :kx], red[ng * kx32 : ng * kx32 + ng]
+    reduce_segments(slab, nslabs, stride,
+                    [(0, ng, kx, kx32, dW_dst), (ng * kx32, 1, ng, ng, db_dst)])
 
 
-def split_mlp_grads(red, k_in, hid, n_out, kp32, no32, has_ln):
-    """Views of the reduced buffer as (dW1, db1, dW2, db2, dgamma, dbeta)."""
-    o = 0
-    dW1 = red[o : o + hid * kp32].view(hid, kp32)[:, :k_in]
-    o += hid * kp32
-    db1 = red[o : o + hid]
-    o += hid
-    dW2 = red[o : o + no32 * hid].view(no32, hid)[:n_out]
-    o += no32 * hid
-    db2 = red[o : o + n_out]
-    o += no32
-    dg = red[o : o + n_out] if has_ln else None
-    o += no32
-    dbt = red[o : o + n_out] if has_ln else None
-    return dW1, db1, dW2, db2, dg, dbt
-
-
-def fused_lin_bwd(x, gy, WA, WB, gx):
-    """Returns the reduced [dW ((nA+nB) x KP32) | db] buffer and KP32."""
+def fused_lin_bwd(x, gy, WA, WB, gx, dWA, dbA, dWB, dbB):
+    """gx = gy [WA; WB] (optional); dWA (nA, k), dbA (nA,), dWB, dbB: destination views
+    (any of them None = not needed)."""
     nA = WA.shape[0]
     nB = WB.shape[0] if WB is not None else 0
     B, rows, k_in = gy.B, gy.rows, x.cols
@@ -497,16 +507,17 @@ def fused_lin_bwd(x, gy, WA, WB, gx):
         flops=2.0 * B * rows * k_in * (nA + nB) * (2 if gx is not None else 1),
         nbytes=4.0 * B * rows * (k_in * (2 if gx is not None else 1) + nA + nB),
     )
-    red = torch.empty(stride, dtype=torch.float32, device=dev)
-    reduce_slabs(slab, nslabs, stride, stride, red)
     kp32 = (k_in + 31) // 32 * 32
     n = nA + nB
-    return red[: n * kp32].view(n, kp32)[:, :k_in], red[n * kp32 : n * kp32 + n]
+    segs = [(0, nA, k_in, kp32, dWA), (n * kp32, 1, nA, nA, dbA)]
+    if nB:
+        segs += [(nA * kp32, nB, k_in, kp32, dWB), (n * kp32 + nA, 1, nB, nB, dbB)]
+    reduce_segments(slab, nslabs, stride, segs)
 
 
 def fused_edge_bwd(g, e, has_egemm, ps, pr, W1e, W2, b2, gamma, g_agg, g_eout, gh_out, gpr, g_e,
-                   mean, d):
-    """Returns (dW1e or None, dW2, db2, dgamma, dbeta) views of the reduced slab."""
+                   mean, d, dW1e, dW2, db2, dgamma, dbeta):
+    """dW1e (d, d) (has_egemm), dW2, db2, dgamma, dbeta: destination views."""
     B = g_agg.B
     stride = lib.nlam_edge_bwd_slab_stride(d)
     nslabs = lib.nlam_bwd_grid(B * g.ntiles)
@@ -532,9 +543,9 @@ def fused_edge_bwd(g, e, has_egemm, ps, pr, W1e, W2, b2, gamma, g_agg, g_eout, g
                           + (2 * B * g.M if has_egemm else 0) + B * g.M
                           + B * (ps.rows + 3 * pr.rows)) + 16.0 * g.M,
     )
-    red = torch.empty(stride, dtype=torch.float32, device=dev)
-    reduce_slabs(slab, nslabs, stride, stride, red)
     dd = d * d
-    dW1e = red[:dd].view(d, d) if has_egemm else None
-    return (dW1e, red[dd : 2 * dd].view(d, d), red[2 * dd : 2 * dd + d],
-            red[2 * dd + d : 2 * dd + 2 * d], red[2 * dd + 2 * d : 2 * dd + 3 * d])
+    segs = [(dd, d, d, d, dW2), (2 * dd, 1, d, d, db2), (2 * dd + d, 1, d, d, dgamma),
+            (2 * dd + 2 * d, 1, d, d, dbeta)]
+    if has_egemm:
+        segs.append((0, d, d, d, dW1e))
+    reduce_segments(slab, nslabs, stride, segs)

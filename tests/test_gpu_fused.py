@@ -179,13 +179,16 @@ def test_fused_mlp_bwd(ka, kb, n_out, ln, res_a, B, rows, need_gx):
     dev = "cuda"
     gxa = torch.full((B, rows, ka), float("nan"), device=dev) if need_gx else None
     gxb = torch.full((B, rows, kb), float("nan"), device=dev) if (need_gx and kb) else None
-    red, kp32, no32 = ops.fused_mlp_bwd(
+    dst = {"dW1": torch.empty(hid, k_in, device=dev), "db1": torch.empty(hid, device=dev),
+           "dW2": torch.empty(n_out, hid, device=dev), "db2": torch.empty(n_out, device=dev),
+           "dgamma": torch.empty(n_out, device=dev), "dbeta": torch.empty(n_out, device=dev)}
+    ops.fused_mlp_bwd(
         ops.mat(xa.detach().to(dev)), ops.mat(xb.detach().to(dev)) if kb else None,
         W1.detach().to(dev), b1.detach().to(dev), W2.detach().to(dev), b2.detach().to(dev),
         gam.detach().to(dev) if ln else None, ops.mat(gy.to(dev)),
         ops.mat(gxa) if need_gx else None, ops.mat(gxb) if gxb is not None else None,
-        res_a, hid, n_out)
-    dW1, db1, dW2, db2, dg, dbt = ops.split_mlp_grads(red, k_in, hid, n_out, kp32, no32, ln)
+        res_a, hid, n_out, dst)
+    dW1, db1, dW2, db2, dg, dbt = (dst[k] for k in ("dW1", "db1", "dW2", "db2", "dgamma", "dbeta"))
     tol = 2e-5 * max(1.0, (B * rows) ** 0.5 / 8)
     assert rel(dW1, W1.grad) < tol and rel(db1, b1.grad) < tol
     assert rel(dW2, W2.grad) < tol and rel(db2, b2.grad) < tol
