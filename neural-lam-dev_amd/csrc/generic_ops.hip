@@ -497,18 +497,22 @@ __global__ __launch_bounds__(256) void segment_sum_vec_kernel(
   const int beg = rowptr[i], end = rowptr[i + 1];
   const float* sb = src + b * src_bstride;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  int p = beg + sub;
-  for (; p + R < end; p += 2 * R) {
-    const int64_t r0 = pos ? (int64_t)pos[p] : p;
-    const int64_t r1 = pos ? (int64_t)pos[p + R] : p + R;
-    const f32x4 v0 = reinterpret_cast<const f32x4*>(sb + r0 * ldsrc)[c4];
-    const f32x4 v1 = reinterpret_cast<const f32x4*>(sb + r1 * ldsrc)[c4];
-    acc += v0;
-    acc += v1;
-  }
-  if (p < end) {
-    const int64_t r0 = pos ? (int64_t)pos[p] : p;
-    acc += reinterpret_cast<const f32x4*>(sb + r0 * ldsrc)[c4];
+  // 4 row loads in flight per sub-group (16 rows per wave at d = 64: one trip covers
+  // a typical in-degree); rows past the segment end are clamped to a valid row and
+  // masked, so the loads are unconditional and issue back to back
+  for (int p = beg + sub; p < end; p += 4 * R) {
+    int64_t r[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int pp = p + u * R < end ? p + u * R : p;
+      r[u] = pos ? (int64_t)pos[pp] : pp;
+    }
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = reinterpret_cast<const f32x4*>(sb + r[u] * ldsrc)[c4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (p + u * R < end) acc += v[u];
   }
 #pragma unroll
   for (int o = LPR; o < 64; o <<= 1) {
