@@ -113,6 +113,97 @@ __global__ __launch_bounds__(256) void gemm_kernel(
   }
 }
 
+// Larger-tile variant for the big shapes of the generic path (hidden_dim 128/256,
+// SplitMLPs): 128x128 output tile, 4 waves each owning 64x64 (2x2 MFMA blocks), K
+// tiles of 16 prefetched into registers while the previous tile is multiplied.
+#define H_TM 128
+#define H_TN 128
+#define H_TK 16
+#define H_LD (H_TM + 4)
+
+__global__ __launch_bounds__(256) void gemm128_kernel(
+    int64_t M, int64_t N, int64_t K, const float* __restrict__ A, int64_t sa_i, int64_t sa_k,
+    const float* __restrict__ B, int64_t sb_k, int64_t sb_j, const float* __restrict__ bias,
+    float* __restrict__ C, int64_t ldc, int accumulate, int splitk, int64_t kchunk,
+    float* __restrict__ ws) {
+  __shared__ float As[H_TK][H_LD];
+  __shared__ float Bs[H_TK][H_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int64_t i0 = (int64_t)blockIdx.x * H_TM, j0 = (int64_t)blockIdx.y * H_TN;
+  const int z = blockIdx.z;
+  const int64_t kbeg = (int64_t)z * kchunk;
+  int64_t kend = kbeg + kchunk;
+  if (kend > K) kend = K;
+  // loader maps: 8 elements per thread per operand, along the contiguous dimension
+  const bool a_kc = sa_k == 1;   // A rows contiguous in k
+  const bool b_kc = sb_k == 1 && sb_j != 1;
+  const int a_i = a_kc ? (tid >> 1) : ((tid & 15) * 8), a_k = a_kc ? ((tid & 1) * 8) : (tid >> 4);
+  const int b_j = b_kc ? (tid >> 1) : ((tid & 15) * 8), b_k = b_kc ? ((tid & 1) * 8) : (tid >> 4);
+  float ra[8], rb[8];
+  auto load_tile = [&](int64_t kt) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int64_t gi = i0 + a_i + (a_kc ? 0 : u), gk = kt + a_k + (a_kc ? u : 0);
+      ra[u] = (gi < M && gk < kend) ? A[gi * sa_i + gk * sa_k] : 0.f;
+      const int64_t gj = j0 + b_j + (b_kc ? 0 : u), gk2 = kt + b_k + (b_kc ? u : 0);
+      rb[u] = (gj < N && gk2 < kend) ? B[gk2 * sb_k + gj * sb_j] : 0.f;
+    }
+  };
+  auto put_tile = [&]() {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      As[a_k + (a_kc ? u : 0)][a_i + (a_kc ? 0 : u)] = ra[u];
+      Bs[b_k + (b_kc ? u : 0)][b_j + (b_kc ? 0 : u)] = rb[u];
+    }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  if (kbeg < kend) load_tile(kbeg);
+  for (int64_t kt = kbeg; kt < kend; kt += H_TK) {
+    __syncthreads();           // previous tile fully consumed
+    put_tile();
+    __syncthreads();
+    if (kt + H_TK < kend) load_tile(kt + H_TK);   // in flight during the MFMAs below
+#pragma unroll
+    for (int kk = 0; kk < H_TK / 2; ++kk) {
+      const int kr = kk * 2 + (lane >> 5), c = lane & 31;
+      const float a0 = As[kr][wr * 64 + c], a1 = As[kr][wr * 64 + 32 + c];
+      const float b0 = Bs[kr][wc * 64 + c], b1 = Bs[kr][wc * 64 + 32 + c];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int bj = 0; bj < 2; ++bj) {
+    const int64_t j = j0 + wc * 64 + bj * 32 + (lane & 31);
+    if (j >= N) continue;
+    const float bv = (bias != nullptr && splitk == 1) ? bias[j] : 0.f;
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t i = i0 + wr * 64 + bi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (i < M) {
+          if (splitk == 1) {
+            float v = acc[bi][bj][r] + bv;
+            if (accumulate) v += C[i * ldc + j];
+            C[i * ldc + j] = v;
+          } else {
+            ws[((int64_t)z * M + i) * N + j] = acc[bi][bj][r];
+          }
+        }
+      }
+  }
+}
+
 __global__ void gemm_splitk_reduce(int64_t M, int64_t N, const float* __restrict__ ws,
                                    int splitk, const float* __restrict__ bias,
                                    float* __restrict__ C, int64_t ldc, int accumulate) {
@@ -138,13 +229,23 @@ extern "C" int nlam_gemm(int64_t M, int64_t N, int64_t K, const float* A, int64_
   int64_t kchunk = (K + splitk - 1) / splitk;
   kchunk = ((kchunk + G_TK - 1) / G_TK) * G_TK;
   if (kchunk == 0) kchunk = G_TK;
-  const int64_t gx = (M + G_TM - 1) / G_TM, gy = (N + G_TN - 1) / G_TN;
-  NLAM_REQUIRE(gy <= 65535 && splitk <= 65535, "nlam_gemm: grid too large");
   hipStream_t s = (hipStream_t)stream;
-  gemm_kernel<<<dim3((unsigned)gx, (unsigned)gy, (unsigned)splitk), 256, 0, s>>>(
-      M, N, K, A, sa_i, sa_k, B, sb_k, sb_j, bias, C, ldc, accumulate, splitk, kchunk,
-      workspace);
-  NLAM_CHECK_LAUNCH("gemm_kernel");
+  NLAM_REQUIRE(splitk <= 65535, "nlam_gemm: grid too large");
+  if (M >= 96 && N >= 96) {   // big shapes: 128x128 tiles with register prefetch
+    const int64_t gx = (M + H_TM - 1) / H_TM, gy = (N + H_TN - 1) / H_TN;
+    NLAM_REQUIRE(gy <= 65535, "nlam_gemm: grid too large");
+    gemm128_kernel<<<dim3((unsigned)gx, (unsigned)gy, (unsigned)splitk), 256, 0, s>>>(
+        M, N, K, A, sa_i, sa_k, B, sb_k, sb_j, bias, C, ldc, accumulate, splitk, kchunk,
+        workspace);
+    NLAM_CHECK_LAUNCH("gemm128_kernel");
+  } else {
+    const int64_t gx = (M + G_TM - 1) / G_TM, gy = (N + G_TN - 1) / G_TN;
+    NLAM_REQUIRE(gy <= 65535, "nlam_gemm: grid too large");
+    gemm_kernel<<<dim3((unsigned)gx, (unsigned)gy, (unsigned)splitk), 256, 0, s>>>(
+        M, N, K, A, sa_i, sa_k, B, sb_k, sb_j, bias, C, ldc, accumulate, splitk, kchunk,
+        workspace);
+    NLAM_CHECK_LAUNCH("gemm_kernel");
+  }
   if (splitk > 1) {
     const int64_t n = M * N;
     gemm_splitk_reduce<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(M, N, workspace, splitk,
@@ -353,12 +454,10 @@ extern "C" int nlam_layernorm_bwd(const float* z, int64_t ldz, const float* gamm
   layernorm_bwd_kernel<<<(unsigned)nb, 256, 0, s>>>(z, ldz, gamma, gy, ldgy, gz, ldgz, partial,
                                                     rows, (int)d, rpb);
   NLAM_CHECK_LAUNCH("layernorm_bwd");
-  const unsigned g = (unsigned)((d + 255) / 256);
-  reduce_partials_kernel<<<g, 256, 0, s>>>(partial, nb, 2 * d, dgamma, (int)d, accumulate);
-  NLAM_CHECK_LAUNCH("layernorm_bwd.dgamma");
-  reduce_partials_kernel<<<g, 256, 0, s>>>(partial + d, nb, 2 * d, dbeta, (int)d, accumulate);
-  NLAM_CHECK_LAUNCH("layernorm_bwd.dbeta");
-  return 0;
+  // fixed-order parallel reduction of the per-block partials (fused_mlp.hip)
+  int rc = nlam_reduce_slabs(partial, nb, 2 * d, d, dgamma, accumulate, stream);
+  if (rc) return rc;
+  return nlam_reduce_slabs(partial + d, nb, 2 * d, d, dbeta, accumulate, stream);
 }
 
 // ----------------------------------------------------------------- colsum
@@ -412,10 +511,7 @@ extern "C" int nlam_colsum(const float* x, int64_t ldx, float* out, int accumula
   hipStream_t s = (hipStream_t)stream;
   colsum_kernel<<<(unsigned)nb, 256, 0, s>>>(x, ldx, partial, rows, (int)d, rpb);
   NLAM_CHECK_LAUNCH("colsum");
-  reduce_partials_kernel<<<(unsigned)((d + 255) / 256), 256, 0, s>>>(partial, nb, d, out, (int)d,
-                                                                     accumulate);
-  NLAM_CHECK_LAUNCH("colsum.reduce");
-  return 0;
+  return nlam_reduce_slabs(partial, nb, d, d, out, accumulate, stream);
 }
 
 // ----------------------------------------------------------- gather / copy

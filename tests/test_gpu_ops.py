@@ -32,7 +32,8 @@ def test_mfma_lane_maps(ops):
 
 
 @pytest.mark.parametrize(
-    "M,N,K", [(1, 1, 1), (7, 5, 3), (64, 64, 64), (130, 70, 33), (1000, 64, 192), (300, 17, 64)]
+    "M,N,K", [(1, 1, 1), (7, 5, 3), (64, 64, 64), (130, 70, 33), (1000, 64, 192), (300, 17, 64),
+              (1000, 128, 384), (513, 256, 100), (129, 97, 1030)]
 )
 def test_gemm_linear(ops, M, N, K):
     gen = torch.Generator().manual_seed(M * 31 + N * 7 + K)
