@@ -1,0 +1,90 @@
+"""Data-parallel equivalence on the GPU: two ranks (two processes sharing the one
+visible card, gloo transport for the rehearsal) each take half of a batch; after the
+flat-buffer all-reduce their averaged gradient equals the single-process gradient of
+the whole batch, and one fused AdamW step leaves both ranks with identical weights."""
+import os
+import socket
+import tempfile
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _build(tmp):
+    import numpy as np
+    from neural_lam_amd import graphgen, synthetic
+    from neural_lam_amd.models import GraphLAM
+
+    info = graphgen.create_graph(tmp + "/graph/g", graphgen.make_xy(30, 28, 5000.0), None, False)
+    n = info["num_grid"]
+    gen = torch.Generator().manual_seed(0)
+    ds = synthetic.SyntheticDatastore(
+        tmp, torch.randn(n, 1, generator=gen).numpy(), np.zeros(5), np.ones(5), np.zeros(5),
+        np.ones(5), (torch.rand(n, generator=gen) < 0.2).float().numpy(), n_forcing=2)
+    torch.manual_seed(7)
+    model = GraphLAM(synthetic.model_args(graph="g", hidden_dim=64, processor_layers=1),
+                     config=None, datastore=ds)
+    return model, n
+
+
+def _worker(rank, world, port, tmp, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from neural_lam_amd import parallel, synthetic
+
+    torch.cuda.set_device(0)
+    model, n = _build(tmp)
+    model = model.cuda()
+    flat = parallel.FlatParams(model)
+    red = parallel.GradAllReduce(flat)
+    red.broadcast_params()
+    opt = parallel.FlatAdamW(flat, lr=1e-2)
+    full = synthetic.random_batch(4, 2, n, n_state=5, n_forcing_window=6, seed=3, device="cuda")
+    mine = tuple(t[rank * 2 : rank * 2 + 2] if t is not None else None for t in full)
+    flat.zero_grad()
+    model.training_step(mine).backward()
+    red.reduce()
+    opt.step(grad_scale=1.0 / world)
+    q.put((rank, (flat.grad / world).cpu().tolist(), flat.flat.cpu().tolist()))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradients_match_single_process():
+    from neural_lam_amd import parallel, synthetic
+
+    with tempfile.TemporaryDirectory() as tmp:
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker, args=(r, 2, port, tmp, q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        model, n = _build(tmp)
+    model = model.cuda()
+    flat = parallel.FlatParams(model)
+    full = synthetic.random_batch(4, 2, n, n_state=5, n_forcing_window=6, seed=3, device="cuda")
+    flat.zero_grad()
+    model.training_step(full).backward()
+    flat.pack_grads()
+    want = flat.grad.cpu()
+    g0, g1 = torch.tensor(res[0][1]), torch.tensor(res[1][1])
+    assert torch.equal(g0, g1)
+    assert float((g0 - want).abs().max() / want.abs().max()) < 1e-4
+    assert torch.equal(torch.tensor(res[0][2]), torch.tensor(res[1][2]))

@@ -1,0 +1,146 @@
+"""Full BASELINE-size checks (MEPS multiscale mesh: 6,561 nodes / 57,616 m2m edges;
+m2g: 255,136 edges) through size-independent properties, where the CPU oracle would
+take too long: agreement of the two independent HIP implementations (fused vs generic
+kernel sequences), invariance to the edge order, independence of batch items,
+linearity of the aggregate, determinism (bitwise repeatability)."""
+import tempfile
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def meps():
+    from neural_lam_amd import graphgen
+    from neural_lam_amd.utils import load_graph
+
+    with tempfile.TemporaryDirectory() as tmp:
+        graphgen.create_graph(tmp, graphgen.make_xy(238, 268))
+        _, g = load_graph(tmp)
+    return g
+
+
+def run_layer(net, x, e, cot_x, cot_e, force_generic):
+    from neural_lam_amd import fused
+
+    old = fused.FORCE_GENERIC
+    fused.FORCE_GENERIC = force_generic
+    try:
+        xs = x.clone().requires_grad_(True)
+        es = e.clone().requires_grad_(True)
+        for p in net.parameters():
+            p.grad = None
+        ox, oe = net(xs, xs, es)
+        ((ox * cot_x).sum() + (oe * cot_e).sum()).backward()
+        return ox.detach(), oe.detach(), xs.grad, es.grad, [p.grad.clone() for p in net.parameters()]
+    finally:
+        fused.FORCE_GENERIC = old
+
+
+def test_m2m_fused_vs_generic_full_size(meps):
+    from neural_lam_amd.interaction_net import InteractionNet
+
+    torch.manual_seed(0)
+    ei = meps["m2m_edge_index"]
+    net = InteractionNet(ei, 64).cuda()
+    B, N, M, d = 2, 6561, ei.shape[1], 64
+    x = torch.randn(B, N, d, device="cuda")
+    e = torch.randn(B, M, d, device="cuda")
+    cx, ce = torch.randn_like(x), torch.randn_like(e)
+    f = run_layer(net, x, e, cx, ce, False)
+    g = run_layer(net, x, e, cx, ce, True)
+    assert rel(f[0], g[0]) < 1e-5 and rel(f[1], g[1]) < 1e-5
+    assert rel(f[2], g[2]) < 1e-4 and rel(f[3], g[3]) < 1e-4
+    for a, b in zip(f[4], g[4]):
+        assert rel(a, b) < 1e-3
+    # determinism: no atomics anywhere => bitwise repeatable
+    f2 = run_layer(net, x, e, cx, ce, False)
+    assert torch.equal(f[0], f2[0]) and torch.equal(f[2], f2[2])
+    assert all(torch.equal(a, b) for a, b in zip(f[4], f2[4]))
+
+
+def test_edge_order_invariance_full_size(meps):
+    """Permuting the edges (edge_index columns and edge_rep rows alike) leaves the node
+    update unchanged and permutes the edge update."""
+    from neural_lam_amd.interaction_net import InteractionNet
+
+    torch.manual_seed(1)
+    ei = meps["m2m_edge_index"]
+    M, d, N = ei.shape[1], 64, 6561
+    perm = torch.randperm(M, generator=torch.Generator().manual_seed(2))
+    net_a = InteractionNet(ei, d).cuda()
+    net_b = InteractionNet(ei[:, perm], d).cuda()
+    net_b.load_state_dict(net_a.state_dict())
+    x = torch.randn(1, N, d, device="cuda")
+    e = torch.randn(1, M, d, device="cuda")
+    xa, ea = net_a(x, x, e)
+    xb, eb = net_b(x, x, e[:, perm.cuda()])
+    assert rel(xb, xa) < 1e-5
+    assert rel(eb, ea[:, perm.cuda()]) < 1e-6
+
+
+def test_batch_items_are_independent(meps):
+    from neural_lam_amd.interaction_net import InteractionNet
+
+    torch.manual_seed(3)
+    ei = meps["g2m_edge_index"]
+    net = InteractionNet(ei, 64, update_edges=False).cuda()
+    n_s, n_r, M = net.tables.n_send, net.tables.n_rec, ei.shape[1]
+    send = torch.randn(3, n_s, 64, device="cuda")
+    rec = torch.randn(n_r, 64, device="cuda")
+    edge = torch.randn(M, 64, device="cuda")
+    full = net(send, rec.unsqueeze(0).expand(3, -1, -1), edge.unsqueeze(0).expand(3, -1, -1))
+    one = net(send[1:2], rec.unsqueeze(0), edge.unsqueeze(0))
+    assert torch.equal(full[1:2], one)
+
+
+def test_aggregate_linearity_m2g_size(meps):
+    from neural_lam_amd import ops
+    from neural_lam_amd.interaction_net import InteractionNet
+
+    ei = meps["m2g_edge_index"]
+    t = InteractionNet(ei, 64, update_edges=False).cuda().tables
+    M, n_r = ei.shape[1], t.n_rec
+    gen = torch.Generator(device="cuda").manual_seed(4)
+    m1 = torch.randn(1, M, 64, device="cuda", generator=gen)
+    m2 = torch.randn(1, M, 64, device="cuda", generator=gen)
+    out = [torch.empty(1, n_r, 64, device="cuda") for _ in range(3)]
+    ops.segment_sum(ops.mat(m1), t.csr_rowptr, t.csr_eid, ops.mat(out[0]))
+    ops.segment_sum(ops.mat(m2), t.csr_rowptr, t.csr_eid, ops.mat(out[1]))
+    ops.segment_sum(ops.mat(2.5 * m1 + m2), t.csr_rowptr, t.csr_eid, ops.mat(out[2]))
+    assert rel(out[2], 2.5 * out[0] + out[1]) < 1e-6
+    # checksum: every message is counted exactly once
+    assert abs(float(out[0].double().sum()) - float(m1.double().sum())) < 1e-3 * M ** 0.5
+
+
+def test_high_in_degree_takes_generic_kernels_and_matches_oracle():
+    """A receiver with more than 32 in-edges is outside the fused tiles' contract."""
+    import nlam_oracle as orc
+    from neural_lam_amd import fused
+    from neural_lam_amd.interaction_net import InteractionNet
+
+    gen = torch.Generator().manual_seed(5)
+    n, M, d = 40, 400, 64
+    send = torch.randint(0, n, (M,), generator=gen)
+    rec = torch.randint(0, n, (M,), generator=gen)
+    rec[:60] = 7                                   # 60+ in-edges on receiver 7
+    rec[60], rec[61], send[62] = 0, n - 1, 0
+    send[63] = n - 1
+    ei = torch.stack((send, rec))
+    torch.manual_seed(6)
+    net = InteractionNet(ei, d)
+    sd = {f"n.{k}": v.clone() for k, v in net.state_dict().items()}
+    net = net.cuda()
+    x = torch.randn(2, n, d, generator=gen)
+    e = torch.randn(2, M, d, generator=gen)
+    assert net.tables.ntiles == 0
+    assert not fused.inet_eligible(net, x.cuda(), x.cuda(), e.cuda())
+    want = orc.interaction_net(sd, "n", ei, x, x, e)
+    got = net(x.cuda(), x.cuda(), e.cuda())
+    assert rel(got[0].cpu(), want[0]) < 1e-4 and rel(got[1].cpu(), want[1]) < 1e-4
