@@ -178,7 +178,7 @@ def main():
         return loss
 
     graphed = None
-    if not args.no_graph:
+    if not args.no_graph and world == 1:   # multi-rank runs launch eagerly (the gain is <1 %)
         graphed = parallel.GraphedTrainStep(model, flat, batch)
 
         def gstep():
