@@ -62,6 +62,7 @@ class FusedMLPFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, res, W1, b1, W2, b2, gamma, beta):
+        ctx.tag = ops._TAG[-1] if ops._TAG else "mlp"
         hid, n_out = W1.shape[0], W2.shape[0]
         xm = mat(x.detach())
         res_is_x = res is x
@@ -85,9 +86,10 @@ class FusedMLPFunction(torch.autograd.Function):
         need_gx = ctx.needs_input_grad[0]
         gx = _empty(xm.B, xm.rows, k_in, device=gy.device) if need_gx else None
         dst = _mlp_grad_dst(W1, W2, ctx.has_ln)
-        ops.fused_mlp_bwd(
-            xm, None, W1, b1, W2, b2, gamma, gym, mat(gx) if need_gx else None, None,
-            ctx.res_mode == 1 and need_gx, hid, n_out, dst)
+        with ops.tag(ctx.tag):
+            ops.fused_mlp_bwd(
+                xm, None, W1, b1, W2, b2, gamma, gym, mat(gx) if need_gx else None, None,
+                ctx.res_mode == 1 and need_gx, hid, n_out, dst)
         dW1, db1, dW2, db2 = dst["dW1"], dst["db1"], dst["dW2"], dst["db2"]
         dg, dbt = dst.get("dgamma"), dst.get("dbeta")
         gres = gy if ctx.res_mode == 2 else None

@@ -86,6 +86,7 @@ class MLPFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, res, n_layers, has_ln, *params):
+        ctx.tag = ops._TAG[-1] if ops._TAG else "mlp"
         weights = list(params[0 : 2 * n_layers : 2])
         biases = list(params[1 : 2 * n_layers : 2])
         ln = (params[2 * n_layers], params[2 * n_layers + 1]) if has_ln else None
@@ -108,9 +109,10 @@ class MLPFunction(torch.autograd.Function):
         ln = (params[2 * n], params[2 * n + 1]) if ctx.has_ln else None
         gy = gy.contiguous()
         need_gx = ctx.needs_input_grad[0]
-        gx, dWs, dbs, dln = mlp_backward(
-            mat(gy), ctx.xm, weights, ln, ctx.saved_bufs, need_gx, gy.device
-        )
+        with ops.tag(ctx.tag):
+            gx, dWs, dbs, dln = mlp_backward(
+                mat(gy), ctx.xm, weights, ln, ctx.saved_bufs, need_gx, gy.device
+            )
         ctx.saved_bufs = None
         grads = []
         for dW, db in zip(dWs, dbs):

@@ -36,9 +36,12 @@ class BaseGraphModel(ARModel):
             update_edges=False,
         )
         self.g2m_gnn.tables.tag, self.m2g_gnn.tables.tag = "g2m", "m2g"
+        for name in ("grid_embedder", "g2m_embedder", "m2g_embedder", "encoding_grid_mlp"):
+            getattr(self, name).tag = name
         self.output_map = utils.make_mlp(
             [args.hidden_dim] * (args.hidden_layers + 1) + [self.grid_output_dim], layer_norm=False
         )
+        self.output_map.tag = "output_map"
 
     def get_num_mesh(self):
         raise NotImplementedError("get_num_mesh not implemented")

@@ -48,6 +48,7 @@ class GraphLAM(BaseGraphModel):
 
         for net in self.processor:
             net.tables.tag = "m2m"
+        self.mesh_embedder.tag, self.m2m_embedder.tag = "mesh_embedder", "m2m_embedder"
 
     def get_num_mesh(self):
         return self.mesh_static_features.shape[0], 0

@@ -80,12 +80,15 @@ class HipMLP(nn.Sequential):
     """make_mlp's Sequential(Linear, SiLU, ..., Linear[, LayerNorm]) as a
     parameter container; forward = libnlam_hip.so kernels."""
 
-    def forward(self, x, res=None):
-        from . import fused
+    tag = "mlp"   # profiler label of this block's launches; the models set it
 
-        if fused.mlp_eligible(self, x):
-            return fused.apply_mlp(self, x, res)
-        return generic.apply_mlp(self, x, res)
+    def forward(self, x, res=None):
+        from . import fused, ops
+
+        with ops.tag(self.tag):
+            if fused.mlp_eligible(self, x):
+                return fused.apply_mlp(self, x, res)
+            return generic.apply_mlp(self, x, res)
 
 
 def make_mlp(blueprint, layer_norm=True):
