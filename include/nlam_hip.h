@@ -314,6 +314,13 @@ int nlam_wmse_bwd(const float* pred, const float* target, const float* keep,
                   const float* w, const float* gloss, float scale, float* g_pred,
                   int64_t rows, int64_t N, int F, void* stream);
 
+/* Diagnostic only: with NLAM_STAMP=1 in the environment nlam_edge_bwd (update_edges
+ * form) runs an instrumented build that sums s_memtime cycles per phase of its tile
+ * loop over all waves: out[0..5] = staging, recompute, LN-backward + column sums,
+ * dW2 + W2^T gz, gh store + receiver reduce, dW1e + W1e^T gh + store.  reset != 0
+ * zeroes the counters after reading. */
+int nlam_debug_edge_bwd_stamps(unsigned long long* out, int reset);
+
 /* Debug / self-test: verifies the MFMA fp32 32x32x2 operand and accumulator
  * lane maps the fused kernels rely on.  out: 32*32 floats = A(32x64) * B(64x32)
  * for the integer test pattern documented in csrc/mfma_probe.hip. */

@@ -13,6 +13,8 @@
 // receivers (nlam_graph_tiles_host): the segmented reduction is tile-local, has
 // a fixed order and needs no atomics.  Rows are gathered / scattered by index
 // but always moved as whole rows (coalesced 16 B per lane).
+#include <stdlib.h>
+
 #include "fused_common.h"
 
 struct EdgeFwdParams {
@@ -225,6 +227,29 @@ extern "C" int nlam_edge_fwd(
   return has_egemm ? launch_edge_fwd<128, true>(p, s) : launch_edge_fwd<128, false>(p, s);
 }
 
+// Diagnostic build only (NLAM_STAMP=1): per-phase cycle sums of the backward tile loop,
+// summed over all waves (s_memtime stamps; they perturb the schedule, read the SHARES).
+__device__ unsigned long long g_edge_bwd_stamps[8];
+extern "C" int nlam_debug_edge_bwd_stamps(unsigned long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_edge_bwd_stamps), sizeof(unsigned long long) * 8) !=
+      hipSuccess)
+    return 1;
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_edge_bwd_stamps), z, sizeof(z)) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#define STAMP_AT(k)                                             \
+  if (STAMP) {                                                  \
+    __builtin_amdgcn_sched_barrier(0);                          \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+    __builtin_amdgcn_s_waitcnt(0xC07F);                         \
+    __builtin_amdgcn_sched_barrier(0);                          \
+    st[k] += now_ - tprev;                                      \
+    tprev = now_;                                               \
+  }
+
 // =============================================================== backward ===
 // Recomputes h, s = silu(h), z = W2 s + b2 from the inputs, then
 //   gm_k = scale * g_agg[rec(k)] + g_eout_k
@@ -242,7 +267,7 @@ struct EdgeBwdParams {
   float* slab; int64_t slab_stride;
 };
 
-template <int D, bool HAS_EGEMM>
+template <int D, bool HAS_EGEMM, bool STAMP = false>
 __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NB = D / 32, NV = D / 64;
@@ -285,6 +310,8 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
   unsigned tt = blockIdx.x * 4 + wave;
   TileCtx cur = load_tile_ctx(p, load_tile_hdr(p, tt, total), lane);
   int4 hdr_n = load_tile_hdr(p, tt + stride, total);
+  unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tprev = STAMP ? __builtin_amdgcn_s_memtime() : 0;
   for (; tt < total; tt += stride) {
     const unsigned b = tt / (unsigned)p.ntiles;
     const int p0 = cur.p0, r0 = cur.r0;
@@ -324,6 +351,7 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
     put_rows_v<NVR, false>(T1, LDT, 0, D, ne, lane, vS);
     put_rows_v<NVR, false>(T2, LDT, 0, D, ne, lane, vG);         // g_agg rows
     wave_sync();
+    STAMP_AT(0)   // gathers landed + staged
     tile_to_acc<NB>(hpre, T1, LDT, lane);
     f32x16 g[NB];
     tile_to_acc<NB>(g, T2, LDT, lane);
@@ -356,6 +384,7 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
     gemm_acc<NB, NB>(z, W2s, LDW, 0, sact, lane);
     float mean, rstd;
     ln_stats<NB>(z, mean, rstd);
+    STAMP_AT(1)   // recompute: GEMM1, silu, GEMM2, stats
     // S is published right away (T2's g_agg / g_eout rows are already in registers):
     // sact's registers are free during the LayerNorm backward.  dbeta from the gm tile.
     wave_sync();
@@ -402,6 +431,7 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
     acc_to_tile<NB>(g, T1, LDT, lane);
     wave_sync();
     tile_colsum<NV>(db2, T1, LDT, 0, ne, lane);
+    STAMP_AT(2)   // LN backward + three column sums + tile transposes
     outer_accum<NB, NB>(dW2, T1, LDT, 0, T2, LDT, 0, lane);
     // gh = (W2^T gz) * silu'(h)   (registers + weights only)
     f32x16 gh[NB];
@@ -414,6 +444,7 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) gh[nb][r] *= nlam_silu_grad(hpre[nb][r]);
+    STAMP_AT(3)   // dW2 outer product + W2^T gz + silu'
     wave_sync();
     acc_to_tile<NB>(gh, T1, LDT, lane);       // GH
     wave_sync();
@@ -433,6 +464,7 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
         }
       }
     }
+    STAMP_AT(4)     // gh store + receiver-side segment reduce
     if (HAS_EGEMM) {
       outer_accum<NB, NB>(dW1, T1, LDT, 0, T0, LDT, 0, lane);
       f32x16 ge[NB];
@@ -449,8 +481,13 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
       store_rows<true>(T2, LDT, 0, D, ne, lane, o_row);
     }
     wave_sync();
+    STAMP_AT(5)     // dW1e outer product + W1e^T gh + g_e store
     cur = nxt;
     hdr_n = hdr_nn;
+  }
+  if (STAMP && lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) atomicAdd(&g_edge_bwd_stamps[k], st[k]);
   }
 
   __syncthreads();
@@ -469,12 +506,12 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
   for (int i = tid; i < D; i += 256) slab[2 * nW + 2 * D + i] = img[i];
 }
 
-template <int D, bool HAS_EGEMM>
+template <int D, bool HAS_EGEMM, bool STAMP = false>
 static int launch_edge_bwd(const EdgeBwdParams& q, hipStream_t s) {
   const size_t lds = ((size_t)(HAS_EGEMM ? 2 : 1) * D * (D + 4) + 2 * D +
                       (size_t)4 * 3 * NLAM_TILE * (D + 4)) * sizeof(float);
   NLAM_REQUIRE(lds <= 160 * 1024, "edge_bwd: LDS footprint %zu B exceeds 160 KiB", lds);
-  auto kern = edge_bwd_kernel<D, HAS_EGEMM>;
+  auto kern = edge_bwd_kernel<D, HAS_EGEMM, STAMP>;
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -536,5 +573,7 @@ extern "C" int nlam_edge_bwd(
   q.g_e = g_e; q.ge_bstride = ge_bstride; q.ge_ld = ge_ld;
   q.slab = slab; q.slab_stride = slab_stride;
   hipStream_t s = (hipStream_t)stream;
+  static const bool stamp = getenv("NLAM_STAMP") != nullptr;
+  if (stamp && has_egemm) return launch_edge_bwd<64, true, true>(q, s);
   return has_egemm ? launch_edge_bwd<64, true>(q, s) : launch_edge_bwd<64, false>(q, s);
 }
