@@ -311,12 +311,14 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
   TileCtx cur = load_tile_ctx(p, load_tile_hdr(p, tt, total), lane);
   int4 hdr_n = load_tile_hdr(p, tt + stride, total);
   unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long tprev = STAMP ? __builtin_amdgcn_s_memtime() : 0;
-  for (; tt < total; tt += stride) {
-    const unsigned b = tt / (unsigned)p.ntiles;
-    const int p0 = cur.p0, r0 = cur.r0;
-    const int ne = cur.ne, nr = cur.nr;
-    const int eid = cur.eid, snd = cur.snd, rcv = cur.rcv;
+  // The five row gathers of a tile (e, ps, pr, g_agg, g_eout) are issued ONE TILE AHEAD,
+  // at the start of the previous tile's last phase, and land while its MFMAs run: with
+  // one wave per SIMD nothing else hides their latency (stamps: 16 % of the tile time).
+  f32x4 vE[NVR], vS[NVR], vR[NVR], vG[NVR], vO[NVR];
+  auto issue_rows = [&](const TileCtx& c, unsigned task) {
+    const unsigned tq = task < total ? task : total - 1;
+    const unsigned b = tq / (unsigned)p.ntiles;
+    const int eid = c.eid, snd = c.snd, rcv = c.rcv;
     const float* eb = p.e.ptr + (int64_t)b * p.e.bstride;
     const float* psb = p.ps.ptr + (int64_t)b * p.ps.bstride;
     const float* prb = p.pr.ptr + (int64_t)b * p.pr.bstride;
@@ -328,13 +330,19 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
     auto pr_row = [&](int s) { return prb + (int64_t)__shfl(rcv, s, 64) * p.pr.ld; };
     auto ga_row = [&](int s) { return gab + (int64_t)__shfl(rcv, s, 64) * q.g_agg.ld; };
     auto go_row = [&](int s) { return gob + (int64_t)__shfl(eid, s, 64) * gold; };
-    // every gather of this tile in flight together; then the next tile's indices
-    f32x4 vE[NVR], vS[NVR], vR[NVR], vG[NVR], vO[NVR];
     load_rows_v<NVR>(vE, D, lane, e_row);
     load_rows_v<NVR>(vS, D, lane, ps_row);
     load_rows_v<NVR>(vR, D, lane, pr_row);
     load_rows_v<NVR>(vG, D, lane, ga_row);
     if (has_geo) load_rows_v<NVR>(vO, D, lane, go_row);
+  };
+  if (tt < total) issue_rows(cur, tt);
+  unsigned long long tprev = STAMP ? __builtin_amdgcn_s_memtime() : 0;
+  for (; tt < total; tt += stride) {
+    const unsigned b = tt / (unsigned)p.ntiles;
+    const int p0 = cur.p0, r0 = cur.r0;
+    const int ne = cur.ne, nr = cur.nr;
+    const int eid = cur.eid, rcv = cur.rcv;
     const TileCtx nxt = load_tile_ctx(p, hdr_n, lane);
     const int4 hdr_nn = load_tile_hdr(p, tt + 2 * stride, total);
 
@@ -432,6 +440,7 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
     wave_sync();
     tile_colsum<NV>(db2, T1, LDT, 0, ne, lane);
     STAMP_AT(2)   // LN backward + three column sums + tile transposes
+    if (!HAS_EGEMM) issue_rows(nxt, tt + stride);  // (no later MFMA phase in this form)
     outer_accum<NB, NB>(dW2, T1, LDT, 0, T2, LDT, 0, lane);
     // gh = (W2^T gz) * silu'(h)   (registers + weights only)
     f32x16 gh[NB];
@@ -465,6 +474,7 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
       }
     }
     STAMP_AT(4)     // gh store + receiver-side segment reduce
+    if (HAS_EGEMM) issue_rows(nxt, tt + stride);   // next gathers fly under the MFMAs below
     if (HAS_EGEMM) {
       outer_accum<NB, NB>(dW1, T1, LDT, 0, T0, LDT, 0, lane);
       f32x16 ge[NB];
