@@ -51,7 +51,6 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
 }
-__device__ __forceinline__ void phase_fence() { __builtin_amdgcn_sched_barrier(0); }
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
@@ -418,50 +417,6 @@ __device__ __forceinline__ void ln_apply(f32x16 (&z)[NB], const float* __restric
   }
 }
 
-// LayerNorm backward in place: z (pre-LN) -> xhat is consumed, gy -> gz.
-// Accumulates per-lane partial dgamma/dbeta (acc layout; rows with valid=false
-// contribute nothing).
-template <int NB>
-__device__ __forceinline__ void ln_backward(const f32x16 (&z)[NB], f32x16 (&gy)[NB],
-                                            const float* __restrict__ gamma, f32x16 (&dgam)[NB],
-                                            f32x16 (&dbet)[NB], bool valid, int lane) {
-  constexpr float inv_d = 1.0f / (32.0f * NB);
-  float mean, rstd;
-  ln_stats<NB>(z, mean, rstd);
-  const int h = lane >> 5;
-  float s1 = 0.f, s2 = 0.f;
-  f32x16 gg[NB];
-#pragma unroll
-  for (int nb = 0; nb < NB; ++nb) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + 32 * nb + 8 * q + 4 * h);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int r = 4 * q + j;
-        const float xh = (z[nb][r] - mean) * rstd;
-        const float go = valid ? gy[nb][r] : 0.f;
-        dgam[nb][r] += go * xh;
-        dbet[nb][r] += go;
-        const float gv = go * g[j];
-        gg[nb][r] = gv;
-        s1 += gv;
-        s2 += gv * xh;
-      }
-    }
-  }
-  s1 += __shfl_xor(s1, 32, 64);
-  s2 += __shfl_xor(s2, 32, 64);
-  const float m1 = s1 * inv_d, m2 = s2 * inv_d;
-#pragma unroll
-  for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float xh = (z[nb][r] - mean) * rstd;
-      gy[nb][r] = rstd * (gg[nb][r] - m1 - xh * m2);
-    }
-}
-
 // ---- coalesced tile -> global row stores -------------------------------------
 template <bool VEC, typename RowPtr>
 __device__ __forceinline__ void store_rows(const float* __restrict__ tile, int ld, int col0,
@@ -513,21 +468,6 @@ __device__ __forceinline__ void store_rows_res(const float* __restrict__ tile, i
   }
 }
 
-// column sums over the 32 lanes t of per-lane partials in acc layout, through an
-// LDS tile: out[f] (+)= sum_t v(t, f).  Used to fold dgamma/dbeta/bias partials.
-template <int NB>
-__device__ __forceinline__ void acc_colsum_to(const f32x16 (&v)[NB], float* __restrict__ tile,
-                                              int ld, float* __restrict__ out, int lane) {
-  acc_to_tile<NB>(v, tile, ld, lane);
-  wave_sync();
-  for (int f = lane; f < 32 * NB; f += 64) {
-    float s = 0.f;
-#pragma unroll 8
-    for (int t = 0; t < NLAM_TILE; ++t) s += tile[t * ld + f];
-    out[f] = s;
-  }
-}
-
 // ---- gradient helpers ----------------------------------------------------------
 // lanes = features: acc[j] += sum_t tile[t][col0 + 64 j + lane]  (j < NV), the
 // per-feature (bias / gamma / beta) gradient contribution of one tile.
@@ -539,56 +479,6 @@ __device__ __forceinline__ void tile_colsum(float (&acc)[NV], const float* __res
     float s = 0.f;
     for (int t = 0; t < nrows; ++t) s += tile[t * ld + col0 + 64 * j + lane];
     acc[j] += s;
-  }
-}
-
-// Segmented sum of a message tile over receiver segments with lanes = features:
-// out_row(i)[f] = scale_i * sum_{s in [rp_i, rp_{i+1})} tile[s][f], i < nr.  `rp` /
-// `scale` are held by lane i (lane i <= nr for rp).  Slot values are read from LDS
-// eight at a time (static, pipelined); the walk over the segments is wave-uniform.
-__device__ __forceinline__ int lane_i(int v, int i) {
-  return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(i));
-}
-__device__ __forceinline__ float lane_f(float v, int i) {
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), __builtin_amdgcn_readfirstlane(i)));
-}
-template <int D, typename OutRow>
-__device__ __forceinline__ void segment_reduce_tile(const float* __restrict__ tile, int ld, int ne,
-                                                    int nr, int rp, float scale, int lane,
-                                                    OutRow out_row) {
-#pragma unroll
-  for (int f0 = 0; f0 < D; f0 += 64) {
-    int i = 0;
-    int end = lane_i(rp, 1);
-    float acc = 0.f;
-    while (i < nr && end == lane_i(rp, i)) {   // receivers without in-edges at the front
-      out_row(i)[f0 + lane] = 0.f;
-      ++i;
-      end = lane_i(rp, i + 1);
-    }
-    for (int s0 = 0; s0 < ne; s0 += 8) {
-      float v[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] = tile[(s0 + k) * ld + f0 + lane];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int s = s0 + k;
-        if (s < ne) {
-          acc += v[k];
-          if (s + 1 == end) {
-            out_row(i)[f0 + lane] = acc * lane_f(scale, i);
-            acc = 0.f;
-            ++i;
-            end = lane_i(rp, i + 1);
-            while (i < nr && end == s + 1) {   // empty receivers in between / at the end
-              out_row(i)[f0 + lane] = 0.f;
-              ++i;
-              end = lane_i(rp, i + 1);
-            }
-          }
-        }
-      }
-    }
   }
 }
 
@@ -629,81 +519,6 @@ __device__ __forceinline__ void fold_vec_lds(const float (&v)[NV], float* __rest
       for (int j = 0; j < NV; ++j) {
         float* dst = img + 64 * j + lane;
         *dst = (w == 0) ? v[j] : (*dst + v[j]);
-      }
-    }
-    __syncthreads();
-  }
-}
-
-
-// ---- workgroup-distributed weight gradients -------------------------------------
-// dW (32 NI x 32 NJ) = sum over rows of G (x) X.  Instead of every wave holding all
-// NI*NJ accumulator blocks for its own tile (128+ registers), the 4 waves of the
-// workgroup run in lockstep: each wave publishes its G / X tiles in LDS, then
-// accumulates only ITS blocks over all four tiles.  With fewer than 4 blocks the
-// tiles are split between the waves that share a block.  MAXB = max(1, NI*NJ/4).
-template <int NI, int NJ>
-struct DwMap {
-  static constexpr int NBLK = NI * NJ;
-  static constexpr int MAXB = NBLK >= 4 ? NBLK / 4 : 1;
-  static_assert(NBLK == 1 || NBLK == 2 || NBLK % 4 == 0, "unsupported block count");
-  __device__ static __forceinline__ int block(int wave, int m) {
-    return NBLK >= 4 ? wave + 4 * m : (NBLK == 2 ? (wave & 1) : 0);
-  }
-  __device__ static __forceinline__ int tile_first(int wave) {
-    return NBLK >= 4 ? 0 : (NBLK == 2 ? (wave >> 1) : wave);
-  }
-  __device__ static __forceinline__ int tile_step() { return NBLK >= 4 ? 1 : (NBLK == 2 ? 2 : 4); }
-};
-
-// Gbase / Xbase: tile of wave 0; wave w2's tile is at + w2 * wstride floats.
-// Call between two __syncthreads() (tiles published / tiles free again).
-template <int NI, int NJ, int MAXB>
-__device__ __forceinline__ void dw_accumulate(f32x16 (&acc)[MAXB],
-                                              const float* __restrict__ Gbase, int ldg,
-                                              const float* __restrict__ Xbase, int ldx,
-                                              int wstride, int wave, int lane) {
-  using M = DwMap<NI, NJ>;
-  static_assert(MAXB == M::MAXB, "accumulator array size");
-  const int i = lane & 31, h = lane >> 5;
-#pragma unroll
-  for (int m = 0; m < M::MAXB; ++m) {
-    const int bid = M::block(wave, m);
-    const int gcol = 32 * (bid / NJ) + i, xcol = 32 * (bid % NJ) + i;
-    for (int w2 = M::tile_first(wave); w2 < 4; w2 += M::tile_step()) {
-      const float* G = Gbase + w2 * wstride;
-      const float* X = Xbase + w2 * wstride;
-#pragma unroll
-      for (int s = 0; s < NLAM_TILE / 2; ++s) {
-        const int t = 2 * s + h;
-        acc[m] = mfma32(G[t * ldg + gcol], X[t * ldx + xcol], acc[m]);
-      }
-    }
-  }
-}
-
-// Sum the waves' blocks into an LDS image [32 NI][ldimg] in wave order (fixed order
-// => deterministic).  All 256 threads; img must not alias live data.
-template <int NI, int NJ, int MAXB>
-__device__ __forceinline__ void dw_fold(const f32x16 (&acc)[MAXB],
-                                        float* __restrict__ img, int ldimg, int tid, int wave,
-                                        int lane) {
-  using M = DwMap<NI, NJ>;
-  static_assert(MAXB == M::MAXB, "accumulator array size");
-  for (int idx = tid; idx < 32 * NI * ldimg; idx += 256) img[idx] = 0.f;
-  __syncthreads();
-  const int h = lane >> 5, j = lane & 31;
-  for (int w = 0; w < 4; ++w) {
-    if (wave == w) {
-#pragma unroll
-      for (int m = 0; m < M::MAXB; ++m) {
-        const int bid = M::block(wave, m);
-        const int ib = bid / NJ, jb = bid % NJ;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int i = 32 * ib + 8 * (r >> 2) + 4 * h + (r & 3);
-          img[i * ldimg + 32 * jb + j] += acc[m][r];
-        }
       }
     }
     __syncthreads();
