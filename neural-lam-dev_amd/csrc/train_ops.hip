@@ -132,13 +132,19 @@ __global__ __launch_bounds__(256) void wmse_partial_kernel(
   }
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
-__global__ void wmse_final_kernel(const float* __restrict__ partial, int n, float scale,
-                                  float* __restrict__ out) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    float s = 0.f;
-    for (int i = 0; i < n; ++i) s += partial[i];
-    out[0] = s * scale;
+// Fixed-shape tree over the block partials (deterministic; one 256-thread workgroup).
+__global__ __launch_bounds__(256) void wmse_final_kernel(const float* __restrict__ partial, int n,
+                                                         float scale, float* __restrict__ out) {
+  __shared__ float red[256];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
   }
+  if (threadIdx.x == 0) out[0] = red[0] * scale;
 }
 extern "C" int64_t nlam_wmse_blocks(void) { return 1024; }
 extern "C" int nlam_wmse_fwd(const float* pred, const float* target, const float* keep,
@@ -148,7 +154,7 @@ extern "C" int nlam_wmse_fwd(const float* pred, const float* target, const float
   hipStream_t s = (hipStream_t)stream;
   wmse_partial_kernel<<<1024, 256, 0, s>>>(pred, target, keep, w, partial, rows, N, F);
   NLAM_CHECK_LAUNCH("wmse_partial");
-  wmse_final_kernel<<<1, 64, 0, s>>>(partial, 1024, scale, out);
+  wmse_final_kernel<<<1, 256, 0, s>>>(partial, 1024, scale, out);
   NLAM_CHECK_LAUNCH("wmse_final");
   return 0;
 }

@@ -136,6 +136,9 @@ def _base(t):
     if t.dim() == 2:
         return t.unsqueeze(0)
     if t.dim() == 3 and t.shape[0] > 1 and t.stride(0) == 0:
+        base = getattr(t, "_nlam_base", None)   # set by ARModel.expand_to_batch
+        if base is not None and base.shape[1:] == t.shape[1:] and base.data_ptr() == t.data_ptr():
+            return base
         return t[:1]
     return t
 
@@ -179,6 +182,8 @@ class FusedInteractionNetFunction(torch.autograd.Function):
             rec_out = _empty(B, N_r, d, device=dev)
             ops.fused_mlp_fwd(rm, mat(agg), V1, c1, V2, c2, gam2, bet2, rm, mat(rec_out), d, d)
             ctx.save_for_backward(W1, b1, W2, b2, gam, V1, c1, V2, c2, gam2)
+            # an unused e' (last processor layer) arrives as None instead of a zero tensor
+            ctx.set_materialize_grads(False)
             ctx.g, ctx.same, ctx.update_edges, ctx.mean = g, same, update_edges, mean
             ctx.mats = (sm, rm, em)
             ctx.bufs = (saved_proj, Pe, agg)
@@ -200,6 +205,8 @@ class FusedInteractionNetFunction(torch.autograd.Function):
             W1e, W1s, W1r = W1[:, :d], W1[:, d : 2 * d], W1[:, 2 * d :]
             same = ctx.same
             # 1. node update backward: g_rec (incl. residual), g_agg
+            if g_rec_out is None:
+                g_rec_out = torch.zeros(B, N_r, d, dtype=torch.float32, device=dev)
             g_rec_out = g_rec_out.contiguous()
             g_rec = _empty(B, N_r, d, device=dev)
             g_agg = _empty(B, N_r, d, device=dev)

@@ -89,7 +89,13 @@ class ARModel(_Base):
 
     @staticmethod
     def expand_to_batch(x, batch_size):
-        return x.unsqueeze(0).expand(batch_size, -1, -1)
+        # same stride-0 view as the reference; the un-expanded (1, N, d) tensor rides along
+        # so the fused operators take it directly and its gradient skips autograd's
+        # zero-fill + slice-copy + batch-sum of the expand (fused._base)
+        base = x.unsqueeze(0)
+        out = base.expand(batch_size, -1, -1)
+        out._nlam_base = base
+        return out
 
     def predict_step(self, prev_state, prev_prev_state, forcing):
         raise NotImplementedError("No prediction step implemented")
