@@ -239,7 +239,8 @@ int nlam_edge_fwd(const int32_t* tiles, int64_t ntiles,
                   float* e_out, int64_t eo_bstride, int64_t eo_ld,
                   int64_t B, int d, void* stream);
 
-/* Backward of nlam_lin_fwd: gx = gy [WA; WB] (optional), per-workgroup slabs
+/* Backward of nlam_lin_fwd: gx = gy [WA; WB] [+ gx_add] (optional; gx_add folds the
+ * autograd accumulation of a second gradient of the same input), per-workgroup slabs
  * [dW ((nA+nB) x KP32) | db (nA+nB)], KP32 = k_in rounded up to 32; number of
  * slabs = nlam_bwd_grid(B * ceil(rows/32)). */
 int64_t nlam_lin_bwd_slab_stride(int k_in, int n_out);
@@ -248,6 +249,7 @@ int nlam_lin_bwd(const float* x, int64_t x_bstride, int64_t x_ld, int k_in,
                  const float* WA, int64_t ldWA, int nA,
                  const float* WB, int64_t ldWB, int nB,
                  float* gx, int64_t gx_bstride, int64_t gx_ld,
+                 const float* gx_add, int64_t ga_bstride, int64_t ga_ld,
                  float* slab, int64_t slab_stride, int64_t B, int64_t rows,
                  void* stream);
 

@@ -698,6 +698,7 @@ struct LinBwdParams {
   const float* WA; int64_t ldWA; int nA;
   const float* WB; int64_t ldWB; int nB;
   float* gx; int64_t gx_bstride; int64_t gx_ld;   // optional
+  const float* gx_add; int64_t ga_bstride; int64_t ga_ld;   // optional addend of gx
   float* slab; int64_t slab_stride;
   int64_t rows; int B;
   int vec_x, vec_gy, vec_gx;
@@ -770,10 +771,18 @@ __global__ __launch_bounds__(256) void lin_bwd_kernel(LinBwdParams q) {
       wave_sync();
       float* ob = q.gx + b * q.gx_bstride + r0 * q.gx_ld;
       auto op = [&](int t) { return ob + (int64_t)t * q.gx_ld; };
-      if (q.vec_gx)
+      if (q.gx_add != nullptr) {
+        const float* ab = q.gx_add + b * q.ga_bstride + r0 * q.ga_ld;
+        auto ap = [&](int t) { return ab + (int64_t)t * q.ga_ld; };
+        if (q.vec_gx)
+          store_rows_res<true>(T0, ldt0, 0, q.x.width, nrows, lane, op, ap);
+        else
+          store_rows_res<false>(T0, ldt0, 0, q.x.width, nrows, lane, op, ap);
+      } else if (q.vec_gx) {
         store_rows<true>(T0, ldt0, 0, q.x.width, nrows, lane, op);
-      else
+      } else {
         store_rows<false>(T0, ldt0, 0, q.x.width, nrows, lane, op);
+      }
       wave_sync();
     }
   }
@@ -816,24 +825,28 @@ extern "C" int nlam_lin_bwd(const float* x, int64_t x_bstride, int64_t x_ld, int
                             const float* WA, int64_t ldWA, int nA,
                             const float* WB, int64_t ldWB, int nB,
                             float* gx, int64_t gx_bstride, int64_t gx_ld,
+                            const float* gx_add, int64_t ga_bstride, int64_t ga_ld,
                             float* slab, int64_t slab_stride, int64_t B, int64_t rows,
                             void* stream) {
   if (B <= 0 || rows <= 0) return 0;
   NLAM_REQUIRE(nA > 0 && nA % 32 == 0 && nB >= 0 && nB % 32 == 0,
                "nlam_lin_bwd: output block widths must be multiples of 32");
+  NLAM_REQUIRE(gx_add == nullptr || gx != nullptr, "nlam_lin_bwd: gx_add without gx");
   LinBwdParams q;
   q.x = RowView{x, x_bstride, x_ld, k_in};
   q.nA = nA; q.nB = WB ? nB : 0;
   q.gy = RowView{gy, gy_bstride, gy_ld, q.nA + q.nB};
   q.WA = WA; q.ldWA = ldWA; q.WB = WB; q.ldWB = ldWB;
   q.gx = gx; q.gx_bstride = gx_bstride; q.gx_ld = gx_ld;
+  q.gx_add = gx_add; q.ga_bstride = ga_bstride; q.ga_ld = ga_ld;
   q.slab = slab; q.slab_stride = slab_stride;
   q.rows = rows; q.B = (int)B;
   NLAM_REQUIRE(slab != nullptr && slab_stride >= nlam_lin_bwd_slab_stride(k_in, q.nA + q.nB),
                "nlam_lin_bwd: slab too small");
   q.vec_x = view_vec_ok(x, x_bstride, x_ld, k_in);
   q.vec_gy = view_vec_ok(gy, gy_bstride, gy_ld, q.nA + q.nB);
-  q.vec_gx = gx && view_vec_ok(gx, gx_bstride, gx_ld, k_in);
+  q.vec_gx = gx && view_vec_ok(gx, gx_bstride, gx_ld, k_in) &&
+             (gx_add == nullptr || view_vec_ok(gx_add, ga_bstride, ga_ld, k_in));
   hipStream_t s = (hipStream_t)stream;
   const int noutb = (q.nA + q.nB) / 32, kb = (k_in + 31) / 32;
   if (noutb == 2 && kb == 2) return launch_lin_bwd<2, 2>(q, s);

@@ -257,9 +257,11 @@ class FusedInteractionNetFunction(torch.autograd.Function):
                     gP1 = _empty(1, N_s, 2 * d, device=dev)
                     ops.sum_batch(gP, gP1)
                     gpm = mat(gP1)
+                # send_rep is rec_rep: one total gradient (node update + residual + both
+                # projections), folded into the store of the projection backward
                 ops.fused_lin_bwd(sm, gpm, W1s, W1r, mat(gx_p), dW1[:, d : 2 * d], None,
-                                  dW1[:, 2 * d :], db1)
-                g_send, g_rec_total = gx_p, g_rec
+                                  dW1[:, 2 * d :], db1, gx_add=mat(g_rec))
+                g_send, g_rec_total = gx_p, None
             else:
                 gPs = (torch.zeros if N_s > g.n_send else torch.empty)(
                     B, N_s, d, dtype=torch.float32, device=dev)
@@ -276,12 +278,10 @@ class FusedInteractionNetFunction(torch.autograd.Function):
                 g_send = _empty(sm.B, N_s, d, device=dev)
                 ops.fused_lin_bwd(sm, gps_m, W1s, None, mat(g_send), dW1[:, d : 2 * d], None,
                                   None, None)
-                gx_r = _empty(rm.B, N_r, d, device=dev)
-                ops.fused_lin_bwd(rm, gpr_in, W1r, None, mat(gx_r), dW1[:, 2 * d :], db1,
-                                  None, None)
                 # receiver gradient: node-update part (+ residual) + projection part
-                ops.add_rows(mat(g_rec), mat(gx_r), mat(g_rec))
-                g_rec_total = g_rec
+                g_rec_total = _empty(rm.B, N_r, d, device=dev)
+                ops.fused_lin_bwd(rm, gpr_in, W1r, None, mat(g_rec_total), dW1[:, 2 * d :], db1,
+                                  None, None, gx_add=mat(g_rec))
             # 5. edge-side first-layer weights
             if ctx.update_edges:
                 g_edge = g_e

@@ -12,7 +12,7 @@ from collections import namedtuple
 
 import torch
 
-from ._lib import check, lib
+from ._lib import NlamError, check, lib
 
 # A (B, rows, cols) fp32 matrix stack in device memory with unit column stride.
 # bstride may be 0 (batch-invariant).  `keep` pins the owning tensor.
@@ -488,9 +488,12 @@ def fused_outer_bwd(g, xa, xb, x_index, dW_dst, db_dst):
                     [(0, ng, kx, kx32, dW_dst), (ng * kx32, 1, ng, ng, db_dst)])
 
 
-def fused_lin_bwd(x, gy, WA, WB, gx, dWA, dbA, dWB, dbB):
-    """gx = gy [WA; WB] (optional); dWA (nA, k), dbA (nA,), dWB, dbB: destination views
-    (any of them None = not needed)."""
+def fused_lin_bwd(x, gy, WA, WB, gx, dWA, dbA, dWB, dbB, gx_add=None):
+    """gx = gy [WA; WB] [+ gx_add] (optional); dWA (nA, k), dbA (nA,), dWB, dbB: destination
+    views (any of them None = not needed)."""
+    if gx_add is not None:
+        if gx is None or (gx_add.B, gx_add.rows, gx_add.cols) != (gx.B, gx.rows, gx.cols):
+            raise NlamError("fused_lin_bwd: gx_add must match gx")
     nA = WA.shape[0]
     nB = WB.shape[0] if WB is not None else 0
     B, rows, k_in = gy.B, gy.rows, x.cols
@@ -503,7 +506,10 @@ def fused_lin_bwd(x, gy, WA, WB, gx, dWA, dbA, dWB, dbB):
         (x.ptr, x.bstride, x.ld, k_in, gy.ptr, gy.bstride, gy.ld, WA.data_ptr(), WA.stride(0), nA,
          _p(WB), WB.stride(0) if WB is not None else 0, nB,
          gx.ptr if gx is not None else None, gx.bstride if gx is not None else 0,
-         gx.ld if gx is not None else 0, slab.data_ptr(), stride, B, rows, stream()),
+         gx.ld if gx is not None else 0,
+         gx_add.ptr if gx_add is not None else None,
+         gx_add.bstride if gx_add is not None else 0, gx_add.ld if gx_add is not None else 0,
+         slab.data_ptr(), stride, B, rows, stream()),
         flops=2.0 * B * rows * k_in * (nA + nB) * (2 if gx is not None else 1),
         nbytes=4.0 * B * rows * (k_in * (2 if gx is not None else 1) + nA + nB),
     )

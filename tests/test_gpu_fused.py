@@ -109,6 +109,35 @@ def _edge_ref(e_term, ps, pr, send, rec, W2, b2, gam, bet, n_rec, mean):
     return m, agg
 
 
+@pytest.mark.parametrize("k_in,nA,nB,B,rows,add", [
+    (64, 64, 64, 2, 333, True), (64, 64, 0, 3, 50, True), (64, 64, 0, 1, 4100, False),
+    (3, 64, 0, 1, 70, False)])
+def test_fused_lin_bwd(k_in, nA, nB, B, rows, add):
+    """gx = gy [WA; WB] (+ gx_add), dW = gy^T x, db = colsum(gy) -- interaction_net.py:109
+    first Linear of edge_mlp, split by operand."""
+    from neural_lam_amd import ops
+
+    gen = torch.Generator().manual_seed(k_in + nA + nB + rows)
+    x = torch.randn(B, rows, k_in, generator=gen)
+    gy = torch.randn(B, rows, nA + nB, generator=gen)
+    W = torch.randn(nA + nB, k_in, generator=gen) / k_in ** 0.5
+    ga = torch.randn(B, rows, k_in, generator=gen) if add else None
+    want_gx = gy @ W + (ga if add else 0)
+    want_dW = torch.einsum("brn,brk->nk", gy, x)
+    want_db = gy.sum((0, 1))
+    dev = "cuda"
+    Wd = W.to(dev)
+    gx = torch.full((B, rows, k_in), float("nan"), device=dev)
+    dW = torch.full((nA + nB, k_in), float("nan"), device=dev)
+    db = torch.full((nA + nB,), float("nan"), device=dev)
+    ops.fused_lin_bwd(ops.mat(x.to(dev)), ops.mat(gy.to(dev)), Wd[:nA], Wd[nA:] if nB else None,
+                      ops.mat(gx), dW[:nA], db[:nA], dW[nA:] if nB else None,
+                      db[nA:] if nB else None, gx_add=ops.mat(ga.to(dev)) if add else None)
+    assert rel(gx, want_gx) < 2e-5
+    assert rel(dW, want_dW) < 2e-5
+    assert rel(db, want_db) < 2e-5
+
+
 @pytest.mark.parametrize("d,egemm,mean,B,n_s,n_r,M", [
     (64, True, False, 2, 50, 50, 400), (64, False, True, 3, 80, 30, 333),
     (64, True, True, 1, 20, 700, 900),
