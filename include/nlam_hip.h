@@ -256,9 +256,9 @@ int nlam_lin_bwd(const float* x, int64_t x_bstride, int64_t x_ld, int k_in,
 /* Backward of nlam_edge_fwd with recomputation.  Inputs as in forward plus
  *   g_agg (B, N_r, d): gradient of the aggregate; g_eout (B, M, d, original
  *   order, may be NULL): gradient of e_out (has_egemm).
- * Outputs: gh_out (B, M, d) = gradient of h in CSR order (pitch d) -- the caller
- * reduces it per sender (nlam_segment_sum over csc_pos) and, for a batch-
- * invariant Pe, over the batch; gpr (B, N_r, d) = per-receiver sum of gh;
+ * Outputs: gh_out (B, M, d) = gradient of h in the original edge order (pitch d) --
+ * the caller reduces it per sender (nlam_segment_sum over csc_eid) and, for a
+ * batch-invariant Pe, over the batch; gpr (B, N_r, d) = per-receiver sum of gh;
  * g_e (B, M, d, original order; has_egemm) = g_eout + W1e^T gh; per-workgroup
  * slabs [dW1e (d x d) | dW2 (d x d) | db2 | dgamma | dbeta], count =
  * nlam_bwd_grid(B * ntiles). */

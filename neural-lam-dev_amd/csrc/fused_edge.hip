@@ -254,14 +254,14 @@ extern "C" int nlam_debug_edge_bwd_stamps(unsigned long long* out, int reset) {
 // Recomputes h, s = silu(h), z = W2 s + b2 from the inputs, then
 //   gm_k = scale * g_agg[rec(k)] + g_eout_k
 //   gz   = LN'(z; gm),   dW2 += gz (x) s,  db2 += gz,  dgamma, dbeta
-//   gh   = (W2^T gz) * silu'(h)       -> gh_out (CSR order), gPr_i = sum_{rec=i} gh
+//   gh   = (W2^T gz) * silu'(h)       -> gh_out (original edge order), gPr_i = sum_{rec=i} gh
 //   dW1e += gh (x) e ;  g_e = g_eout + W1e^T gh                 (has_egemm)
 // Slab per workgroup: [dW1e (D x D) | dW2 (D x D) | db2 | dgamma | dbeta].
 struct EdgeBwdParams {
   EdgeFwdParams f;              // forward operands (agg / e_out unused)
   RowView g_agg;                // (B, N_r, d)
   const float* g_eout; int64_t geo_bstride; int64_t geo_ld;   // (B, M, d) original order, may be NULL
-  float* gh_out; int64_t gh_bstride;                          // (B, M, d) CSR order, pitch d
+  float* gh_out; int64_t gh_bstride;                          // (B, M, d) original edge order, pitch d
   float* gpr; int64_t gpr_bstride; int64_t gpr_ld;            // (B, N_r, d)
   float* g_e; int64_t ge_bstride; int64_t ge_ld;              // (B, M, d) original order (has_egemm)
   float* slab; int64_t slab_stride;
@@ -458,8 +458,8 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
     acc_to_tile<NB>(gh, T1, LDT, lane);       // GH
     wave_sync();
     {
-      float* ghb = q.gh_out + (int64_t)b * q.gh_bstride + (int64_t)p0 * D;
-      auto gh_row = [&](int s) { return ghb + (int64_t)s * D; };
+      float* ghb = q.gh_out + (int64_t)b * q.gh_bstride;
+      auto gh_row = [&](int s) { return ghb + (int64_t)__shfl(eid, s, 64) * D; };
       store_rows<true>(T1, LDT, 0, D, ne, lane, gh_row);
       // receiver-side sum of gh (segments are tile-local)
       float* gb = q.gpr + (int64_t)b * q.gpr_bstride;

@@ -245,11 +245,11 @@ class FusedInteractionNetFunction(torch.autograd.Function):
                 ops.fused_edge_bwd(
                     g, mat(Pe), False, psm, prm, None, W2, b2, gam, mat(g_agg), None, mat(gh),
                     gpr_m, None, ctx.mean, d, None, dW2, db2, dgam, dbet)
-            # 3. sender-side reduction of gh (CSR-ordered rows, sender lists of CSR positions)
+            # 3. sender-side reduction of gh (rows in the original edge order, sender lists of edge ids)
             if same:
                 if N_s > g.n_send:
                     gP[:, g.n_send :, :d].zero_()
-                ops.segment_sum(mat(gh), g.csc_colptr, g.csc_pos, mat(gP[:, : g.n_send], 0, d))
+                ops.segment_sum(mat(gh), g.csc_colptr, g.csc_eid, mat(gP[:, : g.n_send], 0, d))
                 # 4. projections backward (x W1s^T | x W1r^T + b1)
                 gx_p = _empty(sm.B, N_s, d, device=dev)
                 gpm = mat(gP)
@@ -265,7 +265,7 @@ class FusedInteractionNetFunction(torch.autograd.Function):
             else:
                 gPs = (torch.zeros if N_s > g.n_send else torch.empty)(
                     B, N_s, d, dtype=torch.float32, device=dev)
-                ops.segment_sum(mat(gh), g.csc_colptr, g.csc_pos, mat(gPs[:, : g.n_send]))
+                ops.segment_sum(mat(gh), g.csc_colptr, g.csc_eid, mat(gPs[:, : g.n_send]))
                 gps_m, gpr_in = mat(gPs), mat(gPr)
                 if sm.B == 1 and B > 1:
                     t1 = _empty(1, N_s, d, device=dev)
@@ -294,10 +294,8 @@ class FusedInteractionNetFunction(torch.autograd.Function):
                 if em.B == 1 and B > 1:
                     dPe = _empty(1, M, d, device=dev)
                     ops.sum_batch(gh, dPe)
-                dPe_o = _empty(em.B, M, d, device=dev)
-                ops.gather_rows(mat(dPe), g.pos_of_eid, mat(dPe_o))   # CSR -> original order
                 g_edge = _empty(em.B, M, d, device=dev)
-                ops.fused_lin_bwd(em, mat(dPe_o), W1e, None, mat(g_edge), dW1[:, :d], None,
+                ops.fused_lin_bwd(em, mat(dPe), W1e, None, mat(g_edge), dW1[:, :d], None,
                                   None, None)
         return (g_send, g_rec_total, g_edge, None, None, None, None,
                 dW1, db1, dW2, db2, dgam, dbet, dV1, dc1, dV2, dc2, dg2, db2n)
