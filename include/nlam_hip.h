@@ -240,7 +240,9 @@ int nlam_edge_fwd(const int32_t* tiles, int64_t ntiles,
                   int64_t B, int d, void* stream);
 
 /* Backward of nlam_lin_fwd: gx = gy [WA; WB] [+ gx_add] (optional; gx_add folds the
- * autograd accumulation of a second gradient of the same input), per-workgroup slabs
+ * autograd accumulation of a second gradient of the same input).  gy_nsum > 1: x is
+ * batch-invariant and gy is read as sum_{s < gy_nsum} gy[s * gy_sum_stride + ...] (the
+ * expand_to_batch backward of ar_model.py:204-209 folded into the load).  Per-workgroup slabs
  * [dW ((nA+nB) x KP32) | db (nA+nB)], KP32 = k_in rounded up to 32; number of
  * slabs = nlam_bwd_grid(B * ceil(rows/32)). */
 int64_t nlam_lin_bwd_slab_stride(int k_in, int n_out);
@@ -250,6 +252,7 @@ int nlam_lin_bwd(const float* x, int64_t x_bstride, int64_t x_ld, int k_in,
                  const float* WB, int64_t ldWB, int nB,
                  float* gx, int64_t gx_bstride, int64_t gx_ld,
                  const float* gx_add, int64_t ga_bstride, int64_t ga_ld,
+                 int64_t gy_nsum, int64_t gy_sum_stride,
                  float* slab, int64_t slab_stride, int64_t B, int64_t rows,
                  void* stream);
 

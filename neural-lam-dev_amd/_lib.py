@@ -53,7 +53,7 @@ SIGNATURES = {
     "nlam_graph_tiles_host": [_p, _i64, _i32, _i32, _p, _i64],
     "nlam_lin_bwd_slab_stride": [_i32, _i32],
     "nlam_lin_bwd": [_p, _i64, _i64, _i32, _p, _i64, _i64, _p, _i64, _i32, _p, _i64, _i32, _p, _i64,
-                     _i64, _p, _i64, _i64, _p, _i64, _i64, _i64, _p],
+                     _i64, _p, _i64, _i64, _i64, _i64, _p, _i64, _i64, _i64, _p],
     "nlam_edge_bwd_slab_stride": [_i32],
     "nlam_edge_bwd": [_p, _i64, _p, _p, _p, _p, _p, _p, _i64, _i64, _i32, _p, _i64, _i64, _p, _i64,
                       _i64, _p, _i64, _p, _i64, _p, _p, _p, _i64, _i64, _p, _i64, _i64, _p, _i64,

@@ -701,10 +701,11 @@ struct LinBwdParams {
   const float* gx_add; int64_t ga_bstride; int64_t ga_ld;   // optional addend of gx
   float* slab; int64_t slab_stride;
   int64_t rows; int B;
+  int gy_nsum; int64_t gy_sum_stride;   // gy[b] := sum_{s < gy_nsum} gy[b][s * gy_sum_stride + ...]
   int vec_x, vec_gy, vec_gx;
 };
 
-template <int NOUTB, int KB>
+template <int NOUTB, int KB, bool SUMGY = false>
 __global__ __launch_bounds__(256) void lin_bwd_kernel(LinBwdParams q) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int KP32 = 32 * KB, NO = 32 * NOUTB;
@@ -744,6 +745,29 @@ __global__ __launch_bounds__(256) void lin_bwd_kernel(LinBwdParams q) {
       f32x4 vx[4 * KB], vg[4 * NOUTB];
       view_load_v<4 * KB>(vx, q.x, b, r0, nfull, lane);
       view_load_v<4 * NOUTB>(vg, q.gy, b, r0, nfull, lane);
+      // batch-invariant x: the per-sample gradients are summed while loading (fixed
+      // order s = 0, 1, 2, ...; FL slices in flight, bounded by the register budget)
+      if (SUMGY) {
+        constexpr int FL = NOUTB <= 2 ? 3 : 1;
+        const int last = q.gy_nsum - 1;
+        for (int s0 = 1; s0 <= last; s0 += FL) {
+          f32x4 tv[FL][4 * NOUTB];
+#pragma unroll
+          for (int f = 0; f < FL; ++f) {
+            const int sf = s0 + f < last ? s0 + f : last;
+            RowView gv = q.gy;
+            gv.ptr = q.gy.ptr + sf * q.gy_sum_stride;
+            view_load_v<4 * NOUTB>(tv[f], gv, b, r0, nfull, lane);
+          }
+#pragma unroll
+          for (int f = 0; f < FL; ++f) {
+            if (s0 + f <= last) {
+#pragma unroll
+              for (int k = 0; k < 4 * NOUTB; ++k) vg[k] += tv[f][k];
+            }
+          }
+        }
+      }
       put_rows_v<4 * KB, false>(T0, ldt0, 0, q.x.width, nrows, lane, vx);
       put_rows_v<4 * NOUTB, false>(T1, ldt1, 0, n_out, nrows, lane, vg);
     } else {
@@ -794,7 +818,7 @@ __global__ __launch_bounds__(256) void lin_bwd_kernel(LinBwdParams q) {
   for (int i = tid; i < NO; i += 256) slab[NO * KP32 + i] = img[i];
 }
 
-template <int NOUTB, int KB>
+template <int NOUTB, int KB, bool SUMGY = false>
 static int launch_lin_bwd(const LinBwdParams& q, hipStream_t s) {
   constexpr int KP32 = 32 * KB, NO = 32 * NOUTB;
   const size_t lds = ((size_t)NO * (KP32 + 4) + (size_t)4 * NLAM_TILE * (KP32 + 4 + NO + 4)) *
@@ -803,7 +827,7 @@ static int launch_lin_bwd(const LinBwdParams& q, hipStream_t s) {
   const size_t fold_bytes = (size_t)4 * NO * KP32 * sizeof(float);
   NLAM_REQUIRE(fold_bytes <= 160 * 1024, "lin_bwd: fold images exceed LDS");
   const size_t lds_alloc = lds > fold_bytes ? lds : fold_bytes;
-  auto kern = lin_bwd_kernel<NOUTB, KB>;
+  auto kern = lin_bwd_kernel<NOUTB, KB, SUMGY>;
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -826,6 +850,7 @@ extern "C" int nlam_lin_bwd(const float* x, int64_t x_bstride, int64_t x_ld, int
                             const float* WB, int64_t ldWB, int nB,
                             float* gx, int64_t gx_bstride, int64_t gx_ld,
                             const float* gx_add, int64_t ga_bstride, int64_t ga_ld,
+                            int64_t gy_nsum, int64_t gy_sum_stride,
                             float* slab, int64_t slab_stride, int64_t B, int64_t rows,
                             void* stream) {
   if (B <= 0 || rows <= 0) return 0;
@@ -847,8 +872,18 @@ extern "C" int nlam_lin_bwd(const float* x, int64_t x_bstride, int64_t x_ld, int
   q.vec_gy = view_vec_ok(gy, gy_bstride, gy_ld, q.nA + q.nB);
   q.vec_gx = gx && view_vec_ok(gx, gx_bstride, gx_ld, k_in) &&
              (gx_add == nullptr || view_vec_ok(gx_add, ga_bstride, ga_ld, k_in));
+  q.gy_nsum = gy_nsum > 1 ? (int)gy_nsum : 1;
+  q.gy_sum_stride = gy_sum_stride;
+  NLAM_REQUIRE(q.gy_nsum == 1 || (q.vec_x && q.vec_gy && gy_sum_stride % 4 == 0),
+               "nlam_lin_bwd: gy_nsum > 1 needs 16-byte aligned x / gy rows and slices");
   hipStream_t s = (hipStream_t)stream;
   const int noutb = (q.nA + q.nB) / 32, kb = (k_in + 31) / 32;
+  if (q.gy_nsum > 1) {
+    if (noutb == 2 && kb == 2) return launch_lin_bwd<2, 2, true>(q, s);
+    nlam_set_error("nlam_lin_bwd: gy_nsum > 1 unsupported for k_in=%d n_out=%d", k_in,
+                   q.nA + q.nB);
+    return 1;
+  }
   if (noutb == 2 && kb == 2) return launch_lin_bwd<2, 2>(q, s);
   if (noutb == 4 && kb == 2) return launch_lin_bwd<4, 2>(q, s);
   if (noutb == 2 && kb == 1) return launch_lin_bwd<2, 1>(q, s);

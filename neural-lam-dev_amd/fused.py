@@ -253,35 +253,40 @@ class FusedInteractionNetFunction(torch.autograd.Function):
                 # 4. projections backward (x W1s^T | x W1r^T + b1)
                 gx_p = _empty(sm.B, N_s, d, device=dev)
                 gpm = mat(gP)
-                if sm.B == 1 and B > 1:
+                fold = sm.B == 1 and B > 1 and ops.lin_bwd_can_sum(sm, gpm)
+                if sm.B == 1 and B > 1 and not fold:
                     gP1 = _empty(1, N_s, 2 * d, device=dev)
                     ops.sum_batch(gP, gP1)
                     gpm = mat(gP1)
                 # send_rep is rec_rep: one total gradient (node update + residual + both
                 # projections), folded into the store of the projection backward
                 ops.fused_lin_bwd(sm, gpm, W1s, W1r, mat(gx_p), dW1[:, d : 2 * d], None,
-                                  dW1[:, 2 * d :], db1, gx_add=mat(g_rec))
+                                  dW1[:, 2 * d :], db1, gx_add=mat(g_rec), sum_gy_batch=fold)
                 g_send, g_rec_total = gx_p, None
             else:
                 gPs = (torch.zeros if N_s > g.n_send else torch.empty)(
                     B, N_s, d, dtype=torch.float32, device=dev)
                 ops.segment_sum(mat(gh), g.csc_colptr, g.csc_eid, mat(gPs[:, : g.n_send]))
+                # batch-invariant operands: the batch sum of their gradient is folded into
+                # the load of the projection backward when the rows are 16-byte aligned
                 gps_m, gpr_in = mat(gPs), mat(gPr)
-                if sm.B == 1 and B > 1:
+                fold_s = sm.B == 1 and B > 1 and ops.lin_bwd_can_sum(sm, gps_m)
+                fold_r = rm.B == 1 and B > 1 and ops.lin_bwd_can_sum(rm, gpr_in)
+                if sm.B == 1 and B > 1 and not fold_s:
                     t1 = _empty(1, N_s, d, device=dev)
                     ops.sum_batch(gPs, t1)
                     gps_m = mat(t1)
-                if rm.B == 1 and B > 1:
+                if rm.B == 1 and B > 1 and not fold_r:
                     t2 = _empty(1, N_r, d, device=dev)
                     ops.sum_batch(gPr, t2)
                     gpr_in = mat(t2)
                 g_send = _empty(sm.B, N_s, d, device=dev)
                 ops.fused_lin_bwd(sm, gps_m, W1s, None, mat(g_send), dW1[:, d : 2 * d], None,
-                                  None, None)
+                                  None, None, sum_gy_batch=fold_s)
                 # receiver gradient: node-update part (+ residual) + projection part
                 g_rec_total = _empty(rm.B, N_r, d, device=dev)
                 ops.fused_lin_bwd(rm, gpr_in, W1r, None, mat(g_rec_total), dW1[:, 2 * d :], db1,
-                                  None, None, gx_add=mat(g_rec))
+                                  None, None, gx_add=mat(g_rec), sum_gy_batch=fold_r)
             # 5. edge-side first-layer weights
             if ctx.update_edges:
                 g_edge = g_e
@@ -290,13 +295,15 @@ class FusedInteractionNetFunction(torch.autograd.Function):
                     ops.sum_batch(g_e, t4)
                     g_edge = t4
             else:
-                dPe = gh
-                if em.B == 1 and B > 1:
-                    dPe = _empty(1, M, d, device=dev)
-                    ops.sum_batch(gh, dPe)
+                dPe = mat(gh)
+                fold_e = em.B == 1 and B > 1 and ops.lin_bwd_can_sum(em, dPe)
+                if em.B == 1 and B > 1 and not fold_e:
+                    t5 = _empty(1, M, d, device=dev)
+                    ops.sum_batch(gh, t5)
+                    dPe = mat(t5)
                 g_edge = _empty(em.B, M, d, device=dev)
-                ops.fused_lin_bwd(em, mat(dPe), W1e, None, mat(g_edge), dW1[:, :d], None,
-                                  None, None)
+                ops.fused_lin_bwd(em, dPe, W1e, None, mat(g_edge), dW1[:, :d], None,
+                                  None, None, sum_gy_batch=fold_e)
         return (g_send, g_rec_total, g_edge, None, None, None, None,
                 dW1, db1, dW2, db2, dgam, dbet, dV1, dc1, dV2, dc2, dg2, db2n)
 

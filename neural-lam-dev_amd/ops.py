@@ -488,9 +488,25 @@ def fused_outer_bwd(g, xa, xb, x_index, dW_dst, db_dst):
                     [(0, ng, kx, kx32, dW_dst), (ng * kx32, 1, ng, ng, db_dst)])
 
 
-def fused_lin_bwd(x, gy, WA, WB, gx, dWA, dbA, dWB, dbB, gx_add=None):
+def lin_bwd_can_sum(x, gy):
+    """True when nlam_lin_bwd may fold the batch sum of gy (B, rows, n) into its load
+    (batch-invariant x, 16-byte aligned rows)."""
+    if (x.cols + 31) // 32 != 2 or gy.cols != 64:
+        return False
+    return (x.B == 1 and gy.B > 1 and x.ptr % 16 == 0 and x.ld % 4 == 0 and x.cols % 4 == 0
+            and gy.ptr % 16 == 0 and gy.ld % 4 == 0 and gy.cols % 4 == 0 and gy.bstride % 4 == 0)
+
+
+def fused_lin_bwd(x, gy, WA, WB, gx, dWA, dbA, dWB, dbB, gx_add=None, sum_gy_batch=False):
     """gx = gy [WA; WB] [+ gx_add] (optional); dWA (nA, k), dbA (nA,), dWB, dbB: destination
-    views (any of them None = not needed)."""
+    views (any of them None = not needed).  sum_gy_batch: x is (1, rows, k) and gy
+    (B, rows, n) is summed over B while it is loaded."""
+    nsum, sum_stride = 1, 0
+    if sum_gy_batch:
+        if not lin_bwd_can_sum(x, gy):
+            raise NlamError("fused_lin_bwd: sum_gy_batch needs batch-invariant x and aligned rows")
+        nsum, sum_stride = gy.B, gy.bstride
+        gy = gy._replace(B=1, bstride=0)
     if gx_add is not None:
         if gx is None or (gx_add.B, gx_add.rows, gx_add.cols) != (gx.B, gx.rows, gx.cols):
             raise NlamError("fused_lin_bwd: gx_add must match gx")
@@ -509,7 +525,7 @@ def fused_lin_bwd(x, gy, WA, WB, gx, dWA, dbA, dWB, dbB, gx_add=None):
          gx.ld if gx is not None else 0,
          gx_add.ptr if gx_add is not None else None,
          gx_add.bstride if gx_add is not None else 0, gx_add.ld if gx_add is not None else 0,
-         slab.data_ptr(), stride, B, rows, stream()),
+         nsum, sum_stride, slab.data_ptr(), stride, B, rows, stream()),
         flops=2.0 * B * rows * k_in * (nA + nB) * (2 if gx is not None else 1),
         nbytes=4.0 * B * rows * (k_in * (2 if gx is not None else 1) + nA + nB),
     )

@@ -229,6 +229,30 @@ def test_fused_mlp_bwd(ka, kb, n_out, ln, res_a, B, rows, need_gx):
             assert rel(gxb, xb.grad) < 2e-5
 
 
+def test_fused_lin_bwd_batch_invariant_x_sums_gy_on_load():
+    """x (1, rows, k) with per-sample gy (B, rows, n): gx = (sum_b gy_b) W, dW = (sum_b gy_b)^T x
+    -- the backward of expand_to_batch (ar_model.py:204-209) folded into the load."""
+    from neural_lam_amd import ops
+
+    for B, rows in ((4, 1000), (5, 77), (2, 4100)):
+        gen = torch.Generator().manual_seed(B * rows)
+        x = torch.randn(1, rows, 64, generator=gen)
+        gy = torch.randn(B, rows, 64, generator=gen)
+        W = torch.randn(64, 64, generator=gen) / 8
+        gsum = gy.sum(0, keepdim=True)
+        dev = "cuda"
+        gx = torch.full((1, rows, 64), float("nan"), device=dev)
+        dW = torch.full((64, 64), float("nan"), device=dev)
+        db = torch.full((64,), float("nan"), device=dev)
+        xm, gm = ops.mat(x.to(dev)), ops.mat(gy.to(dev))
+        assert ops.lin_bwd_can_sum(xm, gm)
+        ops.fused_lin_bwd(xm, gm, W.to(dev), None, ops.mat(gx), dW, db, None, None,
+                          sum_gy_batch=True)
+        assert rel(gx, gsum @ W) < 2e-5
+        assert rel(dW, torch.einsum("brn,brk->nk", gsum, x)) < 2e-5
+        assert rel(db, gsum.sum((0, 1))) < 2e-5
+
+
 def test_fused_paths_are_taken_for_baseline_shapes():
     """d=64, hidden_layers=1: the fused kernels must be the ones that run."""
     from neural_lam_amd import fused, ops, utils
