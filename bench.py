@@ -241,10 +241,13 @@ def main():
         if os.path.exists(tpath):
             # PMC bytes per launch of the HIP kernel behind this entry point / call site
             base, _, site = name.partition("@")
-            kern = {"nlam_edge_bwd": "edge_bwd_kernel<64, %s>" % ("true" if site == "m2m" else "false"),
-                    "nlam_edge_fwd": "edge_fwd_kernel<64, %s>" % ("true" if site == "m2m" else "false"),
-                    "nlam_segment_sum": "segment_sum_vec_kernel<16>"}.get(base)
-            ent = json.load(open(tpath)).get(kern) if kern else None
+            flag = "true" if site == "m2m" else "false"
+            prefix = {"nlam_edge_bwd": "edge_bwd_kernel<64, %s" % flag,
+                      "nlam_edge_fwd": "edge_fwd_kernel<64, %s" % flag,
+                      "nlam_segment_sum": "segment_sum_"}.get(base)
+            table = json.load(open(tpath))
+            ent = next((v for k, v in sorted(table.items()) if prefix and k.startswith(prefix)),
+                       None)
             traffic = ent["hbm_bytes_per_launch"] if ent else None
         if tf / MFMA_F32_PEAK_TFLOPS >= gbs / HBM_PEAK_GBS:
             roofline = {"kernel": name, "bound": "mfma", "achieved": tf,

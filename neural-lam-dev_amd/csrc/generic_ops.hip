@@ -624,6 +624,51 @@ __global__ __launch_bounds__(256) void segment_sum_vec_kernel(
   }
 }
 
+// Batch-folded form (B >= R): one wavefront per output row serves every sample.  The
+// segment bounds and the position list are read once (wave-uniform) and each of the
+// R = 64/LPR sub-groups walks the list for its own sample with 8 row loads in flight --
+// a quarter of the waves and index fetches of the per-(b, row) form.  Rows are summed in
+// list order (deterministic).
+template <int LPR>
+__global__ __launch_bounds__(256) void segment_sum_bfold_kernel(
+    const float* __restrict__ src, int64_t src_bstride, int64_t ldsrc,
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ pos,
+    const float* __restrict__ scale, float* __restrict__ out, int64_t out_bstride,
+    int64_t ldout, int accumulate, int64_t B, int64_t n_out) {
+  constexpr int R = 64 / LPR;
+  constexpr int U = 8;
+  const int lane = threadIdx.x & 63;
+  const int sub = lane / LPR, c4 = lane % LPR;
+  const int64_t i = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+  if (i >= n_out) return;
+  const int beg = rowptr[i], end = rowptr[i + 1];
+  const float sc = scale ? scale[i] : 1.0f;
+  for (int64_t b0 = 0; b0 < B; b0 += R) {
+    const int64_t b = b0 + sub;
+    const bool valid = b < B;
+    const float* sb = src + (valid ? b : B - 1) * src_bstride;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int p = beg; p < end; p += U) {
+      f32x4 v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int pp = p + u < end ? p + u : end - 1;
+        const int64_t r = pos ? (int64_t)pos[pp] : pp;
+        v[u] = reinterpret_cast<const f32x4*>(sb + r * ldsrc)[c4];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (p + u < end) acc += v[u];
+    }
+    if (valid) {
+      f32x4* o = reinterpret_cast<f32x4*>(out + b * out_bstride + i * ldout) + c4;
+      f32x4 v = acc * sc;
+      if (accumulate) v += *o;
+      *o = v;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void segment_sum_scalar_kernel(
     const float* __restrict__ src, int64_t src_bstride, int64_t ldsrc,
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ pos,
@@ -661,7 +706,14 @@ extern "C" int nlam_segment_sum(const float* src, int64_t src_bstride, int64_t l
   segment_sum_vec_kernel<LPR><<<grid, 256, 0, s>>>(src, src_bstride, ldsrc, rowptr, pos,   \
                                                    scale, out, out_bstride, ldout,         \
                                                    accumulate, B, n_out)
-  if (vec && d == 64) {
+#define SEG_FOLD(LPR)                                                                       \
+  segment_sum_bfold_kernel<LPR><<<(unsigned)((n_out + 3) / 4), 256, 0, s>>>(                \
+      src, src_bstride, ldsrc, rowptr, pos, scale, out, out_bstride, ldout, accumulate, B, n_out)
+  if (vec && d == 64 && B >= 4) {
+    SEG_FOLD(16);
+  } else if (vec && d == 128 && B >= 2) {
+    SEG_FOLD(32);
+  } else if (vec && d == 64) {
     SEG_LAUNCH(16);
   } else if (vec && d == 128) {
     SEG_LAUNCH(32);
@@ -677,6 +729,7 @@ extern "C" int nlam_segment_sum(const float* src, int64_t src_bstride, int64_t l
                                                    n_out, (int)d);
   }
 #undef SEG_LAUNCH
+#undef SEG_FOLD
   NLAM_CHECK_LAUNCH("segment_sum");
   return 0;
 }
@@ -711,10 +764,24 @@ __global__ void sum_batch_kernel(const float* __restrict__ x, int64_t bstride,
     out[i] = s;
   }
 }
+__global__ void sum_batch_vec_kernel(const f32x4* __restrict__ x, int64_t bstride4,
+                                     f32x4* __restrict__ out, int64_t B, int64_t n4) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    f32x4 s = x[i];
+    for (int64_t b = 1; b < B; ++b) s += x[b * bstride4 + i];
+    out[i] = s;
+  }
+}
 extern "C" int nlam_sum_batch(const float* x, int64_t bstride, float* out, int64_t B, int64_t n,
                               void* stream) {
   if (n <= 0) return 0;
-  sum_batch_kernel<<<ew_grid(n), 256, 0, (hipStream_t)stream>>>(x, bstride, out, B, n);
+  if (B > 0 && n % 4 == 0 && bstride % 4 == 0 && nlam_aligned16(x) && nlam_aligned16(out)) {
+    sum_batch_vec_kernel<<<ew_grid(n / 4), 256, 0, (hipStream_t)stream>>>(
+        reinterpret_cast<const f32x4*>(x), bstride / 4, reinterpret_cast<f32x4*>(out), B, n / 4);
+  } else {
+    sum_batch_kernel<<<ew_grid(n), 256, 0, (hipStream_t)stream>>>(x, bstride, out, B, n);
+  }
   NLAM_CHECK_LAUNCH("sum_batch");
   return 0;
 }

@@ -135,3 +135,29 @@ def test_gather_segment(ops, d):
     ops.segment_sum(ops.mat(e1.unsqueeze(0).expand(B, -1, -1)), t.csr_rowptr, t.csr_eid, ops.mat(agg))
     want1 = torch.zeros(n_rec, d).index_add_(0, rec, e1.cpu())
     assert rel(agg[2], want1) < 1e-6
+
+
+@pytest.mark.parametrize("d,B", [(64, 4), (64, 5), (64, 9), (128, 2), (128, 5)])
+def test_segment_sum_batch_folded(ops, d, B):
+    """B >= 64/(d/4): one wavefront per output row serves all samples (mean + accumulate too);
+    long and empty segments included."""
+    from neural_lam_amd.graph import EdgeTables
+
+    gen = torch.Generator().manual_seed(d + B)
+    n_send, n_rec, M = 30, 50, 700
+    send = torch.randint(0, n_send, (M,), generator=gen)
+    rec = torch.randint(0, n_rec, (M,), generator=gen)
+    rec[rec == 3] = 4
+    rec[:60] = 11     # one long segment (> 8 rows in flight per trip)
+    t = EdgeTables(send, rec, n_send, n_rec).cuda()
+    msg = torch.randn(B, M, d, generator=gen)
+    want = torch.zeros(B, n_rec, d).index_add_(1, rec, msg)
+    agg = torch.full((B, n_rec, d), float("nan"), device="cuda")
+    ops.segment_sum(ops.mat(msg.cuda()), t.csr_rowptr, t.csr_eid, ops.mat(agg))
+    assert rel(agg, want) < 1e-6
+    deg = torch.zeros(n_rec).index_add_(0, rec, torch.ones(M)).clamp(min=1)
+    ops.segment_sum(ops.mat(msg.cuda()), t.csr_rowptr, t.csr_eid, ops.mat(agg), scale=t.inv_deg)
+    assert rel(agg, want / deg.view(1, -1, 1)) < 1e-6
+    gs = torch.full((B, n_send, d), float("nan"), device="cuda")
+    ops.segment_sum(ops.mat(msg.cuda()), t.csc_colptr, t.csc_eid, ops.mat(gs))
+    assert rel(gs, torch.zeros(B, n_send, d).index_add_(1, send, msg)) < 1e-6
