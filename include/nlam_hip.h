@@ -198,14 +198,22 @@ int nlam_outer_bwd(const float* g, int64_t g_bstride, int64_t g_ld, int ng,
 int nlam_reduce_slabs(const float* slab, int64_t nslabs, int64_t stride, int64_t n,
                       float* out, int accumulate, void* stream);
 
-/* Sums up to 8 matrix segments of the per-workgroup slabs into (strided)
+/* Sums up to 32 matrix segments of the per-workgroup slabs into (strided)
  * destinations in ONE launch:  dst_k[r*dst_ld_k + c] = sum_s slab[s*stride +
  * src_off_k + r*src_ld_k + c], r < rows_k, c < cols_k.  Array arguments are HOST
- * arrays of length nseg (<= 8).  Fixed summation order (deterministic). */
+ * arrays of length nseg (<= 32).  Fixed summation order (deterministic). */
 int nlam_reduce_slabs_multi(const float* slab, int64_t nslabs, int64_t stride, int nseg,
                             const int64_t* src_off, const int32_t* rows,
                             const int32_t* cols, const int64_t* src_ld,
                             float* const* dst, const int64_t* dst_ld, void* stream);
+/* Same, but every segment names its own slab buffer (slab_k, nslabs_k, stride_k): one
+ * launch finishes all parameter gradients of an InteractionNet layer's backward
+ * (interaction_net.py:86-131; the reductions are launch-latency bound). */
+int nlam_reduce_slabs_batch(int nseg, const float* const* slab, const int64_t* nslabs,
+                            const int64_t* stride, const int64_t* src_off,
+                            const int32_t* rows, const int32_t* cols,
+                            const int64_t* src_ld, float* const* dst,
+                            const int64_t* dst_ld, void* stream);
 
 /* out[:, 0:nA] = x WA^T + bA, out[:, nA:nA+nB] = x WB^T + bB (WB may be NULL):
  * the node-side projections Ps = W1s x_s, Pr = W1r x_r + b1 of the edge MLP's

@@ -45,6 +45,7 @@ SIGNATURES = {
                        _i64, _i64, _i64, _p],
     "nlam_reduce_slabs": [_p, _i64, _i64, _i64, _p, _i32, _p],
     "nlam_reduce_slabs_multi": [_p, _i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p],
+    "nlam_reduce_slabs_batch": [_i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "nlam_lin_fwd": [_p, _i64, _i64, _i32, _p, _i64, _p, _i32, _p, _i64, _p, _i32, _p, _i64, _i64,
                      _i64, _i64, _p],
     "nlam_edge_fwd": [_p, _i64, _p, _p, _p, _p, _p, _p, _i64, _i64, _i32, _p, _i64, _i64, _p, _i64,

@@ -576,8 +576,19 @@ __global__ __launch_bounds__(1024) void reduce_slabs_kernel(const float* __restr
   const int e = threadIdx.x & 31, gsub = threadIdx.x >> 5;
   const int64_t i = (int64_t)blockIdx.x * 32 + e;
   float s = 0.f;
-  if (i < n)
-    for (int64_t k = gsub; k < nslabs; k += 32) s += slab[k * stride + i];
+  if (i < n) {
+    for (int64_t k = gsub; k < nslabs; k += 32 * 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int64_t ku = k + 32 * u;
+        v[u] = slab[(ku < nslabs ? ku : k) * stride + i];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (k + 32 * u < nslabs) s += v[u];
+    }
+  }
   red[gsub][e] = s;
   __syncthreads();
   if (gsub == 0 && i < n) {
@@ -1021,22 +1032,26 @@ extern "C" int nlam_outer_bwd(const float* g, int64_t g_bstride, int64_t g_ld, i
 
 
 // ------------------------------------------------------- multi-segment reduce
-// One launch sums up to 8 matrix segments of the per-workgroup slabs straight into
-// their (possibly strided) destinations, e.g. the three column blocks of
+// One launch sums up to NLAM_MAX_SEGS matrix segments of per-workgroup slabs straight
+// into their (possibly strided) destinations, e.g. the three column blocks of
 // edge_mlp.0.weight's gradient that come from three different kernels:
-//   dst_k[r * dst_ld_k + c] = sum_s slab[s * stride + src_off_k + r * src_ld_k + c]
+//   dst_k[r * dst_ld_k + c] = sum_{s < nslabs_k} slab_k[s * stride_k + src_off_k + r * src_ld_k + c]
+// Every segment names its own slab buffer, so ONE launch finishes all weight gradients
+// of an InteractionNet layer's backward (these reductions are launch-latency bound).
+#define NLAM_MAX_SEGS 32
 struct ReduceSegs {
   int nseg;
-  int64_t src_off[8];
-  int32_t rows[8], cols[8];
-  int64_t src_ld[8], dst_ld[8];
-  float* dst[8];
-  int64_t first[9];   // prefix sums of rows*cols
+  const float* slab[NLAM_MAX_SEGS];
+  int32_t nslabs[NLAM_MAX_SEGS];
+  int64_t stride[NLAM_MAX_SEGS];
+  int64_t src_off[NLAM_MAX_SEGS];
+  int32_t cols[NLAM_MAX_SEGS];
+  int64_t src_ld[NLAM_MAX_SEGS], dst_ld[NLAM_MAX_SEGS];
+  float* dst[NLAM_MAX_SEGS];
+  int64_t first[NLAM_MAX_SEGS + 1];   // prefix sums of rows*cols
 };
 
-__global__ __launch_bounds__(1024) void reduce_slabs_multi_kernel(const float* __restrict__ slab,
-                                                                  int64_t nslabs, int64_t stride,
-                                                                  ReduceSegs q) {
+__global__ __launch_bounds__(1024) void reduce_slabs_multi_kernel(ReduceSegs q) {
   __shared__ float red[32][33];
   const int e = threadIdx.x & 31, gsub = threadIdx.x >> 5;
   const int64_t i = (int64_t)blockIdx.x * 32 + e;
@@ -1046,10 +1061,24 @@ __global__ __launch_bounds__(1024) void reduce_slabs_multi_kernel(const float* _
   const int64_t local = i - q.first[k];
   const int cols = q.cols[k] > 0 ? q.cols[k] : 1;
   const int64_t r = local / cols, c = local - r * cols;
-  const int64_t src = q.src_off[k] + r * q.src_ld[k] + c;
+  const float* __restrict__ slab = q.slab[k] + q.src_off[k] + r * q.src_ld[k] + c;
+  const int64_t nslabs = q.nslabs[k], stride = q.stride[k];
+  // eight slab loads in flight per thread (clamped + masked, so they issue back to
+  // back); the summation order is fixed by the launch shape
   float s = 0.f;
-  if (i < n)
-    for (int64_t sl = gsub; sl < nslabs; sl += 32) s += slab[sl * stride + src];
+  if (i < n) {
+    for (int64_t sl = gsub; sl < nslabs; sl += 32 * 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int64_t su = sl + 32 * u;
+        v[u] = slab[(su < nslabs ? su : sl) * stride];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (sl + 32 * u < nslabs) s += v[u];
+    }
+  }
   red[gsub][e] = s;
   __syncthreads();
   if (gsub == 0 && i < n) {
@@ -1060,27 +1089,56 @@ __global__ __launch_bounds__(1024) void reduce_slabs_multi_kernel(const float* _
   }
 }
 
+static int launch_reduce_segs(ReduceSegs& q, hipStream_t s) {
+  for (int k = q.nseg; k < NLAM_MAX_SEGS; ++k) {
+    q.slab[k] = nullptr; q.nslabs[k] = 0; q.stride[k] = 0; q.src_off[k] = 0; q.cols[k] = 0;
+    q.src_ld[k] = 0; q.dst_ld[k] = 0; q.dst[k] = nullptr; q.first[k + 1] = q.first[q.nseg];
+  }
+  const int64_t n = q.first[q.nseg];
+  if (n <= 0) return 0;
+  reduce_slabs_multi_kernel<<<(unsigned)((n + 31) / 32), 1024, 0, s>>>(q);
+  NLAM_CHECK_LAUNCH("reduce_slabs_multi");
+  return 0;
+}
+
 extern "C" int nlam_reduce_slabs_multi(const float* slab, int64_t nslabs, int64_t stride, int nseg,
                                        const int64_t* src_off, const int32_t* rows,
                                        const int32_t* cols, const int64_t* src_ld,
                                        float* const* dst, const int64_t* dst_ld, void* stream) {
-  NLAM_REQUIRE(nseg >= 1 && nseg <= 8, "reduce_slabs_multi: nseg %d out of [1,8]", nseg);
+  NLAM_REQUIRE(nseg >= 1 && nseg <= NLAM_MAX_SEGS, "reduce_slabs_multi: nseg %d out of [1,%d]",
+               nseg, NLAM_MAX_SEGS);
+  NLAM_REQUIRE(slab != nullptr && nslabs >= 1, "reduce_slabs_multi: no slabs");
   ReduceSegs q;
   q.nseg = nseg;
   q.first[0] = 0;
   for (int k = 0; k < nseg; ++k) {
     NLAM_REQUIRE(rows[k] >= 1 && cols[k] >= 1 && dst[k] != nullptr, "reduce_slabs_multi: bad segment");
-    q.src_off[k] = src_off[k]; q.rows[k] = rows[k]; q.cols[k] = cols[k];
+    q.slab[k] = slab; q.nslabs[k] = (int32_t)nslabs; q.stride[k] = stride;
+    q.src_off[k] = src_off[k]; q.cols[k] = cols[k];
     q.src_ld[k] = src_ld[k]; q.dst_ld[k] = dst_ld[k]; q.dst[k] = dst[k];
     q.first[k + 1] = q.first[k] + (int64_t)rows[k] * cols[k];
   }
-  for (int k = nseg; k < 8; ++k) {
-    q.src_off[k] = 0; q.rows[k] = 0; q.cols[k] = 0; q.src_ld[k] = 0; q.dst_ld[k] = 0;
-    q.dst[k] = nullptr; q.first[k + 1] = q.first[nseg];
+  return launch_reduce_segs(q, (hipStream_t)stream);
+}
+
+extern "C" int nlam_reduce_slabs_batch(int nseg, const float* const* slab, const int64_t* nslabs,
+                                       const int64_t* stride, const int64_t* src_off,
+                                       const int32_t* rows, const int32_t* cols,
+                                       const int64_t* src_ld, float* const* dst,
+                                       const int64_t* dst_ld, void* stream) {
+  NLAM_REQUIRE(nseg >= 1 && nseg <= NLAM_MAX_SEGS, "reduce_slabs_batch: nseg %d out of [1,%d]",
+               nseg, NLAM_MAX_SEGS);
+  ReduceSegs q;
+  q.nseg = nseg;
+  q.first[0] = 0;
+  for (int k = 0; k < nseg; ++k) {
+    NLAM_REQUIRE(slab[k] != nullptr && nslabs[k] >= 1 && rows[k] >= 1 && cols[k] >= 1 &&
+                     dst[k] != nullptr,
+                 "reduce_slabs_batch: bad segment %d", k);
+    q.slab[k] = slab[k]; q.nslabs[k] = (int32_t)nslabs[k]; q.stride[k] = stride[k];
+    q.src_off[k] = src_off[k]; q.cols[k] = cols[k];
+    q.src_ld[k] = src_ld[k]; q.dst_ld[k] = dst_ld[k]; q.dst[k] = dst[k];
+    q.first[k + 1] = q.first[k] + (int64_t)rows[k] * cols[k];
   }
-  const int64_t n = q.first[nseg];
-  reduce_slabs_multi_kernel<<<(unsigned)((n + 31) / 32), 1024, 0, (hipStream_t)stream>>>(
-      slab, nslabs, stride, q);
-  NLAM_CHECK_LAUNCH("reduce_slabs_multi");
-  return 0;
+  return launch_reduce_segs(q, (hipStream_t)stream);
 }

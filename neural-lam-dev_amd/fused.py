@@ -194,7 +194,8 @@ class FusedInteractionNetFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_rec_out, g_edge_out=None):
-        with ops.tag(ctx.g.tag):
+        # every parameter-gradient slab of the layer is reduced by one launch at exit
+        with ops.tag(ctx.g.tag), ops.slab_batch():
             W1, b1, W2, b2, gam, V1, c1, V2, c2, gam2 = ctx.saved_tensors
             g = ctx.g
             sm, rm, em = ctx.mats

@@ -398,27 +398,57 @@ def reduce_slabs(slab, nslabs, stride, n, out, accumulate=False):
             nbytes=4.0 * nslabs * n)
 
 
-def reduce_segments(slab, nslabs, stride, segs):
-    """One launch: for every (src_off, rows, cols, src_ld, dst) sum that matrix segment
-    of the per-workgroup slabs into dst (a 1-D or 2-D fp32 view with unit column
-    stride).  Deterministic."""
-    segs = [sg for sg in segs if sg[4] is not None]
-    for i in range(0, len(segs), 8):
-        part = segs[i : i + 8]
+_SLAB_BATCH = []   # stack of pending (slab, nslabs, stride, src_off, rows, cols, src_ld, dst)
+MAX_SEGS = 32
+
+
+class slab_batch:
+    """Collect the slab reductions issued inside the block and finish them with ONE
+    launch at exit (the destinations must not be read before that)."""
+
+    def __enter__(self):
+        _SLAB_BATCH.append([])
+        return self
+
+    def __exit__(self, et, ev, tb):
+        pending = _SLAB_BATCH.pop()
+        if et is None:
+            _flush_segments(pending)
+        return False
+
+
+def _flush_segments(entries):
+    for i in range(0, len(entries), MAX_SEGS):
+        part = entries[i : i + MAX_SEGS]
         n = len(part)
         I64, I32, P = ctypes.c_int64 * n, ctypes.c_int32 * n, ctypes.c_void_p * n
-        dst_ld = [d.stride(0) if d.dim() == 2 else d.numel() for (_, _, _, _, d) in part]
-        for (_, r, c, _, d) in part:
-            assert d.dtype == torch.float32 and (d.dim() == 1 or d.stride(1) == 1)
-            assert d.numel() == r * c, (tuple(d.shape), r, c)
+        dst_ld = [e[7].stride(0) if e[7].dim() == 2 else e[7].numel() for e in part]
         _launch(
-            "nlam_reduce_slabs_multi", lib.nlam_reduce_slabs_multi,
-            (slab.data_ptr(), nslabs, stride, n, I64(*[sg[0] for sg in part]),
-             I32(*[sg[1] for sg in part]), I32(*[sg[2] for sg in part]),
-             I64(*[sg[3] for sg in part]), P(*[sg[4].data_ptr() for sg in part]), I64(*dst_ld),
-             stream()),
-            nbytes=4.0 * nslabs * sum(sg[1] * sg[2] for sg in part),
+            "nlam_reduce_slabs_multi", lib.nlam_reduce_slabs_batch,
+            (n, P(*[e[0].data_ptr() for e in part]), I64(*[e[1] for e in part]),
+             I64(*[e[2] for e in part]), I64(*[e[3] for e in part]), I32(*[e[4] for e in part]),
+             I32(*[e[5] for e in part]), I64(*[e[6] for e in part]),
+             P(*[e[7].data_ptr() for e in part]), I64(*dst_ld), stream()),
+            nbytes=4.0 * sum(e[1] * e[4] * e[5] for e in part),
         )
+
+
+def reduce_segments(slab, nslabs, stride, segs):
+    """For every (src_off, rows, cols, src_ld, dst) sum that matrix segment of the
+    per-workgroup slabs into dst (a 1-D or 2-D fp32 view with unit column stride).
+    One launch -- or, inside `slab_batch()`, deferred to the block's single launch.
+    Deterministic."""
+    entries = []
+    for (off, r, c, ld, d) in segs:
+        if d is None:
+            continue
+        assert d.dtype == torch.float32 and (d.dim() == 1 or d.stride(1) == 1)
+        assert d.numel() == r * c, (tuple(d.shape), r, c)
+        entries.append((slab, nslabs, stride, off, r, c, ld, d))
+    if _SLAB_BATCH:
+        _SLAB_BATCH[-1].extend(entries)
+    else:
+        _flush_segments(entries)
 
 
 def fused_mlp_bwd(xa, xb, W1, b1, W2, b2, gamma, gy, gxa, gxb, add_gy_to_gxa, hid, n_out, dst):
