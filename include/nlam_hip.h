@@ -333,6 +333,10 @@ int nlam_wmse_bwd(const float* pred, const float* target, const float* keep,
  * dW2 + W2^T gz, gh store + receiver reduce, dW1e + W1e^T gh + store.  reset != 0
  * zeroes the counters after reading. */
 int nlam_debug_edge_bwd_stamps(unsigned long long* out, int reset);
+/* Diagnostic (NLAM_TIMELINE=1 in the environment of the process): nlam_lin_fwd records
+ * s_memrealtime (100 MHz) per workgroup at start / after the weight prologue / at exit;
+ * out: host array of 3 * 1024 values (first 1024 workgroups of the last launch). */
+int nlam_debug_lin_fwd_timeline(unsigned long long* out);
 
 /* Debug / self-test: verifies the MFMA fp32 32x32x2 operand and accumulator
  * lane maps the fused kernels rely on.  out: 32*32 floats = A(32x64) * B(64x32)

@@ -468,6 +468,37 @@ __device__ __forceinline__ void store_rows_res(const float* __restrict__ tile, i
   }
 }
 
+// ---- tile-local segmented sums -------------------------------------------------
+// Rows [0, ne) of the tile are grouped by receiver (lane t < 32 holds rcv of row t, rows of
+// one receiver are consecutive).  Lanes = features.  All 32 row reads are issued up front
+// (no dependent LDS round trip per row); the running sum is emitted at each segment end
+// (wave-uniform bit test), in row order -- bit-identical to a per-receiver loop.
+// emit(receiver, f0, value) stores one 64-float slice.  Returns the number of segments.
+template <int D, typename Emit>
+__device__ __forceinline__ int tile_segment_sums(const float* __restrict__ tile, int ld, int ne,
+                                                 int rcv, int lane, Emit emit) {
+  const int t = lane & 31;
+  const int rnext = __shfl_down(rcv, 1, 64);
+  const bool is_end = (lane < 32) && (t < ne) && (t == ne - 1 || rnext != rcv);
+  const unsigned ends = (unsigned)(__ballot(is_end) & 0xffffffffull);
+#pragma unroll
+  for (int f0 = 0; f0 < D; f0 += 64) {
+    float v[NLAM_TILE];
+#pragma unroll
+    for (int s = 0; s < NLAM_TILE; ++s) v[s] = tile[s * ld + f0 + lane];
+    float acc = 0.f;
+#pragma unroll
+    for (int s = 0; s < NLAM_TILE; ++s) {
+      acc += v[s];
+      if ((ends >> s) & 1u) {
+        emit(__builtin_amdgcn_readlane(rcv, s), f0, acc);
+        acc = 0.f;
+      }
+    }
+  }
+  return __popc(ends);
+}
+
 // ---- gradient helpers ----------------------------------------------------------
 // lanes = features: acc[j] += sum_t tile[t][col0 + 64 j + lane]  (j < NV), the
 // per-feature (bias / gamma / beta) gradient contribution of one tile.

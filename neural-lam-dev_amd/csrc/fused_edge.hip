@@ -61,6 +61,11 @@ __device__ __forceinline__ TileCtx load_tile_ctx(const EdgeFwdParams& p, int4 hd
   c.invd = p.inv_deg ? p.inv_deg[c.r0 + (lane < c.nr ? lane : 0)] : 1.0f;
   return c;
 }
+// every receiver of the tile has at least one in-edge (evaluated at use, not at load)
+__device__ __forceinline__ bool tile_is_dense(const TileCtx& c, int lane) {
+  const int rpn = __shfl_down(c.rp, 1, 64);
+  return __all((lane >= c.nr) || (rpn > c.rp));
+}
 __device__ __forceinline__ int4 load_tile_hdr(const EdgeFwdParams& p, unsigned tt, unsigned total) {
   const unsigned q = tt < total ? tt : total - 1;
   return reinterpret_cast<const int4*>(p.tiles)[q % (unsigned)p.ntiles];
@@ -141,14 +146,21 @@ __global__ __launch_bounds__(256, 2) void edge_fwd_kernel(EdgeFwdParams p) {
     wave_sync();
     {
       float* ab = p.agg + (int64_t)b * p.agg_bstride;
-      for (int i = 0; i < nr; ++i) {
-        const int beg = __shfl(cur.rp, i, 64), end = __shfl(cur.rp, i + 1, 64);
-        const float sc = __shfl(cur.invd, i, 64);
+      if (tile_is_dense(cur, lane)) {   // every receiver has in-edges (all neural-lam graphs)
+        tile_segment_sums<D>(tile, LDT, ne, rcv, lane, [&](int r, int f0, float acc) {
+          const float sc = __shfl(cur.invd, r - r0, 64);
+          ab[(int64_t)r * p.agg_ld + f0 + lane] = acc * sc;
+        });
+      } else {
+        for (int i = 0; i < nr; ++i) {
+          const int beg = __shfl(cur.rp, i, 64), end = __shfl(cur.rp, i + 1, 64);
+          const float sc = __shfl(cur.invd, i, 64);
 #pragma unroll
-        for (int f0 = 0; f0 < D; f0 += 64) {
-          float acc = 0.f;
-          for (int s = beg; s < end; ++s) acc += tile[s * LDT + f0 + lane];
-          ab[(int64_t)(r0 + i) * p.agg_ld + f0 + lane] = acc * sc;
+          for (int f0 = 0; f0 < D; f0 += 64) {
+            float acc = 0.f;
+            for (int s = beg; s < end; ++s) acc += tile[s * LDT + f0 + lane];
+            ab[(int64_t)(r0 + i) * p.agg_ld + f0 + lane] = acc * sc;
+          }
         }
       }
     }
@@ -463,13 +475,19 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
       store_rows<true>(T1, LDT, 0, D, ne, lane, gh_row);
       // receiver-side sum of gh (segments are tile-local)
       float* gb = q.gpr + (int64_t)b * q.gpr_bstride;
-      for (int i = 0; i < nr; ++i) {
-        const int beg = __shfl(cur.rp, i, 64), end = __shfl(cur.rp, i + 1, 64);
+      if (tile_is_dense(cur, lane)) {
+        tile_segment_sums<D>(T1, LDT, ne, rcv, lane, [&](int r, int f0, float acc) {
+          gb[(int64_t)r * q.gpr_ld + f0 + lane] = acc;
+        });
+      } else {
+        for (int i = 0; i < nr; ++i) {
+          const int beg = __shfl(cur.rp, i, 64), end = __shfl(cur.rp, i + 1, 64);
 #pragma unroll
-        for (int f0 = 0; f0 < D; f0 += 64) {
-          float acc = 0.f;
-          for (int s = beg; s < end; ++s) acc += T1[s * LDT + f0 + lane];
-          gb[(int64_t)(r0 + i) * q.gpr_ld + f0 + lane] = acc;
+          for (int f0 = 0; f0 < D; f0 += 64) {
+            float acc = 0.f;
+            for (int s = beg; s < end; ++s) acc += T1[s * LDT + f0 + lane];
+            gb[(int64_t)(r0 + i) * q.gpr_ld + f0 + lane] = acc;
+          }
         }
       }
     }

@@ -7,6 +7,7 @@
 // One wavefront owns a tile of 32 rows (fused_common.h); a 256-thread workgroup
 // keeps the weights in LDS and walks tiles persistently.  Forward saves nothing;
 // backward recomputes the hidden activations from the inputs.
+#include <cstdlib>
 #include "fused_common.h"
 
 struct MlpParams {
@@ -199,12 +200,23 @@ struct LinParams {
   const float* WB; int64_t ldWB; const float* bB; int nB;
   float* out; int64_t out_bstride; int64_t out_ld;
   int64_t rows; int B; int vec_mask;  // bit0: x, bit3: out
+  int timeline;                       // NLAM_TIMELINE=1: per-workgroup 100 MHz stamps
 };
+
+// Diagnostic (NLAM_TIMELINE=1): s_memrealtime (100 MHz, chip-wide) at workgroup start,
+// after the weight prologue and after the tile loop, for up to 1024 workgroups.
+__device__ unsigned long long g_lin_fwd_timeline[3 * 1024];
+extern "C" int nlam_debug_lin_fwd_timeline(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lin_fwd_timeline),
+                             sizeof(unsigned long long) * 3 * 1024) == hipSuccess ? 0 : 1;
+}
 
 template <int NOUTB>
 __global__ __launch_bounds__(256, 2) void lin_fwd_kernel(LinParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool tl = p.timeline && tid == 0 && blockIdx.x < 1024;
+  if (tl) g_lin_fwd_timeline[3 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
   const int ldw = p.k_pad + 4;
   const int n_out = p.nA + p.nB;
   const int ldt = (p.k_pad > 32 * NOUTB ? p.k_pad : 32 * NOUTB) + 4;
@@ -219,6 +231,7 @@ __global__ __launch_bounds__(256, 2) void lin_fwd_kernel(LinParams p) {
     load_vec_lds(bs + p.nA, p.bB, p.nB, 32 * NOUTB - p.nA, tid, 256);
   }
   __syncthreads();
+  if (tl) g_lin_fwd_timeline[3 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
   const int64_t tiles_per_b = (p.rows + NLAM_TILE - 1) / NLAM_TILE;
   const int64_t ntiles = tiles_per_b * p.B;
   for (int64_t tt = (int64_t)blockIdx.x * 4 + wave; tt < ntiles; tt += (int64_t)gridDim.x * 4) {
@@ -247,6 +260,10 @@ __global__ __launch_bounds__(256, 2) void lin_fwd_kernel(LinParams p) {
     else
       store_rows<false>(tile, ldt, 0, n_out, nrows, lane, op);
     wave_sync();
+  }
+  if (tl) {
+    __builtin_amdgcn_s_waitcnt(0);
+    g_lin_fwd_timeline[3 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
   }
 }
 
@@ -285,6 +302,8 @@ extern "C" int nlam_lin_fwd(const float* x, int64_t x_bstride, int64_t x_ld, int
   p.out = out; p.out_bstride = out_bstride; p.out_ld = out_ld;
   p.rows = rows; p.B = (int)B;
   p.vec_mask = 0;
+  static const bool timeline = getenv("NLAM_TIMELINE") && getenv("NLAM_TIMELINE")[0] == '1';
+  p.timeline = timeline ? 1 : 0;
   if (view_vec_ok(x, x_bstride, x_ld, k_in)) p.vec_mask |= 1;
   if (view_vec_ok(out, out_bstride, out_ld, p.nA + p.nB)) p.vec_mask |= 8;
   hipStream_t s = (hipStream_t)stream;
