@@ -95,6 +95,16 @@ def rec_updates_per_layer(args, info):
     return (n[-1] + 2 * sum(n[:-1])) + (n[0] + 2 * sum(n[1:]))
 
 
+def all_receiver_updates(args, info):
+    """Receiver-node updates of one sample-step over every InteractionNet."""
+    mesh = info["num_mesh"]
+    total = args.processor_layers * rec_updates_per_layer(args, info)
+    total += mesh[0] + info["num_grid"]                      # g2m + m2g
+    if args.model != "graph_lam":
+        total += sum(mesh[1:]) + sum(mesh[:-1])              # init up-sweep + read-out
+    return total
+
+
 def host_cores():
     """Threads for the CPU baseline: the cores this process may actually use
     (affinity mask and cgroup CPU quota), capped at 32 -- beyond that the
@@ -290,6 +300,10 @@ def main():
                 "parallelism": f"dp{world}",
             },
             "steps_per_s": 1e3 / ms, "loss": loss_val,
+            # processor updates + g2m (mesh receivers) + m2g (grid receivers)
+            # [+ Hi-LAM init/read-out sweeps] per AR step
+            "all_receiver_updates_per_s": world * B * T * all_receiver_updates(args, info)
+            / (elapsed / args.steps),
             "hip_graph": bool(graphed is not None and graphed.graph is not None),
             "roofline": roofline, "scatter_add_roofline": scatter, "cpu_baseline": cpu,
             "kernels": kernels,
