@@ -19,6 +19,7 @@ _i64, _i32, _p, _f = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_flo
 SIGNATURES = {
     "nlam_last_error": [],
     "nlam_abi_version": [],
+    "nlam_mfma_mode": [],
     "nlam_graph_build_host": [_p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p],
     "nlam_gemm": [_i64, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _p, _p, _i64, _i32, _i32, _p, _p],
     "nlam_silu_fwd": [_p, _p, _i64, _p],

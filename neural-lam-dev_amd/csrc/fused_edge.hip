@@ -16,6 +16,7 @@
 #include <stdlib.h>
 
 #include "fused_common.h"
+#include "fused_bf16x3.h"
 
 struct EdgeFwdParams {
   // graph tables (device)
@@ -71,11 +72,14 @@ __device__ __forceinline__ int4 load_tile_hdr(const EdgeFwdParams& p, unsigned t
   return reinterpret_cast<const int4*>(p.tiles)[q % (unsigned)p.ntiles];
 }
 
-template <int D, bool HAS_EGEMM>
+// B3: the two d x d GEMMs run as split-bf16 MFMAs (fused_bf16x3.h); the weight images have
+// the byte size of the fp32 ones, so the LDS layout is shared.
+template <int D, bool HAS_EGEMM, bool B3 = false>
 __global__ __launch_bounds__(256, 2) void edge_fwd_kernel(EdgeFwdParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NB = D / 32;
   constexpr int LDW = D + 4, LDT = D + 4;
+  static_assert(b3_image_bytes(D, D) == (size_t)D * LDW * sizeof(float), "image sizes differ");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float* W1s = smem;                                   // HAS_EGEMM only
   float* W2s = W1s + (HAS_EGEMM ? D * LDW : 0);
@@ -83,8 +87,14 @@ __global__ __launch_bounds__(256, 2) void edge_fwd_kernel(EdgeFwdParams p) {
   float* gs = b2s + D;
   float* bs = gs + D;
   float* tile = bs + D + wave * (NLAM_TILE * LDT);
-  if (HAS_EGEMM) load_weight_lds(W1s, p.W1e, p.ldW1e, D, D, D, D, tid, 256);
-  load_weight_lds(W2s, p.W2, p.ldW2, D, D, D, D, tid, 256);
+  const B3Image W1im = b3_image(W1s, D, D), W2im = b3_image(W2s, D, D);
+  if (B3) {
+    if (HAS_EGEMM) load_weight_lds_b3(W1im, 0, p.W1e, p.ldW1e, D, D, D, D, tid, 256);
+    load_weight_lds_b3(W2im, 0, p.W2, p.ldW2, D, D, D, D, tid, 256);
+  } else {
+    if (HAS_EGEMM) load_weight_lds(W1s, p.W1e, p.ldW1e, D, D, D, D, tid, 256);
+    load_weight_lds(W2s, p.W2, p.ldW2, D, D, D, D, tid, 256);
+  }
   load_vec_lds(b2s, p.b2, D, D, tid, 256);
   load_vec_lds(gs, p.gamma, D, D, tid, 256);
   load_vec_lds(bs, p.beta, D, D, tid, 256);
@@ -130,14 +140,18 @@ __global__ __launch_bounds__(256, 2) void edge_fwd_kernel(EdgeFwdParams p) {
     put_rows_v<NV, false>(tile, LDT, 0, D, ne, lane, vS);
     wave_sync();
     tile_to_acc<NB>(a1, tile, LDT, lane);
-    if (HAS_EGEMM) gemm_acc<NB, NB>(a1, W1s, LDW, 0, ebuf, lane);
+    if (HAS_EGEMM) {
+      if (B3) gemm_acc_b3<NB, NB>(a1, W1im, 0, ebuf, lane);
+      else gemm_acc<NB, NB>(a1, W1s, LDW, 0, ebuf, lane);
+    }
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) a1[nb][r] = nlam_silu(a1[nb][r]);
     f32x16 m[NB];
     vec_to_acc<NB>(m, b2s, lane);
-    gemm_acc<NB, NB>(m, W2s, LDW, 0, a1, lane);
+    if (B3) gemm_acc_b3<NB, NB>(m, W2im, 0, a1, lane);
+    else gemm_acc<NB, NB>(m, W2s, LDW, 0, a1, lane);
     ln_apply<NB>(m, gs, bs, lane);
 
     // messages -> LDS; segmented reduction with lanes = features
@@ -182,12 +196,12 @@ __global__ __launch_bounds__(256, 2) void edge_fwd_kernel(EdgeFwdParams p) {
   }
 }
 
-template <int D, bool HAS_EGEMM>
+template <int D, bool HAS_EGEMM, bool B3 = false>
 static int launch_edge_fwd(const EdgeFwdParams& p, hipStream_t s) {
   const size_t lds = ((size_t)(HAS_EGEMM ? 2 : 1) * D * (D + 4) + 3 * D +
                       (size_t)4 * NLAM_TILE * (D + 4)) * sizeof(float);
   NLAM_REQUIRE(lds <= 160 * 1024, "edge_fwd: LDS footprint %zu B exceeds 160 KiB", lds);
-  auto kern = edge_fwd_kernel<D, HAS_EGEMM>;
+  auto kern = edge_fwd_kernel<D, HAS_EGEMM, B3>;
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -235,6 +249,9 @@ extern "C" int nlam_edge_fwd(
   p.e_out = e_out; p.eo_bstride = eo_bstride; p.eo_ld = eo_ld;
   p.B = (int)B;
   hipStream_t s = (hipStream_t)stream;
+  if (d == 64 && nlam_mfma_b3() && nlam_aligned16(W2) && ldW2 % 4 == 0 &&
+      (!has_egemm || (nlam_aligned16(W1e) && ldW1e % 4 == 0)))
+    return has_egemm ? launch_edge_fwd<64, true, true>(p, s) : launch_edge_fwd<64, false, true>(p, s);
   if (d == 64) return has_egemm ? launch_edge_fwd<64, true>(p, s) : launch_edge_fwd<64, false>(p, s);
   return has_egemm ? launch_edge_fwd<128, true>(p, s) : launch_edge_fwd<128, false>(p, s);
 }

@@ -9,6 +9,7 @@
 // backward recomputes the hidden activations from the inputs.
 #include <cstdlib>
 #include "fused_common.h"
+#include "fused_bf16x3.h"
 
 struct MlpParams {
   RowView src[2];
@@ -267,6 +268,66 @@ __global__ __launch_bounds__(256, 2) void lin_fwd_kernel(LinParams p) {
   }
 }
 
+// Split-bf16 form of the projection (fused_bf16x3.h): k_in % 32 == 0, float4 views.
+template <int NOUTB, int KB>
+__global__ __launch_bounds__(256, 2) void lin_fwd_b3_kernel(LinParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int K = 32 * KB, NO = 32 * NOUTB;
+  constexpr int ldt = (K > NO ? K : NO) + 4;
+  const B3Image W = b3_image(smem, NO, K);
+  float* bs = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + b3_image_bytes(NO, K));
+  float* tile = bs + NO + wave * (NLAM_TILE * ldt);
+  load_weight_lds_b3(W, 0, p.WA, p.ldWA, p.nA, K, p.nA, K, tid, 256);
+  load_vec_lds(bs, p.bA, p.nA, p.nA, tid, 256);
+  if (p.nB > 0) {
+    load_weight_lds_b3(W, p.nA, p.WB, p.ldWB, p.nB, K, NO - p.nA, K, tid, 256);
+    load_vec_lds(bs + p.nA, p.bB, p.nB, NO - p.nA, tid, 256);
+  }
+  __syncthreads();
+  const int n_out = p.nA + p.nB;
+  const int64_t tiles_per_b = (p.rows + NLAM_TILE - 1) / NLAM_TILE;
+  const int64_t ntiles = tiles_per_b * p.B;
+  for (int64_t tt = (int64_t)blockIdx.x * 4 + wave; tt < ntiles; tt += (int64_t)gridDim.x * 4) {
+    const int64_t b = tt / tiles_per_b;
+    const int64_t r0 = (tt - b * tiles_per_b) * NLAM_TILE;
+    const int nrows = (int)((p.rows - r0) < NLAM_TILE ? (p.rows - r0) : NLAM_TILE);
+    f32x4 vx[8 * KB];
+    view_load_v<8 * KB>(vx, p.x, b, r0, nrows, lane);
+    put_rows_v<8 * KB, false>(tile, ldt, 0, K, nrows, lane, vx);
+    wave_sync();
+    f32x16 xin[KB];
+    tile_to_acc<KB>(xin, tile, ldt, lane);
+    f32x16 a[NOUTB];
+    vec_to_acc<NOUTB>(a, bs, lane);
+    gemm_acc_b3<NOUTB, KB>(a, W, 0, xin, lane);
+    wave_sync();
+    acc_to_tile<NOUTB>(a, tile, ldt, lane);
+    wave_sync();
+    float* ob = p.out + b * p.out_bstride + r0 * p.out_ld;
+    auto op = [&](int t) { return ob + (int64_t)t * p.out_ld; };
+    store_rows<true>(tile, ldt, 0, n_out, nrows, lane, op);
+    wave_sync();
+  }
+}
+
+template <int NOUTB, int KB>
+static int launch_lin_fwd_b3(const LinParams& p, hipStream_t s) {
+  constexpr int K = 32 * KB, NO = 32 * NOUTB;
+  constexpr int ldt = (K > NO ? K : NO) + 4;
+  const size_t lds = b3_image_bytes(NO, K) + NO * 4 + (size_t)4 * NLAM_TILE * ldt * 4;
+  auto kern = lin_fwd_b3_kernel<NOUTB, KB>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  const int64_t ntiles = ((p.rows + NLAM_TILE - 1) / NLAM_TILE) * p.B;
+  kern<<<persistent_grid(ntiles, lds), 256, lds, s>>>(p);
+  NLAM_CHECK_LAUNCH("lin_fwd_b3_kernel");
+  return 0;
+}
+
 template <int NOUTB>
 static int launch_lin_fwd(const LinParams& p, hipStream_t s) {
   const int ldt = (p.k_pad > 32 * NOUTB ? p.k_pad : 32 * NOUTB) + 4;
@@ -307,6 +368,10 @@ extern "C" int nlam_lin_fwd(const float* x, int64_t x_bstride, int64_t x_ld, int
   if (view_vec_ok(x, x_bstride, x_ld, k_in)) p.vec_mask |= 1;
   if (view_vec_ok(out, out_bstride, out_ld, p.nA + p.nB)) p.vec_mask |= 8;
   hipStream_t s = (hipStream_t)stream;
+  if (nlam_mfma_b3() && k_in == 64 && (p.vec_mask & 1) && (p.vec_mask & 8)) {
+    if ((p.nA + p.nB) == 64) return launch_lin_fwd_b3<2, 2>(p, s);
+    if ((p.nA + p.nB) == 128) return launch_lin_fwd_b3<4, 2>(p, s);
+  }
   switch ((p.nA + p.nB) / 32) {
     case 2: return launch_lin_fwd<2>(p, s);
     case 4: return launch_lin_fwd<4>(p, s);

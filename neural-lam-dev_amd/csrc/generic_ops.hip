@@ -3,6 +3,7 @@
 // fused kernels (fused_*.hip) replace them for the BASELINE shapes.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "nlam_common.h"
 
@@ -16,6 +17,18 @@ void nlam_set_error(const char* fmt, ...) {
 }
 extern "C" const char* nlam_last_error(void) { return g_err; }
 extern "C" int nlam_abi_version(void) { return 1; }
+
+// GEMM arithmetic of the fused kernels (see fused_bf16x3.h): NLAM_MFMA=fp32 | bf16x3
+#define NLAM_MFMA_DEFAULT_B3 0
+bool nlam_mfma_b3() {
+  static const int mode = [] {
+    const char* e = getenv("NLAM_MFMA");
+    if (e == nullptr || e[0] == 0) return NLAM_MFMA_DEFAULT_B3;
+    return (e[0] == 'b' || e[0] == 'B') ? 1 : 0;
+  }();
+  return mode != 0;
+}
+extern "C" int nlam_mfma_mode(void) { return nlam_mfma_b3() ? 1 : 0; }
 
 // ------------------------------------------------------------------- GEMM
 // 64x64 output tile per 256-thread workgroup, 4 waves each owning a 32x32
