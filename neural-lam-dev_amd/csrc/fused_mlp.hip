@@ -37,25 +37,35 @@ __device__ __forceinline__ int mlp_ldt(int k_pad) {
   return m + 4;
 }
 
-template <int HID, int NOUTB, bool HAS_LN>
+// B3KB > 0: split-bf16 GEMMs (fused_bf16x3.h) with K padded to 32 * B3KB columns.
+template <int HID, int NOUTB, bool HAS_LN, int B3KB = 0>
 __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(MlpParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NBH = HID / 32;
   constexpr int NVS = HID / 8;   // float4 per lane per source (source width <= HID)
+  constexpr bool B3 = B3KB > 0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool fast_stage = (p.vec_mask & 1) && (p.nsrc == 1 || ((p.vec_mask >> 1) & 1));
-  const int ldw1 = p.k_pad + 4, ldw2 = HID + 4;
-  const int ldt = mlp_ldt<HID, NOUTB>(p.k_pad);
+  const int kp = B3 ? 32 * B3KB : p.k_pad;     // staged / zero-padded K
+  const int ldw1 = kp + 4, ldw2 = HID + 4;
+  const int ldt = mlp_ldt<HID, NOUTB>(kp);
   float* W1s = smem;
-  float* W2s = W1s + HID * ldw1;
+  float* W2s = W1s + HID * ldw1;               // (the bf16 images have the fp32 byte sizes)
   float* b1s = W2s + 32 * NOUTB * ldw2;
   float* b2s = b1s + HID;
   float* gs = b2s + 32 * NOUTB;
   float* bs = gs + 32 * NOUTB;
   float* tile = bs + 32 * NOUTB + wave * (NLAM_TILE * ldt);
+  const B3Image W1im = b3_image(W1s, HID, B3 ? 32 * B3KB : 32);
+  const B3Image W2im = b3_image(W2s, 32 * NOUTB, HID);
 
-  load_weight_lds(W1s, p.W1, p.ldW1, HID, p.k_in, HID, p.k_pad, tid, 256);
-  load_weight_lds(W2s, p.W2, p.ldW2, p.n_out, HID, 32 * NOUTB, HID, tid, 256);
+  if (B3) {
+    load_weight_lds_b3(W1im, 0, p.W1, p.ldW1, HID, p.k_in, HID, 32 * B3KB, tid, 256);
+    load_weight_lds_b3(W2im, 0, p.W2, p.ldW2, p.n_out, HID, 32 * NOUTB, HID, tid, 256);
+  } else {
+    load_weight_lds(W1s, p.W1, p.ldW1, HID, p.k_in, HID, p.k_pad, tid, 256);
+    load_weight_lds(W2s, p.W2, p.ldW2, p.n_out, HID, 32 * NOUTB, HID, tid, 256);
+  }
   load_vec_lds(b1s, p.b1, HID, HID, tid, 256);
   load_vec_lds(b2s, p.b2, p.n_out, 32 * NOUTB, tid, 256);
   load_vec_lds(gs, p.gamma, p.n_out, 32 * NOUTB, tid, 256);
@@ -80,19 +90,26 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(MlpParams p) {
       view_stage_s(tile, ldt, 0, p.src[0], b, r0, nrows, lane);
       if (p.nsrc > 1) view_stage_s(tile, ldt, p.src[0].width, p.src[1], b, r0, nrows, lane);
     }
-    if (p.k_pad > p.k_in) zero_cols(tile, ldt, p.k_in, p.k_pad - p.k_in, lane);
+    if (kp > p.k_in) zero_cols(tile, ldt, p.k_in, kp - p.k_in, lane);
     wave_sync();
 
     f32x16 a1[NBH];
     vec_to_acc<NBH>(a1, b1s, lane);
-    gemm_tile<NBH>(a1, W1s, ldw1, tile, ldt, p.k_pad >> 3, lane);
+    if constexpr (B3) {
+      f32x16 xin[B3KB];
+      tile_to_acc<B3KB>(xin, tile, ldt, lane);
+      gemm_acc_b3<NBH, B3KB>(a1, W1im, 0, xin, lane);
+    } else {
+      gemm_tile<NBH>(a1, W1s, ldw1, tile, ldt, p.k_pad >> 3, lane);
+    }
 #pragma unroll
     for (int nb = 0; nb < NBH; ++nb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) a1[nb][r] = nlam_silu(a1[nb][r]);
     f32x16 a2[NOUTB];
     vec_to_acc<NOUTB>(a2, b2s, lane);
-    gemm_acc<NOUTB, NBH>(a2, W2s, ldw2, 0, a1, lane);
+    if constexpr (B3) gemm_acc_b3<NOUTB, NBH>(a2, W2im, 0, a1, lane);
+    else gemm_acc<NOUTB, NBH>(a2, W2s, ldw2, 0, a1, lane);
     if (HAS_LN) ln_apply<NOUTB>(a2, gs, bs, lane);
 
     wave_sync();  // all operand reads of the tile are done
@@ -128,12 +145,12 @@ static size_t mlp_lds_bytes(int k_pad) {
   return fl * sizeof(float);
 }
 
-template <int HID, int NOUTB, bool HAS_LN>
+template <int HID, int NOUTB, bool HAS_LN, int B3KB = 0>
 static int launch_mlp_fwd(const MlpParams& p, hipStream_t s) {
-  const size_t lds = mlp_lds_bytes<HID, NOUTB>(p.k_pad);
+  const size_t lds = mlp_lds_bytes<HID, NOUTB>(B3KB > 0 ? 32 * B3KB : p.k_pad);
   NLAM_REQUIRE(lds <= 160 * 1024, "mlp_fwd: LDS footprint %zu B exceeds 160 KiB (k_in=%d)", lds,
                p.k_in);
-  auto kern = mlp_fwd_kernel<HID, NOUTB, HAS_LN>;
+  auto kern = mlp_fwd_kernel<HID, NOUTB, HAS_LN, B3KB>;
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -181,6 +198,13 @@ extern "C" int nlam_mlp_fwd(
   hipStream_t s = (hipStream_t)stream;
   const bool ln = gamma != nullptr;
   const int noutb = (n_out + 31) / 32;
+  if (hid == 64 && nlam_mfma_b3()) {
+    const int kb = (p.k_in + 31) / 32;
+    if (ln && kb == 1) return launch_mlp_fwd<64, 2, true, 1>(p, s);
+    if (ln && kb == 2) return launch_mlp_fwd<64, 2, true, 2>(p, s);
+    if (ln && kb == 4) return launch_mlp_fwd<64, 2, true, 4>(p, s);
+    if (!ln && noutb == 1 && kb == 2) return launch_mlp_fwd<64, 1, false, 2>(p, s);
+  }
   if (hid == 64) {
     if (ln) return launch_mlp_fwd<64, 2, true>(p, s);
     if (noutb == 1) return launch_mlp_fwd<64, 1, false>(p, s);
