@@ -134,3 +134,137 @@ __device__ __forceinline__ void gemm_acc_b3(f32x16 (&out)[NB], const B3Image& W,
     }
   }
 }
+
+// ---- transposed fragments (gfx950 ds_read_b64_tr_b16) --------------------------------
+// Per 16-lane group the instruction reads a 4-row x 16-column block of 16-bit elements and
+// hands lane i of the group column i (rows in elements 0..3).  Lane 4 q + p of the group
+// supplies the address of row q, columns 4 p .. 4 p + 3.  EXEC must be all ones.
+// b3_tr_frag returns, for lane (c = lane & 31, kg = lane >> 5), the eight elements
+//   plane[row0 + 4 kg + {0..3}][col0 + c],  plane[row0 + 8 + 4 kg + {0..3}][col0 + c]
+// i.e. the A (or B) fragment of a product that contracts over the image's ROW index in the
+// order the accumulator layout uses (rows 16 s + 8 (i >> 2) + 4 kg + (i & 3), i = 0..7).
+__device__ __forceinline__ bf16x8 b3_tr_frag(const __bf16* __restrict__ plane, int pitch, int row0,
+                                             int col0, int lane) {
+  const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+  const __bf16* a = plane + (row0 + 4 * (g >> 1) + q) * pitch + col0 + 16 * (g & 1) + 4 * p;
+  const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)a);
+  const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a + 8 * pitch));
+  return b3_join(v0, v1);
+}
+// contraction over 16 CONSECUTIVE rows (row0 + 8 kg + {0..7}): the outer products, where
+// both operands come from row tiles and any common row order is valid
+__device__ __forceinline__ bf16x8 b3_tr_frag_rows(const __bf16* __restrict__ plane, int pitch,
+                                                  int row0, int col0, int lane) {
+  const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+  const __bf16* a = plane + (row0 + 8 * (g >> 1) + q) * pitch + col0 + 16 * (g & 1) + 4 * p;
+  const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)a);
+  const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a + 4 * pitch));
+  return b3_join(v0, v1);
+}
+
+// out[kb] += W[rows 32 NB][cols 32 (kb0 + kb) ..]^T . G   (gx = W^T gy), G in accumulator
+// layout; the same image as gemm_acc_b3, read transposed.
+template <int KBO, int NB>
+__device__ __forceinline__ void gemm_acc_wt_b3(f32x16 (&out)[KBO], const B3Image& W, int kb0,
+                                               const f32x16 (&g)[NB], int lane) {
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 bh, bl;
+      b3_split(g[nb], 8 * s, bh, bl);
+#pragma unroll
+      for (int kb = 0; kb < KBO; ++kb) {
+        const bf16x8 ah = b3_tr_frag(W.hi, W.pitch, 32 * nb + 16 * s, 32 * (kb0 + kb), lane);
+        const bf16x8 al = b3_tr_frag(W.lo, W.pitch, 32 * nb + 16 * s, 32 * (kb0 + kb), lane);
+        out[kb] = B3_MFMA(ah, bh, out[kb]);
+        out[kb] = B3_MFMA(ah, bl, out[kb]);
+        out[kb] = B3_MFMA(al, bh, out[kb]);
+      }
+    }
+  }
+}
+
+// ---- row tiles as bf16 planes (operands of the weight-gradient outer products) --------
+// A 32-row tile of `width` features as two planes [32][pitch] (pitch = width32 + 4): the
+// bytes of the fp32 tile [32][width32 + 4], so it can take an fp32 tile's place.
+struct B3Tile {
+  __bf16* hi;
+  __bf16* lo;
+  int pitch;
+};
+__device__ __forceinline__ B3Tile b3_tile(float* tile_base, int width32) {
+  B3Tile t;
+  t.pitch = width32 + 4;
+  t.hi = reinterpret_cast<__bf16*>(tile_base);
+  t.lo = t.hi + NLAM_TILE * t.pitch;
+  return t;
+}
+// accumulator layout (lane = row t, half h) -> planes, feature block col0 / 32 onwards
+template <int NB>
+__device__ __forceinline__ void acc_to_tile_b3(const f32x16 (&acc)[NB], const B3Tile& T, int col0,
+                                               int lane) {
+  const int t = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = acc[nb][4 * q + j];
+      bf16x4 hi, lo;
+      b3_split4(v, hi, lo);
+      const int off = t * T.pitch + col0 + 32 * nb + 8 * q + 4 * h;
+      *reinterpret_cast<bf16x4*>(T.hi + off) = hi;
+      *reinterpret_cast<bf16x4*>(T.lo + off) = lo;
+    }
+  }
+}
+// two-phase staged float4 rows (load_rows_v) -> planes; rows >= nrows are zeroed
+template <int NV>
+__device__ __forceinline__ void put_rows_v_b3(const B3Tile& T, int col0, int width, int nrows,
+                                              int lane, const f32x4 (&v)[NV]) {
+  const int lpr = width >> 2;
+  const int rpi = 64 / lpr;
+  const int sub = lane / lpr, c4 = lane - sub * lpr;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int t = sub + k * rpi;
+    if (sub < rpi && t < NLAM_TILE) {
+      f32x4 x = v[k];
+      if (t >= nrows) x = f32x4{0.f, 0.f, 0.f, 0.f};
+      bf16x4 hi, lo;
+      b3_split4(x, hi, lo);
+      const int off = t * T.pitch + col0 + 4 * c4;
+      *reinterpret_cast<bf16x4*>(T.hi + off) = hi;
+      *reinterpret_cast<bf16x4*>(T.lo + off) = lo;
+    }
+  }
+}
+
+// dW[ib][jb] += sum_t G[t][gcol0 + 32 ib + .] (x) X[t][xcol0 + 32 jb + .] over the 32 tile
+// rows; G and X are bf16-plane tiles.  Result block layout as outer_accum (fused_common.h).
+template <int NI, int NJ>
+__device__ __forceinline__ void outer_accum_b3(f32x16 (&dW)[NI][NJ], const B3Tile& G, int gcol0,
+                                               const B3Tile& X, int xcol0, int lane) {
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    bf16x8 ah[NI], al[NI];
+#pragma unroll
+    for (int ib = 0; ib < NI; ++ib) {
+      ah[ib] = b3_tr_frag_rows(G.hi, G.pitch, 16 * u, gcol0 + 32 * ib, lane);
+      al[ib] = b3_tr_frag_rows(G.lo, G.pitch, 16 * u, gcol0 + 32 * ib, lane);
+    }
+#pragma unroll
+    for (int jb = 0; jb < NJ; ++jb) {
+      const bf16x8 bh = b3_tr_frag_rows(X.hi, X.pitch, 16 * u, xcol0 + 32 * jb, lane);
+      const bf16x8 bl = b3_tr_frag_rows(X.lo, X.pitch, 16 * u, xcol0 + 32 * jb, lane);
+#pragma unroll
+      for (int ib = 0; ib < NI; ++ib) {
+        dW[ib][jb] = B3_MFMA(ah[ib], bh, dW[ib][jb]);
+        dW[ib][jb] = B3_MFMA(ah[ib], bl, dW[ib][jb]);
+        dW[ib][jb] = B3_MFMA(al[ib], bh, dW[ib][jb]);
+      }
+    }
+  }
+}

@@ -824,7 +824,8 @@ struct LinBwdParams {
   int vec_x, vec_gy, vec_gx;
 };
 
-template <int NOUTB, int KB, bool SUMGY = false>
+// B3: split-bf16 MFMAs (needs the float4 views and k_in == 32 KB, n_out == 32 NOUTB).
+template <int NOUTB, int KB, bool SUMGY = false, bool B3 = false>
 __global__ __launch_bounds__(256) void lin_bwd_kernel(LinBwdParams q) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int KP32 = 32 * KB, NO = 32 * NOUTB;
@@ -837,10 +838,18 @@ __global__ __launch_bounds__(256) void lin_bwd_kernel(LinBwdParams q) {
   float* T1base = T0base + NLAM_TILE * ldt0;
   float* T0 = T0base + wave * WSTRIDE;
   float* T1 = T1base + wave * WSTRIDE;
-  load_weight_lds(Ws, q.WA, q.ldWA, q.nA, q.x.width, q.nA, KP32, tid, 256);
-  if (q.nB > 0)
-    load_weight_lds(Ws + q.nA * ldw, q.WB, q.ldWB, q.nB, q.x.width, NO - q.nA, KP32, tid, 256);
+  const B3Image Wim = b3_image(Ws, NO, KP32);      // same bytes as the fp32 image
+  if (B3) {
+    load_weight_lds_b3(Wim, 0, q.WA, q.ldWA, q.nA, q.x.width, q.nA, KP32, tid, 256);
+    if (q.nB > 0)
+      load_weight_lds_b3(Wim, q.nA, q.WB, q.ldWB, q.nB, q.x.width, NO - q.nA, KP32, tid, 256);
+  } else {
+    load_weight_lds(Ws, q.WA, q.ldWA, q.nA, q.x.width, q.nA, KP32, tid, 256);
+    if (q.nB > 0)
+      load_weight_lds(Ws + q.nA * ldw, q.WB, q.ldWB, q.nB, q.x.width, NO - q.nA, KP32, tid, 256);
+  }
   __syncthreads();
+  const B3Tile T0p = b3_tile(T0, KP32), T1p = b3_tile(T1, NO);
   f32x16 dW[NOUTB][KB];
 #pragma unroll
   for (int i = 0; i < NOUTB; ++i)
@@ -887,7 +896,8 @@ __global__ __launch_bounds__(256) void lin_bwd_kernel(LinBwdParams q) {
           }
         }
       }
-      put_rows_v<4 * KB, false>(T0, ldt0, 0, q.x.width, nrows, lane, vx);
+      if (B3) put_rows_v_b3<4 * KB>(T0p, 0, q.x.width, nrows, lane, vx);
+      else put_rows_v<4 * KB, false>(T0, ldt0, 0, q.x.width, nrows, lane, vx);
       put_rows_v<4 * NOUTB, false>(T1, ldt1, 0, n_out, nrows, lane, vg);
     } else {
       view_stage_s(T0, ldt0, 0, q.x, b, r0, nrows, lane);
@@ -897,16 +907,33 @@ __global__ __launch_bounds__(256) void lin_bwd_kernel(LinBwdParams q) {
     if (NO > n_out) zero_cols(T1, ldt1, n_out, NO - n_out, lane);
     wave_sync();
     tile_colsum<NV>(db, T1, ldt1, 0, nrows, lane);
-    outer_accum<NOUTB, KB>(dW, T1, ldt1, 0, T0, ldt0, 0, lane);
     f32x16 gx[KB];
-    if (q.gx != nullptr) {
+    if constexpr (B3) {
+      // gy: fp32 tile -> registers -> bf16 planes in the same LDS (x went there directly)
       f32x16 g[NOUTB];
       tile_to_acc<NOUTB>(g, T1, ldt1, lane);
+      wave_sync();
+      acc_to_tile_b3<NOUTB>(g, T1p, 0, lane);
+      wave_sync();
+      outer_accum_b3<NOUTB, KB>(dW, T1p, 0, T0p, 0, lane);
+      if (q.gx != nullptr) {
 #pragma unroll
-      for (int kb = 0; kb < KB; ++kb)
+        for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) gx[kb][r] = 0.f;
-      gemm_acc_wt<KB, NOUTB>(gx, Ws, ldw, 0, g, lane);
+          for (int r = 0; r < 16; ++r) gx[kb][r] = 0.f;
+        gemm_acc_wt_b3<KB, NOUTB>(gx, Wim, 0, g, lane);
+      }
+    } else {
+      outer_accum<NOUTB, KB>(dW, T1, ldt1, 0, T0, ldt0, 0, lane);
+      if (q.gx != nullptr) {
+        f32x16 g[NOUTB];
+        tile_to_acc<NOUTB>(g, T1, ldt1, lane);
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) gx[kb][r] = 0.f;
+        gemm_acc_wt<KB, NOUTB>(gx, Ws, ldw, 0, g, lane);
+      }
     }
     if (q.gx != nullptr) {
       wave_sync();
@@ -937,7 +964,7 @@ __global__ __launch_bounds__(256) void lin_bwd_kernel(LinBwdParams q) {
   for (int i = tid; i < NO; i += 256) slab[NO * KP32 + i] = img[i];
 }
 
-template <int NOUTB, int KB, bool SUMGY = false>
+template <int NOUTB, int KB, bool SUMGY = false, bool B3 = false>
 static int launch_lin_bwd(const LinBwdParams& q, hipStream_t s) {
   constexpr int KP32 = 32 * KB, NO = 32 * NOUTB;
   const size_t lds = ((size_t)NO * (KP32 + 4) + (size_t)4 * NLAM_TILE * (KP32 + 4 + NO + 4)) *
@@ -946,7 +973,7 @@ static int launch_lin_bwd(const LinBwdParams& q, hipStream_t s) {
   const size_t fold_bytes = (size_t)4 * NO * KP32 * sizeof(float);
   NLAM_REQUIRE(fold_bytes <= 160 * 1024, "lin_bwd: fold images exceed LDS");
   const size_t lds_alloc = lds > fold_bytes ? lds : fold_bytes;
-  auto kern = lin_bwd_kernel<NOUTB, KB, SUMGY>;
+  auto kern = lin_bwd_kernel<NOUTB, KB, SUMGY, B3>;
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -997,6 +1024,13 @@ extern "C" int nlam_lin_bwd(const float* x, int64_t x_bstride, int64_t x_ld, int
                "nlam_lin_bwd: gy_nsum > 1 needs 16-byte aligned x / gy rows and slices");
   hipStream_t s = (hipStream_t)stream;
   const int noutb = (q.nA + q.nB) / 32, kb = (k_in + 31) / 32;
+  const bool b3 = nlam_mfma_b3() && q.vec_x && q.vec_gy && k_in == 32 * kb &&
+                  (q.nA + q.nB) == 32 * noutb;
+  if (b3) {
+    if (q.gy_nsum > 1 && noutb == 2 && kb == 2) return launch_lin_bwd<2, 2, true, true>(q, s);
+    if (q.gy_nsum <= 1 && noutb == 2 && kb == 2) return launch_lin_bwd<2, 2, false, true>(q, s);
+    if (q.gy_nsum <= 1 && noutb == 4 && kb == 2) return launch_lin_bwd<4, 2, false, true>(q, s);
+  }
   if (q.gy_nsum > 1) {
     if (noutb == 2 && kb == 2) return launch_lin_bwd<2, 2, true>(q, s);
     nlam_set_error("nlam_lin_bwd: gy_nsum > 1 unsupported for k_in=%d n_out=%d", k_in,
