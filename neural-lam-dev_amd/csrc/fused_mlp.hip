@@ -426,7 +426,8 @@ struct MlpBwdParams {
 // registers per wave) is not formed here; the kernel stores ga = dL/d(pre-activation)
 // and nlam_outer_bwd computes dW1 = ga^T [x_a | x_b], db1 = colsum(ga) in a lean second
 // pass.  Used for the K = 128 node update, where the in-kernel form spilled.
-template <int HID, int NOUTB, int KB, bool HAS_LN, bool DEFER_DW1>
+// B3: every GEMM / outer product as split-bf16 MFMAs (fused_bf16x3.h).
+template <int HID, int NOUTB, int KB, bool HAS_LN, bool DEFER_DW1, bool B3 = false>
 __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpBwdParams q) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NBH = HID / 32;
@@ -449,12 +450,21 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpBwdParams q) {
   float* T0 = T0base + wave * WSTRIDE;
   float* T1 = T1base + wave * WSTRIDE;
 
-  load_weight_lds(W1s, p.W1, p.ldW1, HID, p.k_in, HID, KP32, tid, 256);
-  load_weight_lds(W2s, p.W2, p.ldW2, p.n_out, HID, 32 * NOUTB, HID, tid, 256);
+  const B3Image W1im = b3_image(W1s, HID, KP32), W2im = b3_image(W2s, 32 * NOUTB, HID);
+  if (B3) {
+    load_weight_lds_b3(W1im, 0, p.W1, p.ldW1, HID, p.k_in, HID, KP32, tid, 256);
+    load_weight_lds_b3(W2im, 0, p.W2, p.ldW2, p.n_out, HID, 32 * NOUTB, HID, tid, 256);
+  } else {
+    load_weight_lds(W1s, p.W1, p.ldW1, HID, p.k_in, HID, KP32, tid, 256);
+    load_weight_lds(W2s, p.W2, p.ldW2, p.n_out, HID, 32 * NOUTB, HID, tid, 256);
+  }
   load_vec_lds(b1s, p.b1, HID, HID, tid, 256);
   load_vec_lds(b2s, p.b2, p.n_out, 32 * NOUTB, tid, 256);
   load_vec_lds(gs, p.gamma, p.n_out, 32 * NOUTB, tid, 256);
   __syncthreads();
+  // bf16-plane views of the two tiles (operands of the outer products)
+  const B3Tile T0s = b3_tile(T0, HID), T0x = b3_tile(T0, KP32);
+  const B3Tile T1o = b3_tile(T1, 32 * NOUTB), T1h = b3_tile(T1, HID);
 
   constexpr int KBA = DEFER_DW1 ? 1 : KB;   // no dW1 accumulators when deferred
   f32x16 dW1[NBH][KBA], dW2[NOUTB][NBH];
@@ -512,7 +522,17 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpBwdParams q) {
     wave_sync();
     f32x16 hpre[NBH];
     vec_to_acc<NBH>(hpre, b1s, lane);
-    gemm_tile<NBH>(hpre, W1s, ldw1, T0, ldt0, p.k_pad >> 3, lane);
+    if constexpr (B3) {
+      constexpr int XB = KB >= 2 ? 2 : 1;      // two input blocks at a time (registers)
+#pragma unroll
+      for (int kb0 = 0; kb0 < KB; kb0 += XB) {
+        f32x16 xin[XB];
+        tile_to_acc<XB>(xin, T0 + 32 * kb0, ldt0, lane);
+        gemm_acc_b3<NBH, XB>(hpre, W1im, kb0, xin, lane);
+      }
+    } else {
+      gemm_tile<NBH>(hpre, W1s, ldw1, T0, ldt0, p.k_pad >> 3, lane);
+    }
     f32x16 sact[NBH];
 #pragma unroll
     for (int nb = 0; nb < NBH; ++nb)
@@ -524,11 +544,13 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpBwdParams q) {
       tile_colsum<NV_O>(dbet, T1, ldt1, 0, nrows, lane);
       f32x16 z[NOUTB];
       vec_to_acc<NOUTB>(z, b2s, lane);
-      gemm_acc<NOUTB, NBH>(z, W2s, ldw2, 0, sact, lane);
+      if constexpr (B3) gemm_acc_b3<NOUTB, NBH>(z, W2im, 0, sact, lane);
+      else gemm_acc<NOUTB, NBH>(z, W2s, ldw2, 0, sact, lane);
       // S goes to T0 right away (X was consumed by the first GEMM): sact's
       // registers are free during the LayerNorm backward
       wave_sync();
-      acc_to_tile<NBH>(sact, T0, ldt0, lane);
+      if constexpr (B3) acc_to_tile_b3<NBH>(sact, T0s, 0, lane);
+      else acc_to_tile<NBH>(sact, T0, ldt0, lane);
       // LayerNorm backward: z -> xhat in place; g (= gy) -> gz
       constexpr float inv_d = 1.0f / (32.0f * NOUTB);
       float mean, rstd;
@@ -568,17 +590,28 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpBwdParams q) {
     // g is gz (zero on padded rows).  Publish GZ (T1); S is in T0.
     wave_sync();
     acc_to_tile<NOUTB>(g, T1, ldt1, lane);
-    if (!HAS_LN) acc_to_tile<NBH>(sact, T0, ldt0, lane);
+    if (!HAS_LN) {
+      if constexpr (B3) acc_to_tile_b3<NBH>(sact, T0s, 0, lane);
+      else acc_to_tile<NBH>(sact, T0, ldt0, lane);
+    }
     wave_sync();
     tile_colsum<NV_O>(db2, T1, ldt1, 0, nrows, lane);
-    outer_accum<NOUTB, NBH>(dW2, T1, ldt1, 0, T0, ldt0, 0, lane);
+    if constexpr (B3) {
+      wave_sync();
+      acc_to_tile_b3<NOUTB>(g, T1o, 0, lane);   // GZ as bf16 planes over the fp32 copy
+      wave_sync();
+      outer_accum_b3<NOUTB, NBH>(dW2, T1o, 0, T0s, 0, lane);
+    } else {
+      outer_accum<NOUTB, NBH>(dW2, T1, ldt1, 0, T0, ldt0, 0, lane);
+    }
     // ga = (W2^T gz) * silu'(h)   (registers + weights only)
     f32x16 ga[NBH];
 #pragma unroll
     for (int nb = 0; nb < NBH; ++nb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) ga[nb][r] = 0.f;
-    gemm_acc_wt<NBH, NOUTB>(ga, W2s, ldw2, 0, g, lane);
+    if constexpr (B3) gemm_acc_wt_b3<NBH, NOUTB>(ga, W2im, 0, g, lane);
+    else gemm_acc_wt<NBH, NOUTB>(ga, W2s, ldw2, 0, g, lane);
 #pragma unroll
     for (int nb = 0; nb < NBH; ++nb)
 #pragma unroll
@@ -594,7 +627,19 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpBwdParams q) {
       stage_x(b, r0, nrows);                        // X again
       wave_sync();
       tile_colsum<NV_H>(db1, T1, ldt1, 0, nrows, lane);
-      outer_accum<NBH, KB>(dW1, T1, ldt1, 0, T0, ldt0, 0, lane);
+      if constexpr (B3) {
+        // X (fp32 tile) -> registers -> planes in place; GA planes over its fp32 copy
+        static_assert(KB <= 2, "B3 in-kernel dW1 supports k_in <= 64");
+        f32x16 xin[KB];
+        tile_to_acc<KB>(xin, T0, ldt0, lane);
+        wave_sync();
+        acc_to_tile_b3<KB>(xin, T0x, 0, lane);
+        acc_to_tile_b3<NBH>(ga, T1h, 0, lane);
+        wave_sync();
+        outer_accum_b3<NBH, KB>(dW1, T1h, 0, T0x, 0, lane);
+      } else {
+        outer_accum<NBH, KB>(dW1, T1, ldt1, 0, T0, ldt0, 0, lane);
+      }
     }
     const bool want_gx = q.gxa != nullptr || q.gxb != nullptr;
     if (want_gx) {
@@ -608,7 +653,8 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpBwdParams q) {
         for (int kb = 0; kb < GXB; ++kb)
 #pragma unroll
           for (int r = 0; r < 16; ++r) gx[kb][r] = 0.f;
-        gemm_acc_wt<GXB, NBH>(gx, W1s, ldw1, 32 * kb0, ga, lane);
+        if constexpr (B3) gemm_acc_wt_b3<GXB, NBH>(gx, W1im, kb0, ga, lane);
+        else gemm_acc_wt<GXB, NBH>(gx, W1s, ldw1, 32 * kb0, ga, lane);
         acc_to_tile<GXB>(gx, T0 + 32 * kb0, ldt0, lane);
       }
       wave_sync();
@@ -716,7 +762,7 @@ extern "C" int nlam_reduce_slabs(const float* slab, int64_t nslabs, int64_t stri
   return 0;
 }
 
-template <int HID, int NOUTB, int KB, bool HAS_LN, bool DEFER_DW1 = false>
+template <int HID, int NOUTB, int KB, bool HAS_LN, bool DEFER_DW1 = false, bool B3 = false>
 static int launch_mlp_bwd(const MlpBwdParams& q, hipStream_t s) {
   constexpr int KP32 = 32 * KB;
   constexpr int ldt0 = (KP32 > HID ? KP32 : HID) + 4;
@@ -727,7 +773,7 @@ static int launch_mlp_bwd(const MlpBwdParams& q, hipStream_t s) {
   static_assert((size_t)4 * HID * KP32 * 4 <= 160 * 1024, "fold images exceed LDS");
   const size_t fold_bytes = (size_t)4 * HID * KP32 * sizeof(float);
   const size_t lds_alloc = lds > fold_bytes ? lds : fold_bytes;
-  auto kern = mlp_bwd_kernel<HID, NOUTB, KB, HAS_LN, DEFER_DW1>;
+  auto kern = mlp_bwd_kernel<HID, NOUTB, KB, HAS_LN, DEFER_DW1, B3>;
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -792,6 +838,12 @@ extern "C" int nlam_mlp_bwd(
   const int kb = (p.k_in + 31) / 32;
   const int noutb = (n_out + 31) / 32;
 #define MLP_BWD_CASE(H, NO, K, L) return launch_mlp_bwd<H, NO, K, L>(q, s)
+  if (hid == 64 && nlam_mfma_b3()) {
+    if (ln && kb == 1) return launch_mlp_bwd<64, 2, 1, true, false, true>(q, s);
+    if (ln && kb == 2) return launch_mlp_bwd<64, 2, 2, true, false, true>(q, s);
+    if (ln && kb == 4 && ga_out != nullptr) return launch_mlp_bwd<64, 2, 4, true, true, true>(q, s);
+    if (!ln && noutb == 1 && kb == 2) return launch_mlp_bwd<64, 1, 2, false, false, true>(q, s);
+  }
   if (hid == 64) {
     if (ln) {
       if (kb == 1) MLP_BWD_CASE(64, 2, 1, true);
@@ -1058,7 +1110,7 @@ struct OuterParams {
   int64_t rows; int B;
 };
 
-template <int NGB, int NXB>
+template <int NGB, int NXB, bool B3 = false>
 __global__ __launch_bounds__(256) void outer_bwd_kernel(OuterParams q) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NG = 32 * NGB, NX = 32 * NXB;
@@ -1106,12 +1158,25 @@ __global__ __launch_bounds__(256) void outer_bwd_kernel(OuterParams q) {
     load_rows_v<8>(va, q.xa.width, lane, xa_row);
     if (xbb) load_rows_v<8>(vb, q.xb.width, lane, xb_row);
     put_rows_v<4 * NGB, false>(TG, ldg, 0, NG, nrows, lane, vg);
-    put_rows_v<8, false>(TX, ldx, 0, q.xa.width, nrows, lane, va);
-    if (xbb) put_rows_v<8, false>(TX, ldx, q.xa.width, q.xb.width, nrows, lane, vb);
-    if (NX > kx) zero_cols(TX, ldx, kx, NX - kx, lane);
-    wave_sync();
-    tile_colsum<NV>(db, TG, ldg, 0, nrows, lane);
-    outer_accum<NGB, NXB>(dW, TG, ldg, 0, TX, ldx, 0, lane);
+    if constexpr (B3) {
+      // X straight to bf16 planes; G as fp32 for the column sums, then re-written as planes
+      const B3Tile TGp = b3_tile(TG, NG), TXp = b3_tile(TX, NX);
+      put_rows_v_b3<8>(TXp, 0, q.xa.width, nrows, lane, va);
+      if (xbb) put_rows_v_b3<8>(TXp, q.xa.width, q.xb.width, nrows, lane, vb);
+      wave_sync();
+      tile_colsum<NV>(db, TG, ldg, 0, nrows, lane);
+      wave_sync();
+      put_rows_v_b3<4 * NGB>(TGp, 0, NG, nrows, lane, vg);
+      wave_sync();
+      outer_accum_b3<NGB, NXB>(dW, TGp, 0, TXp, 0, lane);
+    } else {
+      put_rows_v<8, false>(TX, ldx, 0, q.xa.width, nrows, lane, va);
+      if (xbb) put_rows_v<8, false>(TX, ldx, q.xa.width, q.xb.width, nrows, lane, vb);
+      if (NX > kx) zero_cols(TX, ldx, kx, NX - kx, lane);
+      wave_sync();
+      tile_colsum<NV>(db, TG, ldg, 0, nrows, lane);
+      outer_accum<NGB, NXB>(dW, TG, ldg, 0, TX, ldx, 0, lane);
+    }
     wave_sync();
   }
   __syncthreads();
@@ -1121,14 +1186,14 @@ __global__ __launch_bounds__(256) void outer_bwd_kernel(OuterParams q) {
   for (int i = tid; i < NG; i += 256) slab[NG * NX + i] = smem[i];
 }
 
-template <int NGB, int NXB>
+template <int NGB, int NXB, bool B3 = false>
 static int launch_outer_bwd(const OuterParams& q, hipStream_t s) {
   constexpr int NG = 32 * NGB, NX = 32 * NXB;
   size_t lds = (size_t)4 * NLAM_TILE * (NG + 4 + NX + 4) * sizeof(float);
   const size_t fold = (size_t)4 * NG * NX * sizeof(float);
   if (fold > lds) lds = fold;
   NLAM_REQUIRE(lds <= 160 * 1024, "outer_bwd: LDS footprint %zu B exceeds 160 KiB", lds);
-  auto kern = outer_bwd_kernel<NGB, NXB>;
+  auto kern = outer_bwd_kernel<NGB, NXB, B3>;
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1166,6 +1231,10 @@ extern "C" int nlam_outer_bwd(const float* g, int64_t g_bstride, int64_t g_ld, i
   q.x_index = x_index; q.slab = slab; q.slab_stride = slab_stride; q.rows = rows; q.B = (int)B;
   hipStream_t s = (hipStream_t)stream;
   const int nxb = (kx + 31) / 32;
+  if (nlam_mfma_b3() && kx == 32 * nxb) {
+    if (nxb == 2) return launch_outer_bwd<2, 2, true>(q, s);
+    if (nxb == 4) return launch_outer_bwd<2, 4, true>(q, s);
+  }
   if (nxb <= 2) return launch_outer_bwd<2, 2>(q, s);
   if (nxb <= 4) return launch_outer_bwd<2, 4>(q, s);
   nlam_set_error("nlam_outer_bwd: X width %d unsupported", kx);
