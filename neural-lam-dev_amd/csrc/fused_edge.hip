@@ -296,7 +296,7 @@ struct EdgeBwdParams {
   float* slab; int64_t slab_stride;
 };
 
-template <int D, bool HAS_EGEMM, bool STAMP = false>
+template <int D, bool HAS_EGEMM, bool STAMP = false, bool B3 = false>
 __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NB = D / 32, NV = D / 64;
@@ -315,11 +315,18 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
   float* T0 = T0base + wave * WSTRIDE;
   float* T1 = T1base + wave * WSTRIDE;
   float* T2 = T2base + wave * WSTRIDE;
-  if (HAS_EGEMM) load_weight_lds(W1s, p.W1e, p.ldW1e, D, D, D, D, tid, 256);
-  load_weight_lds(W2s, p.W2, p.ldW2, D, D, D, D, tid, 256);
+  const B3Image W1im = b3_image(W1s, D, D), W2im = b3_image(W2s, D, D);
+  if (B3) {
+    if (HAS_EGEMM) load_weight_lds_b3(W1im, 0, p.W1e, p.ldW1e, D, D, D, D, tid, 256);
+    load_weight_lds_b3(W2im, 0, p.W2, p.ldW2, D, D, D, D, tid, 256);
+  } else {
+    if (HAS_EGEMM) load_weight_lds(W1s, p.W1e, p.ldW1e, D, D, D, D, tid, 256);
+    load_weight_lds(W2s, p.W2, p.ldW2, D, D, D, D, tid, 256);
+  }
   load_vec_lds(b2s, p.b2, D, D, tid, 256);
   load_vec_lds(gs, p.gamma, D, D, tid, 256);
   __syncthreads();
+  const B3Tile T0p = b3_tile(T0, D), T1p = b3_tile(T1, D), T2p = b3_tile(T2, D);
 
   f32x16 dW1[NB][NB], dW2[NB][NB];
 #pragma unroll
@@ -410,7 +417,18 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) g[nb][r] += geo[nb][r];
     }
-    if (HAS_EGEMM) gemm_tile<NB>(hpre, W1s, LDW, T0, LDT, D / 8, lane);
+    if (HAS_EGEMM) {
+      if constexpr (B3) {
+        // E: fp32 tile -> registers (B operand) -> bf16 planes in place (for dW1e later)
+        f32x16 ebuf[NB];
+        tile_to_acc<NB>(ebuf, T0, LDT, lane);
+        gemm_acc_b3<NB, NB>(hpre, W1im, 0, ebuf, lane);
+        wave_sync();
+        acc_to_tile_b3<NB>(ebuf, T0p, 0, lane);
+      } else {
+        gemm_tile<NB>(hpre, W1s, LDW, T0, LDT, D / 8, lane);
+      }
+    }
     f32x16 sact[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
@@ -418,14 +436,16 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
       for (int r = 0; r < 16; ++r) sact[nb][r] = nlam_silu(hpre[nb][r]);
     f32x16 z[NB];
     vec_to_acc<NB>(z, b2s, lane);
-    gemm_acc<NB, NB>(z, W2s, LDW, 0, sact, lane);
+    if constexpr (B3) gemm_acc_b3<NB, NB>(z, W2im, 0, sact, lane);
+    else gemm_acc<NB, NB>(z, W2s, LDW, 0, sact, lane);
     float mean, rstd;
     ln_stats<NB>(z, mean, rstd);
     STAMP_AT(1)   // recompute: GEMM1, silu, GEMM2, stats
     // S is published right away (T2's g_agg / g_eout rows are already in registers):
     // sact's registers are free during the LayerNorm backward.  dbeta from the gm tile.
     wave_sync();
-    acc_to_tile<NB>(sact, T2, LDT, lane);
+    if constexpr (B3) acc_to_tile_b3<NB>(sact, T2p, 0, lane);
+    else acc_to_tile<NB>(sact, T2, LDT, lane);
     acc_to_tile<NB>(g, T1, LDT, lane);
     wave_sync();
     tile_colsum<NV>(dbet, T1, LDT, 0, ne, lane);
@@ -470,14 +490,22 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
     tile_colsum<NV>(db2, T1, LDT, 0, ne, lane);
     STAMP_AT(2)   // LN backward + three column sums + tile transposes
     if (!HAS_EGEMM) issue_rows(nxt, tt + stride);  // (no later MFMA phase in this form)
-    outer_accum<NB, NB>(dW2, T1, LDT, 0, T2, LDT, 0, lane);
+    if constexpr (B3) {
+      wave_sync();
+      acc_to_tile_b3<NB>(g, T1p, 0, lane);      // GZ as bf16 planes over its fp32 copy
+      wave_sync();
+      outer_accum_b3<NB, NB>(dW2, T1p, 0, T2p, 0, lane);
+    } else {
+      outer_accum<NB, NB>(dW2, T1, LDT, 0, T2, LDT, 0, lane);
+    }
     // gh = (W2^T gz) * silu'(h)   (registers + weights only)
     f32x16 gh[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) gh[nb][r] = 0.f;
-    gemm_acc_wt<NB, NB>(gh, W2s, LDW, 0, g, lane);
+    if constexpr (B3) gemm_acc_wt_b3<NB, NB>(gh, W2im, 0, g, lane);
+    else gemm_acc_wt<NB, NB>(gh, W2s, LDW, 0, g, lane);
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -511,13 +539,21 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
     STAMP_AT(4)     // gh store + receiver-side segment reduce
     if (HAS_EGEMM) issue_rows(nxt, tt + stride);   // next gathers fly under the MFMAs below
     if (HAS_EGEMM) {
-      outer_accum<NB, NB>(dW1, T1, LDT, 0, T0, LDT, 0, lane);
+      if constexpr (B3) {
+        wave_sync();
+        acc_to_tile_b3<NB>(gh, T1p, 0, lane);   // GH as bf16 planes (its rows are stored)
+        wave_sync();
+        outer_accum_b3<NB, NB>(dW1, T1p, 0, T0p, 0, lane);
+      } else {
+        outer_accum<NB, NB>(dW1, T1, LDT, 0, T0, LDT, 0, lane);
+      }
       f32x16 ge[NB];
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) ge[nb][r] = has_geo ? geo[nb][r] : 0.f;
-      gemm_acc_wt<NB, NB>(ge, W1s, LDW, 0, gh, lane);
+      if constexpr (B3) gemm_acc_wt_b3<NB, NB>(ge, W1im, 0, gh, lane);
+      else gemm_acc_wt<NB, NB>(ge, W1s, LDW, 0, gh, lane);
       wave_sync();
       acc_to_tile<NB>(ge, T2, LDT, lane);
       wave_sync();
@@ -551,12 +587,12 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
   for (int i = tid; i < D; i += 256) slab[2 * nW + 2 * D + i] = img[i];
 }
 
-template <int D, bool HAS_EGEMM, bool STAMP = false>
+template <int D, bool HAS_EGEMM, bool STAMP = false, bool B3 = false>
 static int launch_edge_bwd(const EdgeBwdParams& q, hipStream_t s) {
   const size_t lds = ((size_t)(HAS_EGEMM ? 2 : 1) * D * (D + 4) + 2 * D +
                       (size_t)4 * 3 * NLAM_TILE * (D + 4)) * sizeof(float);
   NLAM_REQUIRE(lds <= 160 * 1024, "edge_bwd: LDS footprint %zu B exceeds 160 KiB", lds);
-  auto kern = edge_bwd_kernel<D, HAS_EGEMM, STAMP>;
+  auto kern = edge_bwd_kernel<D, HAS_EGEMM, STAMP, B3>;
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -620,5 +656,9 @@ extern "C" int nlam_edge_bwd(
   hipStream_t s = (hipStream_t)stream;
   static const bool stamp = getenv("NLAM_STAMP") != nullptr;
   if (stamp && has_egemm) return launch_edge_bwd<64, true, true>(q, s);
+  if (nlam_mfma_b3() && nlam_aligned16(W2) && ldW2 % 4 == 0 &&
+      (!has_egemm || (nlam_aligned16(W1e) && ldW1e % 4 == 0)))
+    return has_egemm ? launch_edge_bwd<64, true, false, true>(q, s)
+                     : launch_edge_bwd<64, false, false, true>(q, s);
   return has_egemm ? launch_edge_bwd<64, true>(q, s) : launch_edge_bwd<64, false>(q, s);
 }
