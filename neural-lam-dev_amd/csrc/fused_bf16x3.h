@@ -242,6 +242,34 @@ __device__ __forceinline__ void put_rows_v_b3(const B3Tile& T, int col0, int wid
   }
 }
 
+// out[nb] += W[rows 32 nb ..][cols 32 (kb0 + kb) ..] . X^T with X a bf16-plane row tile: the
+// B fragments are plain 8-byte row reads of the planes (no register transpose, no
+// conversion: the rows were split when they were staged).
+template <int NB, int KB>
+__device__ __forceinline__ void gemm_tile_b3(f32x16 (&out)[NB], const B3Image& W, int kb0,
+                                             const B3Tile& X, int xcol0, int lane) {
+  const int t = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int xo = t * X.pitch + xcol0 + 32 * kb + 16 * s + 4 * h;
+      const bf16x8 bh = b3_join(*reinterpret_cast<const bf16x4*>(X.hi + xo),
+                                *reinterpret_cast<const bf16x4*>(X.hi + xo + 8));
+      const bf16x8 bl = b3_join(*reinterpret_cast<const bf16x4*>(X.lo + xo),
+                                *reinterpret_cast<const bf16x4*>(X.lo + xo + 8));
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const bf16x8 ah = b3_row_frag(W.hi, W.pitch, 32 * nb + t, kb0 + kb, s, h);
+        const bf16x8 al = b3_row_frag(W.lo, W.pitch, 32 * nb + t, kb0 + kb, s, h);
+        out[nb] = B3_MFMA(ah, bh, out[nb]);
+        out[nb] = B3_MFMA(ah, bl, out[nb]);
+        out[nb] = B3_MFMA(al, bh, out[nb]);
+      }
+    }
+  }
+}
+
 // dW[ib][jb] += sum_t G[t][gcol0 + 32 ib + .] (x) X[t][xcol0 + 32 jb + .] over the 32 tile
 // rows; G and X are bf16-plane tiles.  Result block layout as outer_accum (fused_common.h).
 template <int NI, int NJ>

@@ -387,7 +387,8 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
     for (int k = 0; k < NVR; ++k) vS[k] += vR[k];
     f32x16 hpre[NB];
     if (HAS_EGEMM) {
-      put_rows_v<NVR, false>(T0, LDT, 0, D, ne, lane, vE);       // E stays in T0
+      if constexpr (B3) put_rows_v_b3<NVR>(T0p, 0, D, ne, lane, vE);   // E stays in T0 (planes)
+      else put_rows_v<NVR, false>(T0, LDT, 0, D, ne, lane, vE);        // E stays in T0
     } else {
 #pragma unroll
       for (int k = 0; k < NVR; ++k) vS[k] += vE[k];              // Pe + Ps + Pr
@@ -419,12 +420,7 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
     }
     if (HAS_EGEMM) {
       if constexpr (B3) {
-        // E: fp32 tile -> registers (B operand) -> bf16 planes in place (for dW1e later)
-        f32x16 ebuf[NB];
-        tile_to_acc<NB>(ebuf, T0, LDT, lane);
-        gemm_acc_b3<NB, NB>(hpre, W1im, 0, ebuf, lane);
-        wave_sync();
-        acc_to_tile_b3<NB>(ebuf, T0p, 0, lane);
+        gemm_tile_b3<NB, NB>(hpre, W1im, 0, T0p, 0, lane);   // E planes serve dW1e later too
       } else {
         gemm_tile<NB>(hpre, W1s, LDW, T0, LDT, D / 8, lane);
       }
@@ -537,13 +533,14 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
       }
     }
     STAMP_AT(4)     // gh store + receiver-side segment reduce
-    if (HAS_EGEMM) issue_rows(nxt, tt + stride);   // next gathers fly under the MFMAs below
+    if (HAS_EGEMM && !B3) issue_rows(nxt, tt + stride);   // next gathers fly under the MFMAs below
     if (HAS_EGEMM) {
       if constexpr (B3) {
         wave_sync();
         acc_to_tile_b3<NB>(gh, T1p, 0, lane);   // GH as bf16 planes (its rows are stored)
         wave_sync();
         outer_accum_b3<NB, NB>(dW1, T1p, 0, T0p, 0, lane);
+        issue_rows(nxt, tt + stride);   // (after the outer product: its fragments are dead)
       } else {
         outer_accum<NB, NB>(dW1, T1, LDT, 0, T0, LDT, 0, lane);
       }

@@ -318,13 +318,12 @@ __global__ __launch_bounds__(256, 2) void lin_fwd_b3_kernel(LinParams p) {
     const int nrows = (int)((p.rows - r0) < NLAM_TILE ? (p.rows - r0) : NLAM_TILE);
     f32x4 vx[8 * KB];
     view_load_v<8 * KB>(vx, p.x, b, r0, nrows, lane);
-    put_rows_v<8 * KB, false>(tile, ldt, 0, K, nrows, lane, vx);
+    const B3Tile Xp = b3_tile(tile, K);
+    put_rows_v_b3<8 * KB>(Xp, 0, K, nrows, lane, vx);
     wave_sync();
-    f32x16 xin[KB];
-    tile_to_acc<KB>(xin, tile, ldt, lane);
     f32x16 a[NOUTB];
     vec_to_acc<NOUTB>(a, bs, lane);
-    gemm_acc_b3<NOUTB, KB>(a, W, 0, xin, lane);
+    gemm_tile_b3<NOUTB, KB>(a, W, 0, Xp, 0, lane);
     wave_sync();
     acc_to_tile<NOUTB>(a, tile, ldt, lane);
     wave_sync();
