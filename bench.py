@@ -281,6 +281,12 @@ def main():
         cpu = cpu_baseline(args, tmp, info, model)
 
     if rank == 0:
+        from neural_lam_amd._lib import lib as _nlam_lib
+        mfma_mode = "bf16x3" if _nlam_lib.nlam_mfma_mode() else "fp32"
+        if roofline is not None and roofline.get("bound") == "mfma":
+            roofline["note"] = ("achieved = algorithmic fp32 flops / s; peak = exact-fp32 MFMA "
+                                "rate" + ("; products run as 3 bf16 MFMA terms (bf16x3)"
+                                          if mfma_mode == "bf16x3" else ""))
         upd_per_layer = rec_updates_per_layer(args, info)
         ms = elapsed / args.steps * 1e3
         value = world * B * T * args.processor_layers * upd_per_layer / (elapsed / args.steps)
@@ -289,6 +295,10 @@ def main():
             "unit": "mesh node-updates/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            # fp32 storage / accumulation / elementwise; GEMM products on the matrix cores as
+            # exact fp32 MFMA ("fp32") or as 3 bf16 MFMA terms of hi/lo-split operands
+            # ("bf16x3", ~2^-16 relative per product; parity tests hold 1e-4 / 2e-3 either way)
+            "mfma_mode": mfma_mode,
             "config": {
                 "workload": f"{args.model} on synthetic MEPS 238x268 grid "
                             f"({info['num_grid']} grid nodes, mesh {info['num_mesh']}, "

@@ -32,7 +32,8 @@ extern "C" {
 const char* nlam_last_error(void);
 /* ABI version of this header; bumped on any signature change. */
 int nlam_abi_version(void);
-/* GEMM arithmetic of the fused kernels, fixed per process by NLAM_MFMA in the environment:
+/* GEMM arithmetic of the fused kernels, fixed per process by NLAM_MFMA in the environment
+ * (fp32 | bf16x3, default bf16x3):
  * 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = split-bf16 ("bf16x3": every fp32 operand
  * as bf16 hi + lo, three v_mfma_f32_32x32x16_bf16 products, fp32 accumulate; ~2^-16
  * relative error per product, tighter than the TF32 of train_model.py:246-248). */

@@ -19,7 +19,7 @@ extern "C" const char* nlam_last_error(void) { return g_err; }
 extern "C" int nlam_abi_version(void) { return 1; }
 
 // GEMM arithmetic of the fused kernels (see fused_bf16x3.h): NLAM_MFMA=fp32 | bf16x3
-#define NLAM_MFMA_DEFAULT_B3 0
+#define NLAM_MFMA_DEFAULT_B3 1
 bool nlam_mfma_b3() {
   static const int mode = [] {
     const char* e = getenv("NLAM_MFMA");

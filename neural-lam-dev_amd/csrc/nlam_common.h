@@ -28,7 +28,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // GEMM arithmetic of the fused kernels: split-bf16 MFMA (default, fused_bf16x3.h) or exact
-// fp32 MFMA (NLAM_MFMA=fp32 in the environment).  Read once per process.
+// fp32 MFMA (NLAM_MFMA=fp32 in the environment).  Read once per process.  The generic
+// kernels (generic_ops.hip) always use the exact fp32 MFMA.
 bool nlam_mfma_b3();
 
 static inline bool nlam_aligned16(const void* p) {

@@ -1,0 +1,25 @@
+"""Both GEMM arithmetic modes of the fused kernels (NLAM_MFMA=fp32 | bf16x3, read once per
+process) hold the model-level parity bars against the reference goldens; each mode runs in
+its own process.  bf16x3 must also stay an order of magnitude inside the bars."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("mode,pred_bar,grad_bar", [("fp32", 2e-6, 1e-5), ("bf16x3", 2e-5, 2e-4)])
+def test_model_parity_in_mode(mode, pred_bar, grad_bar):
+    env = dict(os.environ, NLAM_MFMA=mode)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "parity_margin.py")],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert f"mfma mode: {mode}" in out.stdout
+    rows = re.findall(r"pred (\S+)\s+loss (\S+)\s+worst grad (\S+)", out.stdout)
+    assert len(rows) >= 3, out.stdout
+    for pred, loss, grad in rows:
+        assert float(pred) < pred_bar and float(loss) < 1e-5 and float(grad) < grad_bar, out.stdout
