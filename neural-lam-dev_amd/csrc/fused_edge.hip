@@ -249,8 +249,7 @@ extern "C" int nlam_edge_fwd(
   p.e_out = e_out; p.eo_bstride = eo_bstride; p.eo_ld = eo_ld;
   p.B = (int)B;
   hipStream_t s = (hipStream_t)stream;
-  if (d == 64 && nlam_mfma_b3() && nlam_aligned16(W2) && ldW2 % 4 == 0 &&
-      (!has_egemm || (nlam_aligned16(W1e) && ldW1e % 4 == 0)))
+  if (d == 64 && nlam_mfma_b3())   // (unaligned weights take the scalar image loader)
     return has_egemm ? launch_edge_fwd<64, true, true>(p, s) : launch_edge_fwd<64, false, true>(p, s);
   if (d == 64) return has_egemm ? launch_edge_fwd<64, true>(p, s) : launch_edge_fwd<64, false>(p, s);
   return has_egemm ? launch_edge_fwd<128, true>(p, s) : launch_edge_fwd<128, false>(p, s);
@@ -653,8 +652,7 @@ extern "C" int nlam_edge_bwd(
   hipStream_t s = (hipStream_t)stream;
   static const bool stamp = getenv("NLAM_STAMP") != nullptr;
   if (stamp && has_egemm) return launch_edge_bwd<64, true, true>(q, s);
-  if (nlam_mfma_b3() && nlam_aligned16(W2) && ldW2 % 4 == 0 &&
-      (!has_egemm || (nlam_aligned16(W1e) && ldW1e % 4 == 0)))
+  if (nlam_mfma_b3())
     return has_egemm ? launch_edge_bwd<64, true, false, true>(q, s)
                      : launch_edge_bwd<64, false, false, true>(q, s);
   return has_egemm ? launch_edge_bwd<64, true>(q, s) : launch_edge_bwd<64, false>(q, s);

@@ -20,34 +20,59 @@ import torch.distributed as dist
 
 class FlatParams:
     """Re-homes every parameter of `module` into one contiguous fp32 buffer
-    (views keep names/shapes, so state_dict is unchanged)."""
+    (views keep names/shapes, so state_dict is unchanged).  Every parameter starts on
+    a 64-byte boundary (the kernels' float4 weight loaders need 16-byte aligned rows; a
+    17-wide bias would otherwise misalign everything behind it); the padding stays zero."""
+
+    ALIGN = 16   # elements
 
     def __init__(self, module):
         self.params = [p for p in module.parameters() if p.requires_grad]
-        self.numel = sum(p.numel() for p in self.params)
         dev = self.params[0].device
-        self.flat = torch.empty(self.numel, dtype=torch.float32, device=dev)
-        self.offsets = []
-        off = 0
+        self.offsets, off = [], 0
         for p in self.params:
-            n = p.numel()
-            self.flat[off : off + n].copy_(p.data.reshape(-1))
-            p.data = self.flat[off : off + n].view(p.shape)
             self.offsets.append(off)
-            off += n
+            off += -(-p.numel() // self.ALIGN) * self.ALIGN
+        self.numel = off
+        self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        for p, o in zip(self.params, self.offsets):
+            n = p.numel()
+            self.flat[o : o + n].copy_(p.data.reshape(-1))
+            p.data = self.flat[o : o + n].view(p.shape)
         self.grad = torch.zeros_like(self.flat)
+        self._pad = {}   # pad length -> zeros
+
+    def span(self, lo, hi):
+        """[a, b) element range of params[lo:hi] in the flat buffers (padding included)."""
+        a = self.offsets[lo]
+        b = self.offsets[hi] if hi < len(self.params) else self.numel
+        return a, b
+
+    def gather(self, buf):
+        """The parameters' elements of a flat buffer, padding removed."""
+        return torch.cat([buf[o : o + p.numel()] for p, o in zip(self.params, self.offsets)])
+
+    def _zeros(self, n):
+        z = self._pad.get(n)
+        if z is None:
+            z = self._pad[n] = torch.zeros(n, dtype=torch.float32, device=self.flat.device)
+        return z
 
     def pack_grads(self, lo=0, hi=None):
         """Copy p.grad of params[lo:hi] into their slice of the flat grad buffer."""
         hi = len(self.params) if hi is None else hi
         if hi <= lo:
             return
+        a, b = self.span(lo, hi)
         parts = []
-        for p in self.params[lo:hi]:
-            parts.append(p.grad.reshape(-1) if p.grad is not None else
-                         torch.zeros(p.numel(), dtype=torch.float32, device=self.flat.device))
-        a = self.offsets[lo]
-        b = self.offsets[hi - 1] + self.params[hi - 1].numel()
+        for i in range(lo, hi):
+            p = self.params[i]
+            n = p.numel()
+            parts.append(p.grad.reshape(-1) if p.grad is not None else self._zeros(n))
+            end = self.offsets[i + 1] if i + 1 < len(self.params) else self.numel
+            pad = end - self.offsets[i] - n
+            if pad:
+                parts.append(self._zeros(pad))
         torch.cat(parts, out=self.grad[a:b])
 
     def zero_grad(self):
@@ -97,8 +122,7 @@ class GradAllReduce:
         for lo, hi in self.ranges:
             if not packed:
                 f.pack_grads(lo, hi)
-            a = f.offsets[lo]
-            b = f.offsets[hi - 1] + f.params[hi - 1].numel()
+            a, b = f.span(lo, hi)
             handles.append(dist.all_reduce(f.grad[a:b], op=dist.ReduceOp.SUM, group=self.group,
                                            async_op=True))
         for h in handles:

@@ -28,14 +28,14 @@ def _worker(rank, world, port, bucket_bytes, q):
     flat = parallel.FlatParams(net)
     red = parallel.GradAllReduce(flat, bucket_bytes=bucket_bytes)
     red.broadcast_params()
-    p0 = flat.flat.clone()
+    p0 = flat.gather(flat.flat).clone()
     gen = torch.Generator().manual_seed(100 + rank)
     x = torch.randn(6, 5, generator=gen)
     net(x).pow(2).sum().backward()
     local = torch.cat([p.grad.reshape(-1) for p in flat.params])
     red.reduce()
     # plain lists: tensors in an mp.Queue travel as fds that die with the sender
-    q.put((rank, p0.tolist(), local.tolist(), flat.grad.tolist(), len(red.ranges)))
+    q.put((rank, p0.tolist(), local.tolist(), flat.gather(flat.grad).tolist(), len(red.ranges)))
     dist.destroy_process_group()
 
 
