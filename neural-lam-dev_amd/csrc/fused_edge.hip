@@ -651,6 +651,7 @@ extern "C" int nlam_edge_bwd(
   q.slab = slab; q.slab_stride = slab_stride;
   hipStream_t s = (hipStream_t)stream;
   static const bool stamp = getenv("NLAM_STAMP") != nullptr;
+  if (stamp && has_egemm && nlam_mfma_b3()) return launch_edge_bwd<64, true, true, true>(q, s);
   if (stamp && has_egemm) return launch_edge_bwd<64, true, true>(q, s);
   if (nlam_mfma_b3())
     return has_egemm ? launch_edge_bwd<64, true, false, true>(q, s)
