@@ -7,6 +7,7 @@ It is a pytorch_lightning.LightningModule when Lightning is installed and a
 plain nn.Module otherwise; the method names and batch layout are Lightning's.
 """
 import torch
+import torch.utils.checkpoint
 from torch import nn
 
 from .. import glue, metrics
@@ -59,6 +60,7 @@ class ARModel(_Base):
             _state_feature_weights(config, datastore), dtype=torch.float32
         )
         self.output_std = bool(args.output_std)
+        self.ar_checkpoint = bool(getattr(args, "ar_checkpoint", False))
         if self.output_std:
             self.grid_output_dim = 2 * num_state_vars
         else:
@@ -105,10 +107,21 @@ class ARModel(_Base):
         prev_prev_state = init_states[:, 0]
         prev_state = init_states[:, 1]
         prediction_list, pred_std_list = [], []
+        # args.ar_checkpoint (not a reference option): keep only the states
+        # between AR steps and recompute each predict_step in backward, which lifts the
+        # ar_steps memory ceiling of BPTT at about one extra forward per step
+        ckpt = (getattr(self, "ar_checkpoint", False) and torch.is_grad_enabled()
+                and forcing_features.shape[1] > 1 and not self.output_std)
         for i in range(forcing_features.shape[1]):
-            pred_state, pred_std = self.predict_step(
-                prev_state, prev_prev_state, forcing_features[:, i]
-            )
+            if ckpt:
+                pred_state = torch.utils.checkpoint.checkpoint(
+                    lambda a, b, c: self.predict_step(a, b, c)[0],
+                    prev_state, prev_prev_state, forcing_features[:, i], use_reentrant=False)
+                pred_std = None
+            else:
+                pred_state, pred_std = self.predict_step(
+                    prev_state, prev_prev_state, forcing_features[:, i]
+                )
             new_state = glue.BoundaryMix.apply(pred_state, true_states[:, i], self.boundary_mask)
             prediction_list.append(new_state)
             if self.output_std:

@@ -60,3 +60,36 @@ def test_graphlam_training_loss_decreases():
         opt.step()
         losses.append(float(loss))
     assert losses[-1] < 0.8 * losses[0], losses
+
+
+def test_ar_checkpointing_matches_plain_rollout():
+    """args.ar_checkpoint recomputes each predict_step in backward: same loss
+    and the same parameter gradients as the plain BPTT rollout (ar_model.py:220-267)."""
+    from neural_lam_amd import graphgen, synthetic
+    from neural_lam_amd.models import GraphLAM
+    import numpy as np
+
+    with tempfile.TemporaryDirectory() as tmp:
+        info = graphgen.create_graph(tmp + "/graph/g", graphgen.make_xy(30, 28, 5000.0), None, False)
+        n = info["num_grid"]
+        gen = torch.Generator().manual_seed(0)
+        ds = synthetic.SyntheticDatastore(
+            tmp, torch.randn(n, 1, generator=gen).numpy(), np.zeros(5), np.ones(5), np.zeros(5),
+            np.ones(5), (torch.rand(n, generator=gen) < 0.2).float().numpy(), n_forcing=2)
+        models = []
+        for ck in (False, True):
+            torch.manual_seed(1)
+            models.append(GraphLAM(
+                synthetic.model_args(graph="g", hidden_dim=64, processor_layers=2, ar_checkpoint=ck),
+                config=None, datastore=ds).cuda())
+    batch = synthetic.random_batch(2, 3, n, n_state=5, n_forcing_window=6, device="cuda")
+    losses, grads = [], []
+    for m in models:
+        loss = m.training_step(batch)
+        loss.backward()
+        losses.append(float(loss))
+        grads.append({k: p.grad.clone() for k, p in m.named_parameters()})
+    assert abs(losses[0] - losses[1]) <= 1e-6 * abs(losses[0])
+    for k in grads[0]:
+        a, b = grads[0][k], grads[1][k]
+        assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max() + 1e-30), k
