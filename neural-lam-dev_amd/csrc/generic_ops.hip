@@ -391,19 +391,32 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
   for (int64_t r = rbeg + wave; r < rend; r += 4) {
     const float* zr = z + r * ldz;
     const float* gr = gy + r * ldgy;
+    // the row of z and of gy is read ONCE, both in flight together, and kept in registers
+    float zv[LN_MAXT], gv[LN_MAXT], gmv[LN_MAXT];
+#pragma unroll
+    for (int t = 0; t < LN_MAXT; ++t) {
+      const int c = lane + 64 * t;
+      const bool on = c < d;
+      zv[t] = on ? zr[c] : 0.f;
+      gv[t] = on ? gr[c] : 0.f;
+      gmv[t] = on ? gamma[c] : 0.f;
+    }
     float s = 0.f;
-    for (int c = lane; c < d; c += 64) s += zr[c];
+#pragma unroll
+    for (int t = 0; t < LN_MAXT; ++t) s += zv[t];
     const float mean = wave_sum(s) * inv_d;
     float v = 0.f;
-    for (int c = lane; c < d; c += 64) {
-      const float t = zr[c] - mean;
-      v += t * t;
+#pragma unroll
+    for (int t = 0; t < LN_MAXT; ++t) {
+      const float dt = (lane + 64 * t < d) ? zv[t] - mean : 0.f;
+      v += dt * dt;
     }
     const float rstd = rsqrtf(wave_sum(v) * inv_d + LN_EPS);
     float s1 = 0.f, s2 = 0.f;
-    for (int c = lane; c < d; c += 64) {
-      const float xh = (zr[c] - mean) * rstd;
-      const float g = gr[c] * gamma[c];
+#pragma unroll
+    for (int t = 0; t < LN_MAXT; ++t) {
+      const float xh = (zv[t] - mean) * rstd;
+      const float g = gv[t] * gmv[t];       // 0 beyond d
       s1 += g;
       s2 += g * xh;
     }
@@ -413,9 +426,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
     for (int t = 0; t < LN_MAXT; ++t) {
       const int c = lane + 64 * t;
       if (c < d) {
-        const float xh = (zr[c] - mean) * rstd;
-        const float go = gr[c];
-        gz[r * ldgz + c] = rstd * (go * gamma[c] - m1 - xh * m2);
+        const float xh = (zv[t] - mean) * rstd;
+        const float go = gv[t];
+        gz[r * ldgz + c] = rstd * (go * gmv[t] - m1 - xh * m2);
         dg[t] += go * xh;
         db[t] += go;
       }
@@ -492,11 +505,23 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
   float acc[LN_MAXT];
 #pragma unroll
   for (int t = 0; t < LN_MAXT; ++t) acc[t] = 0.f;
-  for (int64_t r = rbeg + wave; r < rend; r += 4) {
+  // eight rows per trip: their loads are issued together (clamped + masked), the adds keep
+  // the row order
+  for (int64_t r = rbeg + wave; r < rend; r += 4 * 8) {
 #pragma unroll
     for (int t = 0; t < LN_MAXT; ++t) {
       const int c = lane + 64 * t;
-      if (c < d) acc[t] += x[r * ldx + c];
+      if (c < d) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int64_t ru = r + 4 * u;
+          v[u] = x[(ru < rend ? ru : r) * ldx + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (r + 4 * u < rend) acc[t] += v[u];
+      }
     }
   }
   float* pg = partial + (int64_t)blockIdx.x * d;
