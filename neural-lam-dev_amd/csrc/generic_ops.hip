@@ -154,14 +154,31 @@ __global__ __launch_bounds__(256) void gemm128_kernel(
   const int a_i = a_kc ? (tid >> 1) : ((tid & 15) * 8), a_k = a_kc ? ((tid & 1) * 8) : (tid >> 4);
   const int b_j = b_kc ? (tid >> 1) : ((tid & 15) * 8), b_k = b_kc ? ((tid & 1) * 8) : (tid >> 4);
   float ra[8], rb[8];
-  auto load_tile = [&](int64_t kt) {
+  // interior chunks whose 8 elements are contiguous and 16-byte aligned are two float4
+  // loads; edges and odd strides fall back to guarded scalar loads
+  auto load8 = [&](float (&r)[8], const float* __restrict__ P, int64_t s_row, int64_t s_k,
+                   bool kc, int64_t row, int64_t k0, int64_t row_lim) {
+    const int64_t rlast = row + (kc ? 0 : 7), klast = k0 + (kc ? 7 : 0);
+    const float* ptr = P + row * s_row + k0 * s_k;
+    if ((kc ? s_k : s_row) == 1 && rlast < row_lim && klast < kend &&
+        (reinterpret_cast<uintptr_t>(ptr) & 15u) == 0) {
+      const f32x4 v0 = reinterpret_cast<const f32x4*>(ptr)[0];
+      const f32x4 v1 = reinterpret_cast<const f32x4*>(ptr)[1];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int64_t gi = i0 + a_i + (a_kc ? 0 : u), gk = kt + a_k + (a_kc ? u : 0);
-      ra[u] = (gi < M && gk < kend) ? A[gi * sa_i + gk * sa_k] : 0.f;
-      const int64_t gj = j0 + b_j + (b_kc ? 0 : u), gk2 = kt + b_k + (b_kc ? u : 0);
-      rb[u] = (gj < N && gk2 < kend) ? B[gk2 * sb_k + gj * sb_j] : 0.f;
+      for (int u = 0; u < 4; ++u) { r[u] = v0[u]; r[4 + u] = v1[u]; }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int64_t gr = row + (kc ? 0 : u), gk = k0 + (kc ? u : 0);
+        r[u] = (gr < row_lim && gk < kend) ? P[gr * s_row + gk * s_k] : 0.f;
+      }
     }
+  };
+  auto load_tile = [&](int64_t kt) {
+    // A: element (i, k) at A[i*sa_i + k*sa_k]; contiguous along k (a_kc) or along i
+    load8(ra, A, sa_i, sa_k, a_kc, i0 + a_i, kt + a_k, M);
+    // B: element (k, j) at B[k*sb_k + j*sb_j]; contiguous along k (b_kc) or along j
+    load8(rb, B, sb_j, sb_k, b_kc, j0 + b_j, kt + b_k, N);
   };
   auto put_tile = [&]() {
 #pragma unroll
