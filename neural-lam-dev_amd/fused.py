@@ -6,8 +6,8 @@ One InteractionNet layer (interaction_net.py:86-131) runs as
   forward : nlam_lin_fwd (node-side projections of edge_mlp.0)
             nlam_edge_fwd (edge MLP + LN + segmented aggregation [+ e' = e + m])
             nlam_mlp_fwd  (node update [x_r | agg] + residual)
-  backward: nlam_mlp_bwd, nlam_edge_bwd, nlam_segment_sum (sender side),
-            nlam_lin_bwd, nlam_reduce_slabs
+  backward: nlam_mlp_bwd (+ nlam_outer_bwd), nlam_edge_bwd, nlam_segment_sum (sender
+            side), nlam_lin_bwd, one nlam_reduce_slabs_batch for all parameter gradients
 Forward keeps only the layer inputs, the (small) node projections and the
 aggregate; edge-sized activations are recomputed in backward.
 """
