@@ -275,6 +275,28 @@ def main():
             scatter = {"kernel": "nlam_segment_sum@m2m", "bound": "hbm", "achieved": g,
                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g / HBM_PEAK_GBS,
                        "avg_launch_us": agg["ms"] * 1e3 / agg["calls"]}
+            # the same kernel on the same m2m tables, 50 launches between ONE event pair:
+            # a 12-16 us kernel carries a few us of per-launch event overhead above
+            net0 = getattr(model, "processor", None)
+            net0 = getattr(net0, "module_0", None) if net0 is not None else None
+            if net0 is not None:
+                tb = net0.tables
+                Mm, Nr, dd = int(tb.M), int(tb.n_rec), args.hidden_dim
+                msg = torch.randn(B, Mm, dd, device=dev)
+                out_ = torch.empty(B, Nr, dd, device=dev)
+                for _ in range(3):
+                    ops.segment_sum(ops.mat(msg), tb.csr_rowptr, tb.csr_eid, ops.mat(out_))
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(50):
+                    ops.segment_sum(ops.mat(msg), tb.csr_rowptr, tb.csr_eid, ops.mat(out_))
+                e1.record()
+                torch.cuda.synchronize()
+                us = e0.elapsed_time(e1) * 1e3 / 50
+                nbytes = B * (4.0 * dd * (Mm + Nr) + 4.0 * Mm + 4.0 * (Nr + 1))
+                scatter["back_to_back"] = {"launches": 50, "avg_launch_us": us,
+                                           "achieved": nbytes / us / 1e3,
+                                           "frac": nbytes / us / 1e3 / HBM_PEAK_GBS}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
