@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--ar-steps", type=int, default=1)
     ap.add_argument("--hidden-dim", type=int, default=64)
     ap.add_argument("--processor-layers", type=int, default=4)
-    ap.add_argument("--model", default="graph_lam", choices=["graph_lam", "hi_lam"])
+    ap.add_argument("--model", default="graph_lam", choices=["graph_lam", "hi_lam", "hi_lam_parallel"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="skip the per-kernel HIP-event pass (roofline = null)")
@@ -92,6 +92,8 @@ def rec_updates_per_layer(args, info):
     n = info["num_mesh"]
     if args.model == "graph_lam":
         return n[0]
+    if args.model == "hi_lam_parallel":   # one InteractionNet over all levels per layer
+        return sum(n)
     return (n[-1] + 2 * sum(n[:-1])) + (n[0] + 2 * sum(n[1:]))
 
 

@@ -321,3 +321,257 @@ def apply_inet(net, send_rep, rec_rep, edge_rep):
         el[0][0].weight, el[0][0].bias, el[0][1].weight, el[0][1].bias, el[1].weight, el[1].bias,
         al[0][0].weight, al[0][0].bias, al[0][1].weight, al[0][1].bias, al[1].weight, al[1].bias)
     return out
+
+
+# ------------------------------------------- InteractionNet with SplitMLPs
+# HiLAMParallel (hi_lam_parallel.py:26-53) gives every edge set (same-level / up / down per
+# level) its own edge MLP and every mesh level its own node MLP (interaction_net.py:134-163).
+# The receiver-sorted order of the union graph interleaves the edge sets, so the fused kernels
+# run once per edge chunk on that chunk's sub-graph (its own receiver-aligned tiles) and the
+# per-chunk aggregates are summed; the node update runs per row range.  Two composable
+# autograd Functions (the two halves of FusedInteractionNetFunction):
+def inet_split_eligible(net, send_rep, rec_rep, edge_rep):
+    from .interaction_net import SplitMLPs
+
+    if FORCE_GENERIC or not edge_rep.is_cuda or edge_rep.dtype != torch.float32:
+        return False
+    e_split = isinstance(net.edge_mlp, SplitMLPs)
+    a_split = isinstance(net.aggr_mlp, SplitMLPs)
+    if not (e_split or a_split):
+        return False
+    if net.hidden_layers != 1 or net.input_dim != net.hidden_dim:
+        return False
+    if net.hidden_dim not in SUPPORTED_HIDDEN:
+        return False
+    if send_rep.dim() != 3 or rec_rep.dim() != 3 or edge_rep.dim() != 3:
+        return False
+    tabs = list(net.chunk_tables) if e_split else [net.tables]
+    return all(t.ntiles > 0 for t in tabs)
+
+
+class FusedEdgePassFunction(torch.autograd.Function):
+    """(send_rep, rec_rep, edge rows of one chunk) -> (sum-aggregate over the chunk's edges
+    for EVERY receiver, e + m for the chunk's edges): nlam_lin_fwd + nlam_edge_fwd; backward
+    nlam_edge_bwd + nlam_segment_sum + nlam_lin_bwd + one slab reduction."""
+
+    @staticmethod
+    def forward(ctx, send_rep, rec_rep, edge_rep, same, g, update_edges, W1, b1, W2, b2, gam, bet):
+        with ops.tag(g.tag):
+            dev = edge_rep.device
+            d = W2.shape[0]
+            B = max(send_rep.shape[0], rec_rep.shape[0], edge_rep.shape[0])
+            N_s, N_r, M = send_rep.shape[1], rec_rep.shape[1], edge_rep.shape[1]
+            sm, rm, em = mat(send_rep.detach()), mat(rec_rep.detach()), mat(edge_rep.detach())
+            W1e, W1s, W1r = W1[:, :d], W1[:, d : 2 * d], W1[:, 2 * d :]
+            if same:
+                P = _empty(sm.B, N_s, 2 * d, device=dev)
+                ops.fused_lin_fwd(sm, W1s, None, W1r, b1, mat(P))
+                psm, prm = mat(P, 0, d), mat(P, d, d)
+                saved_proj = (P,)
+            else:
+                Ps = _empty(sm.B, N_s, d, device=dev)
+                Pr = _empty(rm.B, N_r, d, device=dev)
+                ops.fused_lin_fwd(sm, W1s, None, None, None, mat(Ps))
+                ops.fused_lin_fwd(rm, W1r, b1, None, None, mat(Pr))
+                psm, prm = mat(Ps), mat(Pr)
+                saved_proj = (Ps, Pr)
+            agg = _empty(B, N_r, d, device=dev)
+            if update_edges:
+                e_out = _empty(B, M, d, device=dev)
+                ops.fused_edge_fwd(g, em, True, psm, prm, W1e, W2, b2, gam, bet, mat(agg),
+                                   mat(e_out), False, d)
+                Pe = None
+            else:
+                e_out = None
+                Pe = _empty(em.B, M, d, device=dev)
+                ops.fused_lin_fwd(em, W1e, None, None, None, mat(Pe))
+                ops.fused_edge_fwd(g, mat(Pe), False, psm, prm, None, W2, b2, gam, bet, mat(agg),
+                                   None, False, d)
+            ctx.save_for_backward(W1, b1, W2, b2, gam)
+            ctx.set_materialize_grads(False)
+            ctx.g, ctx.same, ctx.update_edges = g, same, update_edges
+            ctx.mats = (sm, rm, em)
+            ctx.bufs = (saved_proj, Pe)
+            ctx.dims = (B, N_s, N_r, M, d)
+        if update_edges:
+            return agg, e_out
+        return agg
+
+    @staticmethod
+    def backward(ctx, g_agg, g_edge_out=None):
+        with ops.tag(ctx.g.tag), ops.slab_batch():
+            W1, b1, W2, b2, gam = ctx.saved_tensors
+            g = ctx.g
+            sm, rm, em = ctx.mats
+            saved_proj, Pe = ctx.bufs
+            ctx.bufs = None
+            B, N_s, N_r, M, d = ctx.dims
+            dev = W1.device
+            W1e, W1s, W1r = W1[:, :d], W1[:, d : 2 * d], W1[:, 2 * d :]
+            same = ctx.same
+            if g_agg is None:
+                g_agg = torch.zeros(B, N_r, d, dtype=torch.float32, device=dev)
+            g_agg = g_agg.contiguous()
+            dW1 = _empty(d, 3 * d, device=dev)
+            db1 = _empty(d, device=dev)
+            dW2, db2 = torch.empty_like(W2), _empty(d, device=dev)
+            dgam, dbet = _empty(d, device=dev), _empty(d, device=dev)
+            gh = _empty(B, M, d, device=dev)
+            if same:
+                gP = _empty(B, N_r, 2 * d, device=dev)
+                gpr_m = mat(gP, d, d)
+                psm, prm = mat(saved_proj[0], 0, d), mat(saved_proj[0], d, d)
+            else:
+                gPr = _empty(B, N_r, d, device=dev)
+                gpr_m = mat(gPr)
+                psm, prm = mat(saved_proj[0]), mat(saved_proj[1])
+            if ctx.update_edges:
+                g_e = _empty(B, M, d, device=dev)
+                geo = mat(g_edge_out.contiguous()) if g_edge_out is not None else None
+                ops.fused_edge_bwd(
+                    g, em, True, psm, prm, W1e, W2, b2, gam, mat(g_agg), geo, mat(gh), gpr_m,
+                    mat(g_e), False, d, dW1[:, :d], dW2, db2, dgam, dbet)
+            else:
+                g_e = None
+                ops.fused_edge_bwd(
+                    g, mat(Pe), False, psm, prm, None, W2, b2, gam, mat(g_agg), None, mat(gh),
+                    gpr_m, None, False, d, None, dW2, db2, dgam, dbet)
+            if same:
+                if N_s > g.n_send:
+                    gP[:, g.n_send :, :d].zero_()
+                ops.segment_sum(mat(gh), g.csc_colptr, g.csc_eid, mat(gP[:, : g.n_send], 0, d))
+                gx_p = _empty(sm.B, N_s, d, device=dev)
+                gpm = mat(gP)
+                fold = sm.B == 1 and B > 1 and ops.lin_bwd_can_sum(sm, gpm)
+                if sm.B == 1 and B > 1 and not fold:
+                    gP1 = _empty(1, N_s, 2 * d, device=dev)
+                    ops.sum_batch(gP, gP1)
+                    gpm = mat(gP1)
+                ops.fused_lin_bwd(sm, gpm, W1s, W1r, mat(gx_p), dW1[:, d : 2 * d], None,
+                                  dW1[:, 2 * d :], db1, sum_gy_batch=fold)
+                g_send, g_rec = gx_p, None
+            else:
+                gPs = (torch.zeros if N_s > g.n_send else torch.empty)(
+                    B, N_s, d, dtype=torch.float32, device=dev)
+                ops.segment_sum(mat(gh), g.csc_colptr, g.csc_eid, mat(gPs[:, : g.n_send]))
+                gps_m, gpr_in = mat(gPs), mat(gPr)
+                fold_s = sm.B == 1 and B > 1 and ops.lin_bwd_can_sum(sm, gps_m)
+                fold_r = rm.B == 1 and B > 1 and ops.lin_bwd_can_sum(rm, gpr_in)
+                if sm.B == 1 and B > 1 and not fold_s:
+                    t1 = _empty(1, N_s, d, device=dev)
+                    ops.sum_batch(gPs, t1)
+                    gps_m = mat(t1)
+                if rm.B == 1 and B > 1 and not fold_r:
+                    t2 = _empty(1, N_r, d, device=dev)
+                    ops.sum_batch(gPr, t2)
+                    gpr_in = mat(t2)
+                g_send = _empty(sm.B, N_s, d, device=dev)
+                ops.fused_lin_bwd(sm, gps_m, W1s, None, mat(g_send), dW1[:, d : 2 * d], None,
+                                  None, None, sum_gy_batch=fold_s)
+                g_rec = _empty(rm.B, N_r, d, device=dev)
+                ops.fused_lin_bwd(rm, gpr_in, W1r, None, mat(g_rec), dW1[:, 2 * d :], db1,
+                                  None, None, sum_gy_batch=fold_r)
+            if ctx.update_edges:
+                g_edge = g_e
+                if em.B == 1 and B > 1:
+                    t4 = _empty(1, M, d, device=dev)
+                    ops.sum_batch(g_e, t4)
+                    g_edge = t4
+            else:
+                dPe = mat(gh)
+                fold_e = em.B == 1 and B > 1 and ops.lin_bwd_can_sum(em, dPe)
+                if em.B == 1 and B > 1 and not fold_e:
+                    t5 = _empty(1, M, d, device=dev)
+                    ops.sum_batch(gh, t5)
+                    dPe = mat(t5)
+                g_edge = _empty(em.B, M, d, device=dev)
+                ops.fused_lin_bwd(em, dPe, W1e, None, mat(g_edge), dW1[:, :d], None,
+                                  None, None, sum_gy_batch=fold_e)
+        return (g_send, g_rec, g_edge, None, None, None, dW1, db1, dW2, db2, dgam, dbet)
+
+
+class FusedNodeUpdateFunction(torch.autograd.Function):
+    """x_r + aggr_mlp([x_r | agg]) on a row range (interaction_net.py:106-109)."""
+
+    @staticmethod
+    def forward(ctx, x_r, agg, tag, V1, c1, V2, c2, gam2, bet2):
+        with ops.tag(tag):
+            d = V2.shape[0]
+            rm, am = mat(x_r.detach()), mat(agg.detach())
+            B = max(rm.B, am.B)
+            out = _empty(B, rm.rows, d, device=x_r.device)
+            ops.fused_mlp_fwd(rm, am, V1, c1, V2, c2, gam2, bet2, rm, mat(out), d, d)
+            ctx.save_for_backward(V1, c1, V2, c2, gam2)
+            ctx.mats, ctx.tag, ctx.dims = (rm, am), tag, (B, rm.rows, d)
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        V1, c1, V2, c2, gam2 = ctx.saved_tensors
+        rm, am = ctx.mats
+        B, rows, d = ctx.dims
+        dev = V1.device
+        gy = gy.contiguous()
+        g_rec = _empty(B, rows, d, device=dev)
+        g_agg = _empty(B, rows, d, device=dev)
+        nd = _mlp_grad_dst(V1, V2, True)
+        with ops.tag(ctx.tag), ops.slab_batch():
+            ops.fused_mlp_bwd(rm, am, V1, c1, V2, c2, gam2, mat(gy), mat(g_rec), mat(g_agg), True,
+                              d, d, nd)
+            if rm.B == 1 and B > 1:
+                t3 = _empty(1, rows, d, device=dev)
+                ops.sum_batch(g_rec, t3)
+                g_rec = t3
+            if am.B == 1 and B > 1:
+                t6 = _empty(1, rows, d, device=dev)
+                ops.sum_batch(g_agg, t6)
+                g_agg = t6
+        return (g_rec, g_agg, None, nd["dW1"], nd["db1"], nd["dW2"], nd["db2"], nd["dgamma"],
+                nd["dbeta"])
+
+
+def apply_inet_split(net, send_rep, rec_rep, edge_rep):
+    from .interaction_net import SplitMLPs
+
+    same = send_rep is rec_rep
+    s = _base(send_rep)
+    r = s if same else _base(rec_rep)
+    e = _base(edge_rep)
+    B = max(s.shape[0], r.shape[0], e.shape[0])
+    if isinstance(net.edge_mlp, SplitMLPs):
+        e_mlps, e_sizes, tabs = list(net.edge_mlp.mlps), list(net.edge_mlp.chunk_sizes), list(net.chunk_tables)
+    else:
+        e_mlps, e_sizes, tabs = [net.edge_mlp], [net.tables.M], [net.tables]
+    agg, e_outs, o = None, [], 0
+    for mlp, m, tab in zip(e_mlps, e_sizes, tabs):
+        tab.tag = net.tables.tag
+        lin, ln = _mlp_parts(mlp)
+        out = FusedEdgePassFunction.apply(
+            s, r, e[:, o : o + m], same, tab, net.update_edges,
+            lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias, ln.weight, ln.bias)
+        if net.update_edges:
+            a_c, eo_c = out
+            e_outs.append(eo_c)
+        else:
+            a_c = out
+        agg = a_c if agg is None else agg + a_c
+        o += m
+    if net.aggr == "mean":
+        agg = agg * net.tables.inv_deg.view(1, -1, 1)
+    if isinstance(net.aggr_mlp, SplitMLPs):
+        a_mlps, a_sizes = list(net.aggr_mlp.mlps), list(net.aggr_mlp.chunk_sizes)
+    else:
+        a_mlps, a_sizes = [net.aggr_mlp], [net.num_rec]
+    if r.shape[0] == 1 and B > 1:
+        r = r.expand(B, -1, -1)
+    outs, r0 = [], 0
+    for mlp, n in zip(a_mlps, a_sizes):
+        lin, ln = _mlp_parts(mlp)
+        outs.append(FusedNodeUpdateFunction.apply(
+            r[:, r0 : r0 + n], agg[:, r0 : r0 + n], net.tables.tag,
+            lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias, ln.weight, ln.bias))
+        r0 += n
+    rec_out = outs[0] if len(outs) == 1 else torch.cat(outs, dim=1)
+    if net.update_edges:
+        return rec_out, (e_outs[0] if len(e_outs) == 1 else torch.cat(e_outs, dim=1))
+    return rec_out

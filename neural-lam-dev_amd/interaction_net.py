@@ -81,6 +81,16 @@ class InteractionNet(nn.Module):
             )
         self.update_edges = update_edges
         self.input_dim, self.hidden_dim, self.hidden_layers = input_dim, hidden_dim, hidden_layers
+        # SplitMLPs over the edges (HiLAMParallel): one table set per edge chunk, so that the
+        # fused kernels run chunk by chunk with that chunk's weights (fused.apply_inet_split)
+        self.chunk_tables = None
+        if edge_chunk_sizes is not None:
+            assert sum(edge_chunk_sizes) == send.shape[0], "edge chunk sizes do not add up"
+            tabs, o = [], 0
+            for m in edge_chunk_sizes:
+                tabs.append(EdgeTables(send[o : o + m], rec[o : o + m], num_send, num_rec))
+                o += m
+            self.chunk_tables = nn.ModuleList(tabs)
 
     def forward(self, send_rep, rec_rep, edge_rep):
         if rec_rep.shape[-2] != self.num_rec:
@@ -92,6 +102,8 @@ class InteractionNet(nn.Module):
             raise RuntimeError("send_rep / edge_rep row counts do not match edge_index")
         if fused.inet_eligible(self, send_rep, rec_rep, edge_rep):
             return fused.apply_inet(self, send_rep, rec_rep, edge_rep)
+        if fused.inet_split_eligible(self, send_rep, rec_rep, edge_rep):
+            return fused.apply_inet_split(self, send_rep, rec_rep, edge_rep)
         lead = edge_rep.shape[:-2]
 
         def as3(t):

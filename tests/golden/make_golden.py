@@ -67,6 +67,17 @@ OP_CASES = {
              edge_chunk_sizes=[40, 30, 20], aggr_chunk_sizes=[10, 20]),
     ),
     "op_d4_sum_upd": (4, 3, 12, 9, 37, False, dict(update_edges=True, aggr="sum")),
+    # SplitMLPs at the fused width (HiLAMParallel's operator, hi_lam_parallel.py:26-53)
+    "op_d64_split": (
+        64, 2, 50, 50, 400, True,
+        dict(update_edges=True, aggr="sum", edge_chunk_sizes=[150, 130, 120],
+             aggr_chunk_sizes=[20, 30]),
+    ),
+    "op_d64_split_mean_noupd": (
+        64, 2, 60, 40, 300, False,
+        dict(update_edges=False, aggr="mean", edge_chunk_sizes=[100, 200],
+             aggr_chunk_sizes=[15, 25]),
+    ),
 }
 
 
@@ -188,6 +199,7 @@ MODEL_CASES = {
     "model_graphlam_d64": ("graph_lam", 30, 28, None, False, 64, 2, 2, 2, "wmse", "sum"),
     "model_graphlam_d64_mean": ("graph_lam", 27, 31, None, False, 64, 1, 1, 1, "mse", "mean"),
     "model_hilam_d64": ("hi_lam", 30, 28, 2, True, 64, 1, 2, 1, "wmse", "sum"),
+    "model_hilam_parallel_d64": ("hi_lam_parallel", 30, 28, 2, True, 64, 1, 2, 1, "wmse", "sum"),
 }
 
 
