@@ -10,7 +10,7 @@ and backward are explicit kernel sequences wrapped in torch.autograd.Function
 import torch
 
 from . import ops
-from .ops import Mat, mat
+from .ops import mat
 
 
 def _empty(B, rows, cols, device):

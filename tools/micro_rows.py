@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Fixed vs per-row cost of the fused row kernels: times back-to-back launches for a
 range of row counts (d = 64)."""
-import json, os, sys
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from neural_lam_amd import ops

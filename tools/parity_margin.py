@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Worst-case relative errors of the fused models against the reference goldens, for the
 MFMA mode set in NLAM_MFMA (fp32 | bf16x3).  Tolerances: prediction 1e-4, grads 2e-3."""
-import glob, os, sys, tempfile
+import os, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
