@@ -1,5 +1,9 @@
-"""Training losses on the hot path (reference neural_lam/metrics.py:21-108:
-get_metric, mask_and_reduce_metric, wmse, mse)."""
+"""Metrics of reference neural_lam/metrics.py: the training losses on the hot path (wmse,
+mse: :21-108; the fused kernels of glue.MaskedWMSE take over in training_step) and the
+evaluation metrics of the validation / test loops (wmae, mae, nll, crps_gauss: :111-237).
+Plain tensor expressions on whatever device the tensors live on."""
+import math
+
 import torch
 
 
@@ -26,7 +30,36 @@ def mse(pred, target, pred_std, mask=None, average_grid=True, sum_vars=True):
     return wmse(pred, target, torch.ones_like(pred_std), mask, average_grid, sum_vars)
 
 
-DEFINED_METRICS = {"mse": mse, "wmse": wmse}
+def wmae(pred, target, pred_std, mask=None, average_grid=True, sum_vars=True):
+    """metrics.py:111-139: absolute error weighted by 1/std."""
+    entry = (pred - target).abs() / pred_std
+    return mask_and_reduce_metric(entry, mask, average_grid, sum_vars)
+
+
+def mae(pred, target, pred_std, mask=None, average_grid=True, sum_vars=True):
+    """metrics.py:142-163."""
+    return wmae(pred, target, torch.ones_like(pred_std), mask, average_grid, sum_vars)
+
+
+def nll(pred, target, pred_std, mask=None, average_grid=True, sum_vars=True):
+    """metrics.py:166-190: -log N(target; pred, pred_std^2) per entry."""
+    z = (target - pred) / pred_std
+    entry = 0.5 * z * z + torch.log(pred_std) + 0.5 * math.log(2.0 * math.pi)
+    return mask_and_reduce_metric(entry, mask, average_grid, sum_vars)
+
+
+def crps_gauss(pred, target, pred_std, mask=None, average_grid=True, sum_vars=True):
+    """metrics.py:193-227: closed-form (negative) CRPS of a Gaussian forecast,
+    sigma * ( z (2 Phi(z) - 1) + 2 phi(z) - 1/sqrt(pi) ),  z = (target - pred) / sigma."""
+    z = (target - pred) / pred_std
+    phi = torch.exp(-0.5 * z * z) / math.sqrt(2.0 * math.pi)
+    cdf = 0.5 * (1.0 + torch.erf(z / math.sqrt(2.0)))
+    entry = pred_std * (z * (2.0 * cdf - 1.0) + 2.0 * phi - 1.0 / math.sqrt(math.pi))
+    return mask_and_reduce_metric(entry, mask, average_grid, sum_vars)
+
+
+DEFINED_METRICS = {"mse": mse, "mae": mae, "wmse": wmse, "wmae": wmae, "nll": nll,
+                   "crps_gauss": crps_gauss}
 
 
 def get_metric(metric_name):

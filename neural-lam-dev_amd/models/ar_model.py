@@ -81,6 +81,13 @@ class ARModel(_Base):
         self.register_buffer("boundary_mask", boundary_mask, persistent=False)
         self.register_buffer("interior_mask", 1.0 - self.boundary_mask, persistent=False)
         self.restore_opt = getattr(args, "restore_opt", False)
+        # evaluation state (ar_model.py:133-151); plotting / W&B are out of scope
+        self.val_metrics = {"mse": []}
+        self.test_metrics = {"mse": [], "mae": []}
+        if self.output_std:
+            self.test_metrics["output_std"] = []
+        self.spatial_loss_maps = []
+        self.eval_results = {}   # prefix -> {metric: (pred_steps, d_f) tensor}, rank 0
 
     def configure_optimizers(self):
         return torch.optim.AdamW(self.parameters(), lr=self.args.lr, betas=(0.9, 0.95))
@@ -162,3 +169,111 @@ class ARModel(_Base):
             self.log_dict({"train_loss": batch_loss}, prog_bar=True, on_step=True, on_epoch=True,
                           sync_dist=True, batch_size=batch[0].shape[0])
         return batch_loss
+
+
+    # ------------------------------------------------------------ evaluation
+    # Reference ar_model.py:311-452, 610-696 without the plotting / W&B parts: same
+    # metrics, same logged keys, same aggregation (mean over samples, sqrt for *mse ->
+    # *rmse, rescale by state_std); results are kept in self.eval_results.
+    def _log(self, values, batch_size=None):
+        if hasattr(self, "log_dict") and getattr(self, "_trainer", None) is not None:
+            self.log_dict(values, on_step=False, on_epoch=True, sync_dist=True, batch_size=batch_size)
+        self.last_logged = {k: (float(v) if torch.is_tensor(v) and v.numel() == 1 else v)
+                            for k, v in values.items()}
+
+    def all_gather_cat(self, tensor_to_gather):
+        """(d1, ...) on K ranks -> (K d1, ...) (ar_model.py:311-320)."""
+        if hasattr(self, "all_gather") and getattr(self, "_trainer", None) is not None:
+            return self.all_gather(tensor_to_gather).flatten(0, 1)
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            world = torch.distributed.get_world_size()
+            if world > 1:
+                parts = [torch.empty_like(tensor_to_gather) for _ in range(world)]
+                torch.distributed.all_gather(parts, tensor_to_gather.contiguous())
+                return torch.cat(parts, dim=0)
+        return tensor_to_gather
+
+    def _is_rank_zero(self):
+        tr = getattr(self, "_trainer", None)
+        if tr is not None:
+            return bool(tr.is_global_zero)
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            return torch.distributed.get_rank() == 0
+        return True
+
+    def _steps_to_log(self):
+        return list(getattr(self.args, "val_steps_to_log", [1]))
+
+    def _eval_losses(self, batch, prefix, clip_steps):
+        prediction, target, pred_std, _ = self.common_step(batch)
+        time_step_loss = torch.mean(
+            self.loss(prediction, target, pred_std, mask=self.interior_mask_bool), dim=0)
+        steps = [st for st in self._steps_to_log() if not clip_steps or st <= len(time_step_loss)]
+        log = {f"{prefix}_loss_unroll{st}": time_step_loss[st - 1] for st in steps}
+        log[f"{prefix}_mean_loss"] = torch.mean(time_step_loss)
+        self._log(log, batch_size=batch[0].shape[0])
+        return prediction, target, pred_std
+
+    @torch.no_grad()
+    def validation_step(self, batch, batch_idx=0):
+        """ar_model.py:324-361."""
+        prediction, target, pred_std = self._eval_losses(batch, "val", clip_steps=True)
+        self.val_metrics["mse"].append(
+            metrics.mse(prediction, target, pred_std, mask=self.interior_mask_bool, sum_vars=False))
+
+    def on_validation_epoch_end(self):
+        self.aggregate_metrics(self.val_metrics, prefix="val")
+        for lst in self.val_metrics.values():
+            lst.clear()
+
+    @torch.no_grad()
+    def test_step(self, batch, batch_idx=0):
+        """ar_model.py:375-452 (metrics and spatial loss maps; no example plots)."""
+        prediction, target, pred_std = self._eval_losses(batch, "test", clip_steps=False)
+        for name in ("mse", "mae"):
+            self.test_metrics[name].append(metrics.get_metric(name)(
+                prediction, target, pred_std, mask=self.interior_mask_bool, sum_vars=False))
+        if self.output_std:
+            self.test_metrics["output_std"].append(
+                torch.mean(pred_std[..., self.interior_mask_bool, :], dim=-2))
+        spatial = self.loss(prediction, target, pred_std, average_grid=False)
+        self.spatial_loss_maps.append(spatial[:, [st - 1 for st in self._steps_to_log()]])
+
+    def aggregate_metrics(self, metrics_dict, prefix):
+        """ar_model.py:610-644 without the figures: gathered over ranks, averaged over the
+        evaluated samples, *mse -> *rmse, rescaled to physical units by state_std."""
+        out = {}
+        for name, vals in metrics_dict.items():
+            if not vals:
+                continue
+            gathered = self.all_gather_cat(torch.cat(vals, dim=0))     # (N_eval, steps, d_f)
+            if self._is_rank_zero():
+                avg = torch.mean(gathered, dim=0)
+                if "mse" in name:
+                    avg, name = torch.sqrt(avg), name.replace("mse", "rmse")
+                out[f"{prefix}_{name}"] = avg * self.state_std
+        if self._is_rank_zero():
+            self.eval_results[prefix] = out
+        return out
+
+    def on_test_epoch_end(self):
+        """ar_model.py:646-696: metrics + mean spatial loss maps (kept as tensors)."""
+        out = self.aggregate_metrics(self.test_metrics, prefix="test")
+        if self.spatial_loss_maps:
+            maps = self.all_gather_cat(torch.cat(self.spatial_loss_maps, dim=0))
+            if self._is_rank_zero():
+                out["test_mean_spatial_loss"] = torch.mean(maps, dim=0)   # (N_log, N_grid)
+        for lst in self.test_metrics.values():
+            lst.clear()
+        self.spatial_loss_maps.clear()
+        return out
+
+    def on_load_checkpoint(self, checkpoint):
+        """ar_model.py:698-720: checkpoints from before the encoder refactoring keep the grid
+        MLP under g2m_gnn.grid_mlp.*; optionally drop the optimizer state."""
+        sd = checkpoint["state_dict"]
+        for old in [k for k in sd if k.startswith("g2m_gnn.grid_mlp")]:
+            sd[old.replace("g2m_gnn.grid_mlp", "encoding_grid_mlp")] = sd.pop(old)
+        if not self.restore_opt and "optimizer_states" in checkpoint:
+            opt = self.configure_optimizers()
+            checkpoint["optimizer_states"] = [opt.state_dict()]

@@ -53,7 +53,8 @@ def model_args(**kw):
     (train_model.py:29-209; tests/test_training.py:71-87)."""
     base = dict(graph="multiscale", hidden_dim=64, hidden_layers=1, processor_layers=4,
                 mesh_aggr="sum", output_std=False, loss="wmse", lr=1e-3, restore_opt=False,
-                n_example_pred=0, num_past_forcing_steps=1, num_future_forcing_steps=1)
+                n_example_pred=0, num_past_forcing_steps=1, num_future_forcing_steps=1,
+                val_steps_to_log=[1], metrics_watch=[])
     base.update(kw)
     return types.SimpleNamespace(**base)
 

@@ -93,3 +93,53 @@ def test_ar_checkpointing_matches_plain_rollout():
     for k in grads[0]:
         a, b = grads[0][k], grads[1][k]
         assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max() + 1e-30), k
+
+
+def test_validation_and_test_steps_metrics():
+    """validation_step / test_step / epoch-end aggregation (reference ar_model.py:324-452,
+    610-696, without plotting): logged losses and aggregated RMSE / MAE equal a CPU
+    recomputation from the model's own rollout."""
+    from neural_lam_amd import graphgen, metrics, synthetic
+    from neural_lam_amd.models import GraphLAM
+    import numpy as np
+
+    with tempfile.TemporaryDirectory() as tmp:
+        info = graphgen.create_graph(tmp + "/graph/g", graphgen.make_xy(30, 28, 5000.0), None, False)
+        n = info["num_grid"]
+        gen = torch.Generator().manual_seed(0)
+        std = np.array([1.0, 2.0, 0.5, 1.5, 3.0])
+        ds = synthetic.SyntheticDatastore(
+            tmp, torch.randn(n, 1, generator=gen).numpy(), np.zeros(5), std, np.zeros(5),
+            np.ones(5), (torch.rand(n, generator=gen) < 0.2).float().numpy(), n_forcing=2)
+        torch.manual_seed(1)
+        model = GraphLAM(synthetic.model_args(graph="g", hidden_dim=64, processor_layers=1,
+                                              val_steps_to_log=[1, 2, 5]),
+                         config=None, datastore=ds).cuda()
+    batch = synthetic.random_batch(3, 2, n, n_state=5, n_forcing_window=6, device="cuda")
+    with torch.no_grad():
+        pred, target, pred_std, _ = model.common_step(batch)
+    p, t, s = pred.cpu(), target.cpu(), pred_std.cpu()
+    mask = model.interior_mask_bool.cpu()
+    step_loss = metrics.wmse(p, t, s, mask=mask).mean(0)
+    model.validation_step(batch, 0)
+    logged = model.last_logged
+    assert set(logged) == {"val_loss_unroll1", "val_loss_unroll2", "val_mean_loss"}   # 5 > T: clipped
+    assert abs(logged["val_loss_unroll2"] - float(step_loss[1])) < 1e-5 * abs(float(step_loss[1]))
+    assert abs(logged["val_mean_loss"] - float(step_loss.mean())) < 1e-5 * float(step_loss.mean())
+    model.on_validation_epoch_end()
+    want_rmse = torch.sqrt(metrics.mse(p, t, s, mask=mask, sum_vars=False).mean(0)) * torch.tensor(std, dtype=torch.float32)
+    got = model.eval_results["val"]["val_rmse"].cpu()
+    assert got.shape == (2, 5) and torch.allclose(got, want_rmse, rtol=1e-4, atol=1e-6)
+    assert model.val_metrics["mse"] == []
+    model.args.val_steps_to_log = [1, 2]
+    model.test_step(batch, 0)
+    model.test_step(batch, 1)
+    out = model.on_test_epoch_end()
+    want_mae = metrics.mae(p, t, s, mask=mask, sum_vars=False).mean(0) * torch.tensor(std, dtype=torch.float32)
+    assert torch.allclose(out["test_mae"].cpu(), want_mae, rtol=1e-4, atol=1e-6)
+    assert torch.allclose(out["test_rmse"].cpu(), want_rmse, rtol=1e-4, atol=1e-6)
+    assert out["test_mean_spatial_loss"].shape == (2, n)
+    # checkpoints from before the encoder refactoring (ar_model.py:698-716)
+    ckpt = {"state_dict": {"g2m_gnn.grid_mlp.0.weight": torch.zeros(1), "x": torch.zeros(1)}}
+    model.on_load_checkpoint(ckpt)
+    assert set(ckpt["state_dict"]) == {"encoding_grid_mlp.0.weight", "x"}

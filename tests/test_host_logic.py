@@ -93,3 +93,36 @@ def test_cpu_tensors_fail_loudly():
     mlp = __import__("neural_lam_amd").make_mlp([3, 8, 8])
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         mlp(torch.randn(5, 3))
+
+
+def test_eval_metrics_match_reference_and_closed_forms():
+    """wmae / mae / nll / crps_gauss (reference metrics.py:111-237): against torch.distributions
+    closed forms, and against the reference's own metrics.py when it is present."""
+    import math
+    from neural_lam_amd import metrics as M
+
+    gen = torch.Generator().manual_seed(0)
+    pred = torch.randn(2, 3, 50, 4, generator=gen)
+    target = torch.randn(2, 3, 50, 4, generator=gen)
+    std = torch.rand(4, generator=gen) + 0.5
+    std_full = torch.rand(2, 3, 50, 4, generator=gen) + 0.3
+    mask = torch.rand(50, generator=gen) < 0.7
+    normal = torch.distributions.Normal(pred, std_full)
+    want_nll = (-normal.log_prob(target))[..., mask, :].mean(-2).sum(-1)
+    assert torch.allclose(M.nll(pred, target, std_full, mask=mask), want_nll, rtol=1e-5, atol=1e-6)
+    z = (target - pred) / std
+    sn = torch.distributions.Normal(0.0, 1.0)
+    want_crps = (-std * (math.pi ** -0.5 - 2 * torch.exp(sn.log_prob(z)) - z * (2 * sn.cdf(z) - 1)))
+    assert torch.allclose(M.crps_gauss(pred, target, std, average_grid=False, sum_vars=False),
+                          want_crps, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(M.mae(pred, target, std, sum_vars=False), (pred - target).abs().mean(-2))
+    assert torch.allclose(M.wmae(pred, target, std), ((pred - target).abs() / std).mean(-2).sum(-1))
+    assert set(M.DEFINED_METRICS) == {"mse", "mae", "wmse", "wmae", "nll", "crps_gauss"}
+    from oracle import ref_shim
+    if ref_shim.available():
+        ref = ref_shim.load().metrics
+        for name in M.DEFINED_METRICS:
+            for kw in (dict(), dict(mask=mask, sum_vars=False), dict(average_grid=False)):
+                a = M.get_metric(name)(pred, target, std_full, **kw)
+                b = ref.get_metric(name)(pred, target, std_full, **kw)
+                assert torch.allclose(a, b, rtol=1e-5, atol=1e-6), (name, kw)
