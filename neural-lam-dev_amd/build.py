@@ -8,6 +8,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libnlam_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-mcode-object-version=5", "-O3", "-std=c++17", "-fPIC"]
+# extra flags for experiments, e.g. NLAM_HIPCC_FLAGS="-mllvm -amdgpu-sched-strategy=max-ilp"
+FLAGS += os.environ.get("NLAM_HIPCC_FLAGS", "").split()
 
 
 def sources():
