@@ -270,6 +270,38 @@ __device__ __forceinline__ void gemm_tile_b3(f32x16 (&out)[NB], const B3Image& W
   }
 }
 
+// acc[j] (lanes = features 64 j + lane) += sum over the 32 tile rows of X[t][xcol0 + 64 j + lane]
+// -- the per-feature (bias / gamma / beta) gradient of one tile -- as a ones-vector product on
+// the matrix cores: A = all-ones fragment (exact in bf16, no LDS read), B = transposed plane
+// fragments, 2 MFMAs per 32-column block and K step.  Every row of the 32x32 result block
+// holds the column sums; rows >= nrows of the planes must be zero.  Replaces a 32-step LDS
+// loop (2^-18 relative error per element from the hi/lo split).
+template <int NV>
+__device__ __forceinline__ void tile_colsum_b3(float (&acc)[NV], const B3Tile& X, int xcol0,
+                                               int lane) {
+  bf16x8 ones;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ones[i] = (__bf16)1.0f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    f32x16 c0, c1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c0[r] = c1[r] = 0.f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const bf16x8 b0h = b3_tr_frag_rows(X.hi, X.pitch, 16 * u, xcol0 + 64 * j, lane);
+      const bf16x8 b0l = b3_tr_frag_rows(X.lo, X.pitch, 16 * u, xcol0 + 64 * j, lane);
+      const bf16x8 b1h = b3_tr_frag_rows(X.hi, X.pitch, 16 * u, xcol0 + 64 * j + 32, lane);
+      const bf16x8 b1l = b3_tr_frag_rows(X.lo, X.pitch, 16 * u, xcol0 + 64 * j + 32, lane);
+      c0 = B3_MFMA(ones, b0h, c0);
+      c0 = B3_MFMA(ones, b0l, c0);
+      c1 = B3_MFMA(ones, b1h, c1);
+      c1 = B3_MFMA(ones, b1l, c1);
+    }
+    acc[j] += (lane < 32) ? c0[0] : c1[0];
+  }
+}
+
 // dW[ib][jb] += sum_t G[t][gcol0 + 32 ib + .] (x) X[t][xcol0 + 32 jb + .] over the 32 tile
 // rows; G and X are bf16-plane tiles.  Result block layout as outer_accum (fused_common.h).
 template <int NI, int NJ>

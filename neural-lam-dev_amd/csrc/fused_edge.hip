@@ -441,9 +441,16 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
     wave_sync();
     if constexpr (B3) acc_to_tile_b3<NB>(sact, T2p, 0, lane);
     else acc_to_tile<NB>(sact, T2, LDT, lane);
-    acc_to_tile<NB>(g, T1, LDT, lane);
-    wave_sync();
-    tile_colsum<NV>(dbet, T1, LDT, 0, ne, lane);
+    constexpr bool MCS0 = B3 && !HAS_EGEMM;   // MFMA column sums (see db2 below)
+    if constexpr (MCS0) {
+      acc_to_tile_b3<NB>(g, T1p, 0, lane);
+      wave_sync();
+      tile_colsum_b3<NV>(dbet, T1p, 0, lane);
+    } else {
+      acc_to_tile<NB>(g, T1, LDT, lane);
+      wave_sync();
+      tile_colsum<NV>(dbet, T1, LDT, 0, ne, lane);
+    }
     // LN backward
     constexpr float inv_d = 1.0f / (float)D;
     float s1 = 0.f, s2 = 0.f;
@@ -467,28 +474,40 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
           }
         }
       wave_sync();
-      acc_to_tile<NB>(prod, T1, LDT, lane);
+      if constexpr (MCS0) acc_to_tile_b3<NB>(prod, T1p, 0, lane);
+      else acc_to_tile<NB>(prod, T1, LDT, lane);
     }
     s1 += __shfl_xor(s1, 32, 64);
     s2 += __shfl_xor(s2, 32, 64);
     const float m1 = s1 * inv_d, m2 = s2 * inv_d;
     wave_sync();
-    tile_colsum<NV>(dgam, T1, LDT, 0, ne, lane);
+    if constexpr (MCS0) tile_colsum_b3<NV>(dgam, T1p, 0, lane);
+    else tile_colsum<NV>(dgam, T1, LDT, 0, ne, lane);
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) g[nb][r] = rstd * (g[nb][r] - m1 - z[nb][r] * m2);
     // g = gz (zero on padded slots).  Publish GZ (T1) and S (T2) for the dW2 blocks.
     wave_sync();
-    acc_to_tile<NB>(g, T1, LDT, lane);
-    wave_sync();
-    tile_colsum<NV>(db2, T1, LDT, 0, ne, lane);
+    // MFMA column sums only where the registers allow it (the edge-GEMM form spills)
+    constexpr bool MCS = B3 && !HAS_EGEMM;
+    if constexpr (MCS) {
+      acc_to_tile_b3<NB>(g, T1p, 0, lane);      // GZ straight to bf16 planes
+      wave_sync();
+      tile_colsum_b3<NV>(db2, T1p, 0, lane);    // column sums on the matrix cores
+    } else {
+      acc_to_tile<NB>(g, T1, LDT, lane);
+      wave_sync();
+      tile_colsum<NV>(db2, T1, LDT, 0, ne, lane);
+    }
     STAMP_AT(2)   // LN backward + three column sums + tile transposes
     if (!HAS_EGEMM) issue_rows(nxt, tt + stride);  // (no later MFMA phase in this form)
     if constexpr (B3) {
-      wave_sync();
-      acc_to_tile_b3<NB>(g, T1p, 0, lane);      // GZ as bf16 planes over its fp32 copy
-      wave_sync();
+      if constexpr (!MCS) {
+        wave_sync();
+        acc_to_tile_b3<NB>(g, T1p, 0, lane);      // GZ as bf16 planes over its fp32 copy
+        wave_sync();
+      }
       outer_accum_b3<NB, NB>(dW2, T1p, 0, T2p, 0, lane);
     } else {
       outer_accum<NB, NB>(dW2, T1, LDT, 0, T2, LDT, 0, lane);
