@@ -284,21 +284,22 @@ __device__ __forceinline__ void tile_colsum_b3(float (&acc)[NV], const B3Tile& X
   for (int i = 0; i < 8; ++i) ones[i] = (__bf16)1.0f;
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
-    f32x16 c0, c1;
+    float v[2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) c0[r] = c1[r] = 0.f;
+    for (int blk = 0; blk < 2; ++blk) {      // one 32-column block at a time: 16 live registers
+      f32x16 c;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const bf16x8 b0h = b3_tr_frag_rows(X.hi, X.pitch, 16 * u, xcol0 + 64 * j, lane);
-      const bf16x8 b0l = b3_tr_frag_rows(X.lo, X.pitch, 16 * u, xcol0 + 64 * j, lane);
-      const bf16x8 b1h = b3_tr_frag_rows(X.hi, X.pitch, 16 * u, xcol0 + 64 * j + 32, lane);
-      const bf16x8 b1l = b3_tr_frag_rows(X.lo, X.pitch, 16 * u, xcol0 + 64 * j + 32, lane);
-      c0 = B3_MFMA(ones, b0h, c0);
-      c0 = B3_MFMA(ones, b0l, c0);
-      c1 = B3_MFMA(ones, b1h, c1);
-      c1 = B3_MFMA(ones, b1l, c1);
+      for (int r = 0; r < 16; ++r) c[r] = 0.f;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const bf16x8 bh = b3_tr_frag_rows(X.hi, X.pitch, 16 * u, xcol0 + 64 * j + 32 * blk, lane);
+        const bf16x8 bl = b3_tr_frag_rows(X.lo, X.pitch, 16 * u, xcol0 + 64 * j + 32 * blk, lane);
+        c = B3_MFMA(ones, bh, c);
+        c = B3_MFMA(ones, bl, c);
+      }
+      v[blk] = c[0];
     }
-    acc[j] += (lane < 32) ? c0[0] : c1[0];
+    acc[j] += (lane < 32) ? v[0] : v[1];
   }
 }
 
@@ -324,6 +325,33 @@ __device__ __forceinline__ void outer_accum_b3(f32x16 (&dW)[NI][NJ], const B3Til
         dW[ib][jb] = B3_MFMA(ah[ib], bh, dW[ib][jb]);
         dW[ib][jb] = B3_MFMA(ah[ib], bl, dW[ib][jb]);
         dW[ib][jb] = B3_MFMA(al[ib], bh, dW[ib][jb]);
+      }
+    }
+  }
+}
+
+// out[kb] += W[rows 32 NB][cols 32 (kb0 + kb) ..]^T . G with G a bf16-plane row tile
+// (gx = W^T gy straight from the staged planes: no register copy of gy at all).
+template <int KBO, int NB>
+__device__ __forceinline__ void gemm_tile_wt_b3(f32x16 (&out)[KBO], const B3Image& W, int kb0,
+                                                const B3Tile& G, int gcol0, int lane) {
+  const int t = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int go = t * G.pitch + gcol0 + 32 * nb + 16 * s + 4 * h;
+      const bf16x8 bh = b3_join(*reinterpret_cast<const bf16x4*>(G.hi + go),
+                                *reinterpret_cast<const bf16x4*>(G.hi + go + 8));
+      const bf16x8 bl = b3_join(*reinterpret_cast<const bf16x4*>(G.lo + go),
+                                *reinterpret_cast<const bf16x4*>(G.lo + go + 8));
+#pragma unroll
+      for (int kb = 0; kb < KBO; ++kb) {
+        const bf16x8 ah = b3_tr_frag(W.hi, W.pitch, 32 * nb + 16 * s, 32 * (kb0 + kb), lane);
+        const bf16x8 al = b3_tr_frag(W.lo, W.pitch, 32 * nb + 16 * s, 32 * (kb0 + kb), lane);
+        out[kb] = B3_MFMA(ah, bh, out[kb]);
+        out[kb] = B3_MFMA(ah, bl, out[kb]);
+        out[kb] = B3_MFMA(al, bh, out[kb]);
       }
     }
   }

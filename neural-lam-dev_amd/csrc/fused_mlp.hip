@@ -947,9 +947,13 @@ __global__ __launch_bounds__(256) void lin_bwd_kernel(LinBwdParams q) {
           }
         }
       }
-      if (B3) put_rows_v_b3<4 * KB>(T0p, 0, q.x.width, nrows, lane, vx);
-      else put_rows_v<4 * KB, false>(T0, ldt0, 0, q.x.width, nrows, lane, vx);
-      put_rows_v<4 * NOUTB, false>(T1, ldt1, 0, n_out, nrows, lane, vg);
+      if (B3) {
+        put_rows_v_b3<4 * KB>(T0p, 0, q.x.width, nrows, lane, vx);
+        put_rows_v_b3<4 * NOUTB>(T1p, 0, n_out, nrows, lane, vg);
+      } else {
+        put_rows_v<4 * KB, false>(T0, ldt0, 0, q.x.width, nrows, lane, vx);
+        put_rows_v<4 * NOUTB, false>(T1, ldt1, 0, n_out, nrows, lane, vg);
+      }
     } else {
       view_stage_s(T0, ldt0, 0, q.x, b, r0, nrows, lane);
       view_stage_s(T1, ldt1, 0, q.gy, b, r0, nrows, lane);
@@ -957,24 +961,20 @@ __global__ __launch_bounds__(256) void lin_bwd_kernel(LinBwdParams q) {
     if (KP32 > q.x.width) zero_cols(T0, ldt0, q.x.width, KP32 - q.x.width, lane);
     if (NO > n_out) zero_cols(T1, ldt1, n_out, NO - n_out, lane);
     wave_sync();
-    tile_colsum<NV>(db, T1, ldt1, 0, nrows, lane);
     f32x16 gx[KB];
     if constexpr (B3) {
-      // gy: fp32 tile -> registers -> bf16 planes in the same LDS (x went there directly)
-      f32x16 g[NOUTB];
-      tile_to_acc<NOUTB>(g, T1, ldt1, lane);
-      wave_sync();
-      acc_to_tile_b3<NOUTB>(g, T1p, 0, lane);
-      wave_sync();
+      // x and gy were staged as bf16 planes: column sums, dW and gx all read them directly
+      tile_colsum_b3<NV>(db, T1p, 0, lane);
       outer_accum_b3<NOUTB, KB>(dW, T1p, 0, T0p, 0, lane);
       if (q.gx != nullptr) {
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
           for (int r = 0; r < 16; ++r) gx[kb][r] = 0.f;
-        gemm_acc_wt_b3<KB, NOUTB>(gx, Wim, 0, g, lane);
+        gemm_tile_wt_b3<KB, NOUTB>(gx, Wim, 0, T1p, 0, lane);
       }
     } else {
+      tile_colsum<NV>(db, T1, ldt1, 0, nrows, lane);
       outer_accum<NOUTB, KB>(dW, T1, ldt1, 0, T0, ldt0, 0, lane);
       if (q.gx != nullptr) {
         f32x16 g[NOUTB];
@@ -1156,19 +1156,17 @@ __global__ __launch_bounds__(256) void outer_bwd_kernel(OuterParams q) {
     load_rows_v<4 * NGB>(vg, NG, lane, g_row);
     load_rows_v<8>(va, q.xa.width, lane, xa_row);
     if (xbb) load_rows_v<8>(vb, q.xb.width, lane, xb_row);
-    put_rows_v<4 * NGB, false>(TG, ldg, 0, NG, nrows, lane, vg);
     if constexpr (B3) {
-      // X straight to bf16 planes; G as fp32 for the column sums, then re-written as planes
+      // G and X straight to bf16 planes; the column sums of G run on the matrix cores
       const B3Tile TGp = b3_tile(TG, NG), TXp = b3_tile(TX, NX);
+      put_rows_v_b3<4 * NGB>(TGp, 0, NG, nrows, lane, vg);
       put_rows_v_b3<8>(TXp, 0, q.xa.width, nrows, lane, va);
       if (xbb) put_rows_v_b3<8>(TXp, q.xa.width, q.xb.width, nrows, lane, vb);
       wave_sync();
-      tile_colsum<NV>(db, TG, ldg, 0, nrows, lane);
-      wave_sync();
-      put_rows_v_b3<4 * NGB>(TGp, 0, NG, nrows, lane, vg);
-      wave_sync();
+      tile_colsum_b3<NV>(db, TGp, 0, lane);
       outer_accum_b3<NGB, NXB>(dW, TGp, 0, TXp, 0, lane);
     } else {
+      put_rows_v<4 * NGB, false>(TG, ldg, 0, NG, nrows, lane, vg);
       put_rows_v<8, false>(TX, ldx, 0, q.xa.width, nrows, lane, va);
       if (xbb) put_rows_v<8, false>(TX, ldx, q.xa.width, q.xb.width, nrows, lane, vb);
       if (NX > kx) zero_cols(TX, ldx, kx, NX - kx, lane);
