@@ -431,16 +431,29 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
       for (int r = 0; r < 16; ++r) sact[nb][r] = nlam_silu(hpre[nb][r]);
     f32x16 z[NB];
     vec_to_acc<NB>(z, b2s, lane);
-    if constexpr (B3) gemm_acc_b3<NB, NB>(z, W2im, 0, sact, lane);
-    else gemm_acc<NB, NB>(z, W2s, LDW, 0, sact, lane);
+    // PLN (edge-GEMM form, short of registers): the B fragments of the GEMMs whose operand
+    // also exists as bf16 planes (S, gz, gh) are read from those planes instead of being
+    // split again from registers, which ends the operands' live ranges early (measured:
+    // m2m 150 -> 145 us; the leaner form without the edge GEMM is faster with registers)
+    constexpr bool PLN = B3 && HAS_EGEMM;
+    if constexpr (PLN) {
+      wave_sync();   // (T2's g_agg / g_eout rows are in registers by now)
+      acc_to_tile_b3<NB>(sact, T2p, 0, lane);
+      wave_sync();
+      gemm_tile_b3<NB, NB>(z, W2im, 0, T2p, 0, lane);
+    } else if constexpr (B3) {
+      gemm_acc_b3<NB, NB>(z, W2im, 0, sact, lane);
+    } else {
+      gemm_acc<NB, NB>(z, W2s, LDW, 0, sact, lane);
+    }
     float mean, rstd;
     ln_stats<NB>(z, mean, rstd);
     STAMP_AT(1)   // recompute: GEMM1, silu, GEMM2, stats
     // S is published right away (T2's g_agg / g_eout rows are already in registers):
     // sact's registers are free during the LayerNorm backward.  dbeta from the gm tile.
     wave_sync();
-    if constexpr (B3) acc_to_tile_b3<NB>(sact, T2p, 0, lane);
-    else acc_to_tile<NB>(sact, T2, LDT, lane);
+    if constexpr (B3 && !PLN) acc_to_tile_b3<NB>(sact, T2p, 0, lane);
+    else if constexpr (!B3) acc_to_tile<NB>(sact, T2, LDT, lane);
     constexpr bool MCS0 = B3 && !HAS_EGEMM;   // MFMA column sums (see db2 below)
     if constexpr (MCS0) {
       acc_to_tile_b3<NB>(g, T1p, 0, lane);
@@ -518,7 +531,8 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) gh[nb][r] = 0.f;
-    if constexpr (B3) gemm_acc_wt_b3<NB, NB>(gh, W2im, 0, g, lane);
+    if constexpr (PLN) gemm_tile_wt_b3<NB, NB>(gh, W2im, 0, T1p, 0, lane);   // gz planes
+    else if constexpr (B3) gemm_acc_wt_b3<NB, NB>(gh, W2im, 0, g, lane);
     else gemm_acc_wt<NB, NB>(gh, W2s, LDW, 0, g, lane);
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
@@ -567,7 +581,7 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
       for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) ge[nb][r] = has_geo ? geo[nb][r] : 0.f;
-      if constexpr (B3) gemm_acc_wt_b3<NB, NB>(ge, W1im, 0, gh, lane);
+      if constexpr (B3) gemm_tile_wt_b3<NB, NB>(ge, W1im, 0, T1p, 0, lane);   // gh planes
       else gemm_acc_wt<NB, NB>(ge, W1s, LDW, 0, gh, lane);
       wave_sync();
       acc_to_tile<NB>(ge, T2, LDT, lane);
