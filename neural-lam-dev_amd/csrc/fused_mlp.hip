@@ -1271,9 +1271,12 @@ struct ReduceSegs {
 };
 
 __global__ __launch_bounds__(1024) void reduce_slabs_multi_kernel(ReduceSegs q) {
-  __shared__ float red[32][33];
-  const int e = threadIdx.x & 31, gsub = threadIdx.x >> 5;
-  const int64_t i = (int64_t)blockIdx.x * 32 + e;
+  // 64 consecutive outputs per workgroup (256-byte rows of every slab), 16 sub-groups that
+  // split the slabs; eight slab loads in flight per thread (clamped + masked, so they issue
+  // back to back); the summation order is fixed by the launch shape
+  __shared__ float red[16][65];
+  const int e = threadIdx.x & 63, gsub = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + e;
   const int64_t n = q.first[q.nseg];
   int k = 0;
   while (k + 1 < q.nseg && i >= q.first[k + 1]) ++k;
@@ -1282,20 +1285,18 @@ __global__ __launch_bounds__(1024) void reduce_slabs_multi_kernel(ReduceSegs q) 
   const int64_t r = local / cols, c = local - r * cols;
   const float* __restrict__ slab = q.slab[k] + q.src_off[k] + r * q.src_ld[k] + c;
   const int64_t nslabs = q.nslabs[k], stride = q.stride[k];
-  // eight slab loads in flight per thread (clamped + masked, so they issue back to
-  // back); the summation order is fixed by the launch shape
   float s = 0.f;
   if (i < n) {
-    for (int64_t sl = gsub; sl < nslabs; sl += 32 * 8) {
+    for (int64_t sl = gsub; sl < nslabs; sl += 16 * 8) {
       float v[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int64_t su = sl + 32 * u;
+        const int64_t su = sl + 16 * u;
         v[u] = slab[(su < nslabs ? su : sl) * stride];
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u)
-        if (sl + 32 * u < nslabs) s += v[u];
+        if (sl + 16 * u < nslabs) s += v[u];
     }
   }
   red[gsub][e] = s;
@@ -1303,7 +1304,7 @@ __global__ __launch_bounds__(1024) void reduce_slabs_multi_kernel(ReduceSegs q) 
   if (gsub == 0 && i < n) {
     float v = 0.f;
 #pragma unroll
-    for (int g = 0; g < 32; ++g) v += red[g][e];
+    for (int g = 0; g < 16; ++g) v += red[g][e];
     q.dst[k][r * q.dst_ld[k] + c] = v;
   }
 }
@@ -1315,7 +1316,7 @@ static int launch_reduce_segs(ReduceSegs& q, hipStream_t s) {
   }
   const int64_t n = q.first[q.nseg];
   if (n <= 0) return 0;
-  reduce_slabs_multi_kernel<<<(unsigned)((n + 31) / 32), 1024, 0, s>>>(q);
+  reduce_slabs_multi_kernel<<<(unsigned)((n + 63) / 64), 1024, 0, s>>>(q);
   NLAM_CHECK_LAUNCH("reduce_slabs_multi");
   return 0;
 }
