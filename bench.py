@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="skip the per-kernel HIP-event pass (roofline = null)")
+    ap.add_argument("--no-fp32-compare", action="store_true",
+                    help="skip the extra run with exact fp32 MFMA (NLAM_MFMA=fp32) at N=1")
     ap.add_argument("--no-graph", action="store_true",
                     help="eager launches instead of replaying the captured HIP graph")
     return ap.parse_args()
@@ -304,9 +306,31 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args, tmp, info, model)
 
+    fp32_cmp = None
     if rank == 0:
         from neural_lam_amd._lib import lib as _nlam_lib
         mfma_mode = "bf16x3" if _nlam_lib.nlam_mfma_mode() else "fp32"
+        if (world == 1 and mfma_mode != "fp32" and not args.no_fp32_compare
+                and not args.no_cpu_baseline):
+            # the same step with exact fp32 MFMA (the mode is fixed per process): reported
+            # next to the default so that the split-bf16 gain is visible in the bench line
+            import subprocess
+            cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps),
+                   "--warmup", str(args.warmup), "--batch", str(args.batch),
+                   "--ar-steps", str(args.ar_steps), "--hidden-dim", str(args.hidden_dim),
+                   "--processor-layers", str(args.processor_layers), "--model", args.model,
+                   "--no-cpu-baseline", "--no-kernel-timing", "--no-fp32-compare"]
+            if args.no_graph:
+                cmd.append("--no-graph")
+            try:
+                r = subprocess.run(cmd, env=dict(os.environ, NLAM_MFMA="fp32"),
+                                   capture_output=True, text=True, timeout=600)
+                line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+                j = json.loads(line)
+                fp32_cmp = {"mfma_mode": j.get("mfma_mode"), "ms_per_step": j["ms_per_step"],
+                            "value": j["value"]}
+            except Exception as e:  # reported, never fatal for the bench line
+                fp32_cmp = {"error": repr(e)[:200]}
         if roofline is not None and roofline.get("bound") == "mfma":
             roofline["note"] = ("achieved = algorithmic fp32 flops / s; peak = exact-fp32 MFMA "
                                 "rate" + ("; products run as 3 bf16 MFMA terms (bf16x3)"
@@ -322,7 +346,7 @@ def main():
             # fp32 storage / accumulation / elementwise; GEMM products on the matrix cores as
             # exact fp32 MFMA ("fp32") or as 3 bf16 MFMA terms of hi/lo-split operands
             # ("bf16x3", ~2^-16 relative per product; parity tests hold 1e-4 / 2e-3 either way)
-            "mfma_mode": mfma_mode,
+            "mfma_mode": mfma_mode, "exact_fp32_mfma": fp32_cmp,
             "config": {
                 "workload": f"{args.model} on synthetic MEPS 238x268 grid "
                             f"({info['num_grid']} grid nodes, mesh {info['num_mesh']}, "
