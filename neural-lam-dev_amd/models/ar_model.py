@@ -34,6 +34,35 @@ def _state_feature_weights(config, datastore):
     return [1.0 / n] * n
 
 
+class _RecomputedPredictStep(torch.autograd.Function):
+    """One AR step whose activations are NOT kept: forward runs predict_step under no_grad
+    and saves only its three inputs; backward re-runs it with grad enabled and backpropagates
+    through the fresh graph (parameter gradients accumulate into .grad as usual).  The fused
+    operators keep their activations on ctx (raw device buffers the C ABI reads), which
+    torch.utils.checkpoint's saved-tensor hooks cannot see -- hence this explicit form.
+    `anchor` is a dummy that requires grad so that the first AR step (whose inputs do not)
+    still gets a backward."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, prev_state, prev_prev_state, forcing):
+        ctx.model = model
+        ctx.save_for_backward(prev_state, prev_prev_state, forcing)
+        ctx.need = (prev_state.requires_grad, prev_prev_state.requires_grad)
+        with torch.no_grad():
+            out = model.predict_step(prev_state, prev_prev_state, forcing)[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b, f = ctx.saved_tensors
+        a = a.detach().requires_grad_(ctx.need[0])
+        b = b.detach().requires_grad_(ctx.need[1])
+        with torch.enable_grad():
+            out = ctx.model.predict_step(a, b, f.detach())[0]
+        torch.autograd.backward(out, g)
+        return None, None, a.grad, b.grad, None
+
+
 class ARModel(_Base):
     def __init__(self, args, config, datastore):
         super().__init__()
@@ -115,15 +144,17 @@ class ARModel(_Base):
         prev_state = init_states[:, 1]
         prediction_list, pred_std_list = [], []
         # args.ar_checkpoint (not a reference option): keep only the states
-        # between AR steps and recompute each predict_step in backward, which lifts the
-        # ar_steps memory ceiling of BPTT at about one extra forward per step
+        # between AR steps and recompute each predict_step in backward
+        # (_RecomputedPredictStep), which lifts the ar_steps memory ceiling of BPTT at
+        # about one extra forward per step
         ckpt = (getattr(self, "ar_checkpoint", False) and torch.is_grad_enabled()
                 and forcing_features.shape[1] > 1 and not self.output_std)
         for i in range(forcing_features.shape[1]):
             if ckpt:
-                pred_state = torch.utils.checkpoint.checkpoint(
-                    lambda a, b, c: self.predict_step(a, b, c)[0],
-                    prev_state, prev_prev_state, forcing_features[:, i], use_reentrant=False)
+                if not hasattr(self, "_ckpt_anchor") or self._ckpt_anchor.device != prev_state.device:
+                    self._ckpt_anchor = torch.zeros((), device=prev_state.device, requires_grad=True)
+                pred_state = _RecomputedPredictStep.apply(
+                    self._ckpt_anchor, self, prev_state, prev_prev_state, forcing_features[:, i])
                 pred_std = None
             else:
                 pred_state, pred_std = self.predict_step(

@@ -97,36 +97,121 @@ def bucket_ranges(sizes, bucket_numel):
 
 class GradAllReduce:
     """Bucketed flat-buffer gradient all-reduce (SUM; the 1/world factor is
-    applied by the optimiser)."""
+    applied by the optimiser).
 
-    def __init__(self, flat, bucket_bytes=32 << 20, group=None):
+    Payloads of at least `min_overlap_bytes` (Hi-LAM: 22-89 MB) are overlapped with
+    backward the way Lightning's DDP does for the reference (train_model.py:279): every
+    parameter carries a post-accumulate-grad hook; when the last gradient of a bucket has
+    been produced, that bucket is packed and its all-reduce is issued on a side stream
+    while autograd keeps going; reduce() only issues what is left (parameters that got no
+    gradient) and waits.  Small payloads (GraphLAM: 0.86 MB, latency-bound) stay ONE
+    collective after backward.  Bucket contents and summation are identical either way, so
+    the two schedules give bit-identical results."""
+
+    def __init__(self, flat, bucket_bytes=32 << 20, group=None, overlap=None,
+                 min_overlap_bytes=4 << 20):
         self.flat = flat
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         sizes = [p.numel() for p in flat.params]
+        self.bucket_bytes = bucket_bytes
         self.ranges = bucket_ranges(sizes, max(1, bucket_bytes // 4))
+        if overlap is None:
+            overlap = self.world > 1 and flat.numel * 4 >= min_overlap_bytes
+        self.overlap = bool(overlap)
+        self.side = None
+        self._handles = []
+        self._launched = set()
+        self._dirty = set()
+        self.stats = {"launched_in_backward": 0, "launched_in_reduce": 0}
+        if self.overlap:
+            self._bucket_of = {}
+            self._pending = []
+            for bi, (lo, hi) in enumerate(self.ranges):
+                self._pending.append(hi - lo)
+                for i in range(lo, hi):
+                    self._bucket_of[i] = bi
+            self._left = list(self._pending)
+            for i, p in enumerate(flat.params):
+                p.register_post_accumulate_grad_hook(self._make_hook(i))
+
+    def describe(self):
+        return {"world": self.world, "buckets": len(self.ranges),
+                "bucket_bytes": self.bucket_bytes, "payload_bytes": self.flat.numel * 4,
+                "overlap_with_backward": self.overlap}
 
     def broadcast_params(self, src=0):
         if self.world > 1:
             dist.broadcast(self.flat.flat, src=src, group=self.group)
 
+    # ---- overlap machinery ---------------------------------------------------
+    def _make_hook(self, i):
+        def hook(_param):
+            bi = self._bucket_of[i]
+            if bi in self._launched:
+                # a second gradient contribution after the bucket went out (a re-entrant
+                # inner backward, e.g. args.ar_checkpoint): re-reduce it in reduce()
+                self._dirty.add(bi)
+                return
+            self._left[bi] -= 1
+            if self._left[bi] == 0 and self.world > 1:
+                self._launch(bi, in_backward=True)
+        return hook
+
+    def _launch(self, bi, in_backward, packed=False):
+        f = self.flat
+        lo, hi = self.ranges[bi]
+        a, b = f.span(lo, hi)
+        if f.grad.is_cuda and self.overlap:
+            if self.side is None:
+                self.side = torch.cuda.Stream(device=f.grad.device)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(f.grad.device))
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(ev)
+                if not packed:
+                    f.pack_grads(lo, hi)
+                h = dist.all_reduce(f.grad[a:b], op=dist.ReduceOp.SUM, group=self.group,
+                                    async_op=True)
+        else:
+            if not packed:
+                f.pack_grads(lo, hi)
+            h = dist.all_reduce(f.grad[a:b], op=dist.ReduceOp.SUM, group=self.group,
+                                async_op=True)
+        self._handles.append(h)
+        self._launched.add(bi)
+        self.stats["launched_in_backward" if in_backward else "launched_in_reduce"] += 1
+
     def reduce(self, packed=False):
-        """Pack (unless the caller already did) + all-reduce every bucket; returns
-        when all are complete on the current stream."""
+        """Pack (unless the caller already did) + all-reduce every bucket that backward's
+        hooks have not issued yet; returns when all are complete on the current stream."""
         f = self.flat
         if self.world == 1:
             if not packed:
                 f.pack_grads()
+            self._reset()
             return
-        handles = []
-        for lo, hi in self.ranges:
-            if not packed:
-                f.pack_grads(lo, hi)
-            a, b = f.span(lo, hi)
-            handles.append(dist.all_reduce(f.grad[a:b], op=dist.ReduceOp.SUM, group=self.group,
-                                           async_op=True))
-        for h in handles:
+        for bi in range(len(self.ranges)):
+            if bi not in self._launched:
+                self._launch(bi, in_backward=False, packed=packed)
+        for h in self._handles:
             h.wait()
+        if self._dirty:
+            self._handles = []
+            for bi in sorted(self._dirty):
+                self._launch(bi, in_backward=False)
+            for h in self._handles:
+                h.wait()
+        if self.side is not None:
+            torch.cuda.current_stream(f.grad.device).wait_stream(self.side)
+        self._reset()
+
+    def _reset(self):
+        self._handles = []
+        self._launched = set()
+        self._dirty = set()
+        if self.overlap:
+            self._left = list(self._pending)
 
 
 class FlatAdamW:

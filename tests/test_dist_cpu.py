@@ -75,3 +75,56 @@ def test_bucket_ranges_cover_all_params_in_reverse():
     flat = sorted(i for lo, hi in r for i in range(lo, hi))
     assert flat == list(range(len(sizes)))
     assert r[0][1] == len(sizes) and r[-1][0] == 0
+
+
+def _overlap_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from neural_lam_amd import parallel
+
+    def make():
+        torch.manual_seed(7)
+        return torch.nn.Sequential(
+            torch.nn.Linear(5, 16), torch.nn.SiLU(), torch.nn.Linear(16, 16), torch.nn.SiLU(),
+            torch.nn.Linear(16, 4), torch.nn.LayerNorm(4))
+
+    gen = torch.Generator().manual_seed(100 + rank)
+    x = torch.randn(6, 5, generator=gen)
+    out = {}
+    for name, overlap in (("plain", False), ("overlap", True)):
+        net = make()
+        flat = parallel.FlatParams(net)
+        red = parallel.GradAllReduce(flat, bucket_bytes=256, overlap=overlap)
+        red.broadcast_params()
+        for step in range(2):          # second step: hook state must have been reset
+            flat.zero_grad()
+            net(x).pow(2).sum().backward()
+            launched_before_reduce = red.stats["launched_in_backward"]
+            red.reduce()
+        out[name] = (flat.gather(flat.grad).tolist(), launched_before_reduce,
+                     red.stats["launched_in_reduce"], len(red.ranges))
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+def test_overlap_hooks_fire_during_backward_and_match_plain_path():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in range(world):
+        g_plain, lb_plain, lr_plain, nb = res[rank]["plain"]
+        g_ovl, lb_ovl, lr_ovl, nb2 = res[rank]["overlap"]
+        assert nb == nb2 and nb > 2
+        assert lb_plain == 0 and lr_plain == 2 * nb          # everything issued by reduce()
+        assert lb_ovl == 2 * nb and lr_ovl == 0              # every bucket issued by a hook
+        assert g_plain == g_ovl                               # bit for bit
+    assert res[0]["overlap"][0] == res[1]["overlap"][0]

@@ -82,13 +82,20 @@ def test_ar_checkpointing_matches_plain_rollout():
             models.append(GraphLAM(
                 synthetic.model_args(graph="g", hidden_dim=64, processor_layers=2, ar_checkpoint=ck),
                 config=None, datastore=ds).cuda())
-    batch = synthetic.random_batch(2, 3, n, n_state=5, n_forcing_window=6, device="cuda")
-    losses, grads = [], []
+    batch = synthetic.random_batch(2, 4, n, n_state=5, n_forcing_window=6, device="cuda")
+    losses, grads, peaks = [], [], []
     for m in models:
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
         loss = m.training_step(batch)
         loss.backward()
+        torch.cuda.synchronize()
+        peaks.append(torch.cuda.max_memory_allocated() - base)
         losses.append(float(loss))
         grads.append({k: p.grad.clone() for k, p in m.named_parameters()})
+    # ar_steps = 4: the recomputed rollout holds ONE step's activations at a time
+    assert peaks[1] < 0.6 * peaks[0], peaks
     assert abs(losses[0] - losses[1]) <= 1e-6 * abs(losses[0])
     for k in grads[0]:
         a, b = grads[0][k], grads[1][k]
