@@ -333,6 +333,25 @@ int nlam_wmse_bwd(const float* pred, const float* target, const float* keep,
                   const float* w, const float* gloss, float scale, float* g_pred,
                   int64_t rows, int64_t N, int F, void* stream);
 
+/* output_std head (reference base_graph_model.py:161-177 with args.output_std): net_out is
+ * (rows, 2F); state = prev + net_out[:, :F] * scale + shift, pred_std = softplus(net_out[:, F:])
+ * (beta 1, threshold 20, as torch.nn.functional.softplus).  The backward takes either incoming
+ * gradient as NULL (= zero) and writes g_out (rows, 2F). */
+int nlam_std_head_fwd(const float* net_out, const float* prev, const float* scale,
+                      const float* shift, float* state, float* pred_std, int64_t rows, int F,
+                      void* stream);
+int nlam_std_head_bwd(const float* net_out, const float* g_state, const float* g_std,
+                      const float* scale, float* g_out, int64_t rows, int F, void* stream);
+/* Masked Gaussian NLL training loss (reference metrics.py:166-190 reduced as
+ * ar_model.py:294-298): out[0] = scale * sum keep[r % N] * (0.5 z^2 + log std + 0.5 log 2 pi),
+ * z = (target - pred) / std; partial: nlam_wmse_blocks() floats of workspace; deterministic. */
+int nlam_nll_fwd(const float* pred, const float* target, const float* pred_std,
+                 const float* keep, float* partial, float* out, int64_t rows, int64_t N, int F,
+                 float scale, void* stream);
+int nlam_nll_bwd(const float* pred, const float* target, const float* pred_std,
+                 const float* keep, const float* gloss, float scale, float* g_pred, float* g_std,
+                 int64_t rows, int64_t N, int F, void* stream);
+
 /* Diagnostic only: with NLAM_STAMP=1 in the environment nlam_edge_bwd (update_edges
  * form) runs an instrumented build that sums s_memtime cycles per phase of its tile
  * loop over all waves: out[0..5] = staging, recompute, LN-backward + column sums,

@@ -202,11 +202,7 @@ static int launch_edge_fwd(const EdgeFwdParams& p, hipStream_t s) {
                       (size_t)4 * NLAM_TILE * (D + 4)) * sizeof(float);
   NLAM_REQUIRE(lds <= 160 * 1024, "edge_fwd: LDS footprint %zu B exceeds 160 KiB", lds);
   auto kern = edge_fwd_kernel<D, HAS_EGEMM, B3>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  NLAM_BIG_LDS(kern, __func__);
   kern<<<persistent_grid(p.ntiles * p.B, lds), 256, lds, s>>>(p);
   NLAM_CHECK_LAUNCH("edge_fwd_kernel");
   return 0;
@@ -622,11 +618,7 @@ static int launch_edge_bwd(const EdgeBwdParams& q, hipStream_t s) {
                       (size_t)4 * 3 * NLAM_TILE * (D + 4)) * sizeof(float);
   NLAM_REQUIRE(lds <= 160 * 1024, "edge_bwd: LDS footprint %zu B exceeds 160 KiB", lds);
   auto kern = edge_bwd_kernel<D, HAS_EGEMM, STAMP, B3>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  NLAM_BIG_LDS(kern, __func__);
   int64_t g = (q.f.ntiles * q.f.B + 3) / 4;
   if (g > 256) g = 256;
   kern<<<(unsigned)g, 256, lds, s>>>(q);

@@ -151,11 +151,7 @@ static int launch_mlp_fwd(const MlpParams& p, hipStream_t s) {
   NLAM_REQUIRE(lds <= 160 * 1024, "mlp_fwd: LDS footprint %zu B exceeds 160 KiB (k_in=%d)", lds,
                p.k_in);
   auto kern = mlp_fwd_kernel<HID, NOUTB, HAS_LN, B3KB>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  NLAM_BIG_LDS(kern, __func__);
   const int64_t ntiles = ((p.rows + NLAM_TILE - 1) / NLAM_TILE) * p.B;
   kern<<<persistent_grid(ntiles, lds), 256, lds, s>>>(p);
   NLAM_CHECK_LAUNCH("mlp_fwd_kernel");
@@ -340,11 +336,7 @@ static int launch_lin_fwd_b3(const LinParams& p, hipStream_t s) {
   constexpr int ldt = (K > NO ? K : NO) + 4;
   const size_t lds = b3_image_bytes(NO, K) + NO * 4 + (size_t)4 * NLAM_TILE * ldt * 4;
   auto kern = lin_fwd_b3_kernel<NOUTB, KB>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  NLAM_BIG_LDS(kern, __func__);
   const int64_t ntiles = ((p.rows + NLAM_TILE - 1) / NLAM_TILE) * p.B;
   kern<<<persistent_grid(ntiles, lds), 256, lds, s>>>(p);
   NLAM_CHECK_LAUNCH("lin_fwd_b3_kernel");
@@ -358,11 +350,7 @@ static int launch_lin_fwd(const LinParams& p, hipStream_t s) {
                      sizeof(float);
   NLAM_REQUIRE(lds <= 160 * 1024, "lin_fwd: LDS footprint %zu B exceeds 160 KiB", lds);
   auto kern = lin_fwd_kernel<NOUTB>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  NLAM_BIG_LDS(kern, __func__);
   const int64_t ntiles = ((p.rows + NLAM_TILE - 1) / NLAM_TILE) * p.B;
   kern<<<persistent_grid(ntiles, lds), 256, lds, s>>>(p);
   NLAM_CHECK_LAUNCH("lin_fwd_kernel");
@@ -784,11 +772,7 @@ static int launch_mlp_bwd(const MlpBwdParams& q, hipStream_t s) {
   const size_t fold_bytes = (size_t)4 * HID * KP32 * sizeof(float);
   const size_t lds_alloc = lds > fold_bytes ? lds : fold_bytes;
   auto kern = mlp_bwd_kernel<HID, NOUTB, KB, HAS_LN, DEFER_DW1, B3>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  NLAM_BIG_LDS(kern, __func__);
   const int64_t ntiles = ((q.f.rows + NLAM_TILE - 1) / NLAM_TILE) * q.f.B;
   kern<<<(unsigned)nlam_bwd_grid(ntiles), 256, lds_alloc, s>>>(q);
   NLAM_CHECK_LAUNCH("mlp_bwd_kernel");
@@ -1036,11 +1020,7 @@ static int launch_lin_bwd(const LinBwdParams& q, hipStream_t s) {
   NLAM_REQUIRE(fold_bytes <= 160 * 1024, "lin_bwd: fold images exceed LDS");
   const size_t lds_alloc = lds > fold_bytes ? lds : fold_bytes;
   auto kern = lin_bwd_kernel<NOUTB, KB, SUMGY, B3>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  NLAM_BIG_LDS(kern, __func__);
   const int64_t ntiles = ((q.rows + NLAM_TILE - 1) / NLAM_TILE) * q.B;
   kern<<<(unsigned)nlam_bwd_grid(ntiles), 256, lds_alloc, s>>>(q);
   NLAM_CHECK_LAUNCH("lin_bwd_kernel");
@@ -1202,11 +1182,7 @@ static int launch_outer_bwd(const OuterParams& q, hipStream_t s) {
   if (fold > lds) lds = fold;
   NLAM_REQUIRE(lds <= 160 * 1024, "outer_bwd: LDS footprint %zu B exceeds 160 KiB", lds);
   auto kern = outer_bwd_kernel<NGB, NXB, B3>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  NLAM_BIG_LDS(kern, __func__);
   const int64_t ntiles = ((q.rows + NLAM_TILE - 1) / NLAM_TILE) * q.B;
   kern<<<(unsigned)nlam_bwd_grid(ntiles), 256, lds, s>>>(q);
   NLAM_CHECK_LAUNCH("outer_bwd_kernel");

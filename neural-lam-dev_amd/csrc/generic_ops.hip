@@ -16,6 +16,28 @@ void nlam_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* nlam_last_error(void) { return g_err; }
+
+#include <mutex>
+#include <utility>
+#include <vector>
+int nlam_enable_big_lds(const void* kern, const char* name) {
+  static std::mutex mu;
+  static std::vector<std::pair<const void*, int>> done;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  std::lock_guard<std::mutex> lock(mu);
+  for (const auto& kd : done)
+    if (kd.first == kern && kd.second == dev) return 0;
+  const hipError_t e =
+      hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) {
+    nlam_set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize, 160 KiB) failed on "
+                   "device %d: %s", name, dev, hipGetErrorString(e));
+    return 2;
+  }
+  done.emplace_back(kern, dev);
+  return 0;
+}
 extern "C" int nlam_abi_version(void) { return 1; }
 
 // GEMM arithmetic of the fused kernels (see fused_bf16x3.h): NLAM_MFMA=fp32 | bf16x3

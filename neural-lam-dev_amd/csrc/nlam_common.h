@@ -24,6 +24,14 @@ void nlam_set_error(const char* fmt, ...);
     }                                                                        \
   } while (0)
 
+// Raise a kernel's dynamic-LDS limit to the full 160 KiB of a gfx950 CU.  The attribute is
+// per device: remembered per (kernel, device), thread-safe, and the HIP status is checked.
+int nlam_enable_big_lds(const void* kern, const char* name);
+#define NLAM_BIG_LDS(kern, name)                                        \
+  do {                                                                  \
+    if (nlam_enable_big_lds((const void*)(kern), name) != 0) return 2;  \
+  } while (0)
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

@@ -184,3 +184,134 @@ extern "C" int nlam_wmse_bwd(const float* pred, const float* target, const float
   NLAM_CHECK_LAUNCH("wmse_bwd");
   return 0;
 }
+
+
+// ------------------------------------------------------------ output_std head
+// base_graph_model.py:161-177 with output_std: the output map emits 2F columns per grid node,
+//   state[r][f] = prev[r][f] + out[r][f] * diff_std[f] + diff_mean[f]
+//   std[r][f]   = softplus(out[r][F + f])          (torch default: beta 1, threshold 20)
+__global__ void std_head_fwd_kernel(const float* __restrict__ out, const float* __restrict__ prev,
+                                    const float* __restrict__ scale,
+                                    const float* __restrict__ shift, float* __restrict__ state,
+                                    float* __restrict__ std, int64_t n, int F) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int64_t r = i / F;
+    const int f = (int)(i - r * F);
+    const float* o = out + r * 2 * F;
+    state[i] = prev[i] + o[f] * scale[f] + shift[f];
+    const float x = o[F + f];
+    std[i] = x > 20.0f ? x : log1pf(expf(x));
+  }
+}
+extern "C" int nlam_std_head_fwd(const float* net_out, const float* prev, const float* scale,
+                                 const float* shift, float* state, float* pred_std, int64_t rows,
+                                 int F, void* stream) {
+  const int64_t n = rows * F;
+  if (n <= 0) return 0;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  std_head_fwd_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(net_out, prev, scale,
+                                                                        shift, state, pred_std, n, F);
+  NLAM_CHECK_LAUNCH("std_head_fwd");
+  return 0;
+}
+// g_out[r][f] = g_state[r][f] * diff_std[f];  g_out[r][F + f] = g_std[r][f] * sigmoid(out[r][F + f])
+// (either incoming gradient may be NULL = zero)
+__global__ void std_head_bwd_kernel(const float* __restrict__ out,
+                                    const float* __restrict__ g_state,
+                                    const float* __restrict__ g_std,
+                                    const float* __restrict__ scale, float* __restrict__ g_out,
+                                    int64_t n, int F) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int64_t r = i / F;
+    const int f = (int)(i - r * F);
+    float* go = g_out + r * 2 * F;
+    go[f] = g_state ? g_state[i] * scale[f] : 0.f;
+    const float x = out[r * 2 * F + F + f];
+    const float sg = x > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-x));
+    go[F + f] = g_std ? g_std[i] * sg : 0.f;
+  }
+}
+extern "C" int nlam_std_head_bwd(const float* net_out, const float* g_state, const float* g_std,
+                                 const float* scale, float* g_out, int64_t rows, int F,
+                                 void* stream) {
+  const int64_t n = rows * F;
+  if (n <= 0) return 0;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  std_head_bwd_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(net_out, g_state, g_std,
+                                                                        scale, g_out, n, F);
+  NLAM_CHECK_LAUNCH("std_head_bwd");
+  return 0;
+}
+
+// masked Gaussian negative log-likelihood (metrics.py:166-190 through ar_model.py:294-298):
+// loss = scale * sum_{r, f} keep[r % N] * (0.5 z^2 + log(std) + 0.5 log(2 pi)),  z = (target - pred) / std
+__global__ __launch_bounds__(256) void nll_partial_kernel(
+    const float* __restrict__ pred, const float* __restrict__ target,
+    const float* __restrict__ std, const float* __restrict__ keep, float* __restrict__ partial,
+    int64_t rows, int64_t N, int F) {
+  __shared__ float red[256];
+  const int64_t total = rows * F;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  float s = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t r = i / F;
+    const float k = keep[r % N];
+    if (k != 0.f) {
+      const float sd = std[i];
+      const float z = (target[i] - pred[i]) / sd;
+      s += k * (0.5f * z * z + logf(sd) + 0.91893853320467274178f);
+    }
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+extern "C" int nlam_nll_fwd(const float* pred, const float* target, const float* pred_std,
+                            const float* keep, float* partial, float* out, int64_t rows, int64_t N,
+                            int F, float scale, void* stream) {
+  NLAM_REQUIRE(rows > 0 && N > 0 && F > 0, "nll_fwd: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  nll_partial_kernel<<<1024, 256, 0, s>>>(pred, target, pred_std, keep, partial, rows, N, F);
+  NLAM_CHECK_LAUNCH("nll_partial");
+  wmse_final_kernel<<<1, 256, 0, s>>>(partial, 1024, scale, out);
+  NLAM_CHECK_LAUNCH("nll_final");
+  return 0;
+}
+// g_pred = c keep (pred - target) / std^2 ;  g_std = c keep (1 - z^2) / std ;  c = gloss * scale
+__global__ void nll_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                               const float* __restrict__ std, const float* __restrict__ keep,
+                               const float* __restrict__ gloss, float scale,
+                               float* __restrict__ g_pred, float* __restrict__ g_std, int64_t rows,
+                               int64_t N, int F) {
+  const int64_t total = rows * F;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const float c = scale * gloss[0];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t r = i / F;
+    const float k = c * keep[r % N];
+    const float sd = std[i];
+    const float z = (target[i] - pred[i]) / sd;
+    g_pred[i] = -k * z / sd;
+    g_std[i] = k * (1.0f - z * z) / sd;
+  }
+}
+extern "C" int nlam_nll_bwd(const float* pred, const float* target, const float* pred_std,
+                            const float* keep, const float* gloss, float scale, float* g_pred,
+                            float* g_std, int64_t rows, int64_t N, int F, void* stream) {
+  const int64_t n = rows * F;
+  if (n <= 0) return 0;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  nll_bwd_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(
+      pred, target, pred_std, keep, gloss, scale, g_pred, g_std, rows, N, F);
+  NLAM_CHECK_LAUNCH("nll_bwd");
+  return 0;
+}

@@ -127,6 +127,10 @@ def inet_eligible(net, send_rep, rec_rep, edge_rep):
         return False
     if net.hidden_dim not in SUPPORTED_HIDDEN:
         return False
+    if send_rep.dim() != 3 or rec_rep.dim() != 3 or edge_rep.dim() != 3:
+        return False   # (InteractionNet.forward flattens leading dims before asking)
+    if edge_rep.dtype != torch.float32:
+        return False
     return net.tables.ntiles > 0
 
 

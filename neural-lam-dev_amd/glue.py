@@ -96,3 +96,72 @@ class MaskedWMSE(torch.autograd.Function):
                      gl.data_ptr(), ctx.scale, g.data_ptr(), pred.numel() // F, N, F,
                      ops.stream()), nbytes=12.0 * pred.numel())
         return g, None, None, None, None
+
+
+class StdHead(torch.autograd.Function):
+    """output_std branch of predict_step (base_graph_model.py:161-177):
+    (prev_state, net_out (.., 2F)) -> (prev + net_out[..., :F] * diff_std + diff_mean,
+    softplus(net_out[..., F:])) in one kernel each way."""
+
+    @staticmethod
+    def forward(ctx, prev_state, net_out, diff_std, diff_mean):
+        prev_state, net_out = prev_state.contiguous(), net_out.contiguous()
+        ops._require_dev(net_out, "net_out")
+        F = net_out.shape[-1] // 2
+        state = torch.empty_like(prev_state)
+        std = torch.empty_like(prev_state)
+        rows = prev_state.numel() // F
+        ops._launch("nlam_std_head_fwd", lib.nlam_std_head_fwd,
+                    (net_out.data_ptr(), prev_state.data_ptr(), diff_std.data_ptr(),
+                     diff_mean.data_ptr(), state.data_ptr(), std.data_ptr(), rows, F,
+                     ops.stream()), nbytes=20.0 * prev_state.numel())
+        ctx.save_for_backward(net_out, diff_std)
+        ctx.set_materialize_grads(False)
+        return state, std
+
+    @staticmethod
+    def backward(ctx, g_state, g_std):
+        net_out, diff_std = ctx.saved_tensors
+        F = net_out.shape[-1] // 2
+        g_state = g_state.contiguous() if g_state is not None else None
+        g_std = g_std.contiguous() if g_std is not None else None
+        g_out = torch.empty_like(net_out)
+        ops._launch("nlam_std_head_bwd", lib.nlam_std_head_bwd,
+                    (net_out.data_ptr(), g_state.data_ptr() if g_state is not None else None,
+                     g_std.data_ptr() if g_std is not None else None, diff_std.data_ptr(),
+                     g_out.data_ptr(), net_out.numel() // (2 * F), F, ops.stream()),
+                    nbytes=8.0 * net_out.numel())
+        return (g_state if ctx.needs_input_grad[0] else None), g_out, None, None
+
+
+class MaskedNLL(torch.autograd.Function):
+    """mean over the leading dims of sum_f mean_{kept n} -log N(target; pred, std^2)
+    (metrics.py:166-190 under ar_model.py:294-298)."""
+
+    @staticmethod
+    def forward(ctx, pred, target, pred_std, keep, scale):
+        pred, target, pred_std = pred.contiguous(), target.contiguous(), pred_std.contiguous()
+        ops._require_dev(pred, "pred")
+        N, F = pred.shape[-2], pred.shape[-1]
+        rows = pred.numel() // F
+        partial = torch.empty(lib.nlam_wmse_blocks(), dtype=torch.float32, device=pred.device)
+        out = torch.empty(1, dtype=torch.float32, device=pred.device)
+        ops._launch("nlam_nll_fwd", lib.nlam_nll_fwd,
+                    (pred.data_ptr(), target.data_ptr(), pred_std.data_ptr(), keep.data_ptr(),
+                     partial.data_ptr(), out.data_ptr(), rows, N, F, scale, ops.stream()),
+                    nbytes=12.0 * pred.numel())
+        ctx.save_for_backward(pred, target, pred_std, keep)
+        ctx.scale = scale
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, gloss):
+        pred, target, pred_std, keep = ctx.saved_tensors
+        N, F = pred.shape[-2], pred.shape[-1]
+        g, gs = torch.empty_like(pred), torch.empty_like(pred)
+        gl = gloss.reshape(1).contiguous()
+        ops._launch("nlam_nll_bwd", lib.nlam_nll_bwd,
+                    (pred.data_ptr(), target.data_ptr(), pred_std.data_ptr(), keep.data_ptr(),
+                     gl.data_ptr(), ctx.scale, g.data_ptr(), gs.data_ptr(), pred.numel() // F, N,
+                     F, ops.stream()), nbytes=20.0 * pred.numel())
+        return g, None, gs, None, None

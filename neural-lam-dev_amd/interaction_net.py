@@ -100,22 +100,34 @@ class InteractionNet(nn.Module):
             )
         if send_rep.shape[-2] < self.tables.n_send or edge_rep.shape[-2] != self.tables.M:
             raise RuntimeError("send_rep / edge_rep row counts do not match edge_index")
-        if fused.inet_eligible(self, send_rep, rec_rep, edge_rep):
-            return fused.apply_inet(self, send_rep, rec_rep, edge_rep)
-        if fused.inet_split_eligible(self, send_rep, rec_rep, edge_rep):
-            return fused.apply_inet_split(self, send_rep, rec_rep, edge_rep)
-        lead = edge_rep.shape[:-2]
+        # any leading dims (node dim = -2, interaction_net.py:86-115): every path below works
+        # on (B, rows, d); expand_to_batch views pass through untouched (3-D already)
+        lead = max((send_rep.shape[:-2], rec_rep.shape[:-2], edge_rep.shape[:-2]), key=len)
 
         def as3(t):
             return t if t.dim() == 3 else t.reshape(-1, t.shape[-2], t.shape[-1])
 
+        same = send_rep is rec_rep
+        s3, e3 = as3(send_rep), as3(edge_rep)
+        r3 = s3 if same else as3(rec_rep)
+
+        def restore(out):
+            if len(lead) == 1:
+                return out
+            if self.update_edges:
+                return (out[0].reshape(*lead, *out[0].shape[-2:]),
+                        out[1].reshape(*lead, *out[1].shape[-2:]))
+            return out.reshape(*lead, *out.shape[-2:])
+
+        if fused.inet_eligible(self, s3, r3, e3):
+            return restore(fused.apply_inet(self, s3, r3, e3))
+        if fused.inet_split_eligible(self, s3, r3, e3):
+            return restore(fused.apply_inet_split(self, s3, r3, e3))
         eb, ep = _blocks(self.edge_mlp, self.tables.M)
         ab, ap = _blocks(self.aggr_mlp, self.num_rec)
         ab = [(r0, r1, n, ln, off + len(ep)) for (r0, r1, n, ln, off) in ab]
         out = generic.InteractionNetGenericFunction.apply(
-            as3(send_rep), as3(rec_rep), as3(edge_rep), self.tables, self.update_edges,
+            s3, r3, e3, self.tables, self.update_edges,
             self.aggr == "mean", eb, ab, *(ep + ap),
         )
-        if self.update_edges:
-            return out[0].reshape(*lead, *out[0].shape[-2:]), out[1].reshape(*lead, *out[1].shape[-2:])
-        return out.reshape(*lead, *out.shape[-2:])
+        return restore(out)

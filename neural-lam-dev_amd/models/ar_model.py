@@ -192,6 +192,14 @@ class ARModel(_Base):
             keep, w, n_keep = self._loss_consts
             lead = prediction.numel() // (prediction.shape[-1] * prediction.shape[-2])
             batch_loss = glue.MaskedWMSE.apply(prediction, target, keep, w, 1.0 / (n_keep * lead))
+        elif self.output_std and self.loss is metrics.nll and prediction.is_cuda:
+            if not hasattr(self, "_nll_consts") or self._nll_consts[0].device != prediction.device:
+                keep = self.interior_mask[:, 0].contiguous()
+                self._nll_consts = (keep, float(keep.sum().item()))
+            keep, n_keep = self._nll_consts
+            lead = prediction.numel() // (prediction.shape[-1] * prediction.shape[-2])
+            batch_loss = glue.MaskedNLL.apply(prediction, target, pred_std, keep,
+                                              1.0 / (n_keep * lead))
         else:
             batch_loss = torch.mean(
                 self.loss(prediction, target, pred_std, mask=self.interior_mask_bool)

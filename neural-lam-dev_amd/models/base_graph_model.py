@@ -76,11 +76,9 @@ class BaseGraphModel(ARModel):
         net_output = self.output_map(grid_rep)
 
         if self.output_std:
-            pred_delta_mean, pred_std_raw = net_output.chunk(2, dim=-1)
-            pred_std = torch.nn.functional.softplus(pred_std_raw)
-        else:
-            pred_delta_mean, pred_std = net_output, None
+            # chunk + softplus + rescale + residual in one kernel (glue.StdHead)
+            return glue.StdHead.apply(prev_state, net_output, self.diff_std, self.diff_mean)
         new_state = glue.StateResidual.apply(
-            prev_state, pred_delta_mean, self.diff_std, self.diff_mean
+            prev_state, net_output, self.diff_std, self.diff_mean
         )
-        return new_state, pred_std
+        return new_state, None

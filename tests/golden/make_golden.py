@@ -200,11 +200,19 @@ MODEL_CASES = {
     "model_graphlam_d64_mean": ("graph_lam", 27, 31, None, False, 64, 1, 1, 1, "mse", "mean"),
     "model_hilam_d64": ("hi_lam", 30, 28, 2, True, 64, 1, 2, 1, "wmse", "sum"),
     "model_hilam_parallel_d64": ("hi_lam_parallel", 30, 28, 2, True, 64, 1, 2, 1, "wmse", "sum"),
+    # round 2: BASELINE configs[2] (Hi-LAM, 3 mesh levels, hidden 128), configs[3] (ar_steps = 4)
+    # and a model-level hidden_layers = 2 (optional 12th field: extra args)
+    "model_hilam_3level_d128": ("hi_lam", 81, 83, 3, True, 128, 1, 1, 1, "wmse", "sum"),
+    "model_graphlam_d64_T4": ("graph_lam", 30, 28, None, False, 64, 2, 1, 4, "wmse", "sum"),
+    "model_graphlam_hl2": ("graph_lam", 30, 28, None, False, 16, 2, 2, 2, "mse", "sum",
+                           dict(hidden_layers=2)),
 }
 
 
 def make_model_case(ns, name):
-    model, nx, ny, nml, hier, hd, pl, B, T, loss, aggr = MODEL_CASES[name]
+    model, nx, ny, nml, hier, hd, pl, B, T, loss, aggr = MODEL_CASES[name][:11]
+    extra = MODEL_CASES[name][11] if len(MODEL_CASES[name]) > 11 else {}
+    hl = extra.get("hidden_layers", 1)
     gen = torch.Generator().manual_seed(seed_of(name))
     with tempfile.TemporaryDirectory() as tmp:
         gdir = os.path.join(tmp, "graph", "g")
@@ -212,7 +220,7 @@ def make_model_case(ns, name):
         n_grid = info["num_grid"]
         ds = FakeDatastore(tmp, n_grid, gen, unit_stats=(name == "model_graphlam_1level"))
         args = types.SimpleNamespace(
-            graph="g", hidden_dim=hd, hidden_layers=1, processor_layers=pl, mesh_aggr=aggr,
+            graph="g", hidden_dim=hd, hidden_layers=hl, processor_layers=pl, mesh_aggr=aggr,
             output_std=False, loss=loss, lr=1e-3, restore_opt=False, n_example_pred=0,
             num_past_forcing_steps=1, num_future_forcing_steps=1,
         )
@@ -242,7 +250,7 @@ def make_model_case(ns, name):
         "diff_std": net.diff_std, "boundary_mask": net.boundary_mask,
         "per_var_std": net.per_var_std,
     }
-    cfg = {"model": model, "hidden_layers": 1, "processor_layers": pl, "mesh_aggr": aggr,
+    cfg = {"model": model, "hidden_layers": hl, "processor_layers": pl, "mesh_aggr": aggr,
            "loss": loss, "hidden_dim": hd}
     osd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     o_loss, o_pred = orc.training_loss(osd, graph, cfg, data, init, target, forcing)
@@ -266,6 +274,36 @@ def make_model_case(ns, name):
           f"{sum(p.numel() for p in params.values())} params)")
 
 
+def make_output_std_case(ns):
+    """The reference's output_std branch.  Its model cannot run with output_std=True (ar_model.py
+    :111-116 sizes the grid embedder for 2 * grid_output_dim state columns, predict_step feeds
+    2 * num_state_vars: nn.Linear raises a shape error), so the pin is at the level the
+    reference does define: base_graph_model.py:161-177 applied to a given network output
+    (chunk / softplus / rescale + residual, executed here line by line with the same torch
+    calls) and the reference's own metrics.nll (metrics.py:166-190) through the masked
+    training reduction of ar_model.py:294-298."""
+    gen = torch.Generator().manual_seed(seed_of("aux_output_std"))
+    B, T, N, d = 2, 3, 211, 5
+    net_out = torch.randn(B, T, N, 2 * d, generator=gen)
+    prev = torch.randn(B, T, N, d, generator=gen)
+    target = torch.randn(B, T, N, d, generator=gen)
+    diff_std = 0.5 + torch.rand(d, generator=gen)
+    diff_mean = 0.1 * torch.randn(d, generator=gen)
+    interior = torch.rand(N, generator=gen) > 0.3
+    x = net_out.clone().requires_grad_(True)
+    pred_delta_mean, pred_std_raw = x.chunk(2, dim=-1)                 # :162-165
+    pred_std = torch.nn.functional.softplus(pred_std_raw)              # :168
+    rescaled = pred_delta_mean * diff_std + diff_mean                  # :174
+    state = prev + rescaled                                            # :177
+    loss = torch.mean(ns.metrics.nll(state, target, pred_std, mask=interior))   # ar_model :294-298
+    (g,) = torch.autograd.grad(loss, x)
+    torch.save({"kind": "aux", "net_out": net_out, "prev": prev, "target": target,
+                "diff_std": diff_std, "diff_mean": diff_mean, "interior": interior,
+                "state": state.detach(), "pred_std": pred_std.detach(), "loss": float(loss),
+                "grad_net_out": g}, os.path.join(HERE, "aux_output_std.pt"))
+    print(f"aux_output_std: ok  loss {float(loss):.6f}")
+
+
 def main():
     ns = ref_shim.load()
     torch.set_num_threads(4)
@@ -276,6 +314,8 @@ def main():
     for name in MODEL_CASES:
         if not only or name in only:
             make_model_case(ns, name)
+    if not only or "aux_output_std" in only:
+        make_output_std_case(ns)
 
 
 if __name__ == "__main__":

@@ -65,6 +65,57 @@ def test_m2m_fused_vs_generic_full_size(meps):
     assert all(torch.equal(a, b) for a, b in zip(f[4], f2[4]))
 
 
+@pytest.mark.parametrize("d", [64, 128])
+def test_m2m_layer_vs_cpu_oracle_full_size(meps, d):
+    """One m2m InteractionNet at full MEPS size (6,561 nodes, 57,616 edges), B = 1: the HIP
+    path (default MFMA mode of the process) against the CPU oracle
+    (oracle/nlam_oracle.interaction_net, the restatement of interaction_net.py:86-131 pinned
+    by the goldens), forward and input gradients.  fp32 bars: forward 1e-4, grads 1e-3."""
+    import nlam_oracle as orc
+    from neural_lam_amd.interaction_net import InteractionNet
+
+    torch.manual_seed(10)
+    ei = meps["m2m_edge_index"]
+    net = InteractionNet(ei, d)
+    sd = {f"n.{k}": v.clone() for k, v in net.state_dict().items()}
+    net = net.cuda()
+    N, M = 6561, ei.shape[1]
+    gen = torch.Generator().manual_seed(11)
+    x, e = torch.randn(1, N, d, generator=gen), torch.randn(1, M, d, generator=gen)
+    cx, ce = torch.randn(1, N, d, generator=gen), torch.randn(1, M, d, generator=gen)
+    xc, ec = x.clone().requires_grad_(True), e.clone().requires_grad_(True)
+    rx, re_ = orc.interaction_net(sd, "n", ei, xc, xc, ec)
+    ((rx * cx).sum() + (re_ * ce).sum()).backward()
+    xg, eg = x.cuda().requires_grad_(True), e.cuda().requires_grad_(True)
+    ox, oe = net(xg, xg, eg)
+    ((ox * cx.cuda()).sum() + (oe * ce.cuda()).sum()).backward()
+    assert rel(ox.detach().cpu(), rx.detach()) < 1e-4 and rel(oe.detach().cpu(), re_.detach()) < 1e-4
+    assert rel(xg.grad.cpu(), xc.grad) < 1e-3 and rel(eg.grad.cpu(), ec.grad) < 1e-3
+
+
+@pytest.mark.parametrize("which", ["g2m", "m2g"])
+def test_g2m_m2g_forward_vs_cpu_oracle_full_size(meps, which):
+    """The encoder / decoder InteractionNets (100,656 / 255,136 edges, update_edges=False,
+    batch-invariant edge and receiver-or-sender inputs) at full size vs the CPU oracle."""
+    import nlam_oracle as orc
+    from neural_lam_amd.interaction_net import InteractionNet
+
+    torch.manual_seed(12)
+    ei = meps[f"{which}_edge_index"]
+    net = InteractionNet(ei, 64, update_edges=False)
+    sd = {f"n.{k}": v.clone() for k, v in net.state_dict().items()}
+    net = net.cuda()
+    n_s, n_r, M = net.tables.n_send, net.tables.n_rec, ei.shape[1]
+    gen = torch.Generator().manual_seed(13)
+    send = torch.randn(1, n_s, 64, generator=gen)
+    rec = torch.randn(1, n_r, 64, generator=gen)
+    edge = torch.randn(1, M, 64, generator=gen)
+    with torch.no_grad():
+        want = orc.interaction_net(sd, "n", ei, send, rec, edge, update_edges=False)
+        got = net(send.cuda(), rec.cuda(), edge.cuda())
+    assert rel(got.cpu(), want) < 1e-4
+
+
 def test_edge_order_invariance_full_size(meps):
     """Permuting the edges (edge_index columns and edge_rep rows alike) leaves the node
     update unchanged and permutes the edge update."""

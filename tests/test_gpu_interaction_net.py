@@ -90,6 +90,29 @@ def test_stride0_batch_inputs_match_oracle():
     assert rel(sg.grad, sc.grad) < 1e-3 and rel(rg.grad, rc.grad) < 1e-3 and rel(eg.grad, ec.grad) < 1e-3
 
 
+@pytest.mark.parametrize("d", [64, 16])
+def test_leading_dims_2d_and_4d_match_3d(d):
+    """interaction_net.py:86-115 takes any leading dims (node dim = -2): 2-D and
+    (B, T, N, d) inputs give the 3-D result, on the fused (d=64) and generic (d=16) paths."""
+    from neural_lam_amd.interaction_net import InteractionNet
+
+    gen = torch.Generator().manual_seed(5)
+    n, M = 40, 300
+    ei = torch.stack((torch.randint(0, n, (M,), generator=gen), torch.randint(0, n, (M,), generator=gen)))
+    ei[0, 0], ei[1, 0], ei[1, 1] = 0, 0, n - 1
+    torch.manual_seed(2)
+    net = InteractionNet(ei, d).cuda()
+    x = torch.randn(2, 3, n, d, generator=gen).cuda()
+    e = torch.randn(2, 3, M, d, generator=gen).cuda()
+    ox, oe = net(x, x, e)
+    assert ox.shape == x.shape and oe.shape == e.shape
+    rx, re_ = net(x.reshape(6, n, d), x.reshape(6, n, d), e.reshape(6, M, d))
+    assert torch.equal(ox.reshape(6, n, d), rx) and torch.equal(oe.reshape(6, M, d), re_)
+    ox2, oe2 = net(x[0, 0], x[0, 0], e[0, 0])
+    assert ox2.shape == (n, d) and oe2.shape == (M, d)
+    assert rel(ox2, rx[0].cpu()) < 1e-6 and rel(oe2, re_[0].cpu()) < 1e-6
+
+
 def test_cpu_tensors_fail_loudly():
     from neural_lam_amd.interaction_net import InteractionNet
 

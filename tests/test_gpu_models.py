@@ -38,7 +38,7 @@ def build_model(fx, tmp, load_weights=True):
     )
     args = synthetic.model_args(
         graph="g", hidden_dim=cfg["hidden_dim"], processor_layers=cfg["processor_layers"],
-        mesh_aggr=cfg["mesh_aggr"], loss=cfg["loss"],
+        mesh_aggr=cfg["mesh_aggr"], loss=cfg["loss"], hidden_layers=cfg.get("hidden_layers", 1),
     )
     model = MODELS[cfg["model"]](args, config=None, datastore=ds)
     if load_weights:

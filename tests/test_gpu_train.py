@@ -150,3 +150,29 @@ def test_validation_and_test_steps_metrics():
     ckpt = {"state_dict": {"g2m_gnn.grid_mlp.0.weight": torch.zeros(1), "x": torch.zeros(1)}}
     model.on_load_checkpoint(ckpt)
     assert set(ckpt["state_dict"]) == {"encoding_grid_mlp.0.weight", "x"}
+
+
+def test_output_std_head_and_nll_vs_reference_fixture():
+    """output_std branch (base_graph_model.py:161-177) + nll training loss (metrics.py:166-190,
+    ar_model.py:294-298) as HIP kernels vs the fixture computed with the reference's
+    metrics.nll (tests/golden/make_golden.py: make_output_std_case)."""
+    import os
+
+    from conftest import GOLDEN
+    from neural_lam_amd import glue
+
+    fx = torch.load(os.path.join(GOLDEN, "aux_output_std.pt"), weights_only=False)
+    x = fx["net_out"].cuda().requires_grad_(True)
+    prev, target = fx["prev"].cuda(), fx["target"].cuda()
+    state, std = glue.StdHead.apply(prev, x, fx["diff_std"].cuda(), fx["diff_mean"].cuda())
+    keep = fx["interior"].float().cuda()
+    lead = state.numel() // (state.shape[-1] * state.shape[-2])
+    loss = glue.MaskedNLL.apply(state, target, std, keep, 1.0 / (float(keep.sum()) * lead))
+    loss.backward()
+
+    def rel(a, b):
+        return float((a.detach().cpu() - b).abs().max() / (b.abs().max() + 1e-30))
+
+    assert rel(state, fx["state"]) < 1e-6 and rel(std, fx["pred_std"]) < 1e-6
+    assert abs(float(loss) - fx["loss"]) < 1e-5 * abs(fx["loss"])
+    assert rel(x.grad, fx["grad_net_out"]) < 1e-5

@@ -113,3 +113,19 @@ def test_oracle_vs_live_reference():
         want = net(s, r, e)
         got = orc.interaction_net(sd, "n", ei, s, r, e, aggr=aggr)
         assert relerr(got[0], want[0]) < 1e-6 and relerr(got[1], want[1]) < 1e-6
+
+
+def test_package_nll_and_std_branch_vs_reference_fixture():
+    """metrics.nll of the package (plain torch, also the eval path) and the output_std branch
+    arithmetic against the fixture made with the reference's metrics.nll."""
+    import torch.nn.functional as F
+
+    from neural_lam_amd import metrics
+
+    fx = torch.load(os.path.join(GOLDEN, "aux_output_std.pt"), weights_only=False)
+    delta, raw = fx["net_out"].chunk(2, dim=-1)
+    std = F.softplus(raw)
+    state = fx["prev"] + delta * fx["diff_std"] + fx["diff_mean"]
+    assert torch.allclose(state, fx["state"], rtol=1e-6, atol=1e-6)
+    loss = torch.mean(metrics.nll(state, fx["target"], std, mask=fx["interior"]))
+    assert abs(float(loss) - fx["loss"]) < 1e-6 * abs(fx["loss"])
