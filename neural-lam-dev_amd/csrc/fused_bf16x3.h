@@ -98,6 +98,10 @@ __device__ __forceinline__ void b3_split(const f32x16& x, int r0, bf16x8& hi, bf
     lo[i] = (__bf16)(v - (float)hi[i]);
   }
 }
+__device__ __forceinline__ void b3_hi(const f32x16& x, int r0, bf16x8& hi) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) hi[i] = (__bf16)x[r0 + i];
+}
 __device__ __forceinline__ bf16x8 b3_join(const bf16x4& a, const bf16x4& b) {
   bf16x8 r;
 #pragma unroll
@@ -113,7 +117,9 @@ __device__ __forceinline__ bf16x8 b3_row_frag(const __bf16* __restrict__ plane, 
 #define B3_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
 
 // out[nb] += W[rows 32 nb .. +31][cols k0 + 32 KB features] . IN, IN in accumulator layout.
-template <int NB, int KB>
+// TERMS = 3: split-bf16 (hi hi + hi lo + lo hi); TERMS = 1: plain bf16 products (hi hi only, the
+// "bf16" arithmetic mode: bf16 operands, fp32 accumulate -- the lo planes are never read).
+template <int NB, int KB, int TERMS = 3>
 __device__ __forceinline__ void gemm_acc_b3(f32x16 (&out)[NB], const B3Image& W, int kb0,
                                             const f32x16 (&in)[KB], int lane) {
   const int t = lane & 31, h = lane >> 5;
@@ -122,14 +128,17 @@ __device__ __forceinline__ void gemm_acc_b3(f32x16 (&out)[NB], const B3Image& W,
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       bf16x8 bh, bl;
-      b3_split(in[kb], 8 * s, bh, bl);
+      if constexpr (TERMS == 3) b3_split(in[kb], 8 * s, bh, bl);
+      else b3_hi(in[kb], 8 * s, bh);
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
         const bf16x8 ah = b3_row_frag(W.hi, W.pitch, 32 * nb + t, kb0 + kb, s, h);
-        const bf16x8 al = b3_row_frag(W.lo, W.pitch, 32 * nb + t, kb0 + kb, s, h);
         out[nb] = B3_MFMA(ah, bh, out[nb]);
-        out[nb] = B3_MFMA(ah, bl, out[nb]);
-        out[nb] = B3_MFMA(al, bh, out[nb]);
+        if constexpr (TERMS == 3) {
+          const bf16x8 al = b3_row_frag(W.lo, W.pitch, 32 * nb + t, kb0 + kb, s, h);
+          out[nb] = B3_MFMA(ah, bl, out[nb]);
+          out[nb] = B3_MFMA(al, bh, out[nb]);
+        }
       }
     }
   }
@@ -164,7 +173,7 @@ __device__ __forceinline__ bf16x8 b3_tr_frag_rows(const __bf16* __restrict__ pla
 
 // out[kb] += W[rows 32 NB][cols 32 (kb0 + kb) ..]^T . G   (gx = W^T gy), G in accumulator
 // layout; the same image as gemm_acc_b3, read transposed.
-template <int KBO, int NB>
+template <int KBO, int NB, int TERMS = 3>
 __device__ __forceinline__ void gemm_acc_wt_b3(f32x16 (&out)[KBO], const B3Image& W, int kb0,
                                                const f32x16 (&g)[NB], int lane) {
 #pragma unroll
@@ -172,14 +181,17 @@ __device__ __forceinline__ void gemm_acc_wt_b3(f32x16 (&out)[KBO], const B3Image
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       bf16x8 bh, bl;
-      b3_split(g[nb], 8 * s, bh, bl);
+      if constexpr (TERMS == 3) b3_split(g[nb], 8 * s, bh, bl);
+      else b3_hi(g[nb], 8 * s, bh);
 #pragma unroll
       for (int kb = 0; kb < KBO; ++kb) {
         const bf16x8 ah = b3_tr_frag(W.hi, W.pitch, 32 * nb + 16 * s, 32 * (kb0 + kb), lane);
-        const bf16x8 al = b3_tr_frag(W.lo, W.pitch, 32 * nb + 16 * s, 32 * (kb0 + kb), lane);
         out[kb] = B3_MFMA(ah, bh, out[kb]);
-        out[kb] = B3_MFMA(ah, bl, out[kb]);
-        out[kb] = B3_MFMA(al, bh, out[kb]);
+        if constexpr (TERMS == 3) {
+          const bf16x8 al = b3_tr_frag(W.lo, W.pitch, 32 * nb + 16 * s, 32 * (kb0 + kb), lane);
+          out[kb] = B3_MFMA(ah, bl, out[kb]);
+          out[kb] = B3_MFMA(al, bh, out[kb]);
+        }
       }
     }
   }
@@ -245,7 +257,7 @@ __device__ __forceinline__ void put_rows_v_b3(const B3Tile& T, int col0, int wid
 // out[nb] += W[rows 32 nb ..][cols 32 (kb0 + kb) ..] . X^T with X a bf16-plane row tile: the
 // B fragments are plain 8-byte row reads of the planes (no register transpose, no
 // conversion: the rows were split when they were staged).
-template <int NB, int KB>
+template <int NB, int KB, int TERMS = 3>
 __device__ __forceinline__ void gemm_tile_b3(f32x16 (&out)[NB], const B3Image& W, int kb0,
                                              const B3Tile& X, int xcol0, int lane) {
   const int t = lane & 31, h = lane >> 5;
@@ -256,15 +268,19 @@ __device__ __forceinline__ void gemm_tile_b3(f32x16 (&out)[NB], const B3Image& W
       const int xo = t * X.pitch + xcol0 + 32 * kb + 16 * s + 4 * h;
       const bf16x8 bh = b3_join(*reinterpret_cast<const bf16x4*>(X.hi + xo),
                                 *reinterpret_cast<const bf16x4*>(X.hi + xo + 8));
-      const bf16x8 bl = b3_join(*reinterpret_cast<const bf16x4*>(X.lo + xo),
-                                *reinterpret_cast<const bf16x4*>(X.lo + xo + 8));
+      bf16x8 bl;
+      if constexpr (TERMS == 3)
+        bl = b3_join(*reinterpret_cast<const bf16x4*>(X.lo + xo),
+                     *reinterpret_cast<const bf16x4*>(X.lo + xo + 8));
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
         const bf16x8 ah = b3_row_frag(W.hi, W.pitch, 32 * nb + t, kb0 + kb, s, h);
-        const bf16x8 al = b3_row_frag(W.lo, W.pitch, 32 * nb + t, kb0 + kb, s, h);
         out[nb] = B3_MFMA(ah, bh, out[nb]);
-        out[nb] = B3_MFMA(ah, bl, out[nb]);
-        out[nb] = B3_MFMA(al, bh, out[nb]);
+        if constexpr (TERMS == 3) {
+          const bf16x8 al = b3_row_frag(W.lo, W.pitch, 32 * nb + t, kb0 + kb, s, h);
+          out[nb] = B3_MFMA(ah, bl, out[nb]);
+          out[nb] = B3_MFMA(al, bh, out[nb]);
+        }
       }
     }
   }
@@ -276,7 +292,7 @@ __device__ __forceinline__ void gemm_tile_b3(f32x16 (&out)[NB], const B3Image& W
 // fragments, 2 MFMAs per 32-column block and K step.  Every row of the 32x32 result block
 // holds the column sums; rows >= nrows of the planes must be zero.  Replaces a 32-step LDS
 // loop (2^-18 relative error per element from the hi/lo split).
-template <int NV>
+template <int NV, int TERMS = 3>
 __device__ __forceinline__ void tile_colsum_b3(float (&acc)[NV], const B3Tile& X, int xcol0,
                                                int lane) {
   bf16x8 ones;
@@ -293,9 +309,11 @@ __device__ __forceinline__ void tile_colsum_b3(float (&acc)[NV], const B3Tile& X
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const bf16x8 bh = b3_tr_frag_rows(X.hi, X.pitch, 16 * u, xcol0 + 64 * j + 32 * blk, lane);
-        const bf16x8 bl = b3_tr_frag_rows(X.lo, X.pitch, 16 * u, xcol0 + 64 * j + 32 * blk, lane);
         c = B3_MFMA(ones, bh, c);
-        c = B3_MFMA(ones, bl, c);
+        if constexpr (TERMS == 3) {
+          const bf16x8 bl = b3_tr_frag_rows(X.lo, X.pitch, 16 * u, xcol0 + 64 * j + 32 * blk, lane);
+          c = B3_MFMA(ones, bl, c);
+        }
       }
       v[blk] = c[0];
     }
@@ -305,7 +323,7 @@ __device__ __forceinline__ void tile_colsum_b3(float (&acc)[NV], const B3Tile& X
 
 // dW[ib][jb] += sum_t G[t][gcol0 + 32 ib + .] (x) X[t][xcol0 + 32 jb + .] over the 32 tile
 // rows; G and X are bf16-plane tiles.  Result block layout as outer_accum (fused_common.h).
-template <int NI, int NJ>
+template <int NI, int NJ, int TERMS = 3>
 __device__ __forceinline__ void outer_accum_b3(f32x16 (&dW)[NI][NJ], const B3Tile& G, int gcol0,
                                                const B3Tile& X, int xcol0, int lane) {
 #pragma unroll
@@ -314,17 +332,22 @@ __device__ __forceinline__ void outer_accum_b3(f32x16 (&dW)[NI][NJ], const B3Til
 #pragma unroll
     for (int ib = 0; ib < NI; ++ib) {
       ah[ib] = b3_tr_frag_rows(G.hi, G.pitch, 16 * u, gcol0 + 32 * ib, lane);
-      al[ib] = b3_tr_frag_rows(G.lo, G.pitch, 16 * u, gcol0 + 32 * ib, lane);
+      if constexpr (TERMS == 3)
+        al[ib] = b3_tr_frag_rows(G.lo, G.pitch, 16 * u, gcol0 + 32 * ib, lane);
     }
 #pragma unroll
     for (int jb = 0; jb < NJ; ++jb) {
       const bf16x8 bh = b3_tr_frag_rows(X.hi, X.pitch, 16 * u, xcol0 + 32 * jb, lane);
-      const bf16x8 bl = b3_tr_frag_rows(X.lo, X.pitch, 16 * u, xcol0 + 32 * jb, lane);
+      bf16x8 bl;
+      if constexpr (TERMS == 3)
+        bl = b3_tr_frag_rows(X.lo, X.pitch, 16 * u, xcol0 + 32 * jb, lane);
 #pragma unroll
       for (int ib = 0; ib < NI; ++ib) {
         dW[ib][jb] = B3_MFMA(ah[ib], bh, dW[ib][jb]);
-        dW[ib][jb] = B3_MFMA(ah[ib], bl, dW[ib][jb]);
-        dW[ib][jb] = B3_MFMA(al[ib], bh, dW[ib][jb]);
+        if constexpr (TERMS == 3) {
+          dW[ib][jb] = B3_MFMA(ah[ib], bl, dW[ib][jb]);
+          dW[ib][jb] = B3_MFMA(al[ib], bh, dW[ib][jb]);
+        }
       }
     }
   }
@@ -332,7 +355,7 @@ __device__ __forceinline__ void outer_accum_b3(f32x16 (&dW)[NI][NJ], const B3Til
 
 // out[kb] += W[rows 32 NB][cols 32 (kb0 + kb) ..]^T . G with G a bf16-plane row tile
 // (gx = W^T gy straight from the staged planes: no register copy of gy at all).
-template <int KBO, int NB>
+template <int KBO, int NB, int TERMS = 3>
 __device__ __forceinline__ void gemm_tile_wt_b3(f32x16 (&out)[KBO], const B3Image& W, int kb0,
                                                 const B3Tile& G, int gcol0, int lane) {
   const int t = lane & 31, h = lane >> 5;
@@ -343,15 +366,19 @@ __device__ __forceinline__ void gemm_tile_wt_b3(f32x16 (&out)[KBO], const B3Imag
       const int go = t * G.pitch + gcol0 + 32 * nb + 16 * s + 4 * h;
       const bf16x8 bh = b3_join(*reinterpret_cast<const bf16x4*>(G.hi + go),
                                 *reinterpret_cast<const bf16x4*>(G.hi + go + 8));
-      const bf16x8 bl = b3_join(*reinterpret_cast<const bf16x4*>(G.lo + go),
-                                *reinterpret_cast<const bf16x4*>(G.lo + go + 8));
+      bf16x8 bl;
+      if constexpr (TERMS == 3)
+        bl = b3_join(*reinterpret_cast<const bf16x4*>(G.lo + go),
+                     *reinterpret_cast<const bf16x4*>(G.lo + go + 8));
 #pragma unroll
       for (int kb = 0; kb < KBO; ++kb) {
         const bf16x8 ah = b3_tr_frag(W.hi, W.pitch, 32 * nb + 16 * s, 32 * (kb0 + kb), lane);
-        const bf16x8 al = b3_tr_frag(W.lo, W.pitch, 32 * nb + 16 * s, 32 * (kb0 + kb), lane);
         out[kb] = B3_MFMA(ah, bh, out[kb]);
-        out[kb] = B3_MFMA(ah, bl, out[kb]);
-        out[kb] = B3_MFMA(al, bh, out[kb]);
+        if constexpr (TERMS == 3) {
+          const bf16x8 al = b3_tr_frag(W.lo, W.pitch, 32 * nb + 16 * s, 32 * (kb0 + kb), lane);
+          out[kb] = B3_MFMA(ah, bl, out[kb]);
+          out[kb] = B3_MFMA(al, bh, out[kb]);
+        }
       }
     }
   }

@@ -21,6 +21,9 @@ hierarchical, mesh_{up,down}_{edge_index,features}.pt  (create_graph.py:84-107).
 
 Edge *order* inside a file is sender-major here; the reference's order is
 networkx' adjacency order.  Consumers must treat edge_index as given.
+Pinned against the reference tool itself: tests/golden/make_graph_golden.py runs
+create_graph.py from /root/reference and tests/test_host_logic.py compares edge sets,
+edge features and mesh features of four grids (incl. equidistant-neighbour ties).
 """
 import os
 
@@ -78,7 +81,9 @@ def _ei(send, rec):
 def create_graph(graph_dir, xy, n_max_levels=None, hierarchical=False):
     """Write a graph directory for grid coordinates ``xy`` (nx, ny, 2).
     Returns a dict of sizes."""
-    from scipy.spatial import cKDTree
+    # the reference's class (create_graph.py:299,445,493): scipy.spatial.KDTree defaults to
+    # leafsize 10, cKDTree to 16, and equidistant 4th neighbours are resolved by tree order
+    from scipy.spatial import KDTree as cKDTree
 
     os.makedirs(graph_dir, exist_ok=True)
     nx_ref = 3
@@ -116,7 +121,8 @@ def create_graph(graph_dir, xy, n_max_levels=None, hierarchical=False):
         torch.save(down_ei, os.path.join(graph_dir, "mesh_down_edge_index.pt"))
         torch.save(up_f, os.path.join(graph_dir, "mesh_up_features.pt"))
         torch.save(down_f, os.path.join(graph_dir, "mesh_down_features.pt"))
-        mesh_pos = [torch.from_numpy(p / pos_max).to(torch.float32) for p in level_pos]
+        mesh_pos = [torch.from_numpy(p).to(torch.float32) / torch.tensor(pos_max)
+                    for p in level_pos]
         num_mesh_total = int(sum(sizes))
         info["m2m_edges"] = [int(e.shape[1]) for e in m2m_ei]
         info["updown_edges"] = [int(e.shape[1]) for e in up_ei]
@@ -135,12 +141,23 @@ def create_graph(graph_dir, xy, n_max_levels=None, hierarchical=False):
 
             send_all.append(to_fine(s))
             rec_all.append(to_fine(r))
+            if lev > 0:
+                # networkx.compose (create_graph.py:386) lets the coarser level's node
+                # attributes overwrite the finer ones: a merged node carries the position of
+                # the COARSEST level it belongs to (equal up to rounding, which decides
+                # equidistant-neighbour ties and the last bits of g2m / m2g features)
+                merged_pos = level_pos[0] if lev == 1 else merged_pos
+                merged_pos = merged_pos.copy()
+                merged_pos[to_fine(np.arange(n * n))] = pos
         send, rec = np.concatenate(send_all), np.concatenate(rec_all)
         feat = torch.cat(feat_all, dim=0)
         order = np.argsort(send, kind="stable")
         m2m_ei = [_ei(send[order], rec[order])]
         m2m_f = [feat[torch.from_numpy(order)]]
-        mesh_pos = [torch.from_numpy(level_pos[0] / pos_max).to(torch.float32)]
+        if len(sides) > 1:
+            level_pos[0] = merged_pos
+        # float32 positions divided in float32 (create_graph.py:400,410)
+        mesh_pos = [torch.from_numpy(level_pos[0]).to(torch.float32) / torch.tensor(pos_max)]
         num_mesh_total = n0 * n0
         info["m2m_edges"] = [int(m2m_ei[0].shape[1])]
     torch.save(m2m_ei, os.path.join(graph_dir, "m2m_edge_index.pt"))
@@ -152,7 +169,9 @@ def create_graph(graph_dir, xy, n_max_levels=None, hierarchical=False):
     grid_pos = xy.transpose(1, 0, 2).reshape(Ny * Nx, 2)
     bottom = level_pos[0]
     n0 = sides[0]
-    dm = np.sqrt(((bottom[1] - bottom[0]) ** 2).sum())  # nodes (0,1) and (0,0)
+    # create_graph.py:428-433: distance between bottom-level nodes (0, 1, 0) and (0, 0, 0),
+    # i.e. the spacing along the FIRST lattice index (x); node id = i * n0 + j
+    dm = np.sqrt(((bottom[n0] - bottom[0]) ** 2).sum())
 
     gtree = cKDTree(grid_pos)
     neigh = gtree.query_ball_point(bottom, dm * 0.67)

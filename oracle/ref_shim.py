@@ -114,6 +114,78 @@ def _mod(name, **attrs):
     return m
 
 
+class _Data:
+    """Attribute bag standing in for torch_geometric.data.Data (only what create_graph.py
+    touches: attribute access, assignment, clone())."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+    def clone(self):
+        return _Data(**{k: (v.clone() if torch.is_tensor(v) else v) for k, v in self.__dict__.items()})
+
+
+def _from_networkx(G):
+    """torch_geometric.utils.convert.from_networkx of torch-geometric 2.3.1, restated: nodes
+    are numbered in G.nodes() order, edges listed in G.edges() order, node / edge attributes
+    collected per key in that order and turned into tensors (torch.stack for tensors,
+    torch.tensor otherwise: numpy float64 attributes give float64 tensors)."""
+    import networkx as nx
+    from collections import defaultdict
+
+    G = G.to_directed() if not nx.is_directed(G) else G
+    mapping = dict(zip(G.nodes(), range(G.number_of_nodes())))
+    edge_index = torch.empty((2, G.number_of_edges()), dtype=torch.long)
+    for i, (src, dst) in enumerate(G.edges()):
+        edge_index[0, i] = mapping[src]
+        edge_index[1, i] = mapping[dst]
+    data = defaultdict(list)
+    node_attrs = list(next(iter(G.nodes(data=True)))[-1].keys()) if G.number_of_nodes() else []
+    for _, feat in G.nodes(data=True):
+        if set(feat.keys()) != set(node_attrs):
+            raise ValueError("Not all nodes contain the same attributes")
+        for k, v in feat.items():
+            data[str(k)].append(v)
+    edge_attrs = list(next(iter(G.edges(data=True)))[-1].keys()) if G.number_of_edges() else []
+    for _, _, feat in G.edges(data=True):
+        if set(feat.keys()) != set(edge_attrs):
+            raise ValueError("Not all edges contain the same attributes")
+        for k, v in feat.items():
+            k = f"edge_{k}" if k in node_attrs else k
+            data[str(k)].append(v)
+    out = {}
+    for k, v in data.items():
+        if isinstance(v, (tuple, list)) and torch.is_tensor(v[0]):
+            out[k] = torch.stack(v, dim=0)
+        else:
+            import numpy as np
+
+            out[k] = torch.tensor(np.asarray(v))
+    out["edge_index"] = edge_index.view(2, -1)
+    d = _Data(**out)
+    d.num_nodes = G.number_of_nodes()
+    return d
+
+
+def load_create_graph():
+    """The reference's graph-creation tool (neural_lam/create_graph.py) under stand-ins for
+    torch_geometric (from_networkx restated above; the pyg.utils calls are plot-only) and the
+    config / datastore modules its CLI wrapper imports.  Returns the module."""
+    load()
+    utils_mod = _mod("torch_geometric.utils")
+    conv = _mod("torch_geometric.utils.convert", from_networkx=_from_networkx)
+    utils_mod.convert = conv
+    sys.modules["torch_geometric"].utils = utils_mod
+    sys.modules["neural_lam.config"].load_config_and_datastore = None
+    base = _mod("neural_lam.datastore.base", BaseRegularGridDatastore=object)
+    sys.modules["neural_lam.datastore"].base = base
+    sys.modules["neural_lam.datastore"].__path__ = []
+    import matplotlib
+
+    matplotlib.use("Agg")
+    return importlib.import_module("neural_lam.create_graph")
+
+
 _loaded = None
 
 

@@ -126,3 +126,49 @@ def test_eval_metrics_match_reference_and_closed_forms():
                 a = M.get_metric(name)(pred, target, std_full, **kw)
                 b = ref.get_metric(name)(pred, target, std_full, **kw)
                 assert torch.allclose(a, b, rtol=1e-5, atol=1e-6), (name, kw)
+
+
+GRAPH_FIXTURES = sorted(__import__("glob").glob(os.path.join(GOLDEN, "graph_*.pt")))
+
+
+@pytest.mark.parametrize("path", GRAPH_FIXTURES, ids=[os.path.basename(p)[:-3] for p in GRAPH_FIXTURES])
+def test_graphgen_matches_reference_create_graph(path):
+    """graphgen.py against the REFERENCE's own create_graph.py (fixtures written by
+    tests/golden/make_graph_golden.py from /root/reference): identical edge sets, bit-identical
+    per-edge features and mesh node features, for flat and hierarchical graphs incl. a
+    non-square grid with equidistant-neighbour ties (create_graph.py:157-535)."""
+    import tempfile
+
+    from neural_lam_amd import graphgen
+
+    fx = torch.load(path, weights_only=False)
+    nx, ny, sp, nml, hier = fx["case"]
+    ref = fx["graph"]
+
+    def canon(ei, ft):
+        ei = ei.to(torch.int64)
+        order = torch.argsort(ei[0] * (int(ei.max()) + 1) + ei[1])
+        return ei[:, order].to(torch.int32), ft[order].to(torch.float32)
+
+    with tempfile.TemporaryDirectory() as tmp:
+        graphgen.create_graph(tmp, graphgen.make_xy(nx, ny, sp), nml, hier)
+        for name, want in ref.items():
+            if name == "mesh_features":
+                got = torch.load(os.path.join(tmp, "mesh_features.pt"), weights_only=False)
+                assert len(got) == len(want)
+                for a, b in zip(got, want):
+                    assert torch.equal(a, b)
+                continue
+            ei = torch.load(os.path.join(tmp, f"{name}_edge_index.pt"), weights_only=False)
+            ft = torch.load(os.path.join(tmp, f"{name}_features.pt"), weights_only=False)
+            if isinstance(want["edge_index"], list):
+                assert len(ei) == len(want["edge_index"])
+                pairs = zip(ei, ft, want["edge_index"], want["features"])
+            else:
+                pairs = [(ei, ft, want["edge_index"], want["features"])]
+            for a, fa, b, fb in pairs:
+                ca, cfa = canon(a, fa)
+                assert torch.equal(ca, b), name
+                assert torch.equal(cfa, fb), name
+        if not hier:
+            assert not os.path.exists(os.path.join(tmp, "mesh_up_edge_index.pt"))
