@@ -37,7 +37,7 @@ int nlam_abi_version(void);
  * 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = split-bf16 ("bf16x3": every fp32 operand
  * as bf16 hi + lo, three v_mfma_f32_32x32x16_bf16 products, fp32 accumulate; ~2^-16
  * relative error per product, tighter than the TF32 of train_model.py:246-248). */
-int nlam_mfma_mode(void);
+int nlam_mfma_mode(void);   /* 0 = fp32, 1 = bf16x3 (default), 2 = bf16 (NLAM_MFMA) */
 
 /* ---------------------------------------------------------------- graph --
  * Host-side preprocessing, run once per InteractionNet at construction.
@@ -332,6 +332,63 @@ int nlam_wmse_fwd(const float* pred, const float* target, const float* keep,
 int nlam_wmse_bwd(const float* pred, const float* target, const float* keep,
                   const float* w, const float* gloss, float scale, float* g_pred,
                   int64_t rows, int64_t N, int F, void* stream);
+
+/* ---- hidden_dim 128 ("wide") path: one weight matrix per kernel (csrc/fused_wide.hip) -------
+ * The same reference operators as above -- make_mlp blocks (utils.py:191-214) and the
+ * InteractionNet message / aggregate / update (interaction_net.py:86-131) -- cut at the Linear
+ * boundaries, because two split-bf16 128 x 128 weight images do not fit the 160 KB LDS.
+ * Requires NLAM_MFMA=bf16x3 (default) or bf16.  Index arrays are int32; NULL = identity.
+ *
+ * nlam_tail_fwd: for every position p (< rows; tile k covers positions [32 k, 32 k + 32) in
+ * row mode, or tiles[k] = (p0, p1, r0, r1) in edge mode -- the receiver-aligned tiles of
+ * nlam_graph_tiles_host over receiver-sorted positions):
+ *   h[p]  = a[idx_a[p]] + b[idx_b[p]] + c[idx_c[p]]            (b, c optional; width d)
+ *   m[p]  = [LayerNorm](W2 silu(h[p]) + b2)                     (W2: n_out x d)
+ *   h_out[p] = h[p]                       (optional; (B, rows, d) contiguous rows, kept for backward)
+ *   y[idx_y[p]] = m[p] (+ res[idx_y[p]])  (optional)
+ *   agg[i] = inv_deg[i] * sum_{p: csr_rec[p] = i} m[p]          (optional, edge mode)
+ * i.e. edge_mlp / aggr_mlp / embedder blocks after their first Linear (nlam_lin_fwd). */
+int nlam_tail_fwd(const int32_t* tiles, int64_t ntiles, int64_t rows, const int32_t* csr_rec,
+                  const int32_t* csr_rowptr,
+                  const float* a, int64_t a_bstride, int64_t a_ld, const int32_t* idx_a,
+                  const float* b, int64_t b_bstride, int64_t b_ld, const int32_t* idx_b,
+                  const float* c, int64_t c_bstride, int64_t c_ld, const int32_t* idx_c,
+                  const float* W2, int64_t ldW2, const float* b2, const float* gamma,
+                  const float* beta, int n_out, float* h_out, int64_t h_bstride,
+                  float* y, int64_t y_bstride, int64_t y_ld, const int32_t* idx_y,
+                  const float* res, int64_t res_bstride, int64_t res_ld,
+                  float* agg, int64_t agg_bstride, int64_t agg_ld, const float* inv_deg,
+                  int64_t B, int d, void* stream);
+/* Backward of nlam_tail_fwd from the kept h:  g[p] = scale1[idx_g1[p]] * g1[idx_g1[p]] +
+ * g2[idx_g2[p]] is the gradient of m[p];  gz = LN'(z; g) (= g without LayerNorm) is written to
+ * gz_out (B, rows, ceil32(n_out)) for the weight-gradient pass;  gh[idx_gh[p]] =
+ * (W2^T gz[p]) * silu'(h[p]);  gpr[i] = sum_{p: csr_rec[p] = i} gh[p] (optional, edge mode);
+ * dgamma / dbeta as per-workgroup slabs [dgamma | dbeta] (count nlam_bwd_grid(B * ntiles),
+ * pitch >= nlam_tail_bwd_slab_stride).  dW2 = gz^T silu(h), db2 = colsum(gz): nlam_wide_outer. */
+int64_t nlam_tail_bwd_slab_stride(int n_out);
+int nlam_tail_bwd(const int32_t* tiles, int64_t ntiles, int64_t rows, const int32_t* csr_rec,
+                  const int32_t* csr_rowptr, const float* h, int64_t h_bstride,
+                  const float* g1, int64_t g1_bstride, int64_t g1_ld, const int32_t* idx_g1,
+                  const float* scale1,
+                  const float* g2, int64_t g2_bstride, int64_t g2_ld, const int32_t* idx_g2,
+                  const float* W2, int64_t ldW2, const float* b2, const float* gamma, int n_out,
+                  float* gz_out, int64_t gz_bstride,
+                  float* gh, int64_t gh_bstride, int64_t gh_ld, const int32_t* idx_gh,
+                  float* gpr, int64_t gpr_bstride, int64_t gpr_ld,
+                  float* slab, int64_t slab_stride, int64_t B, int d, void* stream);
+/* gx = gy W [+ gx_add]: data gradient of a Linear (W: n_out x k_in = 128 x 128). */
+int nlam_lin_bwd_data(const float* gy, int64_t gy_bstride, int64_t gy_ld, int n_out,
+                      const float* W, int64_t ldW, int k_in,
+                      float* gx, int64_t gx_bstride, int64_t gx_ld,
+                      const float* gx_add, int64_t ga_bstride, int64_t ga_ld,
+                      int64_t B, int64_t rows, void* stream);
+/* Weight gradient of a Linear as a streaming pass:  dW (ng x nx) = sum_rows g[r]^T (x) f(x[r]),
+ * db (ng) = colsum(g), f = silu if silu_x (x is then the kept pre-activation h) else identity;
+ * per-workgroup slabs [dW | db] (count nlam_bwd_grid(B * ceil(rows / 32)), pitch >= ng nx + ng).
+ * ng in {128, 32}, nx = 128. */
+int nlam_wide_outer(const float* g, int64_t g_bstride, int64_t g_ld, int ng,
+                    const float* x, int64_t x_bstride, int64_t x_ld, int nx, int silu_x,
+                    float* slab, int64_t slab_stride, int64_t B, int64_t rows, void* stream);
 
 /* output_std head (reference base_graph_model.py:161-177 with args.output_std): net_out is
  * (rows, 2F); state = prev + net_out[:, :F] * scale + shift, pred_std = softplus(net_out[:, F:])

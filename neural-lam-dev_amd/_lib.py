@@ -67,6 +67,20 @@ SIGNATURES = {
     "nlam_wmse_blocks": [],
     "nlam_wmse_fwd": [_p, _p, _p, _p, _p, _p, _i64, _i64, _i32, _f, _p],
     "nlam_wmse_bwd": [_p, _p, _p, _p, _p, _f, _p, _i64, _i64, _i32, _p],
+    "nlam_tail_fwd": [_p, _i64, _i64, _p, _p,
+                      _p, _i64, _i64, _p, _p, _i64, _i64, _p, _p, _i64, _i64, _p,
+                      _p, _i64, _p, _p, _p, _i32, _p, _i64,
+                      _p, _i64, _i64, _p, _p, _i64, _i64,
+                      _p, _i64, _i64, _p, _i64, _i32, _p],
+    "nlam_tail_bwd_slab_stride": [_i32],
+    "nlam_tail_bwd": [_p, _i64, _i64, _p, _p, _p, _i64,
+                      _p, _i64, _i64, _p, _p, _p, _i64, _i64, _p,
+                      _p, _i64, _p, _p, _i32, _p, _i64,
+                      _p, _i64, _i64, _p, _p, _i64, _i64,
+                      _p, _i64, _i64, _i32, _p],
+    "nlam_lin_bwd_data": [_p, _i64, _i64, _i32, _p, _i64, _i32, _p, _i64, _i64, _p, _i64, _i64,
+                          _i64, _i64, _p],
+    "nlam_wide_outer": [_p, _i64, _i64, _i32, _p, _i64, _i64, _i32, _i32, _p, _i64, _i64, _i64, _p],
     "nlam_std_head_fwd": [_p, _p, _p, _p, _p, _p, _i64, _i32, _p],
     "nlam_std_head_bwd": [_p, _p, _p, _p, _p, _i64, _i32, _p],
     "nlam_nll_fwd": [_p, _p, _p, _p, _p, _p, _i64, _i64, _i32, _f, _p],
@@ -86,6 +100,7 @@ _RESTYPES = {
     "nlam_wmse_blocks": _i64,
     "nlam_mlp_bwd_slab_stride": _i64,
     "nlam_outer_bwd_slab_stride": _i64,
+    "nlam_tail_bwd_slab_stride": _i64,
 }
 
 

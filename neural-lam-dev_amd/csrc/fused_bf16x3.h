@@ -140,6 +140,9 @@ __device__ __forceinline__ void gemm_acc_b3(f32x16 (&out)[NB], const B3Image& W,
           out[nb] = B3_MFMA(al, bh, out[nb]);
         }
       }
+      // wide shapes: keep the scheduler from hoisting every fragment read of the unrolled
+      // product to the front (16 x 2 x 8 registers at d = 128: spills)
+      if constexpr (NB * KB >= 8) __builtin_amdgcn_sched_barrier(0);
     }
   }
 }
@@ -193,6 +196,7 @@ __device__ __forceinline__ void gemm_acc_wt_b3(f32x16 (&out)[KBO], const B3Image
           out[kb] = B3_MFMA(al, bh, out[kb]);
         }
       }
+      if constexpr (NB * KBO >= 8) __builtin_amdgcn_sched_barrier(0);
     }
   }
 }

@@ -289,8 +289,8 @@ __global__ __launch_bounds__(256, 2) void lin_fwd_kernel(LinParams p) {
 }
 
 // Split-bf16 form of the projection (fused_bf16x3.h): k_in % 32 == 0, float4 views.
-template <int NOUTB, int KB>
-__global__ __launch_bounds__(256, 2) void lin_fwd_b3_kernel(LinParams p) {
+template <int NOUTB, int KB, int TERMS = 3, int MINW = 2>
+__global__ __launch_bounds__(256, MINW) void lin_fwd_b3_kernel(LinParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int K = 32 * KB, NO = 32 * NOUTB;
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256, 2) void lin_fwd_b3_kernel(LinParams p) {
     wave_sync();
     f32x16 a[NOUTB];
     vec_to_acc<NOUTB>(a, bs, lane);
-    gemm_tile_b3<NOUTB, KB>(a, W, 0, Xp, 0, lane);
+    gemm_tile_b3<NOUTB, KB, TERMS>(a, W, 0, Xp, 0, lane);
     wave_sync();
     acc_to_tile<NOUTB>(a, tile, ldt, lane);
     wave_sync();
@@ -330,12 +330,13 @@ __global__ __launch_bounds__(256, 2) void lin_fwd_b3_kernel(LinParams p) {
   }
 }
 
-template <int NOUTB, int KB>
+template <int NOUTB, int KB, int TERMS = 3, int MINW = 2>
 static int launch_lin_fwd_b3(const LinParams& p, hipStream_t s) {
   constexpr int K = 32 * KB, NO = 32 * NOUTB;
   constexpr int ldt = (K > NO ? K : NO) + 4;
   const size_t lds = b3_image_bytes(NO, K) + NO * 4 + (size_t)4 * NLAM_TILE * ldt * 4;
-  auto kern = lin_fwd_b3_kernel<NOUTB, KB>;
+  NLAM_REQUIRE(lds <= 160 * 1024, "lin_fwd_b3: LDS footprint %zu B exceeds 160 KiB", lds);
+  auto kern = lin_fwd_b3_kernel<NOUTB, KB, TERMS, MINW>;
   NLAM_BIG_LDS(kern, __func__);
   const int64_t ntiles = ((p.rows + NLAM_TILE - 1) / NLAM_TILE) * p.B;
   kern<<<persistent_grid(ntiles, lds), 256, lds, s>>>(p);
@@ -383,6 +384,11 @@ extern "C" int nlam_lin_fwd(const float* x, int64_t x_bstride, int64_t x_ld, int
     if ((p.nA + p.nB) == 64) return launch_lin_fwd_b3<2, 2>(p, s);
     if ((p.nA + p.nB) == 128) return launch_lin_fwd_b3<4, 2>(p, s);
   }
+  // hidden 128 (fused_wide.hip): one 128 x 128 image, one wave per SIMD
+  if (nlam_mfma_terms() != 0 && k_in == 128 && (p.nA + p.nB) == 128 && (p.vec_mask & 1) &&
+      (p.vec_mask & 8))
+    return nlam_mfma_terms() == 3 ? launch_lin_fwd_b3<4, 4, 3, 1>(p, s)
+                                  : launch_lin_fwd_b3<4, 4, 1, 1>(p, s);
   switch ((p.nA + p.nB) / 32) {
     case 2: return launch_lin_fwd<2>(p, s);
     case 4: return launch_lin_fwd<4>(p, s);

@@ -1,0 +1,796 @@
+// Wide fused kernels (gfx950): the hidden_dim = 128 path of the InteractionNet / make_mlp
+// blocks (reference interaction_net.py:63-131, utils.py:191-214).
+//
+// At d = 128 one split-bf16 weight matrix (two bf16 planes, 67.6 KB) plus one 32-row tile per
+// wave is what fits next to each other in the 160 KB LDS of a CU, and a d x d weight-gradient
+// accumulator (256 registers per lane) is all a wave can hold.  The layer is therefore cut at
+// the Linear boundaries -- ONE weight matrix per kernel -- and every weight gradient is a lean
+// streaming pass of its own:
+//
+//   nlam_lin_fwd        first Linear of every MLP / the three projections of edge_mlp.0
+//   nlam_tail_fwd       h = a + b[idx] + c[idx];  y = [res +] [LN](W2 silu(h) + b2)
+//                       [+ receiver aggregation over receiver-aligned tiles]; keeps h (training)
+//   nlam_tail_bwd       from h and the incoming gradient: gz = LN'(z; g), gh = (W2^T gz) silu'(h)
+//                       [+ receiver-side segment sums of gh], gamma / beta gradients
+//   nlam_lin_bwd_data   gx = gy W [+ gx_add]
+//   nlam_wide_outer     dW = G^T f(X) (f = identity | silu), db = colsum(G)
+//
+// Row-on-lane layout and split-bf16 ("bf16x3") / plain bf16 MFMA arithmetic as in
+// fused_common.h / fused_bf16x3.h (TERMS = 3 | 1).  h is kept by the forward (HBM is 288 GB;
+// the rows are written once, coalesced) so that the backward neither repeats the first GEMM
+// nor gathers; edge rows h / gz live in receiver-sorted (CSR) POSITION order, which is the
+// order the tiles walk, so they are contiguous.
+#include <stdlib.h>
+
+#include "fused_bf16x3.h"
+#include "fused_common.h"
+
+struct WideTiling {
+  const int32_t* tiles;      // edge mode: (ntiles, 4) = p0, p1, r0, r1; NULL = row mode
+  int64_t ntiles;            // tiles per batch item
+  int64_t rows;              // positions per batch item (M, or the row count)
+  const int32_t* csr_rec;    // edge mode: receiver of a position
+  const int32_t* csr_rowptr; // edge mode: n_rec + 1
+};
+
+struct WTile {
+  int p0, ne, r0, nr;        // wave-uniform
+};
+__device__ __forceinline__ WTile wide_tile(const WideTiling& tl, int64_t k) {
+  WTile w;
+  if (tl.tiles != nullptr) {
+    const int4 hdr = reinterpret_cast<const int4*>(tl.tiles)[k];
+    w.p0 = hdr.x; w.ne = hdr.y - hdr.x; w.r0 = hdr.z; w.nr = hdr.w - hdr.z;
+  } else {
+    w.p0 = (int)(k * NLAM_TILE);
+    const int64_t left = tl.rows - (int64_t)w.p0;
+    w.ne = (int)(left < NLAM_TILE ? left : NLAM_TILE);
+    w.r0 = 0; w.nr = 0;
+  }
+  return w;
+}
+// index of tile slot t (lanes 0..31; clamped to the last valid position so every load is legal)
+__device__ __forceinline__ int wide_index(const int32_t* idx, const WTile& w, int lane) {
+  const int t = lane & 31;
+  const int pos = w.p0 + (t < w.ne ? t : w.ne - 1);
+  return idx ? idx[pos] : pos;
+}
+
+// float4 row registers (load_rows_v layout) -> contiguous global rows base + t * ld
+template <int NV>
+__device__ __forceinline__ void store_rows_regs(float* __restrict__ base, int64_t ld, int width,
+                                                int nrows, int lane, const f32x4 (&v)[NV]) {
+  const int lpr = width >> 2;
+  const int rpi = 64 / lpr;
+  const int sub = lane / lpr, c4 = lane - sub * lpr;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int t = sub + k * rpi;
+    if (sub < rpi && t < nrows) reinterpret_cast<f32x4*>(base + (int64_t)t * ld)[c4] = v[k];
+  }
+}
+
+// per-wave fold of accumulator blocks into the slab, ONE block row at a time (the d = 128
+// images of all block rows together would not fit in LDS).  img: 4 * 32 * ldimg floats.
+template <int NI, int NJ>
+__device__ __forceinline__ void fold_block_rows_to_slab(const f32x16 (&dW)[NI][NJ],
+                                                        float* __restrict__ img, int ldimg,
+                                                        float* __restrict__ slab, int tid, int wave,
+                                                        int lane) {
+  const int h = lane >> 5, j = lane & 31;
+  const int n = 32 * ldimg;
+  float* mine = img + wave * n;
+#pragma unroll
+  for (int ib = 0; ib < NI; ++ib) {
+#pragma unroll
+    for (int jb = 0; jb < NJ; ++jb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = 8 * (r >> 2) + 4 * h + (r & 3);
+        mine[i * ldimg + 32 * jb + j] = dW[ib][jb][r];
+      }
+    __syncthreads();
+    for (int i = tid; i < n; i += 256)
+      slab[ib * n + i] = ((img[i] + img[n + i]) + img[2 * n + i]) + img[3 * n + i];
+    __syncthreads();
+  }
+}
+
+// ============================================================== tail forward ===
+struct TailFwdParams {
+  WideTiling tl;
+  RowView a; const int32_t* idx_a;
+  RowView b; const int32_t* idx_b;       // optional (b.ptr == NULL)
+  RowView c; const int32_t* idx_c;       // optional
+  const float* W2; int64_t ldW2; const float* b2; const float* gamma; const float* beta;
+  int n_out;
+  float* h_out; int64_t h_bstride;       // optional: (B, rows, D), pitch D, position order
+  float* y; int64_t y_bstride; int64_t y_ld; const int32_t* idx_y;   // optional row output
+  RowView res;                           // optional residual (rows addressed like y)
+  float* agg; int64_t agg_bstride; int64_t agg_ld; const float* inv_deg;   // optional (edge mode)
+  int B;
+  int vec_y;                             // y / res rows 16-byte aligned, n_out % 4 == 0
+};
+
+template <int D, int NOUTB, bool HAS_LN, int TERMS>
+__global__ __launch_bounds__(256) void tail_fwd_kernel(TailFwdParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NB = D / 32, NV = D / 8, NO = 32 * NOUTB;
+  constexpr int LDT = D + 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* W2s = smem;
+  float* b2s = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + b3_image_bytes(NO, D));
+  float* gs = b2s + NO;
+  float* bs = gs + NO;
+  float* tile = bs + NO + wave * (NLAM_TILE * LDT);
+  const B3Image W2im = b3_image(W2s, NO, D);
+  load_weight_lds_b3(W2im, 0, p.W2, p.ldW2, p.n_out, D, NO, D, tid, 256);
+  load_vec_lds(b2s, p.b2, p.n_out, NO, tid, 256);
+  load_vec_lds(gs, p.gamma, p.n_out, NO, tid, 256);
+  load_vec_lds(bs, p.beta, p.n_out, NO, tid, 256);
+  __syncthreads();
+
+  const int64_t total = p.tl.ntiles * p.B;
+  for (int64_t tt = (int64_t)blockIdx.x * 4 + wave; tt < total; tt += (int64_t)gridDim.x * 4) {
+    const int64_t b = tt / p.tl.ntiles;
+    const WTile w = wide_tile(p.tl, tt - b * p.tl.ntiles);
+    const int ne = w.ne;
+    const int ia = wide_index(p.idx_a, w, lane);
+    const int ib = p.b.ptr ? wide_index(p.idx_b, w, lane) : 0;
+    const int ic = p.c.ptr ? wide_index(p.idx_c, w, lane) : 0;
+    const int iy = wide_index(p.idx_y, w, lane);
+    const int rcv = p.tl.csr_rec ? wide_index(p.tl.csr_rec, w, lane) : 0;
+    const float* ab = p.a.ptr + b * p.a.bstride;
+    auto a_row = [&](int s) { return ab + (int64_t)__shfl(ia, s, 64) * p.a.ld; };
+    f32x4 vA[NV];
+    load_rows_v<NV>(vA, D, lane, a_row);
+    if (p.b.ptr) {
+      const float* bb = p.b.ptr + b * p.b.bstride;
+      auto b_row = [&](int s) { return bb + (int64_t)__shfl(ib, s, 64) * p.b.ld; };
+      f32x4 vB[NV];
+      load_rows_v<NV>(vB, D, lane, b_row);
+      if (p.c.ptr) {
+        const float* cb = p.c.ptr + b * p.c.bstride;
+        auto c_row = [&](int s) { return cb + (int64_t)__shfl(ic, s, 64) * p.c.ld; };
+        f32x4 vC[NV];
+        load_rows_v<NV>(vC, D, lane, c_row);
+#pragma unroll
+        for (int k = 0; k < NV; ++k) vB[k] += vC[k];
+      }
+#pragma unroll
+      for (int k = 0; k < NV; ++k) vA[k] += vB[k];
+    }
+    if (p.h_out != nullptr)
+      store_rows_regs<NV>(p.h_out + b * p.h_bstride + (int64_t)w.p0 * D, D, D, ne, lane, vA);
+    put_rows_v<NV, false>(tile, LDT, 0, D, ne, lane, vA);
+    wave_sync();
+    f32x16 a1[NB];
+    tile_to_acc<NB>(a1, tile, LDT, lane);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a1[nb][r] = nlam_silu(a1[nb][r]);
+    f32x16 m[NOUTB];
+    vec_to_acc<NOUTB>(m, b2s, lane);
+    gemm_acc_b3<NOUTB, NB, TERMS>(m, W2im, 0, a1, lane);
+    if (HAS_LN) ln_apply<NOUTB>(m, gs, bs, lane);
+    wave_sync();
+    acc_to_tile<NOUTB>(m, tile, LDT, lane);
+    wave_sync();
+    if (p.agg != nullptr) {
+      float* aggb = p.agg + b * p.agg_bstride;
+      const int t = lane & 31;
+      // lane i <= nr: segment boundaries of the tile's receivers (edge mode only)
+      const int ri = w.r0 + (lane < w.nr ? lane : w.nr);
+      const int rp = p.tl.csr_rowptr[ri] - w.p0;
+      const float invd = p.inv_deg ? p.inv_deg[w.r0 + (lane < w.nr ? lane : 0)] : 1.0f;
+      const int rpn = __shfl_down(rp, 1, 64);
+      const bool dense = __all((lane >= w.nr) || (rpn > rp));
+      (void)t;
+      if (dense) {
+        tile_segment_sums<NO>(tile, LDT, ne, rcv, lane, [&](int r, int f0, float acc) {
+          const float sc = __shfl(invd, r - w.r0, 64);
+          aggb[(int64_t)r * p.agg_ld + f0 + lane] = acc * sc;
+        });
+      } else {
+        for (int i = 0; i < w.nr; ++i) {
+          const int beg = __shfl(rp, i, 64), end = __shfl(rp, i + 1, 64);
+          const float sc = __shfl(invd, i, 64);
+#pragma unroll
+          for (int f0 = 0; f0 < NO; f0 += 64) {
+            float acc = 0.f;
+            for (int s = beg; s < end; ++s) acc += tile[s * LDT + f0 + lane];
+            aggb[(int64_t)(w.r0 + i) * p.agg_ld + f0 + lane] = acc * sc;
+          }
+        }
+      }
+    }
+    if (p.y != nullptr) {
+      // scattered rows (idx_y) are float4-only (checked on the host): the scalar stores of
+      // narrow outputs then never shuffle inside a partially active loop
+      float* yb = p.y + b * p.y_bstride;
+      auto y_row = [&](int s) {
+        return yb + (int64_t)(p.idx_y ? __shfl(iy, s, 64) : w.p0 + s) * p.y_ld;
+      };
+      if (p.res.ptr != nullptr) {
+        const float* rb = p.res.ptr + b * p.res.bstride;
+        auto r_row = [&](int s) {
+          return rb + (int64_t)(p.idx_y ? __shfl(iy, s, 64) : w.p0 + s) * p.res.ld;
+        };
+        if (p.vec_y) store_rows_res<true>(tile, LDT, 0, p.n_out, ne, lane, y_row, r_row);
+        else store_rows_res<false>(tile, LDT, 0, p.n_out, ne, lane, y_row, r_row);
+      } else {
+        if (p.vec_y) store_rows<true>(tile, LDT, 0, p.n_out, ne, lane, y_row);
+        else store_rows<false>(tile, LDT, 0, p.n_out, ne, lane, y_row);
+      }
+    }
+    wave_sync();
+  }
+}
+
+static unsigned wide_grid(int64_t total_tiles) {
+  int64_t g = (total_tiles + 3) / 4;
+  if (g > 256) g = 256;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+template <int D, int NOUTB, bool HAS_LN, int TERMS>
+static int launch_tail_fwd(const TailFwdParams& p, hipStream_t s) {
+  const size_t lds = b3_image_bytes(32 * NOUTB, D) + (size_t)3 * 32 * NOUTB * sizeof(float) +
+                     (size_t)4 * NLAM_TILE * (D + 4) * sizeof(float);
+  NLAM_REQUIRE(lds <= 160 * 1024, "tail_fwd: LDS footprint %zu B exceeds 160 KiB", lds);
+  auto kern = tail_fwd_kernel<D, NOUTB, HAS_LN, TERMS>;
+  NLAM_BIG_LDS(kern, "tail_fwd_kernel");
+  kern<<<wide_grid(p.tl.ntiles * p.B), 256, lds, s>>>(p);
+  NLAM_CHECK_LAUNCH("tail_fwd_kernel");
+  return 0;
+}
+
+static bool wide_view_ok(const float* ptr, int64_t bstride, int64_t ld, int d) {
+  return view_vec_ok(ptr, bstride, ld, d);
+}
+
+extern "C" int nlam_tail_fwd(
+    const int32_t* tiles, int64_t ntiles, int64_t rows, const int32_t* csr_rec,
+    const int32_t* csr_rowptr,
+    const float* a, int64_t a_bstride, int64_t a_ld, const int32_t* idx_a,
+    const float* b, int64_t b_bstride, int64_t b_ld, const int32_t* idx_b,
+    const float* c, int64_t c_bstride, int64_t c_ld, const int32_t* idx_c,
+    const float* W2, int64_t ldW2, const float* b2, const float* gamma, const float* beta,
+    int n_out, float* h_out, int64_t h_bstride,
+    float* y, int64_t y_bstride, int64_t y_ld, const int32_t* idx_y,
+    const float* res, int64_t res_bstride, int64_t res_ld,
+    float* agg, int64_t agg_bstride, int64_t agg_ld, const float* inv_deg,
+    int64_t B, int d, void* stream) {
+  if (B <= 0 || rows <= 0) return 0;
+  NLAM_REQUIRE(d == 128, "nlam_tail_fwd: hidden width %d unsupported (128)", d);
+  NLAM_REQUIRE(nlam_mfma_terms() != 0, "nlam_tail_fwd: needs NLAM_MFMA=bf16x3|bf16");
+  NLAM_REQUIRE(n_out >= 1 && n_out <= d, "nlam_tail_fwd: n_out %d out of range", n_out);
+  NLAM_REQUIRE((gamma == nullptr) == (beta == nullptr), "nlam_tail_fwd: gamma/beta mismatch");
+  NLAM_REQUIRE(gamma == nullptr || n_out == d, "nlam_tail_fwd: LayerNorm needs n_out == d");
+  NLAM_REQUIRE(gamma != nullptr || n_out <= 32, "nlam_tail_fwd: no-LN form supports n_out <= 32");
+  NLAM_REQUIRE(wide_view_ok(a, a_bstride, a_ld, d) && (!b || wide_view_ok(b, b_bstride, b_ld, d)) &&
+                   (!c || wide_view_ok(c, c_bstride, c_ld, d)) && (!c || b),
+               "nlam_tail_fwd: sources must be 16-byte aligned rows of width d");
+  NLAM_REQUIRE(h_out == nullptr || (nlam_aligned16(h_out) && h_bstride % 4 == 0),
+               "nlam_tail_fwd: h_out misaligned");
+  NLAM_REQUIRE(agg == nullptr || (tiles != nullptr && csr_rec != nullptr && csr_rowptr != nullptr &&
+                                  agg_ld >= n_out && n_out == d),
+               "nlam_tail_fwd: aggregation needs edge tiles and n_out == d");
+  NLAM_REQUIRE(tiles != nullptr || ntiles == (rows + NLAM_TILE - 1) / NLAM_TILE,
+               "nlam_tail_fwd: row mode expects ntiles == ceil(rows / 32)");
+  TailFwdParams p;
+  p.tl = WideTiling{tiles, ntiles, rows, csr_rec, csr_rowptr};
+  p.a = RowView{a, a_bstride, a_ld, d}; p.idx_a = idx_a;
+  p.b = RowView{b, b_bstride, b_ld, d}; p.idx_b = idx_b;
+  p.c = RowView{c, c_bstride, c_ld, d}; p.idx_c = idx_c;
+  p.W2 = W2; p.ldW2 = ldW2; p.b2 = b2; p.gamma = gamma; p.beta = beta; p.n_out = n_out;
+  p.h_out = h_out; p.h_bstride = h_bstride;
+  p.y = y; p.y_bstride = y_bstride; p.y_ld = y_ld; p.idx_y = idx_y;
+  p.res = RowView{res, res_bstride, res_ld, n_out};
+  p.agg = agg; p.agg_bstride = agg_bstride; p.agg_ld = agg_ld; p.inv_deg = inv_deg;
+  p.B = (int)B;
+  p.vec_y = (y != nullptr && view_vec_ok(y, y_bstride, y_ld, n_out) &&
+             (res == nullptr || view_vec_ok(res, res_bstride, res_ld, n_out))) ? 1 : 0;
+  NLAM_REQUIRE(idx_y == nullptr || y == nullptr || p.vec_y,
+               "nlam_tail_fwd: scattered output rows must be 16-byte aligned, n_out %% 4 == 0");
+  hipStream_t s = (hipStream_t)stream;
+  const bool t3 = nlam_mfma_terms() == 3;
+  if (gamma != nullptr)
+    return t3 ? launch_tail_fwd<128, 4, true, 3>(p, s) : launch_tail_fwd<128, 4, true, 1>(p, s);
+  return t3 ? launch_tail_fwd<128, 1, false, 3>(p, s) : launch_tail_fwd<128, 1, false, 1>(p, s);
+}
+
+// ============================================================= tail backward ===
+// Slab per workgroup: [dgamma (32 NOUTB) | dbeta (32 NOUTB)]  (HAS_LN only).
+struct TailBwdParams {
+  WideTiling tl;
+  const float* h; int64_t h_bstride;                     // (B, rows, D), pitch D
+  RowView g1; const int32_t* idx_g1; const float* scale1; // incoming gradient rows (scaled)
+  RowView g2; const int32_t* idx_g2;                      // optional addend
+  const float* W2; int64_t ldW2; const float* b2; const float* gamma; int n_out;
+  float* gz_out; int64_t gz_bstride;                     // (B, rows, 32 NOUTB), position order
+  float* gh; int64_t gh_bstride; int64_t gh_ld; const int32_t* idx_gh;   // (B, rows, D)
+  float* gpr; int64_t gpr_bstride; int64_t gpr_ld;       // optional receiver-side sums of gh
+  float* slab; int64_t slab_stride;
+  int B;
+  int vec_g;                                             // g1 / g2 rows float4-loadable
+};
+
+template <int D, int NOUTB, bool HAS_LN, int TERMS>
+__global__ __launch_bounds__(256) void tail_bwd_kernel(TailBwdParams q) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NB = D / 32, NV = D / 8, NO = 32 * NOUTB, NVG = NO / 8;
+  constexpr int NV_O = (NO + 63) / 64;
+  constexpr int LDT = D + 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int t = lane & 31, hh = lane >> 5;
+  float* W2s = smem;
+  float* b2s = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + b3_image_bytes(NO, D));
+  float* gs = b2s + NO;
+  float* tile = gs + NO + wave * (NLAM_TILE * LDT);
+  const B3Image W2im = b3_image(W2s, NO, D);
+  load_weight_lds_b3(W2im, 0, q.W2, q.ldW2, q.n_out, D, NO, D, tid, 256);
+  load_vec_lds(b2s, q.b2, q.n_out, NO, tid, 256);
+  load_vec_lds(gs, q.gamma, q.n_out, NO, tid, 256);
+  __syncthreads();
+
+  // per-feature partial sums (lanes = features 64 j + lane), accumulated over the tiles
+  float dgam[NV_O], dbet[NV_O];
+#pragma unroll
+  for (int j = 0; j < NV_O; ++j) dgam[j] = dbet[j] = 0.f;
+  const B3Tile Tp = b3_tile(tile, NO);   // bf16-plane view of the tile (column sums)
+
+  const int64_t total = q.tl.ntiles * q.B;
+  for (int64_t tt = (int64_t)blockIdx.x * 4 + wave; tt < total; tt += (int64_t)gridDim.x * 4) {
+    const int64_t b = tt / q.tl.ntiles;
+    const WTile w = wide_tile(q.tl, tt - b * q.tl.ntiles);
+    const int ne = w.ne;
+    const int i1 = wide_index(q.idx_g1, w, lane);
+    const int i2 = q.g2.ptr ? wide_index(q.idx_g2, w, lane) : 0;
+    const int igh = wide_index(q.idx_gh, w, lane);
+    const int rcv = q.tl.csr_rec ? wide_index(q.tl.csr_rec, w, lane) : 0;
+    const float sc1 = q.scale1 ? q.scale1[i1] : 1.0f;
+    const float* g1b = q.g1.ptr + b * q.g1.bstride;
+    const float* g2b = q.g2.ptr ? q.g2.ptr + b * q.g2.bstride : nullptr;
+    auto g1_row = [&](int s) { return g1b + (int64_t)__shfl(i1, s, 64) * q.g1.ld; };
+    auto g2_row = [&](int s) { return g2b + (int64_t)__shfl(i2, s, 64) * q.g2.ld; };
+    // ---- h rows (contiguous) -> tile -> accumulator layout.  h is staged twice (here for
+    // s = silu(h), below for silu'(h)) instead of living in 64 registers across the whole
+    // tile: at d = 128 that is the difference between spilling and not (L2-hot re-read).
+    const float* hb = q.h + b * q.h_bstride + (int64_t)w.p0 * D;
+    const int last = ne - 1;
+    auto h_row = [&](int s) { return hb + (int64_t)(s < last ? s : last) * D; };
+    {
+      f32x4 vH[NV];
+      load_rows_v<NV>(vH, D, lane, h_row);
+      put_rows_v<NV, false>(tile, LDT, 0, D, ne, lane, vH);
+      wave_sync();
+    }
+    // ---- incoming gradient rows -> tile (their loads fly under the GEMM below)
+    f32x4 vG[NVG];
+    if (q.vec_g) {
+      load_rows_v<NVG>(vG, NO, lane, g1_row);
+      if (g2b) {
+        // row scale (mean aggregation): the rows of float4 k belong to slot sub + k * rpi
+        constexpr int lpr = NO >> 2;
+        constexpr int rpi = 64 / lpr;
+        const int sub = lane / lpr;
+        f32x4 vO[NVG];
+        load_rows_v<NVG>(vO, NO, lane, g2_row);
+#pragma unroll
+        for (int k = 0; k < NVG; ++k) {
+          const int ts = sub + k * rpi;
+          const float sc = __shfl(sc1, ts < NLAM_TILE ? ts : 0, 64);
+          vG[k] = vG[k] * sc + vO[k];
+        }
+      } else if (q.scale1 != nullptr) {
+        constexpr int lpr = NO >> 2;
+        constexpr int rpi = 64 / lpr;
+        const int sub = lane / lpr;
+#pragma unroll
+        for (int k = 0; k < NVG; ++k) {
+          const int ts = sub + k * rpi;
+          vG[k] *= __shfl(sc1, ts < NLAM_TILE ? ts : 0, 64);
+        }
+      }
+    }
+    f32x16 z[NOUTB];
+    if (HAS_LN) {
+      f32x16 sact[NB];
+      tile_to_acc<NB>(sact, tile, LDT, lane);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sact[nb][r] = nlam_silu(sact[nb][r]);
+      vec_to_acc<NOUTB>(z, b2s, lane);
+      gemm_acc_b3<NOUTB, NB, TERMS>(z, W2im, 0, sact, lane);
+    }
+    wave_sync();
+    if (q.vec_g) {
+      put_rows_v<NVG, false>(tile, LDT, 0, NO, ne, lane, vG);
+    } else {
+      // narrow / unaligned gradient rows (e.g. the 17-wide output map): scalar staging
+      // (uniform trip count; the index shuffles stay outside the divergent part)
+      for (int idx = lane; idx < NLAM_TILE * NO; idx += 64) {
+        const int tr = idx / NO, cc = idx - tr * NO;
+        const float* r1 = g1_row(tr);
+        const float* r2 = g2b ? g2_row(tr) : nullptr;
+        const float sc = __shfl(sc1, tr, 64);
+        float v = 0.f;
+        if (tr < ne && cc < q.n_out) {
+          v = r1[cc] * sc;
+          if (r2) v += r2[cc];
+        }
+        tile[tr * LDT + cc] = v;
+      }
+    }
+    wave_sync();
+    f32x16 g[NOUTB];
+    tile_to_acc<NOUTB>(g, tile, LDT, lane);
+    if (HAS_LN) {
+      constexpr float inv_d = 1.0f / (float)NO;
+      float mean, rstd;
+      ln_stats<NOUTB>(z, mean, rstd);
+      // dbeta: column sums of the incoming gradient, on the matrix cores from bf16 planes
+      wave_sync();
+      acc_to_tile_b3<NOUTB>(g, Tp, 0, lane);
+      wave_sync();
+      tile_colsum_b3<NV_O, TERMS>(dbet, Tp, 0, lane);
+      wave_sync();
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int nb = 0; nb < NOUTB; ++nb) {
+        f32x16 prod[1];
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+          const f32x4 gm = *reinterpret_cast<const f32x4*>(gs + 32 * nb + 8 * qq + 4 * hh);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int r = 4 * qq + j;
+            const float xh = (z[nb][r] - mean) * rstd;
+            z[nb][r] = xh;
+            prod[0][r] = g[nb][r] * xh;          // gy * xhat -> dgamma
+            const float gv = g[nb][r] * gm[j];
+            g[nb][r] = gv;
+            s1 += gv;
+            s2 += gv * xh;
+          }
+        }
+        acc_to_tile_b3<1>(prod, Tp, 32 * nb, lane);
+      }
+      wave_sync();
+      tile_colsum_b3<NV_O, TERMS>(dgam, Tp, 0, lane);
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      const float m1 = s1 * inv_d, m2 = s2 * inv_d;
+#pragma unroll
+      for (int nb = 0; nb < NOUTB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g[nb][r] = rstd * (g[nb][r] - m1 - z[nb][r] * m2);
+    }
+    // g = gz (zero on padded slots / columns): publish it for the weight-gradient pass
+    wave_sync();
+    acc_to_tile<NOUTB>(g, tile, LDT, lane);
+    wave_sync();
+    {
+      float* gzb = q.gz_out + b * q.gz_bstride + (int64_t)w.p0 * NO;
+      auto gz_row = [&](int s) { return gzb + (int64_t)s * NO; };
+      store_rows<true>(tile, LDT, 0, NO, ne, lane, gz_row);
+    }
+    // gh = (W2^T gz) * silu'(h)
+    f32x16 gh[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) gh[nb][r] = 0.f;
+    {
+      // h again (its loads fly under the GEMM)
+      f32x4 vH[NV];
+      load_rows_v<NV>(vH, D, lane, h_row);
+      gemm_acc_wt_b3<NB, NOUTB, TERMS>(gh, W2im, 0, g, lane);
+      wave_sync();   // (the gz rows of the tile are stored)
+      put_rows_v<NV, false>(tile, LDT, 0, D, ne, lane, vH);
+      wave_sync();
+    }
+    {
+      f32x16 hpre[NB];
+      tile_to_acc<NB>(hpre, tile, LDT, lane);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gh[nb][r] *= nlam_silu_grad(hpre[nb][r]);
+    }
+    wave_sync();
+    acc_to_tile<NB>(gh, tile, LDT, lane);
+    wave_sync();
+    {
+      float* ghb = q.gh + b * q.gh_bstride;
+      auto gh_row = [&](int s) { return ghb + (int64_t)__shfl(igh, s, 64) * q.gh_ld; };
+      store_rows<true>(tile, LDT, 0, D, ne, lane, gh_row);
+    }
+    if (q.gpr != nullptr) {
+      float* gb = q.gpr + b * q.gpr_bstride;
+      const int ri = w.r0 + (lane < w.nr ? lane : w.nr);
+      const int rp = q.tl.csr_rowptr[ri] - w.p0;
+      const int rpn = __shfl_down(rp, 1, 64);
+      const bool dense = __all((lane >= w.nr) || (rpn > rp));
+      if (dense) {
+        tile_segment_sums<D>(tile, LDT, ne, rcv, lane, [&](int r, int f0, float acc) {
+          gb[(int64_t)r * q.gpr_ld + f0 + lane] = acc;
+        });
+      } else {
+        for (int i = 0; i < w.nr; ++i) {
+          const int beg = __shfl(rp, i, 64), end = __shfl(rp, i + 1, 64);
+#pragma unroll
+          for (int f0 = 0; f0 < D; f0 += 64) {
+            float acc = 0.f;
+            for (int s = beg; s < end; ++s) acc += tile[s * LDT + f0 + lane];
+            gb[(int64_t)(w.r0 + i) * q.gpr_ld + f0 + lane] = acc;
+          }
+        }
+      }
+    }
+    wave_sync();
+  }
+  (void)t;
+  if (HAS_LN) {
+    __syncthreads();
+    float* img = smem;
+    float* slab = q.slab + (int64_t)blockIdx.x * q.slab_stride;
+    fold_vec_lds<NV_O>(dgam, img, wave, lane);
+    for (int i = tid; i < NO; i += 256) slab[i] = img[i];
+    __syncthreads();
+    fold_vec_lds<NV_O>(dbet, img, wave, lane);
+    for (int i = tid; i < NO; i += 256) slab[NO + i] = img[i];
+  }
+}
+
+template <int D, int NOUTB, bool HAS_LN, int TERMS>
+static int launch_tail_bwd(const TailBwdParams& q, hipStream_t s) {
+  const size_t lds = b3_image_bytes(32 * NOUTB, D) + (size_t)2 * 32 * NOUTB * sizeof(float) +
+                     (size_t)4 * NLAM_TILE * (D + 4) * sizeof(float);
+  NLAM_REQUIRE(lds <= 160 * 1024, "tail_bwd: LDS footprint %zu B exceeds 160 KiB", lds);
+  auto kern = tail_bwd_kernel<D, NOUTB, HAS_LN, TERMS>;
+  NLAM_BIG_LDS(kern, "tail_bwd_kernel");
+  kern<<<wide_grid(q.tl.ntiles * q.B), 256, lds, s>>>(q);
+  NLAM_CHECK_LAUNCH("tail_bwd_kernel");
+  return 0;
+}
+
+extern "C" int64_t nlam_tail_bwd_slab_stride(int n_out) { return 2 * (int64_t)((n_out + 31) & ~31); }
+
+extern "C" int nlam_tail_bwd(
+    const int32_t* tiles, int64_t ntiles, int64_t rows, const int32_t* csr_rec,
+    const int32_t* csr_rowptr, const float* h, int64_t h_bstride,
+    const float* g1, int64_t g1_bstride, int64_t g1_ld, const int32_t* idx_g1, const float* scale1,
+    const float* g2, int64_t g2_bstride, int64_t g2_ld, const int32_t* idx_g2,
+    const float* W2, int64_t ldW2, const float* b2, const float* gamma, int n_out,
+    float* gz_out, int64_t gz_bstride,
+    float* gh, int64_t gh_bstride, int64_t gh_ld, const int32_t* idx_gh,
+    float* gpr, int64_t gpr_bstride, int64_t gpr_ld,
+    float* slab, int64_t slab_stride, int64_t B, int d, void* stream) {
+  if (B <= 0 || rows <= 0) return 0;
+  NLAM_REQUIRE(d == 128, "nlam_tail_bwd: hidden width %d unsupported (128)", d);
+  NLAM_REQUIRE(nlam_mfma_terms() != 0, "nlam_tail_bwd: needs NLAM_MFMA=bf16x3|bf16");
+  NLAM_REQUIRE(n_out >= 1 && n_out <= d, "nlam_tail_bwd: n_out out of range");
+  NLAM_REQUIRE(gamma == nullptr || n_out == d, "nlam_tail_bwd: LayerNorm needs n_out == d");
+  NLAM_REQUIRE(gamma != nullptr || n_out <= 32, "nlam_tail_bwd: no-LN form supports n_out <= 32");
+  NLAM_REQUIRE(h != nullptr && nlam_aligned16(h) && h_bstride % 4 == 0, "nlam_tail_bwd: bad h");
+  NLAM_REQUIRE(g1 != nullptr && gz_out != nullptr && nlam_aligned16(gz_out) && gz_bstride % 4 == 0,
+               "nlam_tail_bwd: g1 / gz_out missing or misaligned");
+  NLAM_REQUIRE(gh != nullptr && view_vec_ok(gh, gh_bstride, gh_ld, d), "nlam_tail_bwd: bad gh view");
+  NLAM_REQUIRE(gpr == nullptr || (tiles != nullptr && csr_rec != nullptr && csr_rowptr != nullptr &&
+                                  gpr_ld >= d), "nlam_tail_bwd: gpr needs edge tiles");
+  NLAM_REQUIRE(gamma == nullptr || (slab != nullptr && slab_stride >= nlam_tail_bwd_slab_stride(n_out)),
+               "nlam_tail_bwd: slab too small");
+  NLAM_REQUIRE(tiles != nullptr || ntiles == (rows + NLAM_TILE - 1) / NLAM_TILE,
+               "nlam_tail_bwd: row mode expects ntiles == ceil(rows / 32)");
+  TailBwdParams q;
+  q.tl = WideTiling{tiles, ntiles, rows, csr_rec, csr_rowptr};
+  q.h = h; q.h_bstride = h_bstride;
+  q.g1 = RowView{g1, g1_bstride, g1_ld, n_out}; q.idx_g1 = idx_g1; q.scale1 = scale1;
+  q.g2 = RowView{g2, g2_bstride, g2_ld, n_out}; q.idx_g2 = idx_g2;
+  q.W2 = W2; q.ldW2 = ldW2; q.b2 = b2; q.gamma = gamma; q.n_out = n_out;
+  q.gz_out = gz_out; q.gz_bstride = gz_bstride;
+  q.gh = gh; q.gh_bstride = gh_bstride; q.gh_ld = gh_ld; q.idx_gh = idx_gh;
+  q.gpr = gpr; q.gpr_bstride = gpr_bstride; q.gpr_ld = gpr_ld;
+  q.slab = slab; q.slab_stride = slab_stride; q.B = (int)B;
+  const int no = (n_out + 31) & ~31;
+  q.vec_g = (n_out == no && view_vec_ok(g1, g1_bstride, g1_ld, n_out) &&
+             (g2 == nullptr || view_vec_ok(g2, g2_bstride, g2_ld, n_out))) ? 1 : 0;
+  hipStream_t s = (hipStream_t)stream;
+  const bool t3 = nlam_mfma_terms() == 3;
+  if (gamma != nullptr)
+    return t3 ? launch_tail_bwd<128, 4, true, 3>(q, s) : launch_tail_bwd<128, 4, true, 1>(q, s);
+  return t3 ? launch_tail_bwd<128, 1, false, 3>(q, s) : launch_tail_bwd<128, 1, false, 1>(q, s);
+}
+
+// ====================================================== data gradient of a Linear ===
+// gx (B, rows, 32 KB) = gy (B, rows, 32 NOUTB) . W (32 NOUTB x 32 KB) [+ gx_add]
+struct LinBwdDataParams {
+  RowView gy;
+  const float* W; int64_t ldW; int n_out; int k_in;
+  float* gx; int64_t gx_bstride; int64_t gx_ld;
+  const float* gx_add; int64_t ga_bstride; int64_t ga_ld;
+  int64_t rows; int B;
+};
+
+template <int NOUTB, int KB, int TERMS>
+__global__ __launch_bounds__(256) void lin_bwd_data_kernel(LinBwdDataParams q) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NO = 32 * NOUTB, K = 32 * KB;
+  constexpr int LDT = (NO > K ? NO : K) + 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const B3Image Wim = b3_image(smem, NO, K);
+  float* tile = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + b3_image_bytes(NO, K)) +
+                wave * (NLAM_TILE * LDT);
+  load_weight_lds_b3(Wim, 0, q.W, q.ldW, q.n_out, q.k_in, NO, K, tid, 256);
+  __syncthreads();
+  const int64_t tiles_per_b = (q.rows + NLAM_TILE - 1) / NLAM_TILE;
+  const int64_t ntiles = tiles_per_b * q.B;
+  for (int64_t tt = (int64_t)blockIdx.x * 4 + wave; tt < ntiles; tt += (int64_t)gridDim.x * 4) {
+    const int64_t b = tt / tiles_per_b;
+    const int64_t r0 = (tt - b * tiles_per_b) * NLAM_TILE;
+    const int nrows = (int)((q.rows - r0) < NLAM_TILE ? (q.rows - r0) : NLAM_TILE);
+    f32x4 vg[4 * NOUTB];
+    view_load_v<4 * NOUTB>(vg, q.gy, b, r0, nrows, lane);
+    const B3Tile Gp = b3_tile(tile, NO);
+    put_rows_v_b3<4 * NOUTB>(Gp, 0, NO, nrows, lane, vg);
+    wave_sync();
+    f32x16 gx[KB];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) gx[kb][r] = 0.f;
+    gemm_tile_wt_b3<KB, NOUTB, TERMS>(gx, Wim, 0, Gp, 0, lane);
+    wave_sync();
+    acc_to_tile<KB>(gx, tile, LDT, lane);
+    wave_sync();
+    float* ob = q.gx + b * q.gx_bstride + r0 * q.gx_ld;
+    auto op = [&](int t) { return ob + (int64_t)t * q.gx_ld; };
+    if (q.gx_add != nullptr) {
+      const float* ab = q.gx_add + b * q.ga_bstride + r0 * q.ga_ld;
+      auto ap = [&](int t) { return ab + (int64_t)t * q.ga_ld; };
+      store_rows_res<true>(tile, LDT, 0, q.k_in, nrows, lane, op, ap);
+    } else {
+      store_rows<true>(tile, LDT, 0, q.k_in, nrows, lane, op);
+    }
+    wave_sync();
+  }
+}
+
+template <int NOUTB, int KB, int TERMS>
+static int launch_lin_bwd_data(const LinBwdDataParams& q, hipStream_t s) {
+  constexpr int NO = 32 * NOUTB, K = 32 * KB;
+  constexpr int LDT = (NO > K ? NO : K) + 4;
+  const size_t lds = b3_image_bytes(NO, K) + (size_t)4 * NLAM_TILE * LDT * sizeof(float);
+  NLAM_REQUIRE(lds <= 160 * 1024, "lin_bwd_data: LDS footprint %zu B exceeds 160 KiB", lds);
+  auto kern = lin_bwd_data_kernel<NOUTB, KB, TERMS>;
+  NLAM_BIG_LDS(kern, "lin_bwd_data_kernel");
+  const int64_t ntiles = ((q.rows + NLAM_TILE - 1) / NLAM_TILE) * q.B;
+  kern<<<wide_grid(ntiles), 256, lds, s>>>(q);
+  NLAM_CHECK_LAUNCH("lin_bwd_data_kernel");
+  return 0;
+}
+
+extern "C" int nlam_lin_bwd_data(const float* gy, int64_t gy_bstride, int64_t gy_ld, int n_out,
+                                 const float* W, int64_t ldW, int k_in,
+                                 float* gx, int64_t gx_bstride, int64_t gx_ld,
+                                 const float* gx_add, int64_t ga_bstride, int64_t ga_ld,
+                                 int64_t B, int64_t rows, void* stream) {
+  if (B <= 0 || rows <= 0) return 0;
+  NLAM_REQUIRE(nlam_mfma_terms() != 0, "nlam_lin_bwd_data: needs NLAM_MFMA=bf16x3|bf16");
+  NLAM_REQUIRE(n_out == 128 && k_in == 128, "nlam_lin_bwd_data: shape %d x %d unsupported (128 x 128)",
+               n_out, k_in);
+  NLAM_REQUIRE(view_vec_ok(gy, gy_bstride, gy_ld, n_out) && view_vec_ok(gx, gx_bstride, gx_ld, k_in) &&
+                   (gx_add == nullptr || view_vec_ok(gx_add, ga_bstride, ga_ld, k_in)),
+               "nlam_lin_bwd_data: operand rows must be 16-byte aligned with pitch %% 4 == 0");
+  LinBwdDataParams q;
+  q.gy = RowView{gy, gy_bstride, gy_ld, n_out};
+  q.W = W; q.ldW = ldW; q.n_out = n_out; q.k_in = k_in;
+  q.gx = gx; q.gx_bstride = gx_bstride; q.gx_ld = gx_ld;
+  q.gx_add = gx_add; q.ga_bstride = ga_bstride; q.ga_ld = ga_ld;
+  q.rows = rows; q.B = (int)B;
+  hipStream_t s = (hipStream_t)stream;
+  return nlam_mfma_terms() == 3 ? launch_lin_bwd_data<4, 4, 3>(q, s)
+                                : launch_lin_bwd_data<4, 4, 1>(q, s);
+}
+
+// ================================================= streaming weight gradients ===
+// dW (32 NGB x 32 NXB) = sum_rows G[r]^T (x) f(X[r]),  db = colsum(G);  f = silu when SILU_X
+// (X is then the kept pre-activation h).  Slab per workgroup: [dW | db (32 NGB)].
+struct WideOuterParams {
+  RowView g;        // (B, rows, 32 NGB)
+  RowView x;        // (B, rows, 32 NXB); batch-invariant x (bstride 0) allowed
+  float* slab; int64_t slab_stride;
+  int64_t rows; int B;
+};
+
+template <int NGB, int NXB, int TERMS, bool SILU_X>
+__global__ __launch_bounds__(256) void wide_outer_kernel(WideOuterParams q) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NG = 32 * NGB, NX = 32 * NXB;
+  constexpr int NV = (NG + 63) / 64;
+  constexpr int ldg = NG + 4, ldx = NX + 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* TG = smem + wave * (NLAM_TILE * (ldg + ldx));
+  float* TX = TG + NLAM_TILE * ldg;
+  f32x16 dW[NGB][NXB];
+#pragma unroll
+  for (int i = 0; i < NGB; ++i)
+#pragma unroll
+    for (int j = 0; j < NXB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dW[i][j][r] = 0.f;
+  float db[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) db[j] = 0.f;
+  const int64_t tiles_per_b = (q.rows + NLAM_TILE - 1) / NLAM_TILE;
+  const int64_t ntiles = tiles_per_b * q.B;
+  const B3Tile TGp = b3_tile(TG, NG), TXp = b3_tile(TX, NX);
+  for (int64_t tt = (int64_t)blockIdx.x * 4 + wave; tt < ntiles; tt += (int64_t)gridDim.x * 4) {
+    const int64_t b = tt / tiles_per_b;
+    const int64_t r0 = (tt - b * tiles_per_b) * NLAM_TILE;
+    const int nrows = (int)((q.rows - r0) < NLAM_TILE ? (q.rows - r0) : NLAM_TILE);
+    f32x4 vg[4 * NGB], vx[4 * NXB];
+    view_load_v<4 * NGB>(vg, q.g, b, r0, nrows, lane);
+    view_load_v<4 * NXB>(vx, q.x, b, r0, nrows, lane);
+    if (SILU_X) {
+#pragma unroll
+      for (int k = 0; k < 4 * NXB; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vx[k][j] = nlam_silu(vx[k][j]);
+    }
+    put_rows_v_b3<4 * NGB>(TGp, 0, NG, nrows, lane, vg);
+    put_rows_v_b3<4 * NXB>(TXp, 0, NX, nrows, lane, vx);
+    wave_sync();
+    tile_colsum_b3<NV, TERMS>(db, TGp, 0, lane);
+    outer_accum_b3<NGB, NXB, TERMS>(dW, TGp, 0, TXp, 0, lane);
+    wave_sync();
+  }
+  __syncthreads();
+  float* slab = q.slab + (int64_t)blockIdx.x * q.slab_stride;
+  fold_block_rows_to_slab<NGB, NXB>(dW, smem, NX, slab, tid, wave, lane);
+  fold_vec_lds<NV>(db, smem, wave, lane);
+  for (int i = tid; i < NG; i += 256) slab[NG * NX + i] = smem[i];
+}
+
+template <int NGB, int NXB, int TERMS, bool SILU_X>
+static int launch_wide_outer(const WideOuterParams& q, hipStream_t s) {
+  constexpr int NG = 32 * NGB, NX = 32 * NXB;
+  size_t lds = (size_t)4 * NLAM_TILE * (NG + 4 + NX + 4) * sizeof(float);
+  const size_t fold = (size_t)4 * 32 * NX * sizeof(float);
+  if (fold > lds) lds = fold;
+  NLAM_REQUIRE(lds <= 160 * 1024, "wide_outer: LDS footprint %zu B exceeds 160 KiB", lds);
+  auto kern = wide_outer_kernel<NGB, NXB, TERMS, SILU_X>;
+  NLAM_BIG_LDS(kern, "wide_outer_kernel");
+  const int64_t ntiles = ((q.rows + NLAM_TILE - 1) / NLAM_TILE) * q.B;
+  kern<<<wide_grid(ntiles), 256, lds, s>>>(q);
+  NLAM_CHECK_LAUNCH("wide_outer_kernel");
+  return 0;
+}
+
+extern "C" int nlam_wide_outer(const float* g, int64_t g_bstride, int64_t g_ld, int ng,
+                               const float* x, int64_t x_bstride, int64_t x_ld, int nx, int silu_x,
+                               float* slab, int64_t slab_stride, int64_t B, int64_t rows,
+                               void* stream) {
+  if (B <= 0 || rows <= 0) return 0;
+  NLAM_REQUIRE(nlam_mfma_terms() != 0, "nlam_wide_outer: needs NLAM_MFMA=bf16x3|bf16");
+  NLAM_REQUIRE((ng == 128 || ng == 32) && nx == 128, "nlam_wide_outer: shape %d x %d unsupported",
+               ng, nx);
+  NLAM_REQUIRE(view_vec_ok(g, g_bstride, g_ld, ng) && view_vec_ok(x, x_bstride, x_ld, nx),
+               "nlam_wide_outer: operand rows must be 16-byte aligned with pitch %% 4 == 0");
+  NLAM_REQUIRE(slab != nullptr && slab_stride >= (int64_t)ng * nx + ng, "nlam_wide_outer: slab too small");
+  WideOuterParams q;
+  q.g = RowView{g, g_bstride, g_ld, ng};
+  q.x = RowView{x, x_bstride, x_ld, nx};
+  q.slab = slab; q.slab_stride = slab_stride; q.rows = rows; q.B = (int)B;
+  hipStream_t s = (hipStream_t)stream;
+  const bool t3 = nlam_mfma_terms() == 3;
+#define WO(NGB, SX) (t3 ? launch_wide_outer<NGB, 4, 3, SX>(q, s) : launch_wide_outer<NGB, 4, 1, SX>(q, s))
+  if (ng == 128) return silu_x ? WO(4, true) : WO(4, false);
+  return silu_x ? WO(1, true) : WO(1, false);
+#undef WO
+}

@@ -41,16 +41,27 @@ int nlam_enable_big_lds(const void* kern, const char* name) {
 extern "C" int nlam_abi_version(void) { return 1; }
 
 // GEMM arithmetic of the fused kernels (see fused_bf16x3.h): NLAM_MFMA=fp32 | bf16x3
-#define NLAM_MFMA_DEFAULT_B3 1
-bool nlam_mfma_b3() {
+#define NLAM_MFMA_DEFAULT_MODE 1
+static int nlam_mfma_mode_value() {
   static const int mode = [] {
     const char* e = getenv("NLAM_MFMA");
-    if (e == nullptr || e[0] == 0) return NLAM_MFMA_DEFAULT_B3;
-    return (e[0] == 'b' || e[0] == 'B') ? 1 : 0;
+    if (e == nullptr || e[0] == 0) return NLAM_MFMA_DEFAULT_MODE;
+    if (e[0] == 'b' || e[0] == 'B') {
+      // "bf16x3" / "b3" -> 1 (split-bf16);  "bf16" -> 2 (plain bf16 products)
+      for (const char* c = e; *c; ++c)
+        if (*c == '3') return 1;
+      return 2;
+    }
+    return 0;
   }();
-  return mode != 0;
+  return mode;
 }
-extern "C" int nlam_mfma_mode(void) { return nlam_mfma_b3() ? 1 : 0; }
+bool nlam_mfma_b3() { return nlam_mfma_mode_value() != 0; }
+int nlam_mfma_terms() {
+  const int m = nlam_mfma_mode_value();
+  return m == 0 ? 0 : (m == 1 ? 3 : 1);
+}
+extern "C" int nlam_mfma_mode(void) { return nlam_mfma_mode_value(); }
 
 // ------------------------------------------------------------------- GEMM
 // 64x64 output tile per 256-thread workgroup, 4 waves each owning a 32x32

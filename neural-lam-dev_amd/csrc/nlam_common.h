@@ -39,6 +39,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // fp32 MFMA (NLAM_MFMA=fp32 in the environment).  Read once per process.  The generic
 // kernels (generic_ops.hip) always use the exact fp32 MFMA.
 bool nlam_mfma_b3();
+// bf16 MFMA terms per fp32 product: 0 = exact fp32 MFMA, 3 = split-bf16 (NLAM_MFMA=bf16x3, the
+// default), 1 = plain bf16 products with fp32 accumulate (NLAM_MFMA=bf16: the reference's
+// `--precision bf16-mixed` arithmetic; fp32 storage, LayerNorm, residuals and aggregates).
+// The d = 64 kernels run their bf16x3 form in both bf16 modes.
+int nlam_mfma_terms();
 
 static inline bool nlam_aligned16(const void* p) {
   return (reinterpret_cast<uintptr_t>(p) & 15u) == 0;

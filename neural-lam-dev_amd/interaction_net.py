@@ -5,7 +5,7 @@ assertions; the arithmetic runs in libnlam_hip.so.
 import torch
 from torch import nn
 
-from . import fused, generic, utils
+from . import fused, generic, utils, wide
 from .graph import EdgeTables, normalise_edge_index
 
 
@@ -121,6 +121,8 @@ class InteractionNet(nn.Module):
 
         if fused.inet_eligible(self, s3, r3, e3):
             return restore(fused.apply_inet(self, s3, r3, e3))
+        if wide.inet_eligible(self, s3, r3, e3):
+            return restore(wide.apply_inet(self, s3, r3, e3))
         if fused.inet_split_eligible(self, s3, r3, e3):
             return restore(fused.apply_inet_split(self, s3, r3, e3))
         eb, ep = _blocks(self.edge_mlp, self.tables.M)

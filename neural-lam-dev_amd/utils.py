@@ -83,11 +83,13 @@ class HipMLP(nn.Sequential):
     tag = "mlp"   # profiler label of this block's launches; the models set it
 
     def forward(self, x, res=None):
-        from . import fused, ops
+        from . import fused, ops, wide
 
         with ops.tag(self.tag):
             if fused.mlp_eligible(self, x):
                 return fused.apply_mlp(self, x, res)
+            if wide.mlp_eligible(self, x, res):
+                return wide.apply_mlp(self, x, res)
             return generic.apply_mlp(self, x, res)
 
 

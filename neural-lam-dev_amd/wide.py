@@ -1,0 +1,425 @@
+"""hidden_dim 128 path of the fused gfx950 kernels (csrc/fused_wide.hip).
+
+Same operators as fused.py -- the make_mlp blocks (reference utils.py:191-214) and one
+InteractionNet layer (interaction_net.py:86-131) -- but cut at the Linear boundaries: at d = 128
+two split-bf16 weight images (2 x 67.6 KB) plus row tiles exceed the 160 KB LDS of a CU and a
+d x d weight-gradient accumulator fills a wave's registers, so every kernel holds ONE weight
+matrix and every weight gradient is a streaming pass of its own:
+
+  forward : nlam_lin_fwd   x3   Pe = W1e e, Ps = W1s x_s, Pr = W1r x_r + b1
+            nlam_tail_fwd       h = Pe + Ps[send] + Pr[rec]; m = LN(W2 silu(h) + b2);
+                                agg = segment-sum(m) over receiver-aligned tiles; e' = e + m
+            nlam_lin_fwd   x2 + nlam_tail_fwd   node update  x_r + LN(V2 silu(V1 [x_r | agg] + c1) + c2)
+  backward: nlam_tail_bwd (node), nlam_tail_bwd (edges, + receiver-side sums of gh),
+            nlam_segment_sum (sender side), nlam_lin_bwd_data (data gradients),
+            nlam_wide_outer (every weight / bias gradient), one slab reduction per layer.
+The pre-activations h are kept by the forward (the backward neither repeats the first GEMM nor
+gathers); memory is sized for 288 GB of HBM.  Arithmetic: NLAM_MFMA=bf16x3 (default, fp32-grade)
+or bf16 (plain bf16 products, fp32 accumulate); exact-fp32 mode takes the generic kernels.
+"""
+import torch
+
+from . import ops
+from ._lib import lib
+from .ops import _launch, _p, mat, stream
+
+WIDE_HIDDEN = (128,)
+
+
+def enabled():
+    return int(lib.nlam_mfma_mode()) != 0
+
+
+def _empty(*shape, device):
+    return torch.empty(*shape, dtype=torch.float32, device=device)
+
+
+def _aligned(m, width=None):
+    width = m.cols if width is None else width
+    return (m.ptr % 16 == 0 and m.ld % 4 == 0 and m.bstride % 4 == 0 and width % 4 == 0)
+
+
+# ------------------------------------------------------------ C-ABI wrappers
+class Tiling:
+    """Row mode (tiles of 32 consecutive rows) or edge mode (receiver-aligned tiles of an
+    EdgeTables over its receiver-sorted positions)."""
+
+    def __init__(self, rows, tables=None):
+        self.rows = int(rows)
+        self.g = tables
+        if tables is None:
+            self.args = (None, (self.rows + 31) // 32, self.rows, None, None)
+            self.ntiles = (self.rows + 31) // 32
+        else:
+            self.args = (tables.tiles.data_ptr(), tables.ntiles, self.rows,
+                         tables.csr_rec.data_ptr(), tables.csr_rowptr.data_ptr())
+            self.ntiles = tables.ntiles
+
+
+def _src(m, idx=None):
+    if m is None:
+        return (None, 0, 0, None)
+    return (m.ptr, m.bstride, m.ld, idx.data_ptr() if idx is not None else None)
+
+
+def tail_fwd(tl, a, idx_a, b, idx_b, c, idx_c, W2, b2, gamma, beta, h_out, y, idx_y, res, agg,
+             inv_deg, B, d):
+    n_out = W2.shape[0]
+    _launch(
+        "nlam_tail_fwd", lib.nlam_tail_fwd,
+        tl.args + _src(a, idx_a) + _src(b, idx_b) + _src(c, idx_c)
+        + (W2.data_ptr(), W2.stride(0), _p(b2), _p(gamma), _p(beta), n_out,
+           h_out.data_ptr() if h_out is not None else None,
+           h_out.stride(0) if h_out is not None else 0)
+        + ((y.ptr, y.bstride, y.ld) if y is not None else (None, 0, 0))
+        + (idx_y.data_ptr() if idx_y is not None else None,)
+        + ((res.ptr, res.bstride, res.ld) if res is not None else (None, 0, 0))
+        + ((agg.ptr, agg.bstride, agg.ld) if agg is not None else (None, 0, 0))
+        + (inv_deg.data_ptr() if inv_deg is not None else None, B, d, stream()),
+        flops=2.0 * B * tl.rows * d * n_out,
+        nbytes=4.0 * B * tl.rows * (d * (1 + (h_out is not None)) + n_out * (y is not None)
+                                    * (1 + (res is not None)))
+        + 4.0 * d * B * (agg.rows if agg is not None else 0),
+    )
+
+
+def tail_bwd(tl, h, g1, idx_g1, scale1, g2, idx_g2, W2, b2, gamma, gz_out, gh, idx_gh, gpr, B, d,
+             dgamma, dbeta):
+    n_out = W2.shape[0]
+    dev = W2.device
+    stride = int(lib.nlam_tail_bwd_slab_stride(n_out))
+    nslabs = int(lib.nlam_bwd_grid(B * tl.ntiles))
+    slab = torch.empty(nslabs * stride, dtype=torch.float32, device=dev) if gamma is not None else None
+    _launch(
+        "nlam_tail_bwd", lib.nlam_tail_bwd,
+        tl.args + (h.data_ptr(), h.stride(0))
+        + (g1.ptr, g1.bstride, g1.ld, idx_g1.data_ptr() if idx_g1 is not None else None,
+           scale1.data_ptr() if scale1 is not None else None)
+        + ((g2.ptr, g2.bstride, g2.ld, idx_g2.data_ptr() if idx_g2 is not None else None)
+           if g2 is not None else (None, 0, 0, None))
+        + (W2.data_ptr(), W2.stride(0), _p(b2), _p(gamma), n_out, gz_out.data_ptr(),
+           gz_out.stride(0), gh.ptr, gh.bstride, gh.ld,
+           idx_gh.data_ptr() if idx_gh is not None else None)
+        + ((gpr.ptr, gpr.bstride, gpr.ld) if gpr is not None else (None, 0, 0))
+        + (slab.data_ptr() if slab is not None else None, stride, B, d, stream()),
+        flops=2.0 * B * tl.rows * d * n_out * (2 if gamma is not None else 1),
+        nbytes=4.0 * B * tl.rows * (2 * d + 2 * n_out + (n_out if g2 is not None else 0)),
+    )
+    if gamma is not None:
+        no = (n_out + 31) // 32 * 32
+        ops.reduce_segments(slab, nslabs, stride,
+                            [(0, 1, n_out, n_out, dgamma), (no, 1, n_out, n_out, dbeta)])
+
+
+def lin_bwd_data(gy, W, gx, gx_add=None):
+    """gx = gy W (+ gx_add); W: (128, 128) view (any row pitch)."""
+    n_out, k_in = W.shape
+    _launch(
+        "nlam_lin_bwd_data", lib.nlam_lin_bwd_data,
+        (gy.ptr, gy.bstride, gy.ld, n_out, W.data_ptr(), W.stride(0), k_in, gx.ptr, gx.bstride,
+         gx.ld) + ((gx_add.ptr, gx_add.bstride, gx_add.ld) if gx_add is not None else (None, 0, 0))
+        + (gx.B, gx.rows, stream()),
+        flops=2.0 * gx.B * gx.rows * n_out * k_in,
+        nbytes=4.0 * gx.B * gx.rows * (n_out + k_in * (2 if gx_add is not None else 1)),
+    )
+
+
+def outer(g, x, dW, db, silu_x=False, rows_out=None):
+    """dW (rows_out x 128 view) = sum_rows g^T f(x); db = colsum(g).  g: (B, rows, 128 | 32)."""
+    ng, nx = g.cols, x.cols
+    B, rows = g.B, g.rows
+    stride = ng * nx + ng
+    nslabs = int(lib.nlam_bwd_grid(B * ((rows + 31) // 32)))
+    slab = torch.empty(nslabs * stride, dtype=torch.float32, device=dW.device)
+    _launch(
+        "nlam_wide_outer", lib.nlam_wide_outer,
+        (g.ptr, g.bstride, g.ld, ng, x.ptr, x.bstride, x.ld, nx, int(silu_x), slab.data_ptr(),
+         stride, B, rows, stream()),
+        flops=2.0 * B * rows * ng * nx, nbytes=4.0 * B * rows * (ng + nx),
+    )
+    r = ng if rows_out is None else rows_out
+    ops.reduce_segments(slab, nslabs, stride,
+                        [(0, r, nx, nx, dW), (ng * nx, 1, r, r, db)])
+
+
+def _first_linear(x, W, b, out):
+    """out = x W^T + b: the split-bf16 128 -> 128 projection, or the generic-K kernel."""
+    ops.fused_lin_fwd(x, W, b, None, None, out)
+
+
+def _first_linear_bwd(x, ga, W, need_gx, gx_add, dW, db, dev):
+    """Backward of out = x W^T + b given ga = dL/dout: returns gx (or None), fills dW / db."""
+    k_in = W.shape[1]
+    gx = None
+    wide_ok = k_in == 128 and _aligned(x)
+    if need_gx:
+        gx = _empty(ga.B, ga.rows, k_in, device=dev)
+        if wide_ok:
+            lin_bwd_data(ga, W, mat(gx), gx_add)
+        else:
+            ops.linear_bwd_data(ga, W, mat(gx))
+            if gx_add is not None:
+                ops.add_rows(mat(gx), gx_add, mat(gx))
+    if wide_ok:
+        outer(ga, x, dW, db)
+    else:
+        ops.linear_bwd_weight(ga, x, dW, db)   # generic split-K GEMM (narrow / unaligned inputs)
+    return gx
+
+
+# ----------------------------------------------------------------------- MLP
+def mlp_eligible(seq, x, res=None):
+    from .fused import FORCE_GENERIC, _mlp_parts
+
+    if FORCE_GENERIC or not x.is_cuda or x.dtype != torch.float32 or not enabled():
+        return False
+    if res is not None and res is not x and res.shape[:-1] != x.shape[:-1]:
+        return False
+    lin, ln = _mlp_parts(seq)
+    if len(lin) != 2:
+        return False
+    hid, k_in = lin[0].weight.shape
+    n_out = lin[1].weight.shape[0]
+    if hid not in WIDE_HIDDEN or lin[1].weight.shape[1] != hid or k_in > 128:
+        return False
+    if ln is not None:
+        return n_out == hid
+    return n_out <= 32
+
+
+class WideMLPFunction(torch.autograd.Function):
+    """y = [res +] [LN](W2 silu(W1 x + b1) + b2), x: (..., rows, k_in), hidden 128."""
+
+    @staticmethod
+    def forward(ctx, x, res, W1, b1, W2, b2, gamma, beta):
+        ctx.tag = ops._TAG[-1] if ops._TAG else "mlp"
+        dev = x.device
+        hid, n_out = W1.shape[0], W2.shape[0]
+        xm = mat(x.detach())
+        res_is_x = res is x
+        rm = xm if res_is_x else (mat(res.detach()) if res is not None else None)
+        B, rows = xm.B, xm.rows
+        h = _empty(B, rows, hid, device=dev)
+        _first_linear(xm, W1, b1, mat(h))
+        out = _empty(B, rows, n_out, device=dev)
+        tail_fwd(Tiling(rows), mat(h), None, None, None, None, None, W2, b2, gamma, beta, None,
+                 mat(out), None, rm, None, None, B, hid)
+        ctx.save_for_backward(W1, b1, W2, b2, gamma, h)
+        ctx.xm, ctx.x_shape = xm, x.shape
+        ctx.res_mode = 0 if res is None else (1 if res_is_x else 2)
+        ctx.B = B
+        return out.reshape(*x.shape[:-1], n_out)
+
+    @staticmethod
+    def backward(ctx, gy):
+        W1, b1, W2, b2, gamma, h = ctx.saved_tensors
+        hid, k_in = W1.shape
+        n_out = W2.shape[0]
+        xm, B = ctx.xm, ctx.B
+        dev = W1.device
+        rows = xm.rows
+        gy = gy.contiguous().reshape(B, rows, n_out)
+        gym = mat(gy)
+        no = (n_out + 31) // 32 * 32
+        has_ln = gamma is not None
+        dW1, db1 = torch.empty_like(W1), _empty(hid, device=dev)
+        dW2, db2 = torch.empty_like(W2), _empty(n_out, device=dev)
+        dg = _empty(n_out, device=dev) if has_ln else None
+        dbt = _empty(n_out, device=dev) if has_ln else None
+        need_gx = ctx.needs_input_grad[0]
+        with ops.tag(ctx.tag), ops.slab_batch():
+            gz = _empty(B, rows, no, device=dev)
+            ga = _empty(B, rows, hid, device=dev)
+            tail_bwd(Tiling(rows), h, gym, None, None, None, None, W2, b2, gamma, gz, mat(ga),
+                     None, None, B, hid, dg, dbt)
+            outer(mat(gz), mat(h), dW2, db2, silu_x=True, rows_out=n_out)
+            gx_add = gym if (ctx.res_mode == 1 and need_gx) else None
+            gx = _first_linear_bwd(xm, mat(ga), W1, need_gx, gx_add, dW1, db1, dev)
+        gres = gy if ctx.res_mode == 2 else None
+        if gx is not None:
+            gx = gx.reshape(ctx.x_shape)
+        return (gx, gres, dW1, db1, dW2, db2, dg, dbt)
+
+
+def apply_mlp(seq, x, res=None):
+    from .fused import _mlp_parts
+
+    lin, ln = _mlp_parts(seq)
+    return WideMLPFunction.apply(
+        x, res, lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias,
+        ln.weight if ln is not None else None, ln.bias if ln is not None else None)
+
+
+# ---------------------------------------------------------- InteractionNet
+def inet_eligible(net, send_rep, rec_rep, edge_rep):
+    from .fused import FORCE_GENERIC
+    from .interaction_net import SplitMLPs
+
+    if FORCE_GENERIC or not edge_rep.is_cuda or edge_rep.dtype != torch.float32 or not enabled():
+        return False
+    if isinstance(net.edge_mlp, SplitMLPs) or isinstance(net.aggr_mlp, SplitMLPs):
+        return False
+    if net.hidden_layers != 1 or net.input_dim != net.hidden_dim:
+        return False
+    if net.hidden_dim not in WIDE_HIDDEN:
+        return False
+    if send_rep.dim() != 3 or rec_rep.dim() != 3 or edge_rep.dim() != 3:
+        return False
+    for t in (send_rep, rec_rep, edge_rep):
+        if not _aligned(mat(t.detach())):
+            return False
+    return net.tables.ntiles > 0
+
+
+class WideInteractionNetFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, send_rep, rec_rep, edge_rep, same, g, update_edges, mean,
+                W1, b1, W2, b2, gam, bet, V1, c1, V2, c2, gam2, bet2):
+        with ops.tag(g.tag):
+            dev = edge_rep.device
+            d = W2.shape[0]
+            B = max(send_rep.shape[0], rec_rep.shape[0], edge_rep.shape[0])
+            N_s, N_r, M = send_rep.shape[1], rec_rep.shape[1], edge_rep.shape[1]
+            sm, rm, em = mat(send_rep.detach()), mat(rec_rep.detach()), mat(edge_rep.detach())
+            W1e, W1s, W1r = W1[:, :d], W1[:, d : 2 * d], W1[:, 2 * d :]
+            Ps = _empty(sm.B, N_s, d, device=dev)
+            Pr = _empty(rm.B, N_r, d, device=dev)
+            Pe = _empty(em.B, M, d, device=dev)
+            _first_linear(sm, W1s, None, mat(Ps))
+            _first_linear(rm, W1r, b1, mat(Pr))
+            _first_linear(em, W1e, None, mat(Pe))
+            h_e = _empty(B, M, d, device=dev)
+            agg = _empty(B, N_r, d, device=dev)
+            e_out = _empty(B, M, d, device=dev) if update_edges else None
+            tl = Tiling(M, g)
+            tail_fwd(tl, mat(Pe), g.csr_eid, mat(Ps), g.csr_send, mat(Pr), g.csr_rec, W2, b2, gam,
+                     bet, h_e, mat(e_out) if update_edges else None,
+                     g.csr_eid if update_edges else None, em if update_edges else None,
+                     mat(agg), g.inv_deg if mean else None, B, d)
+            del Pe, Ps, Pr
+            # node update x_r + LN(V2 silu(V1 [x_r | agg] + c1) + c2)
+            hn1 = _empty(rm.B, N_r, d, device=dev)
+            hn2 = _empty(B, N_r, d, device=dev)
+            _first_linear(rm, V1[:, :d], c1, mat(hn1))
+            _first_linear(mat(agg), V1[:, d:], None, mat(hn2))
+            h_n = _empty(B, N_r, d, device=dev)
+            rec_out = _empty(B, N_r, d, device=dev)
+            tail_fwd(Tiling(N_r), mat(hn1), None, mat(hn2), None, None, None, V2, c2, gam2, bet2,
+                     h_n, mat(rec_out), None, rm, None, None, B, d)
+            ctx.save_for_backward(W1, b1, W2, b2, gam, V1, c1, V2, c2, gam2, h_e, h_n, agg)
+            ctx.set_materialize_grads(False)
+            ctx.g, ctx.same, ctx.update_edges, ctx.mean = g, same, update_edges, mean
+            ctx.mats = (sm, rm, em)
+            ctx.dims = (B, N_s, N_r, M, d)
+        if update_edges:
+            return rec_out, e_out
+        return rec_out
+
+    @staticmethod
+    def backward(ctx, g_rec_out, g_edge_out=None):
+        with ops.tag(ctx.g.tag), ops.slab_batch():
+            W1, b1, W2, b2, gam, V1, c1, V2, c2, gam2, h_e, h_n, agg = ctx.saved_tensors
+            g = ctx.g
+            sm, rm, em = ctx.mats
+            B, N_s, N_r, M, d = ctx.dims
+            dev = W1.device
+            W1e, W1s, W1r = W1[:, :d], W1[:, d : 2 * d], W1[:, 2 * d :]
+            same = ctx.same
+            if g_rec_out is None:
+                g_rec_out = torch.zeros(B, N_r, d, dtype=torch.float32, device=dev)
+            g_rec_out = g_rec_out.contiguous()
+            dW1 = _empty(d, 3 * d, device=dev)
+            db1 = _empty(d, device=dev)
+            dW2, db2 = torch.empty_like(W2), _empty(d, device=dev)
+            dgam, dbet = _empty(d, device=dev), _empty(d, device=dev)
+            dV1, dc1 = torch.empty_like(V1), _empty(d, device=dev)
+            dV2, dc2 = torch.empty_like(V2), _empty(d, device=dev)
+            dg2, db2n = _empty(d, device=dev), _empty(d, device=dev)
+            # 1. node update backward
+            gz_n = _empty(B, N_r, d, device=dev)
+            ga_n = _empty(B, N_r, d, device=dev)
+            tail_bwd(Tiling(N_r), h_n, mat(g_rec_out), None, None, None, None, V2, c2, gam2, gz_n,
+                     mat(ga_n), None, None, B, d, dg2, db2n)
+            outer(mat(gz_n), mat(h_n), dV2, dc2, silu_x=True)
+            g_rec = _empty(B, N_r, d, device=dev)       # node-update part + residual
+            lin_bwd_data(mat(ga_n), V1[:, :d], mat(g_rec), mat(g_rec_out))
+            g_agg = _empty(B, N_r, d, device=dev)
+            lin_bwd_data(mat(ga_n), V1[:, d:], mat(g_agg))
+            outer(mat(ga_n), rm, dV1[:, :d], dc1)
+            dummy = _empty(d, device=dev)
+            outer(mat(ga_n), mat(agg), dV1[:, d:], dummy)
+            if rm.B == 1 and B > 1:
+                t3 = _empty(1, N_r, d, device=dev)
+                ops.sum_batch(g_rec, t3)
+                g_rec = t3
+            # 2. edge backward
+            gz_e = _empty(B, M, d, device=dev)
+            gh = _empty(B, M, d, device=dev)
+            gPr = _empty(B, N_r, d, device=dev)
+            geo = None
+            if ctx.update_edges and g_edge_out is not None:
+                geo = mat(g_edge_out.contiguous())
+            tail_bwd(Tiling(M, g), h_e, mat(g_agg), g.csr_rec, g.inv_deg if ctx.mean else None,
+                     geo, g.csr_eid if geo is not None else None, W2, b2, gam, gz_e, mat(gh),
+                     g.csr_eid, mat(gPr), B, d, dgam, dbet)
+            outer(mat(gz_e), mat(h_e), dW2, db2, silu_x=True)
+            # 3. sender-side reduction of gh (edge order; sender lists of edge ids)
+            gPs = (torch.zeros if N_s > g.n_send else torch.empty)(
+                B, N_s, d, dtype=torch.float32, device=dev)
+            ops.segment_sum(mat(gh), g.csc_colptr, g.csc_eid, mat(gPs[:, : g.n_send]))
+            # 4. projections backward (batch-invariant operands: gradients summed over B first)
+            gps_m, gpr_m = mat(gPs), mat(gPr)
+            if sm.B == 1 and B > 1:
+                t1 = _empty(1, N_s, d, device=dev)
+                ops.sum_batch(gPs, t1)
+                gps_m = mat(t1)
+            if rm.B == 1 and B > 1:
+                t2 = _empty(1, N_r, d, device=dev)
+                ops.sum_batch(gPr, t2)
+                gpr_m = mat(t2)
+            outer(gps_m, sm, dW1[:, d : 2 * d], dummy)
+            outer(gpr_m, rm, dW1[:, 2 * d :], db1)
+            if same:
+                t4 = _empty(sm.B, N_s, d, device=dev)
+                lin_bwd_data(gps_m, W1s, mat(t4), mat(g_rec))
+                g_send = _empty(sm.B, N_s, d, device=dev)
+                lin_bwd_data(gpr_m, W1r, mat(g_send), mat(t4))
+                g_rec_total = None
+            else:
+                g_send = _empty(sm.B, N_s, d, device=dev)
+                lin_bwd_data(gps_m, W1s, mat(g_send))
+                g_rec_total = _empty(rm.B, N_r, d, device=dev)
+                lin_bwd_data(gpr_m, W1r, mat(g_rec_total), mat(g_rec))
+            # 5. edge-side first layer (Pe = W1e e; e' = e + m adds g_e' to the edge gradient)
+            outer(mat(gh), em, dW1[:, :d], dummy)
+            if ctx.update_edges:
+                g_e = _empty(B, M, d, device=dev)
+                lin_bwd_data(mat(gh), W1e, mat(g_e), geo)
+                g_edge = g_e
+                if em.B == 1 and B > 1:
+                    t5 = _empty(1, M, d, device=dev)
+                    ops.sum_batch(g_e, t5)
+                    g_edge = t5
+            else:
+                dPe = mat(gh)
+                if em.B == 1 and B > 1:
+                    t6 = _empty(1, M, d, device=dev)
+                    ops.sum_batch(gh, t6)
+                    dPe = mat(t6)
+                g_edge = _empty(em.B, M, d, device=dev)
+                lin_bwd_data(dPe, W1e, mat(g_edge))
+        return (g_send, g_rec_total, g_edge, None, None, None, None,
+                dW1, db1, dW2, db2, dgam, dbet, dV1, dc1, dV2, dc2, dg2, db2n)
+
+
+def apply_inet(net, send_rep, rec_rep, edge_rep):
+    from .fused import _base, _mlp_parts
+
+    same = send_rep is rec_rep
+    s, e = _base(send_rep), _base(edge_rep)
+    r = s if same else _base(rec_rep)
+    el, al = _mlp_parts(net.edge_mlp), _mlp_parts(net.aggr_mlp)
+    return WideInteractionNetFunction.apply(
+        s, r, e, same, net.tables, net.update_edges, net.aggr == "mean",
+        el[0][0].weight, el[0][0].bias, el[0][1].weight, el[0][1].bias, el[1].weight, el[1].bias,
+        al[0][0].weight, al[0][0].bias, al[0][1].weight, al[0][1].bias, al[1].weight, al[1].bias)

@@ -12,7 +12,12 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("mode,pred_bar,grad_bar", [("fp32", 2e-6, 1e-5), ("bf16x3", 2e-5, 2e-4)])
+# fp32 / bf16x3: an order of magnitude inside the 1e-4 / 2e-3 bars, at hidden 64 AND 128 (the
+# d = 128 golden runs the wide kernels in bf16x3 and the generic exact-fp32 kernels in fp32 mode).
+# bf16: plain bf16 products, fp32 accumulate -- the bf16-mixed tolerance of SURVEY.md 8c (2e-2);
+# only the d = 128 kernels change arithmetic in that mode.
+@pytest.mark.parametrize("mode,pred_bar,grad_bar",
+                         [("fp32", 2e-6, 1e-5), ("bf16x3", 2e-5, 2e-4), ("bf16", 2e-2, 2e-1)])
 def test_model_parity_in_mode(mode, pred_bar, grad_bar):
     env = dict(os.environ, NLAM_MFMA=mode)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "parity_margin.py")],
@@ -22,4 +27,5 @@ def test_model_parity_in_mode(mode, pred_bar, grad_bar):
     rows = re.findall(r"pred (\S+)\s+loss (\S+)\s+worst grad (\S+)", out.stdout)
     assert len(rows) >= 3, out.stdout
     for pred, loss, grad in rows:
-        assert float(pred) < pred_bar and float(loss) < 1e-5 and float(grad) < grad_bar, out.stdout
+        loss_bar = 1e-5 if mode != "bf16" else 2e-2
+        assert float(pred) < pred_bar and float(loss) < loss_bar and float(grad) < grad_bar, out.stdout

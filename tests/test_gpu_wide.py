@@ -1,0 +1,173 @@
+"""hidden_dim 128 ("wide") kernels through the C ABI: operator and MLP parity with the CPU oracle
+(oracle/nlam_oracle.py, pinned by the reference goldens), all call shapes the models use
+(shared / separate senders, sum / mean with empty receivers, update_edges on / off, stride-0
+batch-invariant inputs, narrow embedder inputs, the 17-wide output map), and proof that the wide
+kernels -- not the generic GEMM sequence -- are what runs.  fp32 bars (default bf16x3
+arithmetic): forward 1e-4, gradients 1e-3 relative to max|ref|."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return float((a.detach().cpu() - b.detach()).abs().max() / (b.detach().abs().max() + 1e-30))
+
+
+def _edges(gen, n_s, n_r, M, shared, empty_receivers=False):
+    rec = torch.randint(0, n_r, (M,), generator=gen)
+    send = torch.randint(0, n_s, (M,), generator=gen)
+    if empty_receivers:   # (mean clamps the count to 1); in-degrees stay <= 32
+        for r_empty in (7, 20, 30):
+            rec[rec == r_empty] = r_empty + 1
+    rec[0], rec[1], send[2] = 0, n_r - 1, 0
+    return torch.stack((send + (0 if shared else n_r), rec))
+
+
+@pytest.mark.parametrize("shared,upd,aggr,B", [(True, True, "sum", 2), (False, False, "mean", 3),
+                                                (False, True, "mean", 1), (True, False, "sum", 2)])
+def test_wide_interaction_net_vs_oracle(shared, upd, aggr, B):
+    import nlam_oracle as orc
+    from neural_lam_amd import wide
+    from neural_lam_amd.interaction_net import InteractionNet
+
+    d = 128
+    gen = torch.Generator().manual_seed(7 + B)
+    n_s, n_r, M = (45, 45, 410) if shared else (70, 38, 333)
+    ei = _edges(gen, n_s, n_r, M, shared, empty_receivers=(aggr == "mean"))
+    torch.manual_seed(5)
+    net = InteractionNet(ei, d, update_edges=upd, aggr=aggr)
+    with torch.no_grad():
+        for k, p in net.named_parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn(p.shape, generator=gen))
+    sd = {f"n.{k}": v.detach().clone() for k, v in net.state_dict().items()}
+    net = net.cuda()
+    send = torch.randn(B, n_s, d, generator=gen)
+    rec = send if shared else torch.randn(B, n_r, d, generator=gen)
+    edge = torch.randn(B, M, d, generator=gen)
+    cr, ce = torch.randn(B, n_r, d, generator=gen), torch.randn(B, M, d, generator=gen)
+
+    def run(fwd, s, r, e, cr, ce):
+        out = fwd(s, r, e)
+        o_r, o_e = out if upd else (out, None)
+        loss = (o_r * cr).sum() + ((o_e * ce).sum() if upd else 0.0)
+        loss.backward()
+        return o_r, o_e
+
+    sc = send.clone().requires_grad_(True)
+    rc = sc if shared else rec.clone().requires_grad_(True)
+    ec = edge.clone().requires_grad_(True)
+    osd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    w_r, w_e = run(lambda s, r, e: orc.interaction_net(osd, "n", ei, s, r, e, update_edges=upd,
+                                                       aggr=aggr), sc, rc, ec, cr, ce)
+    sg = send.cuda().requires_grad_(True)
+    rg = sg if shared else rec.cuda().requires_grad_(True)
+    eg = edge.cuda().requires_grad_(True)
+    assert wide.inet_eligible(net, sg, rg, eg)
+    g_r, g_e = run(net, sg, rg, eg, cr.cuda(), ce.cuda())
+    assert rel(g_r, w_r) < 1e-4
+    if upd:
+        assert rel(g_e, w_e) < 1e-4
+    assert rel(sg.grad, sc.grad) < 1e-3 and rel(eg.grad, ec.grad) < 1e-3
+    if not shared:
+        assert rel(rg.grad, rc.grad) < 1e-3
+    for k, p in net.named_parameters():
+        assert rel(p.grad, osd[f"n.{k}"].grad) < 1e-3, k
+
+
+def test_wide_stride0_batch_inputs_match_oracle():
+    """g2m-style call at d = 128: receiver and edge reps are stride-0 expands (expand_to_batch)."""
+    import nlam_oracle as orc
+    from neural_lam_amd.interaction_net import InteractionNet
+
+    gen = torch.Generator().manual_seed(21)
+    d, B, n_s, n_r, M = 128, 3, 60, 20, 150
+    ei = _edges(gen, n_s, n_r, M, shared=False)
+    torch.manual_seed(3)
+    net = InteractionNet(ei, d, update_edges=False)
+    sd = {f"n.{k}": v.clone() for k, v in net.state_dict().items()}
+    net = net.cuda()
+    send = torch.randn(B, n_s, d, generator=gen)
+    rec1, edge1 = torch.randn(n_r, d, generator=gen), torch.randn(M, d, generator=gen)
+    sc, rc, ec = (t.clone().requires_grad_(True) for t in (send, rec1, edge1))
+    want = orc.interaction_net(sd, "n", ei, sc, rc.unsqueeze(0).expand(B, -1, -1),
+                               ec.unsqueeze(0).expand(B, -1, -1), update_edges=False)
+    (want ** 2).sum().backward()
+    sg, rg, eg = (t.cuda().requires_grad_(True) for t in (send, rec1, edge1))
+    got = net(sg, rg.unsqueeze(0).expand(B, -1, -1), eg.unsqueeze(0).expand(B, -1, -1))
+    (got ** 2).sum().backward()
+    assert rel(got, want) < 1e-4
+    assert rel(sg.grad, sc.grad) < 1e-3 and rel(rg.grad, rc.grad) < 1e-3 and rel(eg.grad, ec.grad) < 1e-3
+
+
+@pytest.mark.parametrize("blueprint,ln,res,rows,B", [
+    ([3, 128, 128], True, False, 77, 1),        # edge / mesh embedders (narrow static features)
+    ([17, 128, 128], True, False, 100, 2),      # grid embedder (unaligned 17-wide rows)
+    ([128, 128, 128], True, True, 131, 2),      # encoding_grid_mlp with fused residual
+    ([128, 128, 17], False, False, 90, 2),      # output map: no LayerNorm, 17 columns
+    ([128, 128, 5], False, False, 33, 1),
+])
+def test_wide_mlp_vs_oracle(blueprint, ln, res, rows, B):
+    import nlam_oracle as orc
+    from neural_lam_amd import ops, utils, wide
+
+    gen = torch.Generator().manual_seed(sum(blueprint) + rows)
+    torch.manual_seed(9)
+    mlp = utils.make_mlp(blueprint, layer_norm=ln)
+    with torch.no_grad():
+        for p in mlp.parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn(p.shape, generator=gen))
+    sd = {f"m.{k}": v.detach().clone().requires_grad_(True) for k, v in mlp.state_dict().items()}
+    mlp = mlp.cuda()
+    x = torch.randn(B, rows, blueprint[0], generator=gen)
+    cot = torch.randn(B, rows, blueprint[-1], generator=gen)
+    xc = x.clone().requires_grad_(True)
+    want = orc.mlp(sd, "m", xc, 1, layer_norm=ln)
+    if res:
+        want = xc + want
+    (want * cot).sum().backward()
+    xg = x.cuda().requires_grad_(True)
+    assert wide.mlp_eligible(mlp, xg, xg if res else None)
+    ops.PROFILER = ops.KernelProfiler()
+    try:
+        got = mlp(xg, res=xg) if res else mlp(xg)
+        (got * cot.cuda()).sum().backward()
+        stats = ops.PROFILER.collect()
+    finally:
+        ops.PROFILER = None
+    names = {k.split("@")[0] for k in stats}
+    assert {"nlam_tail_fwd", "nlam_tail_bwd", "nlam_wide_outer"} <= names
+    assert rel(got, want) < 1e-4
+    assert rel(xg.grad, xc.grad) < 1e-3
+    for k, p in mlp.named_parameters():
+        assert rel(p.grad, sd[f"m.{k}"].grad) < 1e-3, k
+
+
+def test_wide_paths_are_taken_at_hidden_128():
+    """d = 128, hidden_layers = 1: the wide kernels must be the ones that run -- no generic GEMM
+    on the 128-wide operands (narrow embedder inputs may use it for their first layer only)."""
+    from neural_lam_amd import fused, ops, wide
+    from neural_lam_amd.interaction_net import InteractionNet
+
+    gen = torch.Generator().manual_seed(0)
+    ei = torch.stack((torch.randint(0, 30, (200,), generator=gen),
+                      torch.randint(0, 30, (200,), generator=gen)))
+    ei[0, 0], ei[1, 0], ei[1, 1] = 0, 0, 29
+    net = InteractionNet(ei, 128).cuda()
+    x = torch.randn(2, 30, 128, device="cuda", requires_grad=True)
+    e = torch.randn(2, 200, 128, device="cuda", requires_grad=True)
+    assert not fused.inet_eligible(net, x, x, e) and wide.inet_eligible(net, x, x, e)
+    ops.PROFILER = ops.KernelProfiler()
+    try:
+        o_x, o_e = net(x, x, e)
+        (o_x.sum() + o_e.sum()).backward()
+        stats = ops.PROFILER.collect()
+    finally:
+        ops.PROFILER = None
+    names = {k.split("@")[0] for k in stats}
+    assert {"nlam_lin_fwd", "nlam_tail_fwd", "nlam_tail_bwd", "nlam_lin_bwd_data",
+            "nlam_wide_outer", "nlam_segment_sum"} <= names
+    assert "nlam_gemm" not in names and "nlam_layernorm_fwd" not in names
+    assert stats["nlam_tail_fwd@inet"]["calls"] == 2 and stats["nlam_tail_bwd@inet"]["calls"] == 2
