@@ -385,10 +385,32 @@ int nlam_lin_bwd_data(const float* gy, int64_t gy_bstride, int64_t gy_ld, int n_
 /* Weight gradient of a Linear as a streaming pass:  dW (ng x nx) = sum_rows g[r]^T (x) f(x[r]),
  * db (ng) = colsum(g), f = silu if silu_x (x is then the kept pre-activation h) else identity;
  * per-workgroup slabs [dW | db] (count nlam_bwd_grid(B * ceil(rows / 32)), pitch >= ng nx + ng).
- * ng in {128, 32}, nx = 128. */
+ * (ng, nx) in {(128, 128), (32, 128), (128, <= 64)}; pitch >= ng * ceil32(nx) + ng; narrow or
+ * unaligned x rows (static features of the embedders) are staged by scalar loads. */
 int nlam_wide_outer(const float* g, int64_t g_bstride, int64_t g_ld, int ng,
                     const float* x, int64_t x_bstride, int64_t x_ld, int nx, int silu_x,
                     float* slab, int64_t slab_stride, int64_t B, int64_t rows, void* stream);
+
+/* Several INDEPENDENT problems of one kind in one launch (n <= 8; arrays of n entries): the small
+ * mesh levels of Hi-LAM (reference hi_lam.py:82-207: 10 InteractionNets per processor layer on
+ * 81 ... 6,561-node levels) are bound by the latency of their launches, not by their work.
+ * nlam_lin_fwd_multi: out_k = x_k W_k^T + bias_k (bias_k may be NULL), all 128 -> 128.
+ * nlam_lin_bwd_data_multi / nlam_wide_outer_multi: as the single forms, all 128 x 128. */
+int nlam_lin_fwd_multi(int n, const float* const* x, const int64_t* x_bstride, const int64_t* x_ld,
+                       const float* const* W, const int64_t* ldW, const float* const* bias,
+                       float* const* out, const int64_t* out_bstride, const int64_t* out_ld,
+                       const int64_t* B, const int64_t* rows, void* stream);
+int nlam_lin_bwd_data_multi(int n, const float* const* gy, const int64_t* gy_bstride,
+                            const int64_t* gy_ld, const float* const* W, const int64_t* ldW,
+                            float* const* gx, const int64_t* gx_bstride, const int64_t* gx_ld,
+                            const float* const* gx_add, const int64_t* ga_bstride,
+                            const int64_t* ga_ld, const int64_t* B, const int64_t* rows,
+                            void* stream);
+int nlam_wide_outer_multi(int n, const float* const* g, const int64_t* g_bstride,
+                          const int64_t* g_ld, const float* const* x, const int64_t* x_bstride,
+                          const int64_t* x_ld, const int32_t* silu_x, float* const* slab,
+                          const int64_t* slab_stride, const int64_t* B, const int64_t* rows,
+                          void* stream);
 
 /* output_std head (reference base_graph_model.py:161-177 with args.output_std): net_out is
  * (rows, 2F); state = prev + net_out[:, :F] * scale + shift, pred_std = softplus(net_out[:, F:])

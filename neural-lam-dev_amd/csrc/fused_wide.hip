@@ -618,8 +618,8 @@ struct LinBwdDataParams {
 };
 
 template <int NOUTB, int KB, int TERMS>
-__global__ __launch_bounds__(256) void lin_bwd_data_kernel(LinBwdDataParams q) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+__device__ __forceinline__ void lin_bwd_data_body(const LinBwdDataParams& q, int bid, int gdim,
+                                                  float* smem) {
   constexpr int NO = 32 * NOUTB, K = 32 * KB;
   constexpr int LDT = (NO > K ? NO : K) + 4;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -630,7 +630,7 @@ __global__ __launch_bounds__(256) void lin_bwd_data_kernel(LinBwdDataParams q) {
   __syncthreads();
   const int64_t tiles_per_b = (q.rows + NLAM_TILE - 1) / NLAM_TILE;
   const int64_t ntiles = tiles_per_b * q.B;
-  for (int64_t tt = (int64_t)blockIdx.x * 4 + wave; tt < ntiles; tt += (int64_t)gridDim.x * 4) {
+  for (int64_t tt = (int64_t)bid * 4 + wave; tt < ntiles; tt += (int64_t)gdim * 4) {
     const int64_t b = tt / tiles_per_b;
     const int64_t r0 = (tt - b * tiles_per_b) * NLAM_TILE;
     const int nrows = (int)((q.rows - r0) < NLAM_TILE ? (q.rows - r0) : NLAM_TILE);
@@ -661,17 +661,80 @@ __global__ __launch_bounds__(256) void lin_bwd_data_kernel(LinBwdDataParams q) {
   }
 }
 
+// Up to NLAM_WIDE_MAXP independent problems of one kernel type in ONE launch: Hi-LAM's small
+// mesh levels are bound by the latency of their ~24 launches per InteractionNet, not by work.
+// Workgroup b serves problem k with first[k] <= b < first[k + 1] as block b - first[k] of
+// first[k + 1] - first[k].
+#define NLAM_WIDE_MAXP 8
+template <typename P>
+struct WideMulti {
+  int n;
+  int first[NLAM_WIDE_MAXP + 1];
+  P p[NLAM_WIDE_MAXP];
+};
+template <typename P>
+__device__ __forceinline__ int wide_multi_find(const WideMulti<P>& m, int b) {
+  int k = 0;
+  while (k + 1 < m.n && b >= m.first[k + 1]) ++k;
+  return k;
+}
+
 template <int NOUTB, int KB, int TERMS>
-static int launch_lin_bwd_data(const LinBwdDataParams& q, hipStream_t s) {
+__global__ __launch_bounds__(256) void lin_bwd_data_kernel(WideMulti<LinBwdDataParams> m) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int k = wide_multi_find(m, blockIdx.x);
+  lin_bwd_data_body<NOUTB, KB, TERMS>(m.p[k], blockIdx.x - m.first[k], m.first[k + 1] - m.first[k],
+                                      smem);
+}
+
+// grid shares of the problems of a multi launch: wide_grid() each, scaled down to <= 512 in all
+template <typename P, typename TilesOf>
+static unsigned wide_multi_grid(WideMulti<P>& m, TilesOf tiles_of) {
+  int64_t want[NLAM_WIDE_MAXP], sum = 0;
+  for (int k = 0; k < m.n; ++k) {
+    want[k] = wide_grid(tiles_of(m.p[k]));
+    sum += want[k];
+  }
+  m.first[0] = 0;
+  for (int k = 0; k < m.n; ++k) {
+    int64_t g = sum > 512 ? (want[k] * 512 + sum - 1) / sum : want[k];
+    if (g < 1) g = 1;
+    m.first[k + 1] = m.first[k] + (int)g;
+  }
+  for (int k = m.n; k < NLAM_WIDE_MAXP; ++k) m.first[k + 1] = m.first[m.n];
+  return (unsigned)m.first[m.n];
+}
+
+template <int NOUTB, int KB, int TERMS>
+static int launch_lin_bwd_data(WideMulti<LinBwdDataParams>& m, hipStream_t s) {
   constexpr int NO = 32 * NOUTB, K = 32 * KB;
   constexpr int LDT = (NO > K ? NO : K) + 4;
   const size_t lds = b3_image_bytes(NO, K) + (size_t)4 * NLAM_TILE * LDT * sizeof(float);
   NLAM_REQUIRE(lds <= 160 * 1024, "lin_bwd_data: LDS footprint %zu B exceeds 160 KiB", lds);
   auto kern = lin_bwd_data_kernel<NOUTB, KB, TERMS>;
   NLAM_BIG_LDS(kern, "lin_bwd_data_kernel");
-  const int64_t ntiles = ((q.rows + NLAM_TILE - 1) / NLAM_TILE) * q.B;
-  kern<<<wide_grid(ntiles), 256, lds, s>>>(q);
+  const unsigned grid = wide_multi_grid(m, [](const LinBwdDataParams& q) {
+    return ((q.rows + NLAM_TILE - 1) / NLAM_TILE) * q.B;
+  });
+  kern<<<grid, 256, lds, s>>>(m);
   NLAM_CHECK_LAUNCH("lin_bwd_data_kernel");
+  return 0;
+}
+
+static int lin_bwd_data_fill(LinBwdDataParams& q, const float* gy, int64_t gy_bstride, int64_t gy_ld,
+                             int n_out, const float* W, int64_t ldW, int k_in, float* gx,
+                             int64_t gx_bstride, int64_t gx_ld, const float* gx_add,
+                             int64_t ga_bstride, int64_t ga_ld, int64_t B, int64_t rows) {
+  NLAM_REQUIRE(n_out == 128 && k_in == 128, "nlam_lin_bwd_data: shape %d x %d unsupported (128 x 128)",
+               n_out, k_in);
+  NLAM_REQUIRE(view_vec_ok(gy, gy_bstride, gy_ld, n_out) && view_vec_ok(gx, gx_bstride, gx_ld, k_in) &&
+                   (gx_add == nullptr || view_vec_ok(gx_add, ga_bstride, ga_ld, k_in)),
+               "nlam_lin_bwd_data: operand rows must be 16-byte aligned with pitch %% 4 == 0");
+  q.gy = RowView{gy, gy_bstride, gy_ld, n_out};
+  q.W = W; q.ldW = ldW; q.n_out = n_out; q.k_in = k_in;
+  q.gx = gx; q.gx_bstride = gx_bstride; q.gx_ld = gx_ld;
+  q.gx_add = gx_add; q.ga_bstride = ga_bstride; q.ga_ld = ga_ld;
+  q.rows = rows; q.B = (int)B;
   return 0;
 }
 
@@ -682,20 +745,39 @@ extern "C" int nlam_lin_bwd_data(const float* gy, int64_t gy_bstride, int64_t gy
                                  int64_t B, int64_t rows, void* stream) {
   if (B <= 0 || rows <= 0) return 0;
   NLAM_REQUIRE(nlam_mfma_terms() != 0, "nlam_lin_bwd_data: needs NLAM_MFMA=bf16x3|bf16");
-  NLAM_REQUIRE(n_out == 128 && k_in == 128, "nlam_lin_bwd_data: shape %d x %d unsupported (128 x 128)",
-               n_out, k_in);
-  NLAM_REQUIRE(view_vec_ok(gy, gy_bstride, gy_ld, n_out) && view_vec_ok(gx, gx_bstride, gx_ld, k_in) &&
-                   (gx_add == nullptr || view_vec_ok(gx_add, ga_bstride, ga_ld, k_in)),
-               "nlam_lin_bwd_data: operand rows must be 16-byte aligned with pitch %% 4 == 0");
-  LinBwdDataParams q;
-  q.gy = RowView{gy, gy_bstride, gy_ld, n_out};
-  q.W = W; q.ldW = ldW; q.n_out = n_out; q.k_in = k_in;
-  q.gx = gx; q.gx_bstride = gx_bstride; q.gx_ld = gx_ld;
-  q.gx_add = gx_add; q.ga_bstride = ga_bstride; q.ga_ld = ga_ld;
-  q.rows = rows; q.B = (int)B;
+  WideMulti<LinBwdDataParams> m;
+  m.n = 1;
+  if (lin_bwd_data_fill(m.p[0], gy, gy_bstride, gy_ld, n_out, W, ldW, k_in, gx, gx_bstride, gx_ld,
+                        gx_add, ga_bstride, ga_ld, B, rows))
+    return 1;
   hipStream_t s = (hipStream_t)stream;
-  return nlam_mfma_terms() == 3 ? launch_lin_bwd_data<4, 4, 3>(q, s)
-                                : launch_lin_bwd_data<4, 4, 1>(q, s);
+  return nlam_mfma_terms() == 3 ? launch_lin_bwd_data<4, 4, 3>(m, s)
+                                : launch_lin_bwd_data<4, 4, 1>(m, s);
+}
+
+extern "C" int nlam_lin_bwd_data_multi(int n, const float* const* gy, const int64_t* gy_bstride,
+                                       const int64_t* gy_ld, const float* const* W,
+                                       const int64_t* ldW, float* const* gx,
+                                       const int64_t* gx_bstride, const int64_t* gx_ld,
+                                       const float* const* gx_add, const int64_t* ga_bstride,
+                                       const int64_t* ga_ld, const int64_t* B, const int64_t* rows,
+                                       void* stream) {
+  NLAM_REQUIRE(n >= 1 && n <= NLAM_WIDE_MAXP, "nlam_lin_bwd_data_multi: n %d out of [1, %d]", n,
+               NLAM_WIDE_MAXP);
+  NLAM_REQUIRE(nlam_mfma_terms() != 0, "nlam_lin_bwd_data_multi: needs NLAM_MFMA=bf16x3|bf16");
+  WideMulti<LinBwdDataParams> m;
+  m.n = 0;
+  for (int k = 0; k < n; ++k) {
+    if (B[k] <= 0 || rows[k] <= 0) continue;
+    if (lin_bwd_data_fill(m.p[m.n], gy[k], gy_bstride[k], gy_ld[k], 128, W[k], ldW[k], 128, gx[k],
+                          gx_bstride[k], gx_ld[k], gx_add[k], ga_bstride[k], ga_ld[k], B[k], rows[k]))
+      return 1;
+    ++m.n;
+  }
+  if (m.n == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  return nlam_mfma_terms() == 3 ? launch_lin_bwd_data<4, 4, 3>(m, s)
+                                : launch_lin_bwd_data<4, 4, 1>(m, s);
 }
 
 // ================================================= streaming weight gradients ===
@@ -706,11 +788,13 @@ struct WideOuterParams {
   RowView x;        // (B, rows, 32 NXB); batch-invariant x (bstride 0) allowed
   float* slab; int64_t slab_stride;
   int64_t rows; int B;
+  int silu_x;
+  int x_vec;        // x rows float4-loadable (else scalar staging: narrow static features)
 };
 
-template <int NGB, int NXB, int TERMS, bool SILU_X>
-__global__ __launch_bounds__(256) void wide_outer_kernel(WideOuterParams q) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+template <int NGB, int NXB, int TERMS>
+__device__ __forceinline__ void wide_outer_body(const WideOuterParams& q, int bid, int gdim,
+                                                float* smem) {
   constexpr int NG = 32 * NGB, NX = 32 * NXB;
   constexpr int NV = (NG + 63) / 64;
   constexpr int ldg = NG + 4, ldx = NX + 4;
@@ -730,45 +814,103 @@ __global__ __launch_bounds__(256) void wide_outer_kernel(WideOuterParams q) {
   const int64_t tiles_per_b = (q.rows + NLAM_TILE - 1) / NLAM_TILE;
   const int64_t ntiles = tiles_per_b * q.B;
   const B3Tile TGp = b3_tile(TG, NG), TXp = b3_tile(TX, NX);
-  for (int64_t tt = (int64_t)blockIdx.x * 4 + wave; tt < ntiles; tt += (int64_t)gridDim.x * 4) {
+  const bool silu_x = q.silu_x != 0;
+  for (int64_t tt = (int64_t)bid * 4 + wave; tt < ntiles; tt += (int64_t)gdim * 4) {
     const int64_t b = tt / tiles_per_b;
     const int64_t r0 = (tt - b * tiles_per_b) * NLAM_TILE;
     const int nrows = (int)((q.rows - r0) < NLAM_TILE ? (q.rows - r0) : NLAM_TILE);
-    f32x4 vg[4 * NGB], vx[4 * NXB];
-    view_load_v<4 * NGB>(vg, q.g, b, r0, nrows, lane);
-    view_load_v<4 * NXB>(vx, q.x, b, r0, nrows, lane);
-    if (SILU_X) {
-#pragma unroll
-      for (int k = 0; k < 4 * NXB; ++k)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) vx[k][j] = nlam_silu(vx[k][j]);
+    constexpr int NVX = NXB >= 4 ? 4 * NXB : 8;   // float4 per lane that cover 32 rows of x
+    {
+      f32x4 vg[4 * NGB];
+      view_load_v<4 * NGB>(vg, q.g, b, r0, nrows, lane);
+      put_rows_v_b3<4 * NGB>(TGp, 0, NG, nrows, lane, vg);
     }
-    put_rows_v_b3<4 * NGB>(TGp, 0, NG, nrows, lane, vg);
-    put_rows_v_b3<4 * NXB>(TXp, 0, NX, nrows, lane, vx);
+    bool x_vec = true;   // (128-wide x: always float4 rows, checked on the host)
+    if constexpr (NXB < 4) x_vec = q.x_vec != 0;
+    if (x_vec) {
+      f32x4 vx[NVX];
+      RowView xv = q.x;
+      if constexpr (NXB >= 4) xv.width = NX;   // compile-time row mapping for the 128-wide form
+      view_load_v<NVX>(vx, xv, b, r0, nrows, lane);
+      if (silu_x) {
+#pragma unroll
+        for (int k = 0; k < NVX; ++k)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) vx[k][j] = nlam_silu(vx[k][j]);
+      }
+      put_rows_v_b3<NVX>(TXp, 0, xv.width, nrows, lane, vx);
+      if (NXB < 4 && q.x.width < NX) {   // zero the K padding (dropped columns, kept finite)
+        const int padw = NX - q.x.width;
+        for (int idx = lane; idx < NLAM_TILE * padw; idx += 64) {
+          const int tr = idx / padw, cc = q.x.width + idx - tr * padw;
+          TXp.hi[tr * TXp.pitch + cc] = (__bf16)0.f;
+          TXp.lo[tr * TXp.pitch + cc] = (__bf16)0.f;
+        }
+      }
+    } else if constexpr (NXB < 4) {
+      const float* xb = q.x.ptr + b * q.x.bstride + r0 * q.x.ld;
+      for (int idx = lane; idx < NLAM_TILE * NX; idx += 64) {
+        const int tr = idx / NX, cc = idx - tr * NX;
+        float v = (tr < nrows && cc < q.x.width) ? xb[(int64_t)tr * q.x.ld + cc] : 0.f;
+        if (silu_x) v = nlam_silu(v);
+        const __bf16 hi = (__bf16)v;
+        TXp.hi[tr * TXp.pitch + cc] = hi;
+        TXp.lo[tr * TXp.pitch + cc] = (__bf16)(v - (float)hi);
+      }
+    }
     wave_sync();
     tile_colsum_b3<NV, TERMS>(db, TGp, 0, lane);
     outer_accum_b3<NGB, NXB, TERMS>(dW, TGp, 0, TXp, 0, lane);
     wave_sync();
   }
   __syncthreads();
-  float* slab = q.slab + (int64_t)blockIdx.x * q.slab_stride;
+  float* slab = q.slab + (int64_t)bid * q.slab_stride;
   fold_block_rows_to_slab<NGB, NXB>(dW, smem, NX, slab, tid, wave, lane);
   fold_vec_lds<NV>(db, smem, wave, lane);
   for (int i = tid; i < NG; i += 256) slab[NG * NX + i] = smem[i];
 }
 
-template <int NGB, int NXB, int TERMS, bool SILU_X>
-static int launch_wide_outer(const WideOuterParams& q, hipStream_t s) {
+template <int NGB, int NXB, int TERMS>
+__global__ __launch_bounds__(256) void wide_outer_kernel(WideMulti<WideOuterParams> m) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int k = wide_multi_find(m, blockIdx.x);
+  wide_outer_body<NGB, NXB, TERMS>(m.p[k], blockIdx.x - m.first[k], m.first[k + 1] - m.first[k],
+                                   smem);
+}
+
+template <int NGB, int NXB, int TERMS>
+static int launch_wide_outer(WideMulti<WideOuterParams>& m, hipStream_t s) {
   constexpr int NG = 32 * NGB, NX = 32 * NXB;
   size_t lds = (size_t)4 * NLAM_TILE * (NG + 4 + NX + 4) * sizeof(float);
   const size_t fold = (size_t)4 * 32 * NX * sizeof(float);
   if (fold > lds) lds = fold;
   NLAM_REQUIRE(lds <= 160 * 1024, "wide_outer: LDS footprint %zu B exceeds 160 KiB", lds);
-  auto kern = wide_outer_kernel<NGB, NXB, TERMS, SILU_X>;
+  auto kern = wide_outer_kernel<NGB, NXB, TERMS>;
   NLAM_BIG_LDS(kern, "wide_outer_kernel");
-  const int64_t ntiles = ((q.rows + NLAM_TILE - 1) / NLAM_TILE) * q.B;
-  kern<<<wide_grid(ntiles), 256, lds, s>>>(q);
+  // every problem's slab count is what the host sized its slab buffer for: nlam_bwd_grid(tiles)
+  m.first[0] = 0;
+  for (int k = 0; k < m.n; ++k)
+    m.first[k + 1] = m.first[k] + (int)wide_grid(((m.p[k].rows + NLAM_TILE - 1) / NLAM_TILE) * m.p[k].B);
+  for (int k = m.n; k < NLAM_WIDE_MAXP; ++k) m.first[k + 1] = m.first[m.n];
+  kern<<<(unsigned)m.first[m.n], 256, lds, s>>>(m);
   NLAM_CHECK_LAUNCH("wide_outer_kernel");
+  return 0;
+}
+
+static int wide_outer_fill(WideOuterParams& q, const float* g, int64_t g_bstride, int64_t g_ld, int ng,
+                           const float* x, int64_t x_bstride, int64_t x_ld, int nx, int silu_x,
+                           float* slab, int64_t slab_stride, int64_t B, int64_t rows) {
+  NLAM_REQUIRE((ng == 128 || ng == 32) && nx >= 1 && (nx <= 64 || nx == 128) && (ng == 128 || nx == 128),
+               "nlam_wide_outer: shape %d x %d unsupported", ng, nx);
+  NLAM_REQUIRE(view_vec_ok(g, g_bstride, g_ld, ng) && x != nullptr && x_ld >= nx,
+               "nlam_wide_outer: g rows must be 16-byte aligned with pitch %% 4 == 0");
+  const int nxp = (nx + 31) & ~31;
+  NLAM_REQUIRE(slab != nullptr && slab_stride >= (int64_t)ng * nxp + ng, "nlam_wide_outer: slab too small");
+  q.g = RowView{g, g_bstride, g_ld, ng};
+  q.x = RowView{x, x_bstride, x_ld, nx};
+  q.slab = slab; q.slab_stride = slab_stride; q.rows = rows; q.B = (int)B; q.silu_x = silu_x;
+  q.x_vec = view_vec_ok(x, x_bstride, x_ld, nx) ? 1 : 0;
+  NLAM_REQUIRE(nx < 128 || q.x_vec, "nlam_wide_outer: 128-wide x rows must be 16-byte aligned");
   return 0;
 }
 
@@ -778,19 +920,131 @@ extern "C" int nlam_wide_outer(const float* g, int64_t g_bstride, int64_t g_ld, 
                                void* stream) {
   if (B <= 0 || rows <= 0) return 0;
   NLAM_REQUIRE(nlam_mfma_terms() != 0, "nlam_wide_outer: needs NLAM_MFMA=bf16x3|bf16");
-  NLAM_REQUIRE((ng == 128 || ng == 32) && nx == 128, "nlam_wide_outer: shape %d x %d unsupported",
-               ng, nx);
-  NLAM_REQUIRE(view_vec_ok(g, g_bstride, g_ld, ng) && view_vec_ok(x, x_bstride, x_ld, nx),
-               "nlam_wide_outer: operand rows must be 16-byte aligned with pitch %% 4 == 0");
-  NLAM_REQUIRE(slab != nullptr && slab_stride >= (int64_t)ng * nx + ng, "nlam_wide_outer: slab too small");
-  WideOuterParams q;
-  q.g = RowView{g, g_bstride, g_ld, ng};
-  q.x = RowView{x, x_bstride, x_ld, nx};
-  q.slab = slab; q.slab_stride = slab_stride; q.rows = rows; q.B = (int)B;
+  WideMulti<WideOuterParams> m;
+  m.n = 1;
+  if (wide_outer_fill(m.p[0], g, g_bstride, g_ld, ng, x, x_bstride, x_ld, nx, silu_x, slab,
+                      slab_stride, B, rows))
+    return 1;
   hipStream_t s = (hipStream_t)stream;
   const bool t3 = nlam_mfma_terms() == 3;
-#define WO(NGB, SX) (t3 ? launch_wide_outer<NGB, 4, 3, SX>(q, s) : launch_wide_outer<NGB, 4, 1, SX>(q, s))
-  if (ng == 128) return silu_x ? WO(4, true) : WO(4, false);
-  return silu_x ? WO(1, true) : WO(1, false);
-#undef WO
+  if (ng == 32) return t3 ? launch_wide_outer<1, 4, 3>(m, s) : launch_wide_outer<1, 4, 1>(m, s);
+  if (nx <= 32) return t3 ? launch_wide_outer<4, 1, 3>(m, s) : launch_wide_outer<4, 1, 1>(m, s);
+  if (nx <= 64) return t3 ? launch_wide_outer<4, 2, 3>(m, s) : launch_wide_outer<4, 2, 1>(m, s);
+  return t3 ? launch_wide_outer<4, 4, 3>(m, s) : launch_wide_outer<4, 4, 1>(m, s);
+}
+
+// all problems 128 x 128
+extern "C" int nlam_wide_outer_multi(int n, const float* const* g, const int64_t* g_bstride,
+                                     const int64_t* g_ld, const float* const* x,
+                                     const int64_t* x_bstride, const int64_t* x_ld,
+                                     const int32_t* silu_x, float* const* slab,
+                                     const int64_t* slab_stride, const int64_t* B,
+                                     const int64_t* rows, void* stream) {
+  NLAM_REQUIRE(n >= 1 && n <= NLAM_WIDE_MAXP, "nlam_wide_outer_multi: n %d out of [1, %d]", n,
+               NLAM_WIDE_MAXP);
+  NLAM_REQUIRE(nlam_mfma_terms() != 0, "nlam_wide_outer_multi: needs NLAM_MFMA=bf16x3|bf16");
+  WideMulti<WideOuterParams> m;
+  m.n = 0;
+  for (int k = 0; k < n; ++k) {
+    if (B[k] <= 0 || rows[k] <= 0) continue;
+    if (wide_outer_fill(m.p[m.n], g[k], g_bstride[k], g_ld[k], 128, x[k], x_bstride[k], x_ld[k], 128,
+                        silu_x[k], slab[k], slab_stride[k], B[k], rows[k]))
+      return 1;
+    ++m.n;
+  }
+  if (m.n == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  return nlam_mfma_terms() == 3 ? launch_wide_outer<4, 4, 3>(m, s) : launch_wide_outer<4, 4, 1>(m, s);
+}
+
+// ===================================== projections (first Linear), several per launch ===
+// out = x W^T + b with W 128 x 128 (the split-bf16 image of nlam_lin_fwd's wide form)
+struct WideLinParams {
+  RowView x;
+  const float* W; int64_t ldW; const float* bias;
+  float* out; int64_t out_bstride; int64_t out_ld;
+  int64_t rows; int B;
+};
+
+template <int TERMS>
+__device__ __forceinline__ void wide_lin_fwd_body(const WideLinParams& p, int bid, int gdim,
+                                                  float* smem) {
+  constexpr int K = 128, NO = 128, KB = 4, NOUTB = 4;
+  constexpr int ldt = K + 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const B3Image W = b3_image(smem, NO, K);
+  float* bs = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + b3_image_bytes(NO, K));
+  float* tile = bs + NO + wave * (NLAM_TILE * ldt);
+  load_weight_lds_b3(W, 0, p.W, p.ldW, NO, K, NO, K, tid, 256);
+  load_vec_lds(bs, p.bias, NO, NO, tid, 256);
+  __syncthreads();
+  const int64_t tiles_per_b = (p.rows + NLAM_TILE - 1) / NLAM_TILE;
+  const int64_t ntiles = tiles_per_b * p.B;
+  for (int64_t tt = (int64_t)bid * 4 + wave; tt < ntiles; tt += (int64_t)gdim * 4) {
+    const int64_t b = tt / tiles_per_b;
+    const int64_t r0 = (tt - b * tiles_per_b) * NLAM_TILE;
+    const int nrows = (int)((p.rows - r0) < NLAM_TILE ? (p.rows - r0) : NLAM_TILE);
+    f32x4 vx[8 * KB];
+    view_load_v<8 * KB>(vx, p.x, b, r0, nrows, lane);
+    const B3Tile Xp = b3_tile(tile, K);
+    put_rows_v_b3<8 * KB>(Xp, 0, K, nrows, lane, vx);
+    wave_sync();
+    f32x16 a[NOUTB];
+    vec_to_acc<NOUTB>(a, bs, lane);
+    gemm_tile_b3<NOUTB, KB, TERMS>(a, W, 0, Xp, 0, lane);
+    wave_sync();
+    acc_to_tile<NOUTB>(a, tile, ldt, lane);
+    wave_sync();
+    float* ob = p.out + b * p.out_bstride + r0 * p.out_ld;
+    auto op = [&](int t) { return ob + (int64_t)t * p.out_ld; };
+    store_rows<true>(tile, ldt, 0, NO, nrows, lane, op);
+    wave_sync();
+  }
+}
+
+template <int TERMS>
+__global__ __launch_bounds__(256) void wide_lin_fwd_kernel(WideMulti<WideLinParams> m) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int k = wide_multi_find(m, blockIdx.x);
+  wide_lin_fwd_body<TERMS>(m.p[k], blockIdx.x - m.first[k], m.first[k + 1] - m.first[k], smem);
+}
+
+template <int TERMS>
+static int launch_wide_lin_fwd(WideMulti<WideLinParams>& m, hipStream_t s) {
+  const size_t lds = b3_image_bytes(128, 128) + 128 * sizeof(float) +
+                     (size_t)4 * NLAM_TILE * 132 * sizeof(float);
+  auto kern = wide_lin_fwd_kernel<TERMS>;
+  NLAM_BIG_LDS(kern, "wide_lin_fwd_kernel");
+  const unsigned grid = wide_multi_grid(m, [](const WideLinParams& q) {
+    return ((q.rows + NLAM_TILE - 1) / NLAM_TILE) * q.B;
+  });
+  kern<<<grid, 256, lds, s>>>(m);
+  NLAM_CHECK_LAUNCH("wide_lin_fwd_kernel");
+  return 0;
+}
+
+extern "C" int nlam_lin_fwd_multi(int n, const float* const* x, const int64_t* x_bstride,
+                                  const int64_t* x_ld, const float* const* W, const int64_t* ldW,
+                                  const float* const* bias, float* const* out,
+                                  const int64_t* out_bstride, const int64_t* out_ld,
+                                  const int64_t* B, const int64_t* rows, void* stream) {
+  NLAM_REQUIRE(n >= 1 && n <= NLAM_WIDE_MAXP, "nlam_lin_fwd_multi: n %d out of [1, %d]", n,
+               NLAM_WIDE_MAXP);
+  NLAM_REQUIRE(nlam_mfma_terms() != 0, "nlam_lin_fwd_multi: needs NLAM_MFMA=bf16x3|bf16");
+  WideMulti<WideLinParams> m;
+  m.n = 0;
+  for (int k = 0; k < n; ++k) {
+    if (B[k] <= 0 || rows[k] <= 0) continue;
+    NLAM_REQUIRE(view_vec_ok(x[k], x_bstride[k], x_ld[k], 128) &&
+                     view_vec_ok(out[k], out_bstride[k], out_ld[k], 128),
+                 "nlam_lin_fwd_multi: operand rows must be 16-byte aligned, width 128");
+    WideLinParams& q = m.p[m.n++];
+    q.x = RowView{x[k], x_bstride[k], x_ld[k], 128};
+    q.W = W[k]; q.ldW = ldW[k]; q.bias = bias[k];
+    q.out = out[k]; q.out_bstride = out_bstride[k]; q.out_ld = out_ld[k];
+    q.rows = rows[k]; q.B = (int)B[k];
+  }
+  if (m.n == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  return nlam_mfma_terms() == 3 ? launch_wide_lin_fwd<3>(m, s) : launch_wide_lin_fwd<1>(m, s);
 }

@@ -73,4 +73,10 @@ class EdgeTables(torch.nn.Module):
                 "tiles", torch.from_numpy(tiles[: 4 * nt].copy()).view(nt, 4), persistent=False
             )
         else:
+            import warnings
+
+            warnings.warn(
+                f"neural_lam_amd: a receiver has {self.max_in_degree} in-edges (> 32): this "
+                "InteractionNet runs on the generic HIP kernel sequence (several times slower) "
+                "instead of the fused receiver-aligned tiles", RuntimeWarning, stacklevel=3)
             self.tiles = None

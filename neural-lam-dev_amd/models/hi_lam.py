@@ -16,20 +16,23 @@ class HiLAM(BaseHiGraphModel):
         self.mesh_up_gnns = nn.ModuleList([self.make_up_gnns(args) for _ in range(P)])
         self.mesh_up_same_gnns = nn.ModuleList([self.make_same_gnns(args) for _ in range(P)])
 
-    def _gnns(self, args, edge_indices):
-        return nn.ModuleList(
+    def _gnns(self, args, edge_indices, tag):
+        nets = nn.ModuleList(
             [InteractionNet(ei, args.hidden_dim, hidden_layers=args.hidden_layers)
              for ei in edge_indices]
         )
+        for level, net in enumerate(nets):   # profiler labels: same0 / up1 / down0 ...
+            net.tables.tag = f"{tag}{level}"
+        return nets
 
     def make_same_gnns(self, args):
-        return self._gnns(args, self.m2m_edge_index)
+        return self._gnns(args, self.m2m_edge_index, "same")
 
     def make_up_gnns(self, args):
-        return self._gnns(args, self.mesh_up_edge_index)
+        return self._gnns(args, self.mesh_up_edge_index, "up")
 
     def make_down_gnns(self, args):
-        return self._gnns(args, self.mesh_down_edge_index)
+        return self._gnns(args, self.mesh_down_edge_index, "down")
 
     def mesh_down_step(self, nodes, same, down, down_gnns, same_gnns):
         """hi_lam.py:82-124: same(L-1); then for l = L-2..0: down(l+1->l), same(l)."""

@@ -127,8 +127,9 @@ def lin_bwd_data(gy, W, gx, gx_add=None):
 def outer(g, x, dW, db, silu_x=False, rows_out=None):
     """dW (rows_out x 128 view) = sum_rows g^T f(x); db = colsum(g).  g: (B, rows, 128 | 32)."""
     ng, nx = g.cols, x.cols
+    nxp = (nx + 31) // 32 * 32
     B, rows = g.B, g.rows
-    stride = ng * nx + ng
+    stride = ng * nxp + ng
     nslabs = int(lib.nlam_bwd_grid(B * ((rows + 31) // 32)))
     slab = torch.empty(nslabs * stride, dtype=torch.float32, device=dW.device)
     _launch(
@@ -139,7 +140,89 @@ def outer(g, x, dW, db, silu_x=False, rows_out=None):
     )
     r = ng if rows_out is None else rows_out
     ops.reduce_segments(slab, nslabs, stride,
-                        [(0, r, nx, nx, dW), (ng * nx, 1, r, r, db)])
+                        [(0, r, nx, nxp, dW), (ng * nxp, 1, r, r, db)])
+
+
+def _arr(ctype, vals):
+    return (ctype * len(vals))(*vals)
+
+
+def _parr(vals):
+    import ctypes
+    return (ctypes.c_void_p * len(vals))(*vals)
+
+
+def lin_fwd_multi(problems):
+    """[(x Mat, W (128,128) view, bias or None, out Mat)] -> one launch (aligned 128-wide rows)."""
+    import ctypes
+    I64 = ctypes.c_int64
+    n = len(problems)
+    _launch(
+        "nlam_lin_fwd_multi", lib.nlam_lin_fwd_multi,
+        (n, _parr([x.ptr for x, _, _, _ in problems]), _arr(I64, [x.bstride for x, _, _, _ in problems]),
+         _arr(I64, [x.ld for x, _, _, _ in problems]), _parr([W.data_ptr() for _, W, _, _ in problems]),
+         _arr(I64, [W.stride(0) for _, W, _, _ in problems]),
+         _parr([_p(b) for _, _, b, _ in problems]), _parr([o.ptr for _, _, _, o in problems]),
+         _arr(I64, [o.bstride for _, _, _, o in problems]), _arr(I64, [o.ld for _, _, _, o in problems]),
+         _arr(I64, [o.B for _, _, _, o in problems]), _arr(I64, [o.rows for _, _, _, o in problems]),
+         stream()),
+        flops=sum(2.0 * o.B * o.rows * 128 * 128 for _, _, _, o in problems),
+        nbytes=sum(8.0 * o.B * o.rows * 128 for _, _, _, o in problems),
+    )
+
+
+def lin_bwd_data_multi(problems):
+    """[(gy Mat, W (128,128) view, gx Mat, gx_add Mat or None)] -> one launch."""
+    import ctypes
+    I64 = ctypes.c_int64
+    n = len(problems)
+    _launch(
+        "nlam_lin_bwd_data_multi", lib.nlam_lin_bwd_data_multi,
+        (n, _parr([g.ptr for g, _, _, _ in problems]), _arr(I64, [g.bstride for g, _, _, _ in problems]),
+         _arr(I64, [g.ld for g, _, _, _ in problems]), _parr([W.data_ptr() for _, W, _, _ in problems]),
+         _arr(I64, [W.stride(0) for _, W, _, _ in problems]),
+         _parr([x.ptr for _, _, x, _ in problems]), _arr(I64, [x.bstride for _, _, x, _ in problems]),
+         _arr(I64, [x.ld for _, _, x, _ in problems]),
+         _parr([a.ptr if a is not None else None for _, _, _, a in problems]),
+         _arr(I64, [a.bstride if a is not None else 0 for _, _, _, a in problems]),
+         _arr(I64, [a.ld if a is not None else 0 for _, _, _, a in problems]),
+         _arr(I64, [x.B for _, _, x, _ in problems]), _arr(I64, [x.rows for _, _, x, _ in problems]),
+         stream()),
+        flops=sum(2.0 * x.B * x.rows * 128 * 128 for _, _, x, _ in problems),
+        nbytes=sum(4.0 * x.B * x.rows * 128 * (2 + (a is not None)) for _, _, x, a in problems),
+    )
+
+
+def outer_multi(problems):
+    """[(g Mat (.., 128), x Mat (.., 128), dW view, db, silu_x)] -> one launch + the layer's slab
+    reduction (all 128 x 128)."""
+    import ctypes
+    I64, I32 = ctypes.c_int64, ctypes.c_int32
+    n = len(problems)
+    dev = problems[0][2].device
+    stride = 128 * 128 + 128
+    slabs, ns = [], []
+    for g, x, dW, db, sx in problems:
+        nsl = int(lib.nlam_bwd_grid(g.B * ((g.rows + 31) // 32)))
+        ns.append(nsl)
+        slabs.append(torch.empty(nsl * stride, dtype=torch.float32, device=dev))
+    _launch(
+        "nlam_wide_outer_multi", lib.nlam_wide_outer_multi,
+        (n, _parr([g.ptr for g, _, _, _, _ in problems]),
+         _arr(I64, [g.bstride for g, _, _, _, _ in problems]),
+         _arr(I64, [g.ld for g, _, _, _, _ in problems]),
+         _parr([x.ptr for _, x, _, _, _ in problems]),
+         _arr(I64, [x.bstride for _, x, _, _, _ in problems]),
+         _arr(I64, [x.ld for _, x, _, _, _ in problems]),
+         _arr(I32, [int(sx) for _, _, _, _, sx in problems]),
+         _parr([sl.data_ptr() for sl in slabs]), _arr(I64, [stride] * n),
+         _arr(I64, [g.B for g, _, _, _, _ in problems]),
+         _arr(I64, [g.rows for g, _, _, _, _ in problems]), stream()),
+        flops=sum(2.0 * g.B * g.rows * 128 * 128 for g, _, _, _, _ in problems),
+        nbytes=sum(8.0 * g.B * g.rows * 128 for g, _, _, _, _ in problems),
+    )
+    for (g, x, dW, db, sx), sl, nsl in zip(problems, slabs, ns):
+        ops.reduce_segments(sl, nsl, stride, [(0, 128, 128, 128, dW), (128 * 128, 1, 128, 128, db)])
 
 
 def _first_linear(x, W, b, out):
@@ -160,10 +243,10 @@ def _first_linear_bwd(x, ga, W, need_gx, gx_add, dW, db, dev):
             ops.linear_bwd_data(ga, W, mat(gx))
             if gx_add is not None:
                 ops.add_rows(mat(gx), gx_add, mat(gx))
-    if wide_ok:
-        outer(ga, x, dW, db)
+    if wide_ok or k_in <= 64:
+        outer(ga, x, dW, db)    # (narrow / unaligned static features: scalar staging, K padded)
     else:
-        ops.linear_bwd_weight(ga, x, dW, db)   # generic split-K GEMM (narrow / unaligned inputs)
+        ops.linear_bwd_weight(ga, x, dW, db)   # generic split-K GEMM
     return gx
 
 
@@ -285,9 +368,10 @@ class WideInteractionNetFunction(torch.autograd.Function):
             Ps = _empty(sm.B, N_s, d, device=dev)
             Pr = _empty(rm.B, N_r, d, device=dev)
             Pe = _empty(em.B, M, d, device=dev)
-            _first_linear(sm, W1s, None, mat(Ps))
-            _first_linear(rm, W1r, b1, mat(Pr))
-            _first_linear(em, W1e, None, mat(Pe))
+            hn1 = _empty(rm.B, N_r, d, device=dev)
+            # the four projections that only need the layer inputs: ONE launch
+            lin_fwd_multi([(sm, W1s, None, mat(Ps)), (rm, W1r, b1, mat(Pr)),
+                           (em, W1e, None, mat(Pe)), (rm, V1[:, :d], c1, mat(hn1))])
             h_e = _empty(B, M, d, device=dev)
             agg = _empty(B, N_r, d, device=dev)
             e_out = _empty(B, M, d, device=dev) if update_edges else None
@@ -298,9 +382,7 @@ class WideInteractionNetFunction(torch.autograd.Function):
                      mat(agg), g.inv_deg if mean else None, B, d)
             del Pe, Ps, Pr
             # node update x_r + LN(V2 silu(V1 [x_r | agg] + c1) + c2)
-            hn1 = _empty(rm.B, N_r, d, device=dev)
             hn2 = _empty(B, N_r, d, device=dev)
-            _first_linear(rm, V1[:, :d], c1, mat(hn1))
             _first_linear(mat(agg), V1[:, d:], None, mat(hn2))
             h_n = _empty(B, N_r, d, device=dev)
             rec_out = _empty(B, N_r, d, device=dev)
@@ -340,14 +422,13 @@ class WideInteractionNetFunction(torch.autograd.Function):
             ga_n = _empty(B, N_r, d, device=dev)
             tail_bwd(Tiling(N_r), h_n, mat(g_rec_out), None, None, None, None, V2, c2, gam2, gz_n,
                      mat(ga_n), None, None, B, d, dg2, db2n)
-            outer(mat(gz_n), mat(h_n), dV2, dc2, silu_x=True)
             g_rec = _empty(B, N_r, d, device=dev)       # node-update part + residual
-            lin_bwd_data(mat(ga_n), V1[:, :d], mat(g_rec), mat(g_rec_out))
             g_agg = _empty(B, N_r, d, device=dev)
-            lin_bwd_data(mat(ga_n), V1[:, d:], mat(g_agg))
-            outer(mat(ga_n), rm, dV1[:, :d], dc1)
-            dummy = _empty(d, device=dev)
-            outer(mat(ga_n), mat(agg), dV1[:, d:], dummy)
+            lin_bwd_data_multi([(mat(ga_n), V1[:, :d], mat(g_rec), mat(g_rec_out)),
+                                (mat(ga_n), V1[:, d:], mat(g_agg), None)])
+            dummy = [_empty(d, device=dev) for _ in range(4)]
+            outers = [(mat(gz_n), mat(h_n), dV2, dc2, True), (mat(ga_n), rm, dV1[:, :d], dc1, False),
+                      (mat(ga_n), mat(agg), dV1[:, d:], dummy[0], False)]
             if rm.B == 1 and B > 1:
                 t3 = _empty(1, N_r, d, device=dev)
                 ops.sum_batch(g_rec, t3)
@@ -362,7 +443,7 @@ class WideInteractionNetFunction(torch.autograd.Function):
             tail_bwd(Tiling(M, g), h_e, mat(g_agg), g.csr_rec, g.inv_deg if ctx.mean else None,
                      geo, g.csr_eid if geo is not None else None, W2, b2, gam, gz_e, mat(gh),
                      g.csr_eid, mat(gPr), B, d, dgam, dbet)
-            outer(mat(gz_e), mat(h_e), dW2, db2, silu_x=True)
+            outers.append((mat(gz_e), mat(h_e), dW2, db2, True))
             # 3. sender-side reduction of gh (edge order; sender lists of edge ids)
             gPs = (torch.zeros if N_s > g.n_send else torch.empty)(
                 B, N_s, d, dtype=torch.float32, device=dev)
@@ -377,37 +458,34 @@ class WideInteractionNetFunction(torch.autograd.Function):
                 t2 = _empty(1, N_r, d, device=dev)
                 ops.sum_batch(gPr, t2)
                 gpr_m = mat(t2)
-            outer(gps_m, sm, dW1[:, d : 2 * d], dummy)
-            outer(gpr_m, rm, dW1[:, 2 * d :], db1)
+            outers += [(gps_m, sm, dW1[:, d : 2 * d], dummy[1], False),
+                       (gpr_m, rm, dW1[:, 2 * d :], db1, False),
+                       (mat(gh), em, dW1[:, :d], dummy[2], False)]
+            # 5. data gradients of the three projections (e' = e + m adds g_e' to the edge one)
+            dPe = mat(gh)
+            if not ctx.update_edges and em.B == 1 and B > 1:
+                t6 = _empty(1, M, d, device=dev)
+                ops.sum_batch(gh, t6)
+                dPe = mat(t6)
+            g_e = _empty(dPe.B, M, d, device=dev)
+            g_send = _empty(sm.B, N_s, d, device=dev)
             if same:
                 t4 = _empty(sm.B, N_s, d, device=dev)
-                lin_bwd_data(gps_m, W1s, mat(t4), mat(g_rec))
-                g_send = _empty(sm.B, N_s, d, device=dev)
+                lin_bwd_data_multi([(gps_m, W1s, mat(t4), mat(g_rec)), (dPe, W1e, mat(g_e), geo)])
                 lin_bwd_data(gpr_m, W1r, mat(g_send), mat(t4))
                 g_rec_total = None
             else:
-                g_send = _empty(sm.B, N_s, d, device=dev)
-                lin_bwd_data(gps_m, W1s, mat(g_send))
                 g_rec_total = _empty(rm.B, N_r, d, device=dev)
-                lin_bwd_data(gpr_m, W1r, mat(g_rec_total), mat(g_rec))
-            # 5. edge-side first layer (Pe = W1e e; e' = e + m adds g_e' to the edge gradient)
-            outer(mat(gh), em, dW1[:, :d], dummy)
-            if ctx.update_edges:
-                g_e = _empty(B, M, d, device=dev)
-                lin_bwd_data(mat(gh), W1e, mat(g_e), geo)
-                g_edge = g_e
-                if em.B == 1 and B > 1:
-                    t5 = _empty(1, M, d, device=dev)
-                    ops.sum_batch(g_e, t5)
-                    g_edge = t5
-            else:
-                dPe = mat(gh)
-                if em.B == 1 and B > 1:
-                    t6 = _empty(1, M, d, device=dev)
-                    ops.sum_batch(gh, t6)
-                    dPe = mat(t6)
-                g_edge = _empty(em.B, M, d, device=dev)
-                lin_bwd_data(dPe, W1e, mat(g_edge))
+                lin_bwd_data_multi([(gps_m, W1s, mat(g_send), None),
+                                    (gpr_m, W1r, mat(g_rec_total), mat(g_rec)),
+                                    (dPe, W1e, mat(g_e), geo)])
+            g_edge = g_e
+            if ctx.update_edges and em.B == 1 and B > 1:
+                t5 = _empty(1, M, d, device=dev)
+                ops.sum_batch(g_e, t5)
+                g_edge = t5
+            # 6. every weight / bias gradient of the layer: one streaming launch
+            outer_multi(outers)
         return (g_send, g_rec_total, g_edge, None, None, None, None,
                 dW1, db1, dW2, db2, dgam, dbet, dV1, dc1, dV2, dc2, dg2, db2n)
 

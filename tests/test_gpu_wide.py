@@ -167,7 +167,9 @@ def test_wide_paths_are_taken_at_hidden_128():
     finally:
         ops.PROFILER = None
     names = {k.split("@")[0] for k in stats}
-    assert {"nlam_lin_fwd", "nlam_tail_fwd", "nlam_tail_bwd", "nlam_lin_bwd_data",
-            "nlam_wide_outer", "nlam_segment_sum"} <= names
+    assert {"nlam_lin_fwd_multi", "nlam_lin_fwd", "nlam_tail_fwd", "nlam_tail_bwd",
+            "nlam_lin_bwd_data_multi", "nlam_wide_outer_multi", "nlam_segment_sum"} <= names
+    # launch budget of one wide InteractionNet (forward 4, backward 9 incl. the slab reduction)
+    assert sum(v["calls"] for v in stats.values()) <= 14, stats
     assert "nlam_gemm" not in names and "nlam_layernorm_fwd" not in names
     assert stats["nlam_tail_fwd@inet"]["calls"] == 2 and stats["nlam_tail_bwd@inet"]["calls"] == 2
