@@ -412,6 +412,12 @@ int nlam_wide_outer_multi(int n, const float* const* g, const int64_t* g_bstride
                           const int64_t* slab_stride, const int64_t* B, const int64_t* rows,
                           void* stream);
 
+/* Grid feature rows of predict_step (reference base_graph_model.py:116-124): out (B, N, sum w) =
+ * concatenation of up to four (B | 1, N, w_k) sources along the feature axis (bstride 0 =
+ * batch-invariant static features). */
+int nlam_concat_rows(int nsrc, const float* const* src, const int64_t* bstride, const int64_t* ld,
+                     const int32_t* width, float* out, int64_t B, int64_t N, void* stream);
+
 /* output_std head (reference base_graph_model.py:161-177 with args.output_std): net_out is
  * (rows, 2F); state = prev + net_out[:, :F] * scale + shift, pred_std = softplus(net_out[:, F:])
  * (beta 1, threshold 20, as torch.nn.functional.softplus).  The backward takes either incoming

@@ -72,6 +72,11 @@ extern "C" int nlam_mfma_mode(void) { return nlam_mfma_mode_value(); }
 #define G_TN 64
 #define G_TK 16
 
+typedef __bf16 g_bf16x8 __attribute__((ext_vector_type(8)));
+// BF16 (NLAM_MFMA=bf16, the bf16-mixed arithmetic of the reference's `--precision bf16-mixed`):
+// operands rounded to bf16 when the fragments are read from LDS, one
+// v_mfma_f32_32x32x16_bf16 per 16-deep K tile, fp32 accumulate; storage stays fp32.
+template <bool BF16>
 __global__ __launch_bounds__(256) void gemm_kernel(
     int64_t M, int64_t N, int64_t K, const float* __restrict__ A, int64_t sa_i,
     int64_t sa_k, const float* __restrict__ B, int64_t sb_k, int64_t sb_j,
@@ -132,11 +137,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(
       }
     }
     __syncthreads();
+    if constexpr (BF16) {
+      g_bf16x8 a, b;
 #pragma unroll
-    for (int kk = 0; kk < G_TK / 2; ++kk) {
-      const float a = As[kk * 2 + (lane >> 5)][wr * 32 + (lane & 31)];
-      const float b = Bs[kk * 2 + (lane >> 5)][wc * 32 + (lane & 31)];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+      for (int u = 0; u < 8; ++u) {
+        a[u] = (__bf16)As[8 * (lane >> 5) + u][wr * 32 + (lane & 31)];
+        b[u] = (__bf16)Bs[8 * (lane >> 5) + u][wc * 32 + (lane & 31)];
+      }
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < G_TK / 2; ++kk) {
+        const float a = As[kk * 2 + (lane >> 5)][wr * 32 + (lane & 31)];
+        const float b = Bs[kk * 2 + (lane >> 5)][wc * 32 + (lane & 31)];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+      }
     }
     __syncthreads();
   }
@@ -167,6 +182,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(
 #define H_TK 16
 #define H_LD (H_TM + 4)
 
+template <bool BF16>
 __global__ __launch_bounds__(256) void gemm128_kernel(
     int64_t M, int64_t N, int64_t K, const float* __restrict__ A, int64_t sa_i, int64_t sa_k,
     const float* __restrict__ B, int64_t sb_k, int64_t sb_j, const float* __restrict__ bias,
@@ -233,15 +249,31 @@ __global__ __launch_bounds__(256) void gemm128_kernel(
     put_tile();
     __syncthreads();
     if (kt + H_TK < kend) load_tile(kt + H_TK);   // in flight during the MFMAs below
+    if constexpr (BF16) {
+      const int kg = lane >> 5, c = lane & 31;
+      g_bf16x8 a0, a1, b0, b1;
 #pragma unroll
-    for (int kk = 0; kk < H_TK / 2; ++kk) {
-      const int kr = kk * 2 + (lane >> 5), c = lane & 31;
-      const float a0 = As[kr][wr * 64 + c], a1 = As[kr][wr * 64 + 32 + c];
-      const float b0 = Bs[kr][wc * 64 + c], b1 = Bs[kr][wc * 64 + 32 + c];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      for (int u = 0; u < 8; ++u) {
+        a0[u] = (__bf16)As[8 * kg + u][wr * 64 + c];
+        a1[u] = (__bf16)As[8 * kg + u][wr * 64 + 32 + c];
+        b0[u] = (__bf16)Bs[8 * kg + u][wc * 64 + c];
+        b1[u] = (__bf16)Bs[8 * kg + u][wc * 64 + 32 + c];
+      }
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < H_TK / 2; ++kk) {
+        const int kr = kk * 2 + (lane >> 5), c = lane & 31;
+        const float a0 = As[kr][wr * 64 + c], a1 = As[kr][wr * 64 + 32 + c];
+        const float b0 = Bs[kr][wc * 64 + c], b1 = Bs[kr][wc * 64 + 32 + c];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      }
     }
   }
 #pragma unroll
@@ -294,19 +326,30 @@ extern "C" int nlam_gemm(int64_t M, int64_t N, int64_t K, const float* A, int64_
   if (kchunk == 0) kchunk = G_TK;
   hipStream_t s = (hipStream_t)stream;
   NLAM_REQUIRE(splitk <= 65535, "nlam_gemm: grid too large");
+  const bool bf16 = nlam_mfma_terms() == 1;   // NLAM_MFMA=bf16: bf16 products, fp32 accumulate
   if (M >= 96 && N >= 96) {   // big shapes: 128x128 tiles with register prefetch
     const int64_t gx = (M + H_TM - 1) / H_TM, gy = (N + H_TN - 1) / H_TN;
     NLAM_REQUIRE(gy <= 65535, "nlam_gemm: grid too large");
-    gemm128_kernel<<<dim3((unsigned)gx, (unsigned)gy, (unsigned)splitk), 256, 0, s>>>(
-        M, N, K, A, sa_i, sa_k, B, sb_k, sb_j, bias, C, ldc, accumulate, splitk, kchunk,
-        workspace);
+    if (bf16)
+      gemm128_kernel<true><<<dim3((unsigned)gx, (unsigned)gy, (unsigned)splitk), 256, 0, s>>>(
+          M, N, K, A, sa_i, sa_k, B, sb_k, sb_j, bias, C, ldc, accumulate, splitk, kchunk,
+          workspace);
+    else
+      gemm128_kernel<false><<<dim3((unsigned)gx, (unsigned)gy, (unsigned)splitk), 256, 0, s>>>(
+          M, N, K, A, sa_i, sa_k, B, sb_k, sb_j, bias, C, ldc, accumulate, splitk, kchunk,
+          workspace);
     NLAM_CHECK_LAUNCH("gemm128_kernel");
   } else {
     const int64_t gx = (M + G_TM - 1) / G_TM, gy = (N + G_TN - 1) / G_TN;
     NLAM_REQUIRE(gy <= 65535, "nlam_gemm: grid too large");
-    gemm_kernel<<<dim3((unsigned)gx, (unsigned)gy, (unsigned)splitk), 256, 0, s>>>(
-        M, N, K, A, sa_i, sa_k, B, sb_k, sb_j, bias, C, ldc, accumulate, splitk, kchunk,
-        workspace);
+    if (bf16)
+      gemm_kernel<true><<<dim3((unsigned)gx, (unsigned)gy, (unsigned)splitk), 256, 0, s>>>(
+          M, N, K, A, sa_i, sa_k, B, sb_k, sb_j, bias, C, ldc, accumulate, splitk, kchunk,
+          workspace);
+    else
+      gemm_kernel<false><<<dim3((unsigned)gx, (unsigned)gy, (unsigned)splitk), 256, 0, s>>>(
+          M, N, K, A, sa_i, sa_k, B, sb_k, sb_j, bias, C, ldc, accumulate, splitk, kchunk,
+          workspace);
     NLAM_CHECK_LAUNCH("gemm_kernel");
   }
   if (splitk > 1) {

@@ -315,3 +315,55 @@ extern "C" int nlam_nll_bwd(const float* pred, const float* target, const float*
   NLAM_CHECK_LAUNCH("nll_bwd");
   return 0;
 }
+
+
+// ------------------------------------------------------------ grid feature concat
+// out[b][n][:] = [src0[b][n][:w0] | src1[b][n][:w1] | src2 | src3]  (base_graph_model.py:116-124:
+// prev_state, prev_prev_state, forcing, static features; a source with bstride 0 is
+// batch-invariant).  One pass, coalesced stores of the (narrow, unaligned) concatenated rows.
+struct ConcatParams {
+  const float* src[4];
+  int64_t bstride[4];
+  int64_t ld[4];
+  int w[4];
+  int nsrc;
+  float* out;
+  int64_t B, N;
+  int W;
+};
+__global__ void concat_rows_kernel(ConcatParams p) {
+  const int64_t total = p.B * p.N * p.W;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t row = i / p.W;
+    int c = (int)(i - row * p.W);
+    const int64_t b = row / p.N, n = row - b * p.N;
+    int k = 0;
+    while (k + 1 < p.nsrc && c >= p.w[k]) { c -= p.w[k]; ++k; }
+    p.out[i] = p.src[k][b * p.bstride[k] + n * p.ld[k] + c];
+  }
+}
+extern "C" int nlam_concat_rows(int nsrc, const float* const* src, const int64_t* bstride,
+                                const int64_t* ld, const int32_t* width, float* out, int64_t B,
+                                int64_t N, void* stream) {
+  NLAM_REQUIRE(nsrc >= 1 && nsrc <= 4, "nlam_concat_rows: nsrc %d out of [1, 4]", nsrc);
+  ConcatParams p;
+  p.nsrc = nsrc; p.out = out; p.B = B; p.N = N; p.W = 0;
+  for (int k = 0; k < 4; ++k) {
+    p.src[k] = k < nsrc ? src[k] : nullptr;
+    p.bstride[k] = k < nsrc ? bstride[k] : 0;
+    p.ld[k] = k < nsrc ? ld[k] : 0;
+    p.w[k] = k < nsrc ? width[k] : 0;
+    if (k < nsrc) {
+      NLAM_REQUIRE(src[k] != nullptr && width[k] >= 1 && ld[k] >= width[k], "nlam_concat_rows: bad source %d", k);
+      p.W += width[k];
+    }
+  }
+  const int64_t n = B * N * p.W;
+  if (n <= 0) return 0;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  concat_rows_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(p);
+  NLAM_CHECK_LAUNCH("concat_rows");
+  return 0;
+}

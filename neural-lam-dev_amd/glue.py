@@ -165,3 +165,47 @@ class MaskedNLL(torch.autograd.Function):
                      gl.data_ptr(), ctx.scale, g.data_ptr(), gs.data_ptr(), pred.numel() // F, N,
                      F, ops.stream()), nbytes=20.0 * pred.numel())
         return g, None, gs, None, None
+
+
+class ConcatRows(torch.autograd.Function):
+    """torch.cat(sources, dim=-1) of (B | 1, N, w_k) grid feature tensors in one kernel
+    (base_graph_model.py:116-124); a stride-0 expand (expand_to_batch) is read in place."""
+
+    @staticmethod
+    def forward(ctx, *srcs):
+        import ctypes
+
+        from .fused import _base
+
+        base = [_base(t.detach()) for t in srcs]
+        B = max(t.shape[0] for t in srcs)
+        N = srcs[0].shape[-2]
+        mats = [ops.mat(t) for t in base]
+        W = sum(m.cols for m in mats)
+        out = torch.empty(B, N, W, dtype=torch.float32, device=srcs[0].device)
+        n = len(mats)
+        ops._launch(
+            "nlam_concat_rows", lib.nlam_concat_rows,
+            (n, (ctypes.c_void_p * n)(*[m.ptr for m in mats]),
+             (ctypes.c_int64 * n)(*[m.bstride for m in mats]),
+             (ctypes.c_int64 * n)(*[m.ld for m in mats]),
+             (ctypes.c_int32 * n)(*[m.cols for m in mats]), out.data_ptr(), B, N, ops.stream()),
+            nbytes=8.0 * out.numel())
+        ctx.widths = [m.cols for m in mats]
+        ctx.batch = [t.shape[0] if t.dim() == 3 else 1 for t in srcs]
+        ctx.expanded = [t.dim() == 3 and t.shape[0] > 1 and t.stride(0) == 0 for t in srcs]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        outs, o = [], 0
+        for k, w in enumerate(ctx.widths):
+            if ctx.needs_input_grad[k]:
+                gk = g[..., o : o + w]
+                if ctx.expanded[k]:
+                    gk = gk.sum(dim=0, keepdim=True).expand(g.shape[0], -1, -1)
+                outs.append(gk)
+            else:
+                outs.append(None)
+            o += w
+        return tuple(outs)

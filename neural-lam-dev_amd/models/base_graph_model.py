@@ -55,11 +55,12 @@ class BaseGraphModel(ARModel):
     def predict_step(self, prev_state, prev_prev_state, forcing):
         """X_{t-1}, X_t, forcing -> X_{t+1}  (base_graph_model.py:106-177)."""
         batch_size = prev_state.shape[0]
-        grid_features = torch.cat(
-            (prev_state, prev_prev_state, forcing,
-             self.expand_to_batch(self.grid_static_features, batch_size)),
-            dim=-1,
-        )
+        srcs = (prev_state, prev_prev_state, forcing,
+                self.expand_to_batch(self.grid_static_features, batch_size))
+        if prev_state.is_cuda:
+            grid_features = glue.ConcatRows.apply(*srcs)   # one kernel, static features in place
+        else:
+            grid_features = torch.cat(srcs, dim=-1)
         grid_emb = self.grid_embedder(grid_features)
         g2m_emb = self.g2m_embedder(self.g2m_features)
         m2g_emb = self.m2g_embedder(self.m2g_features)

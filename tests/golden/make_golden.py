@@ -61,6 +61,9 @@ OP_CASES = {
     "op_d64_sum_upd": (64, 2, 40, 40, 300, True, dict(update_edges=True, aggr="sum")),
     "op_d64_mean_noupd": (64, 2, 70, 50, 260, False, dict(update_edges=False, aggr="mean")),
     "op_d128_sum_upd": (128, 1, 33, 33, 200, True, dict(update_edges=True, aggr="sum")),
+    # BASELINE configs[4] width (bf16-mixed arithmetic is checked against this fp32 reference
+    # at the 2e-2 tolerance of SURVEY.md 8c)
+    "op_d256_sum_upd": (256, 1, 30, 30, 160, True, dict(update_edges=True, aggr="sum")),
     "op_d16_hl2_split": (
         16, 2, 30, 30, 90, True,
         dict(update_edges=True, aggr="sum", hidden_layers=2,

@@ -29,3 +29,19 @@ def test_model_parity_in_mode(mode, pred_bar, grad_bar):
     for pred, loss, grad in rows:
         loss_bar = 1e-5 if mode != "bf16" else 2e-2
         assert float(pred) < pred_bar and float(loss) < loss_bar and float(grad) < grad_bar, out.stdout
+
+
+@pytest.mark.parametrize("mode,fwd_bar,grad_bar", [("bf16x3", 1e-4, 1e-3), ("bf16", 2e-2, 2e-1)])
+def test_operator_parity_wide_widths_in_mode(mode, fwd_bar, grad_bar):
+    """InteractionNet at hidden 128 (wide kernels) and 256 (generic kernels; BASELINE
+    configs[4] width) against the reference goldens: fp32 bars in the default mode, the
+    bf16-mixed tolerance (2e-2) with plain bf16 products (NLAM_MFMA=bf16)."""
+    env = dict(os.environ, NLAM_MFMA=mode)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "parity_op.py")],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert f"mfma mode: {mode}" in out.stdout
+    rows = re.findall(r"d(\d+)\s+fwd (\S+)\s+input grads (\S+)\s+param grads (\S+)", out.stdout)
+    assert {int(r[0]) for r in rows} >= {128, 256}, out.stdout
+    for d, fwd, gin, gpar in rows:
+        assert float(fwd) < fwd_bar and float(gin) < grad_bar and float(gpar) < grad_bar, out.stdout
