@@ -568,7 +568,9 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
         acc_to_tile_b3<NB>(gh, T1p, 0, lane);   // GH as bf16 planes (its rows are stored)
         wave_sync();
         outer_accum_b3<NB, NB>(dW1, T1p, 0, T0p, 0, lane);
+        STAMP_AT(5)     // GH planes + dW1e outer product
         issue_rows(nxt, tt + stride);   // (after the outer product: its fragments are dead)
+        STAMP_AT(6)     // issue of the next tile's five row gathers
       } else {
         outer_accum<NB, NB>(dW1, T1, LDT, 0, T0, LDT, 0, lane);
       }
@@ -587,7 +589,7 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
       store_rows<true>(T2, LDT, 0, D, ne, lane, o_row);
     }
     wave_sync();
-    STAMP_AT(5)     // dW1e outer product + W1e^T gh + g_e store
+    STAMP_AT(7)     // W1e^T gh + g_e store
     cur = nxt;
     hdr_n = hdr_nn;
   }

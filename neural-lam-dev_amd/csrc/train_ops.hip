@@ -331,7 +331,23 @@ struct ConcatParams {
   int64_t B, N;
   int W;
 };
+// one 64-lane group per output row (W <= 64: 32-bit index math, one division per row)
 __global__ void concat_rows_kernel(ConcatParams p) {
+  const int col = threadIdx.x & 63;
+  const int64_t rows = p.B * p.N;
+  int k = 0, c = col;
+  while (k + 1 < p.nsrc && c >= p.w[k]) { c -= p.w[k]; ++k; }
+  const float* src = p.src[k];
+  const int64_t bs = p.bstride[k], ld = p.ld[k];
+  const int64_t stride = (int64_t)gridDim.x * (blockDim.x >> 6);
+  for (int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); row < rows;
+       row += stride) {
+    const int64_t b = row / p.N, n = row - b * p.N;
+    if (col < p.W) p.out[row * p.W + col] = src[b * bs + n * ld + c];
+  }
+}
+// generic width
+__global__ void concat_rows_wide_kernel(ConcatParams p) {
   const int64_t total = p.B * p.N * p.W;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
@@ -361,9 +377,15 @@ extern "C" int nlam_concat_rows(int nsrc, const float* const* src, const int64_t
   }
   const int64_t n = B * N * p.W;
   if (n <= 0) return 0;
-  int64_t blocks = (n + 255) / 256;
-  if (blocks > 8192) blocks = 8192;
-  concat_rows_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(p);
+  if (p.W <= 64) {
+    int64_t blocks = (B * N + 3) / 4;
+    if (blocks > 16384) blocks = 16384;
+    concat_rows_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(p);
+  } else {
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    concat_rows_wide_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(p);
+  }
   NLAM_CHECK_LAUNCH("concat_rows");
   return 0;
 }

@@ -192,8 +192,6 @@ class ConcatRows(torch.autograd.Function):
              (ctypes.c_int32 * n)(*[m.cols for m in mats]), out.data_ptr(), B, N, ops.stream()),
             nbytes=8.0 * out.numel())
         ctx.widths = [m.cols for m in mats]
-        ctx.batch = [t.shape[0] if t.dim() == 3 else 1 for t in srcs]
-        ctx.expanded = [t.dim() == 3 and t.shape[0] > 1 and t.stride(0) == 0 for t in srcs]
         return out
 
     @staticmethod
@@ -201,10 +199,7 @@ class ConcatRows(torch.autograd.Function):
         outs, o = [], 0
         for k, w in enumerate(ctx.widths):
             if ctx.needs_input_grad[k]:
-                gk = g[..., o : o + w]
-                if ctx.expanded[k]:
-                    gk = gk.sum(dim=0, keepdim=True).expand(g.shape[0], -1, -1)
-                outs.append(gk)
+                outs.append(g[..., o : o + w])   # (autograd's expand backward sums over B)
             else:
                 outs.append(None)
             o += w

@@ -176,3 +176,25 @@ def test_output_std_head_and_nll_vs_reference_fixture():
     assert rel(state, fx["state"]) < 1e-6 and rel(std, fx["pred_std"]) < 1e-6
     assert abs(float(loss) - fx["loss"]) < 1e-5 * abs(fx["loss"])
     assert rel(x.grad, fx["grad_net_out"]) < 1e-5
+
+
+@pytest.mark.parametrize("widths", [(17, 17, 18, 4), (5, 5, 6, 1), (40, 40, 30)])
+def test_concat_rows_matches_torch_cat(widths):
+    """Grid feature concat of predict_step (base_graph_model.py:116-124) as one kernel: equals
+    torch.cat, reads a stride-0 expand_to_batch source in place, gradients are the slices."""
+    from neural_lam_amd import glue
+    from neural_lam_amd.models.ar_model import ARModel
+
+    B, N = 3, 211
+    gen = torch.Generator().manual_seed(sum(widths))
+    srcs = [torch.randn(B, N, w, generator=gen).cuda().requires_grad_(True) for w in widths[:-1]]
+    static = torch.randn(N, widths[-1], generator=gen).cuda().requires_grad_(True)
+    exp = ARModel.expand_to_batch(static, B)
+    got = glue.ConcatRows.apply(*srcs, exp)
+    want = torch.cat([*srcs, static.unsqueeze(0).expand(B, -1, -1)], dim=-1)
+    assert torch.equal(got, want)
+    cot = torch.randn(B, N, sum(widths), generator=gen).cuda()
+    g_got = torch.autograd.grad((got * cot).sum(), [*srcs, static])
+    g_want = torch.autograd.grad((want * cot).sum(), [*srcs, static])
+    for a, b in zip(g_got, g_want):
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-6)

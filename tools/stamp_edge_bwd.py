@@ -23,10 +23,11 @@ for it in range(3):
     (ox.sum() + oe.sum()).backward()
     torch.cuda.synchronize()
     lib.nlam_debug_edge_bwd_stamps(buf, 1)
-vals = [buf[i] for i in range(6)]
+vals = [buf[i] for i in range(8)]
 tot = sum(vals)
 names = ["stage(gathers)", "recompute GEMM1+silu+GEMM2", "LN bwd + colsums", "dW2 + W2^T gz + silu'",
-         "gh store + gPr reduce", "dW1e + W1e^T gh + store"]
+         "gh store + gPr reduce", "GH planes + dW1e outer", "issue next tile's gathers",
+         "W1e^T gh + g_e store"]
 ntiles = net.tables.ntiles * B
 for n, v in zip(names, vals):
     print(f"{n:30s} {100*v/tot:5.1f} %   {v/ntiles:9.0f} cycles/tile")
