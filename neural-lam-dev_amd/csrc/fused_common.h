@@ -178,6 +178,65 @@ __device__ __forceinline__ void put_rows_v(float* __restrict__ tile, int ld, int
     }
   }
 }
+// ---- gathers by per-lane row index --------------------------------------------------
+// The lambda / __shfl form above costs one ds_bpermute per row load, and under register
+// pressure the compiler serialises them (shuffle -> wait -> address -> load): in-kernel stamps
+// of edge_bwd showed 5.6 k cycles to ISSUE the 40 row loads of a tile.  Fetching each lane's
+// indices from the global tables instead exposes a dependent global latency (measured: worse).
+// So the slot indices a tile already holds (lanes 0..31, prefetched one tile ahead) are stashed
+// in a 32-entry LDS table per index kind, and every lane reads the indices of ITS rows (slot
+// sub + k * rpi) with plain, batched ds_reads; the row loads follow without cross-lane traffic.
+// Padded slots hold a valid (clamped) index and are zeroed by put_rows_v.
+__device__ __forceinline__ void stash_slot_index(int* __restrict__ tab, int value, int lane) {
+  if (lane < NLAM_TILE) tab[lane] = value;
+}
+template <int NV>
+__device__ __forceinline__ void lane_row_index(int (&idx)[NV], const int* __restrict__ tab,
+                                               int width, int lane) {
+  const int lpr = width >> 2;
+  const int rpi = 64 / lpr;
+  const int sub = lane / lpr;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int t = sub + k * rpi;
+    idx[k] = tab[(sub < rpi && t < NLAM_TILE) ? t : 0];
+  }
+}
+template <int NV>
+__device__ __forceinline__ void load_rows_i(f32x4 (&v)[NV], const float* __restrict__ base,
+                                            int64_t ld, const int (&idx)[NV], int width, int lane) {
+  const int lpr = width >> 2;
+  const int rpi = 64 / lpr;
+  const int sub = lane / lpr;
+  const int c4 = sub < rpi ? lane - sub * lpr : 0;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    if (k * rpi < NLAM_TILE)   // wave-uniform
+      v[k] = reinterpret_cast<const f32x4*>(base + (int64_t)idx[k] * ld)[c4];
+  }
+}
+// tile rows -> global rows base + idx[k] * ld (scatter by per-lane row index), optionally + res
+template <int NV, bool RES>
+__device__ __forceinline__ void store_rows_i(const float* __restrict__ tile, int ldt, int col0,
+                                             int width, int nrows, int lane,
+                                             float* __restrict__ base, int64_t ld,
+                                             const int (&idx)[NV],
+                                             const float* __restrict__ rbase = nullptr,
+                                             int64_t rld = 0) {
+  const int lpr = width >> 2;
+  const int rpi = 64 / lpr;
+  const int sub = lane / lpr, c4 = lane - sub * lpr;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int t = sub + k * rpi;
+    if (sub < rpi && t < nrows) {
+      f32x4 x = *(reinterpret_cast<const f32x4*>(tile + t * ldt + col0) + c4);
+      if (RES) x += reinterpret_cast<const f32x4*>(rbase + (int64_t)idx[k] * rld)[c4];
+      reinterpret_cast<f32x4*>(base + (int64_t)idx[k] * ld)[c4] = x;
+    }
+  }
+}
+
 // scalar form for narrow / unaligned sources (width <= 2 NS)
 template <int NS, typename RowPtr>
 __device__ __forceinline__ void load_rows_s(float (&v)[NS], int width, int lane, RowPtr row_ptr) {
@@ -509,6 +568,27 @@ __device__ __forceinline__ void tile_colsum(float (&acc)[NV], const float* __res
   for (int j = 0; j < NV; ++j) {
     float s = 0.f;
     for (int t = 0; t < nrows; ++t) s += tile[t * ld + col0 + 64 * j + lane];
+    acc[j] += s;
+  }
+}
+
+// Same over ALL 32 tile rows (the caller guarantees that rows >= nrows hold zeros): a fixed trip
+// count lets four row reads fly per wait (eight spill in edge_bwd) instead of one dependent LDS round trip per row
+// (stamps of edge_bwd: the three runtime-length column sums were ~5 k of a 41 k-cycle tile).
+template <int NV>
+__device__ __forceinline__ void tile_colsum_all(float (&acc)[NV], const float* __restrict__ tile,
+                                                int ld, int col0, int lane) {
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    float s = 0.f;
+#pragma unroll 1
+    for (int t0 = 0; t0 < NLAM_TILE; t0 += 4) {
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = tile[(t0 + u) * ld + col0 + 64 * j + lane];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s += v[u];
+    }
     acc[j] += s;
   }
 }

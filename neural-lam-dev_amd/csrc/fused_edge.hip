@@ -87,6 +87,8 @@ __global__ __launch_bounds__(256, 2) void edge_fwd_kernel(EdgeFwdParams p) {
   float* gs = b2s + D;
   float* bs = gs + D;
   float* tile = bs + D + wave * (NLAM_TILE * LDT);
+  // per-wave slot-index tables [eid | send | rec] (see lane_row_index)
+  int* itab = reinterpret_cast<int*>(bs + D + 4 * (NLAM_TILE * LDT)) + wave * (3 * NLAM_TILE);
   const B3Image W1im = b3_image(W1s, D, D), W2im = b3_image(W2s, D, D);
   if (B3) {
     if (HAS_EGEMM) load_weight_lds_b3(W1im, 0, p.W1e, p.ldW1e, D, D, D, D, tid, 256);
@@ -114,14 +116,22 @@ __global__ __launch_bounds__(256, 2) void edge_fwd_kernel(EdgeFwdParams p) {
     const float* eb = p.e.ptr + (int64_t)b * p.e.bstride;
     const float* psb = p.ps.ptr + (int64_t)b * p.ps.bstride;
     const float* prb = p.pr.ptr + (int64_t)b * p.pr.bstride;
-    auto e_row = [&](int s) { return eb + (int64_t)__shfl(eid, s, 64) * p.e.ld; };
-    auto ps_row = [&](int s) { return psb + (int64_t)__shfl(snd, s, 64) * p.ps.ld; };
-    auto pr_row = [&](int s) { return prb + (int64_t)__shfl(rcv, s, 64) * p.pr.ld; };
-    // all row gathers of this tile in flight together, then the next tile's indices
+    // all row gathers of this tile in flight together (per-lane row indices: no shuffles),
+    // then the next tile's indices
     f32x4 vE[NV], vS[NV], vR[NV];
-    load_rows_v<NV>(vE, D, lane, e_row);
-    load_rows_v<NV>(vS, D, lane, ps_row);
-    load_rows_v<NV>(vR, D, lane, pr_row);
+    {
+      stash_slot_index(itab, eid, lane);
+      stash_slot_index(itab + NLAM_TILE, snd, lane);
+      stash_slot_index(itab + 2 * NLAM_TILE, rcv, lane);
+      wave_sync();
+      int ie[NV], is[NV], ir[NV];
+      lane_row_index<NV>(ie, itab, D, lane);
+      lane_row_index<NV>(is, itab + NLAM_TILE, D, lane);
+      lane_row_index<NV>(ir, itab + 2 * NLAM_TILE, D, lane);
+      load_rows_i<NV>(vE, eb, p.e.ld, ie, D, lane);
+      load_rows_i<NV>(vS, psb, p.ps.ld, is, D, lane);
+      load_rows_i<NV>(vR, prb, p.pr.ld, ir, D, lane);
+    }
     const TileCtx nxt = load_tile_ctx(p, hdr_n, lane);
     const int4 hdr_nn = load_tile_hdr(p, tt + 2 * stride, total);
 #pragma unroll
@@ -187,8 +197,9 @@ __global__ __launch_bounds__(256, 2) void edge_fwd_kernel(EdgeFwdParams p) {
       acc_to_tile<NB>(ebuf, tile, LDT, lane);
       wave_sync();
       float* ob = p.e_out + (int64_t)b * p.eo_bstride;
-      auto o_row = [&](int s) { return ob + (int64_t)__shfl(eid, s, 64) * p.eo_ld; };
-      store_rows<true>(tile, LDT, 0, D, ne, lane, o_row);
+      int ie[NV];
+      lane_row_index<NV>(ie, itab, D, lane);   // (this tile's table is still in place)
+      store_rows_i<NV, false>(tile, LDT, 0, D, ne, lane, ob, p.eo_ld, ie);
     }
     wave_sync();
     cur = nxt;
@@ -199,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void edge_fwd_kernel(EdgeFwdParams p) {
 template <int D, bool HAS_EGEMM, bool B3 = false>
 static int launch_edge_fwd(const EdgeFwdParams& p, hipStream_t s) {
   const size_t lds = ((size_t)(HAS_EGEMM ? 2 : 1) * D * (D + 4) + 3 * D +
-                      (size_t)4 * NLAM_TILE * (D + 4)) * sizeof(float);
+                      (size_t)4 * NLAM_TILE * (D + 4) + 4 * 3 * NLAM_TILE) * sizeof(float);
   NLAM_REQUIRE(lds <= 160 * 1024, "edge_fwd: LDS footprint %zu B exceeds 160 KiB", lds);
   auto kern = edge_fwd_kernel<D, HAS_EGEMM, B3>;
   NLAM_BIG_LDS(kern, __func__);
@@ -310,6 +321,8 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
   float* T0 = T0base + wave * WSTRIDE;
   float* T1 = T1base + wave * WSTRIDE;
   float* T2 = T2base + wave * WSTRIDE;
+  // per-wave slot-index tables, double-buffered over tiles: [2][eid | send | rec][32]
+  int* itab = reinterpret_cast<int*>(T0base + 4 * WSTRIDE) + wave * (6 * NLAM_TILE);
   const B3Image W1im = b3_image(W1s, D, D), W2im = b3_image(W2s, D, D);
   if (B3) {
     if (HAS_EGEMM) load_weight_lds_b3(W1im, 0, p.W1e, p.ldW1e, D, D, D, D, tid, 256);
@@ -346,7 +359,7 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
   // at the start of the previous tile's last phase, and land while its MFMAs run: with
   // one wave per SIMD nothing else hides their latency (stamps: 16 % of the tile time).
   f32x4 vE[NVR], vS[NVR], vR[NVR], vG[NVR], vO[NVR];
-  auto issue_rows = [&](const TileCtx& c, unsigned task) {
+  auto issue_rows = [&](const TileCtx& c, unsigned task, int par) {
     const unsigned tq = task < total ? task : total - 1;
     const unsigned b = tq / (unsigned)p.ntiles;
     const int eid = c.eid, snd = c.snd, rcv = c.rcv;
@@ -356,18 +369,24 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
     const float* gab = q.g_agg.ptr + (int64_t)b * q.g_agg.bstride;
     const float* gob = has_geo ? q.g_eout + (int64_t)b * q.geo_bstride : eb;
     const int64_t gold = has_geo ? q.geo_ld : p.e.ld;
-    auto e_row = [&](int s) { return eb + (int64_t)__shfl(eid, s, 64) * p.e.ld; };
-    auto ps_row = [&](int s) { return psb + (int64_t)__shfl(snd, s, 64) * p.ps.ld; };
-    auto pr_row = [&](int s) { return prb + (int64_t)__shfl(rcv, s, 64) * p.pr.ld; };
-    auto ga_row = [&](int s) { return gab + (int64_t)__shfl(rcv, s, 64) * q.g_agg.ld; };
-    auto go_row = [&](int s) { return gob + (int64_t)__shfl(eid, s, 64) * gold; };
-    load_rows_v<NVR>(vE, D, lane, e_row);
-    load_rows_v<NVR>(vS, D, lane, ps_row);
-    load_rows_v<NVR>(vR, D, lane, pr_row);
-    load_rows_v<NVR>(vG, D, lane, ga_row);
-    if (has_geo) load_rows_v<NVR>(vO, D, lane, go_row);
+    // slot indices -> this wave's LDS table (buffer `par`), per-lane row indices back
+    int* tab = itab + par * (3 * NLAM_TILE);
+    stash_slot_index(tab, eid, lane);
+    stash_slot_index(tab + NLAM_TILE, snd, lane);
+    stash_slot_index(tab + 2 * NLAM_TILE, rcv, lane);
+    wave_sync();
+    int ie[NVR], is[NVR], ir[NVR];
+    lane_row_index<NVR>(ie, tab, D, lane);
+    lane_row_index<NVR>(is, tab + NLAM_TILE, D, lane);
+    lane_row_index<NVR>(ir, tab + 2 * NLAM_TILE, D, lane);
+    load_rows_i<NVR>(vE, eb, p.e.ld, ie, D, lane);
+    load_rows_i<NVR>(vS, psb, p.ps.ld, is, D, lane);
+    load_rows_i<NVR>(vR, prb, p.pr.ld, ir, D, lane);
+    load_rows_i<NVR>(vG, gab, q.g_agg.ld, ir, D, lane);
+    if (has_geo) load_rows_i<NVR>(vO, gob, gold, ie, D, lane);
   };
-  if (tt < total) issue_rows(cur, tt);
+  int par = 0;
+  if (tt < total) issue_rows(cur, tt, 0);
   unsigned long long tprev = STAMP ? __builtin_amdgcn_s_memtime() : 0;
   for (; tt < total; tt += stride) {
     const unsigned b = tt / (unsigned)p.ntiles;
@@ -458,7 +477,7 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
     } else {
       acc_to_tile<NB>(g, T1, LDT, lane);
       wave_sync();
-      tile_colsum<NV>(dbet, T1, LDT, 0, ne, lane);
+      tile_colsum_all<NV>(dbet, T1, LDT, 0, lane);   // (padded rows are zero)
     }
     // LN backward
     constexpr float inv_d = 1.0f / (float)D;
@@ -491,7 +510,7 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
     const float m1 = s1 * inv_d, m2 = s2 * inv_d;
     wave_sync();
     if constexpr (MCS0) tile_colsum_b3<NV>(dgam, T1p, 0, lane);
-    else tile_colsum<NV>(dgam, T1, LDT, 0, ne, lane);
+    else tile_colsum_all<NV>(dgam, T1, LDT, 0, lane);
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -507,10 +526,10 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
     } else {
       acc_to_tile<NB>(g, T1, LDT, lane);
       wave_sync();
-      tile_colsum<NV>(db2, T1, LDT, 0, ne, lane);
+      tile_colsum_all<NV>(db2, T1, LDT, 0, lane);
     }
     STAMP_AT(2)   // LN backward + three column sums + tile transposes
-    if (!HAS_EGEMM) issue_rows(nxt, tt + stride);  // (no later MFMA phase in this form)
+    if (!HAS_EGEMM) issue_rows(nxt, tt + stride, par ^ 1);  // (no later MFMA phase in this form)
     if constexpr (B3) {
       if constexpr (!MCS) {
         wave_sync();
@@ -540,8 +559,9 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
     wave_sync();
     {
       float* ghb = q.gh_out + (int64_t)b * q.gh_bstride;
-      auto gh_row = [&](int s) { return ghb + (int64_t)__shfl(eid, s, 64) * D; };
-      store_rows<true>(T1, LDT, 0, D, ne, lane, gh_row);
+      int ie[NVR];
+      lane_row_index<NVR>(ie, itab + par * (3 * NLAM_TILE), D, lane);   // this tile's eid table
+      store_rows_i<NVR, false>(T1, LDT, 0, D, ne, lane, ghb, D, ie);
       // receiver-side sum of gh (segments are tile-local)
       float* gb = q.gpr + (int64_t)b * q.gpr_bstride;
       if (tile_is_dense(cur, lane)) {
@@ -561,7 +581,7 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
       }
     }
     STAMP_AT(4)     // gh store + receiver-side segment reduce
-    if (HAS_EGEMM && !B3) issue_rows(nxt, tt + stride);   // next gathers fly under the MFMAs below
+    if (HAS_EGEMM && !B3) issue_rows(nxt, tt + stride, par ^ 1);   // next gathers fly under the MFMAs below
     if (HAS_EGEMM) {
       if constexpr (B3) {
         wave_sync();
@@ -569,7 +589,7 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
         wave_sync();
         outer_accum_b3<NB, NB>(dW1, T1p, 0, T0p, 0, lane);
         STAMP_AT(5)     // GH planes + dW1e outer product
-        issue_rows(nxt, tt + stride);   // (after the outer product: its fragments are dead)
+        issue_rows(nxt, tt + stride, par ^ 1);   // (after the outer product: its fragments are dead)
         STAMP_AT(6)     // issue of the next tile's five row gathers
       } else {
         outer_accum<NB, NB>(dW1, T1, LDT, 0, T0, LDT, 0, lane);
@@ -585,13 +605,15 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
       acc_to_tile<NB>(ge, T2, LDT, lane);
       wave_sync();
       float* ob = q.g_e + (int64_t)b * q.ge_bstride;
-      auto o_row = [&](int s) { return ob + (int64_t)__shfl(eid, s, 64) * q.ge_ld; };
-      store_rows<true>(T2, LDT, 0, D, ne, lane, o_row);
+      int ie[NVR];
+      lane_row_index<NVR>(ie, itab + par * (3 * NLAM_TILE), D, lane);
+      store_rows_i<NVR, false>(T2, LDT, 0, D, ne, lane, ob, q.ge_ld, ie);
     }
     wave_sync();
     STAMP_AT(7)     // W1e^T gh + g_e store
     cur = nxt;
     hdr_n = hdr_nn;
+    par ^= 1;
   }
   if (STAMP && lane == 0) {
 #pragma unroll
@@ -617,7 +639,7 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
 template <int D, bool HAS_EGEMM, bool STAMP = false, bool B3 = false>
 static int launch_edge_bwd(const EdgeBwdParams& q, hipStream_t s) {
   const size_t lds = ((size_t)(HAS_EGEMM ? 2 : 1) * D * (D + 4) + 2 * D +
-                      (size_t)4 * 3 * NLAM_TILE * (D + 4)) * sizeof(float);
+                      (size_t)4 * 3 * NLAM_TILE * (D + 4) + 4 * 6 * NLAM_TILE) * sizeof(float);
   NLAM_REQUIRE(lds <= 160 * 1024, "edge_bwd: LDS footprint %zu B exceeds 160 KiB", lds);
   auto kern = edge_bwd_kernel<D, HAS_EGEMM, STAMP, B3>;
   NLAM_BIG_LDS(kern, __func__);

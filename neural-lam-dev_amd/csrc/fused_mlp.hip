@@ -534,7 +534,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpBwdParams q) {
     f32x16 g[NOUTB];
     tile_to_acc<NOUTB>(g, T1, ldt1, lane);
     if (HAS_LN) {
-      tile_colsum<NV_O>(dbet, T1, ldt1, 0, nrows, lane);
+      tile_colsum_all<NV_O>(dbet, T1, ldt1, 0, lane);
       f32x16 z[NOUTB];
       vec_to_acc<NOUTB>(z, b2s, lane);
       if constexpr (B3) gemm_acc_b3<NOUTB, NBH>(z, W2im, 0, sact, lane);
@@ -574,7 +574,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpBwdParams q) {
       wave_sync();
       acc_to_tile<NOUTB>(prod, T1, ldt1, lane);
       wave_sync();
-      tile_colsum<NV_O>(dgam, T1, ldt1, 0, nrows, lane);
+      tile_colsum_all<NV_O>(dgam, T1, ldt1, 0, lane);
 #pragma unroll
       for (int nb = 0; nb < NOUTB; ++nb)
 #pragma unroll
@@ -596,7 +596,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpBwdParams q) {
       acc_to_tile<NOUTB>(g, T1, ldt1, lane);
       if (!HAS_LN) acc_to_tile_b3<NBH>(sact, T0s, 0, lane);
       wave_sync();
-      tile_colsum<NV_O>(db2, T1, ldt1, 0, nrows, lane);
+      tile_colsum_all<NV_O>(db2, T1, ldt1, 0, lane);
       wave_sync();
       acc_to_tile_b3<NOUTB>(g, T1o, 0, lane);   // GZ as bf16 planes over the fp32 copy
       wave_sync();
@@ -605,7 +605,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpBwdParams q) {
       acc_to_tile<NOUTB>(g, T1, ldt1, lane);
       if (!HAS_LN) acc_to_tile<NBH>(sact, T0, ldt0, lane);
       wave_sync();
-      tile_colsum<NV_O>(db2, T1, ldt1, 0, nrows, lane);
+      tile_colsum_all<NV_O>(db2, T1, ldt1, 0, lane);
       outer_accum<NOUTB, NBH>(dW2, T1, ldt1, 0, T0, ldt0, 0, lane);
     }
     // ga = (W2^T gz) * silu'(h)   (registers + weights only)
@@ -630,7 +630,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpBwdParams q) {
     } else {
       stage_x(b, r0, nrows);                        // X again
       wave_sync();
-      tile_colsum<NV_H>(db1, T1, ldt1, 0, nrows, lane);
+      tile_colsum_all<NV_H>(db1, T1, ldt1, 0, lane);
       if constexpr (B3) {
         // X (fp32 tile) -> registers -> planes in place; GA planes over its fp32 copy
         static_assert(KB <= 2, "B3 in-kernel dW1 supports k_in <= 64");
@@ -975,7 +975,7 @@ __global__ __launch_bounds__(256) void lin_bwd_kernel(LinBwdParams q) {
         gemm_tile_wt_b3<KB, NOUTB>(gx, Wim, 0, T1p, 0, lane);
       }
     } else {
-      tile_colsum<NV>(db, T1, ldt1, 0, nrows, lane);
+      tile_colsum_all<NV>(db, T1, ldt1, 0, lane);
       outer_accum<NOUTB, KB>(dW, T1, ldt1, 0, T0, ldt0, 0, lane);
       if (q.gx != nullptr) {
         f32x16 g[NOUTB];
@@ -1168,7 +1168,7 @@ __global__ __launch_bounds__(256) void outer_bwd_kernel(OuterParams q) {
       if (xbb) put_rows_v<8, false>(TX, ldx, q.xa.width, q.xb.width, nrows, lane, vb);
       if (NX > kx) zero_cols(TX, ldx, kx, NX - kx, lane);
       wave_sync();
-      tile_colsum<NV>(db, TG, ldg, 0, nrows, lane);
+      tile_colsum_all<NV>(db, TG, ldg, 0, lane);
       outer_accum<NGB, NXB>(dW, TG, ldg, 0, TX, ldx, 0, lane);
     }
     wave_sync();

@@ -123,6 +123,8 @@ __global__ __launch_bounds__(256) void tail_fwd_kernel(TailFwdParams p) {
   float* gs = b2s + NO;
   float* bs = gs + NO;
   float* tile = bs + NO + wave * (NLAM_TILE * LDT);
+  // per-wave slot-index tables [a | b | c | y] (see lane_row_index)
+  int* itab = reinterpret_cast<int*>(bs + NO + 4 * (NLAM_TILE * LDT)) + wave * (4 * NLAM_TILE);
   const B3Image W2im = b3_image(W2s, NO, D);
   load_weight_lds_b3(W2im, 0, p.W2, p.ldW2, p.n_out, D, NO, D, tid, 256);
   load_vec_lds(b2s, p.b2, p.n_out, NO, tid, 256);
@@ -130,30 +132,57 @@ __global__ __launch_bounds__(256) void tail_fwd_kernel(TailFwdParams p) {
   load_vec_lds(bs, p.beta, p.n_out, NO, tid, 256);
   __syncthreads();
 
+  // slot indices of a tile (lanes 0..31), fetched ONE TILE AHEAD so that the row gathers do
+  // not wait for an index load
+  struct Ctx { WTile w; int ia, ib, ic, iy, rcv; };
+  auto load_ctx = [&](int64_t task, int64_t total) {
+    Ctx c;
+    const int64_t tq = task < total ? task : total - 1;
+    const int64_t bq = tq / p.tl.ntiles;
+    c.w = wide_tile(p.tl, tq - bq * p.tl.ntiles);
+    c.ia = wide_index(p.idx_a, c.w, lane);
+    c.ib = p.b.ptr ? wide_index(p.idx_b, c.w, lane) : 0;
+    c.ic = p.c.ptr ? wide_index(p.idx_c, c.w, lane) : 0;
+    c.iy = wide_index(p.idx_y, c.w, lane);
+    c.rcv = p.tl.csr_rec ? wide_index(p.tl.csr_rec, c.w, lane) : 0;
+    return c;
+  };
   const int64_t total = p.tl.ntiles * p.B;
-  for (int64_t tt = (int64_t)blockIdx.x * 4 + wave; tt < total; tt += (int64_t)gridDim.x * 4) {
+  const int64_t tstride = (int64_t)gridDim.x * 4;
+  int64_t tt = (int64_t)blockIdx.x * 4 + wave;
+  if (tt >= total) return;
+  Ctx cur = load_ctx(tt, total);
+  for (; tt < total; tt += tstride) {
     const int64_t b = tt / p.tl.ntiles;
-    const WTile w = wide_tile(p.tl, tt - b * p.tl.ntiles);
+    const WTile w = cur.w;
     const int ne = w.ne;
-    const int ia = wide_index(p.idx_a, w, lane);
-    const int ib = p.b.ptr ? wide_index(p.idx_b, w, lane) : 0;
-    const int ic = p.c.ptr ? wide_index(p.idx_c, w, lane) : 0;
-    const int iy = wide_index(p.idx_y, w, lane);
-    const int rcv = p.tl.csr_rec ? wide_index(p.tl.csr_rec, w, lane) : 0;
-    const float* ab = p.a.ptr + b * p.a.bstride;
-    auto a_row = [&](int s) { return ab + (int64_t)__shfl(ia, s, 64) * p.a.ld; };
+    const int rcv = cur.rcv;
+    stash_slot_index(itab, cur.ia, lane);
+    stash_slot_index(itab + NLAM_TILE, cur.ib, lane);
+    stash_slot_index(itab + 2 * NLAM_TILE, cur.ic, lane);
+    stash_slot_index(itab + 3 * NLAM_TILE, cur.iy, lane);
+    wave_sync();
+    int iy[NV];
+    lane_row_index<NV>(iy, itab + 3 * NLAM_TILE, D, lane);
     f32x4 vA[NV];
-    load_rows_v<NV>(vA, D, lane, a_row);
+    {
+      int ia[NV];
+      lane_row_index<NV>(ia, itab, D, lane);
+      load_rows_i<NV>(vA, p.a.ptr + b * p.a.bstride, p.a.ld, ia, D, lane);
+    }
+    const Ctx nxt = load_ctx(tt + tstride, total);   // (lands during this tile's work)
     if (p.b.ptr) {
-      const float* bb = p.b.ptr + b * p.b.bstride;
-      auto b_row = [&](int s) { return bb + (int64_t)__shfl(ib, s, 64) * p.b.ld; };
       f32x4 vB[NV];
-      load_rows_v<NV>(vB, D, lane, b_row);
+      {
+        int ib[NV];
+        lane_row_index<NV>(ib, itab + NLAM_TILE, D, lane);
+        load_rows_i<NV>(vB, p.b.ptr + b * p.b.bstride, p.b.ld, ib, D, lane);
+      }
       if (p.c.ptr) {
-        const float* cb = p.c.ptr + b * p.c.bstride;
-        auto c_row = [&](int s) { return cb + (int64_t)__shfl(ic, s, 64) * p.c.ld; };
         f32x4 vC[NV];
-        load_rows_v<NV>(vC, D, lane, c_row);
+        int ic[NV];
+        lane_row_index<NV>(ic, itab + 2 * NLAM_TILE, D, lane);
+        load_rows_i<NV>(vC, p.c.ptr + b * p.c.bstride, p.c.ld, ic, D, lane);
 #pragma unroll
         for (int k = 0; k < NV; ++k) vB[k] += vC[k];
       }
@@ -206,25 +235,27 @@ __global__ __launch_bounds__(256) void tail_fwd_kernel(TailFwdParams p) {
       }
     }
     if (p.y != nullptr) {
-      // scattered rows (idx_y) are float4-only (checked on the host): the scalar stores of
-      // narrow outputs then never shuffle inside a partially active loop
+      // scattered rows (idx_y) are float4-only (checked on the host); narrow outputs are
+      // contiguous rows and take the scalar path
       float* yb = p.y + b * p.y_bstride;
-      auto y_row = [&](int s) {
-        return yb + (int64_t)(p.idx_y ? __shfl(iy, s, 64) : w.p0 + s) * p.y_ld;
-      };
-      if (p.res.ptr != nullptr) {
-        const float* rb = p.res.ptr + b * p.res.bstride;
-        auto r_row = [&](int s) {
-          return rb + (int64_t)(p.idx_y ? __shfl(iy, s, 64) : w.p0 + s) * p.res.ld;
-        };
-        if (p.vec_y) store_rows_res<true>(tile, LDT, 0, p.n_out, ne, lane, y_row, r_row);
-        else store_rows_res<false>(tile, LDT, 0, p.n_out, ne, lane, y_row, r_row);
+      const float* rb = p.res.ptr ? p.res.ptr + b * p.res.bstride : nullptr;
+      if (p.vec_y && NO == D) {
+        if (rb) store_rows_i<NV, true>(tile, LDT, 0, D, ne, lane, yb, p.y_ld, iy, rb, p.res.ld);
+        else store_rows_i<NV, false>(tile, LDT, 0, D, ne, lane, yb, p.y_ld, iy);
       } else {
-        if (p.vec_y) store_rows<true>(tile, LDT, 0, p.n_out, ne, lane, y_row);
-        else store_rows<false>(tile, LDT, 0, p.n_out, ne, lane, y_row);
+        auto y_row = [&](int s) { return yb + (int64_t)(w.p0 + s) * p.y_ld; };
+        auto r_row = [&](int s) { return rb + (int64_t)(w.p0 + s) * p.res.ld; };
+        if (rb) {
+          if (p.vec_y) store_rows_res<true>(tile, LDT, 0, p.n_out, ne, lane, y_row, r_row);
+          else store_rows_res<false>(tile, LDT, 0, p.n_out, ne, lane, y_row, r_row);
+        } else {
+          if (p.vec_y) store_rows<true>(tile, LDT, 0, p.n_out, ne, lane, y_row);
+          else store_rows<false>(tile, LDT, 0, p.n_out, ne, lane, y_row);
+        }
       }
     }
     wave_sync();
+    cur = nxt;
   }
 }
 
@@ -238,7 +269,8 @@ static unsigned wide_grid(int64_t total_tiles) {
 template <int D, int NOUTB, bool HAS_LN, int TERMS>
 static int launch_tail_fwd(const TailFwdParams& p, hipStream_t s) {
   const size_t lds = b3_image_bytes(32 * NOUTB, D) + (size_t)3 * 32 * NOUTB * sizeof(float) +
-                     (size_t)4 * NLAM_TILE * (D + 4) * sizeof(float);
+                     (size_t)4 * NLAM_TILE * (D + 4) * sizeof(float) +
+                     (size_t)4 * 4 * NLAM_TILE * sizeof(int);
   NLAM_REQUIRE(lds <= 160 * 1024, "tail_fwd: LDS footprint %zu B exceeds 160 KiB", lds);
   auto kern = tail_fwd_kernel<D, NOUTB, HAS_LN, TERMS>;
   NLAM_BIG_LDS(kern, "tail_fwd_kernel");
@@ -293,8 +325,8 @@ extern "C" int nlam_tail_fwd(
   p.B = (int)B;
   p.vec_y = (y != nullptr && view_vec_ok(y, y_bstride, y_ld, n_out) &&
              (res == nullptr || view_vec_ok(res, res_bstride, res_ld, n_out))) ? 1 : 0;
-  NLAM_REQUIRE(idx_y == nullptr || y == nullptr || p.vec_y,
-               "nlam_tail_fwd: scattered output rows must be 16-byte aligned, n_out %% 4 == 0");
+  NLAM_REQUIRE(idx_y == nullptr || y == nullptr || (p.vec_y && n_out == d),
+               "nlam_tail_fwd: scattered output rows must be 16-byte aligned and d wide");
   hipStream_t s = (hipStream_t)stream;
   const bool t3 = nlam_mfma_terms() == 3;
   if (gamma != nullptr)
@@ -330,6 +362,7 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(TailBwdParams q) {
   float* b2s = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + b3_image_bytes(NO, D));
   float* gs = b2s + NO;
   float* tile = gs + NO + wave * (NLAM_TILE * LDT);
+  int* itab = reinterpret_cast<int*>(gs + NO + 4 * (NLAM_TILE * LDT)) + wave * (4 * NLAM_TILE);
   const B3Image W2im = b3_image(W2s, NO, D);
   load_weight_lds_b3(W2im, 0, q.W2, q.ldW2, q.n_out, D, NO, D, tid, 256);
   load_vec_lds(b2s, q.b2, q.n_out, NO, tid, 256);
@@ -342,16 +375,38 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(TailBwdParams q) {
   for (int j = 0; j < NV_O; ++j) dgam[j] = dbet[j] = 0.f;
   const B3Tile Tp = b3_tile(tile, NO);   // bf16-plane view of the tile (column sums)
 
+  // slot indices / row scales of a tile (lanes 0..31), fetched one tile ahead
+  struct Ctx { WTile w; int i1, i2, igh, rcv; float sc1; };
+  auto load_ctx = [&](int64_t task, int64_t total) {
+    Ctx c;
+    const int64_t tq = task < total ? task : total - 1;
+    const int64_t bq = tq / q.tl.ntiles;
+    c.w = wide_tile(q.tl, tq - bq * q.tl.ntiles);
+    c.i1 = wide_index(q.idx_g1, c.w, lane);
+    c.i2 = q.g2.ptr ? wide_index(q.idx_g2, c.w, lane) : 0;
+    c.igh = wide_index(q.idx_gh, c.w, lane);
+    c.rcv = q.tl.csr_rec ? wide_index(q.tl.csr_rec, c.w, lane) : 0;
+    c.sc1 = q.scale1 ? q.scale1[c.i1] : 1.0f;   // (dependent load, hidden by the prefetch)
+    return c;
+  };
   const int64_t total = q.tl.ntiles * q.B;
-  for (int64_t tt = (int64_t)blockIdx.x * 4 + wave; tt < total; tt += (int64_t)gridDim.x * 4) {
+  const int64_t tstride = (int64_t)gridDim.x * 4;
+  int64_t tt = (int64_t)blockIdx.x * 4 + wave;
+  Ctx cur = load_ctx(tt, total > 0 ? total : 1);
+  for (; tt < total; tt += tstride) {
     const int64_t b = tt / q.tl.ntiles;
-    const WTile w = wide_tile(q.tl, tt - b * q.tl.ntiles);
+    const WTile w = cur.w;
     const int ne = w.ne;
-    const int i1 = wide_index(q.idx_g1, w, lane);
-    const int i2 = q.g2.ptr ? wide_index(q.idx_g2, w, lane) : 0;
-    const int igh = wide_index(q.idx_gh, w, lane);
-    const int rcv = q.tl.csr_rec ? wide_index(q.tl.csr_rec, w, lane) : 0;
-    const float sc1 = q.scale1 ? q.scale1[i1] : 1.0f;
+    const int i1 = cur.i1, i2 = cur.i2;
+    const int rcv = cur.rcv;
+    const float sc1 = cur.sc1;
+    // per-wave slot tables [g1 | g2 | gh | scale bits] -> per-lane row indices
+    stash_slot_index(itab, cur.i1, lane);
+    stash_slot_index(itab + NLAM_TILE, cur.i2, lane);
+    stash_slot_index(itab + 2 * NLAM_TILE, cur.igh, lane);
+    stash_slot_index(itab + 3 * NLAM_TILE, __float_as_int(cur.sc1), lane);
+    wave_sync();
+    const Ctx nxt = load_ctx(tt + tstride, total);
     const float* g1b = q.g1.ptr + b * q.g1.bstride;
     const float* g2b = q.g2.ptr ? q.g2.ptr + b * q.g2.bstride : nullptr;
     auto g1_row = [&](int s) { return g1b + (int64_t)__shfl(i1, s, 64) * q.g1.ld; };
@@ -371,29 +426,25 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(TailBwdParams q) {
     // ---- incoming gradient rows -> tile (their loads fly under the GEMM below)
     f32x4 vG[NVG];
     if (q.vec_g) {
-      load_rows_v<NVG>(vG, NO, lane, g1_row);
+      // per-lane row indices (and row scales) straight from the tables: no shuffles
+      int ig[NVG];
+      lane_row_index<NVG>(ig, itab, NO, lane);
+      load_rows_i<NVG>(vG, g1b, q.g1.ld, ig, NO, lane);
       if (g2b) {
-        // row scale (mean aggregation): the rows of float4 k belong to slot sub + k * rpi
-        constexpr int lpr = NO >> 2;
-        constexpr int rpi = 64 / lpr;
-        const int sub = lane / lpr;
         f32x4 vO[NVG];
-        load_rows_v<NVG>(vO, NO, lane, g2_row);
+        lane_row_index<NVG>(ig, itab + NLAM_TILE, NO, lane);
+        load_rows_i<NVG>(vO, g2b, q.g2.ld, ig, NO, lane);
+        if (q.scale1 != nullptr) {
+          lane_row_index<NVG>(ig, itab + 3 * NLAM_TILE, NO, lane);
 #pragma unroll
-        for (int k = 0; k < NVG; ++k) {
-          const int ts = sub + k * rpi;
-          const float sc = __shfl(sc1, ts < NLAM_TILE ? ts : 0, 64);
-          vG[k] = vG[k] * sc + vO[k];
+          for (int k = 0; k < NVG; ++k) vG[k] *= __int_as_float(ig[k]);
         }
+#pragma unroll
+        for (int k = 0; k < NVG; ++k) vG[k] += vO[k];
       } else if (q.scale1 != nullptr) {
-        constexpr int lpr = NO >> 2;
-        constexpr int rpi = 64 / lpr;
-        const int sub = lane / lpr;
+        lane_row_index<NVG>(ig, itab + 3 * NLAM_TILE, NO, lane);
 #pragma unroll
-        for (int k = 0; k < NVG; ++k) {
-          const int ts = sub + k * rpi;
-          vG[k] *= __shfl(sc1, ts < NLAM_TILE ? ts : 0, 64);
-        }
+        for (int k = 0; k < NVG; ++k) vG[k] *= __int_as_float(ig[k]);
       }
     }
     f32x16 z[NOUTB];
@@ -507,8 +558,9 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(TailBwdParams q) {
     wave_sync();
     {
       float* ghb = q.gh + b * q.gh_bstride;
-      auto gh_row = [&](int s) { return ghb + (int64_t)__shfl(igh, s, 64) * q.gh_ld; };
-      store_rows<true>(tile, LDT, 0, D, ne, lane, gh_row);
+      int igh[NV];
+      lane_row_index<NV>(igh, itab + 2 * NLAM_TILE, D, lane);
+      store_rows_i<NV, false>(tile, LDT, 0, D, ne, lane, ghb, q.gh_ld, igh);
     }
     if (q.gpr != nullptr) {
       float* gb = q.gpr + b * q.gpr_bstride;
@@ -533,6 +585,7 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(TailBwdParams q) {
       }
     }
     wave_sync();
+    cur = nxt;
   }
   (void)t;
   if (HAS_LN) {
@@ -550,7 +603,8 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(TailBwdParams q) {
 template <int D, int NOUTB, bool HAS_LN, int TERMS>
 static int launch_tail_bwd(const TailBwdParams& q, hipStream_t s) {
   const size_t lds = b3_image_bytes(32 * NOUTB, D) + (size_t)2 * 32 * NOUTB * sizeof(float) +
-                     (size_t)4 * NLAM_TILE * (D + 4) * sizeof(float);
+                     (size_t)4 * NLAM_TILE * (D + 4) * sizeof(float) +
+                     (size_t)4 * 4 * NLAM_TILE * sizeof(int);
   NLAM_REQUIRE(lds <= 160 * 1024, "tail_bwd: LDS footprint %zu B exceeds 160 KiB", lds);
   auto kern = tail_bwd_kernel<D, NOUTB, HAS_LN, TERMS>;
   NLAM_BIG_LDS(kern, "tail_bwd_kernel");
