@@ -443,6 +443,9 @@ int nlam_nll_bwd(const float* pred, const float* target, const float* pred_std,
  * dW2 + W2^T gz, gh store + receiver reduce, dW1e + W1e^T gh + store.  reset != 0
  * zeroes the counters after reading. */
 int nlam_debug_edge_bwd_stamps(unsigned long long* out, int reset);
+/* Same for nlam_mlp_bwd: out[0..6] = staging, GEMM1 + silu, GEMM2 + LN backward, planes + dW2,
+ * W2^T gz, X again + dW1 (or the ga store), W1^T ga + stores. */
+int nlam_debug_mlp_bwd_stamps(unsigned long long* out, int reset);
 /* Diagnostic (NLAM_TIMELINE=1 in the environment of the process): nlam_lin_fwd records
  * s_memrealtime (100 MHz) per workgroup at start / after the weight prologue / at exit;
  * out: host array of 3 * 1024 values (first 1024 workgroups of the last launch). */

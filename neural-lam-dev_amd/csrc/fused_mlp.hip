@@ -121,7 +121,8 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(MlpParams p) {
       const float* rb = p.res + b * p.res_bstride + r0 * p.res_ld;
       auto rp = [&](int t) { return rb + (int64_t)t * p.res_ld; };
       if (((p.vec_mask >> 2) & 1) && ((p.vec_mask >> 3) & 1))
-        store_rows_res<true>(tile, ldt, 0, p.n_out, nrows, lane, op, rp);
+        store_rows_res<true, 1>(tile, ldt, 0, p.n_out, nrows, lane, op, rp);   // (2 waves / SIMD:
+        // larger batches of residual loads spill here and cost more than they hide)
       else
         store_rows_res<false>(tile, ldt, 0, p.n_out, nrows, lane, op, rp);
     } else {
@@ -413,15 +414,43 @@ struct MlpBwdParams {
   float* slab; int64_t slab_stride;
   float* ga_out;               // DEFER_DW1: (B, rows, HID) gradient of the hidden pre-activation
   int vec_gy, vec_gxa, vec_gxb;
+  int stamp;                   // NLAM_STAMP=1: per-phase s_memtime sums (diagnostic)
 };
+
+__device__ unsigned long long g_mlp_bwd_stamps[8];
+extern "C" int nlam_debug_mlp_bwd_stamps(unsigned long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mlp_bwd_stamps), sizeof(unsigned long long) * 8) !=
+      hipSuccess)
+    return 1;
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_mlp_bwd_stamps), z, sizeof(z)) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#define MSTAMP(k)                                                   \
+  if (q.stamp) {                                                    \
+    __builtin_amdgcn_sched_barrier(0);                              \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();   \
+    __builtin_amdgcn_s_waitcnt(0xC07F);                             \
+    __builtin_amdgcn_sched_barrier(0);                              \
+    mst[k] += now_ - mprev;                                         \
+    mprev = now_;                                                   \
+  }
 
 // DEFER_DW1: the first layer's weight gradient (HID x KP32 = up to 128 accumulator
 // registers per wave) is not formed here; the kernel stores ga = dL/d(pre-activation)
 // and nlam_outer_bwd computes dW1 = ga^T [x_a | x_b], db1 = colsum(ga) in a lean second
 // pass.  Used for the K = 128 node update, where the in-kernel form spilled.
 // B3: every GEMM / outer product as split-bf16 MFMAs (fused_bf16x3.h).
-template <int HID, int NOUTB, int KB, bool HAS_LN, bool DEFER_DW1, bool B3 = false>
+// XP (B3, K <= 64, float4 views): the input rows are staged ONCE, as bf16 planes in a third
+// tile that stays put for the whole tile (B operand of the first GEMM and of the dW1 outer
+// product), and the x / gy rows of the NEXT tile are loaded into registers in the middle of
+// the current one.  Stamps of the plain form: 25 % of a tile waiting for its rows, another
+// 10 % re-staging X for dW1.
+template <int HID, int NOUTB, int KB, bool HAS_LN, bool DEFER_DW1, bool B3 = false, bool XP = false>
 __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpBwdParams q) {
+  static_assert(!XP || (B3 && !DEFER_DW1 && KB <= 2), "XP: B3, in-kernel dW1, K <= 64");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NBH = HID / 32;
   constexpr int KP32 = 32 * KB;
@@ -442,6 +471,8 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpBwdParams q) {
   float* T1base = T0base + NLAM_TILE * ldt0;
   float* T0 = T0base + wave * WSTRIDE;
   float* T1 = T1base + wave * WSTRIDE;
+  float* T2 = T0base + 4 * WSTRIDE + wave * (NLAM_TILE * (KP32 + 4));   // XP: X planes
+  const B3Tile T2x = b3_tile(T2, KP32);
 
   const B3Image W1im = b3_image(W1s, HID, KP32), W2im = b3_image(W2s, 32 * NOUTB, HID);
   if (B3) {
@@ -497,11 +528,39 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpBwdParams q) {
 
   const int64_t tiles_per_b = (p.rows + NLAM_TILE - 1) / NLAM_TILE;
   const int64_t ntiles = tiles_per_b * p.B;
+  unsigned long long mst[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long mprev = q.stamp ? __builtin_amdgcn_s_memtime() : 0;
+  // XP: rows of the next tile, in flight from the middle of the current one
+  f32x4 pva[XP ? NVS : 1], pvg[XP ? NVS : 1];   // (XP takes single-source inputs only)
+  auto issue_next = [&](int64_t task) {
+    if constexpr (XP) {
+      const int64_t tq = task < ntiles ? task : ntiles - 1;
+      const int64_t bq = tq / tiles_per_b;
+      const int64_t rq = (tq - bq * tiles_per_b) * NLAM_TILE;
+      const int nq = (int)((p.rows - rq) < NLAM_TILE ? (p.rows - rq) : NLAM_TILE);
+      view_load_v<NVS>(pva, p.src[0], bq, rq, nq, lane);
+      view_load_v<NVS>(pvg, q.gy, bq, rq, nq, lane);
+    }
+  };
+  if (XP && (int64_t)blockIdx.x * 4 + wave < ntiles) issue_next((int64_t)blockIdx.x * 4 + wave);
   for (int64_t tt = (int64_t)blockIdx.x * 4 + wave; tt < ntiles; tt += (int64_t)gridDim.x * 4) {
     const int64_t b = tt / tiles_per_b;
     const int64_t r0 = (tt - b * tiles_per_b) * NLAM_TILE;
     const int nfull = (int)((p.rows - r0) < NLAM_TILE ? (p.rows - r0) : NLAM_TILE);
     const int nrows = nfull;
+    if constexpr (XP) {
+      // ---- the prefetched rows: X as bf16 planes (T2, kept), gy as fp32 (T1)
+      put_rows_v_b3<NVS>(T2x, 0, p.src[0].width, nrows, lane, pva);
+      if (KP32 > p.k_in) {
+        const int padw = KP32 - p.k_in;
+        for (int idx = lane; idx < NLAM_TILE * padw; idx += 64) {
+          const int tr = idx / padw, cc = p.k_in + idx - tr * padw;
+          T2x.hi[tr * T2x.pitch + cc] = (__bf16)0.f;
+          T2x.lo[tr * T2x.pitch + cc] = (__bf16)0.f;
+        }
+      }
+      put_rows_v<NVS, false>(T1, ldt1, 0, p.n_out, nrows, lane, pvg);
+    } else {
     // ---- recompute forward; gy rows go to T1 right away (latencies overlap)
     stage_x(b, r0, nrows);
     if (q.vec_gy) {
@@ -511,11 +570,15 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpBwdParams q) {
     } else {
       view_stage_s(T1, ldt1, 0, q.gy, b, r0, nrows, lane);
     }
+    }
     if (32 * NOUTB > p.n_out) zero_cols(T1, ldt1, p.n_out, 32 * NOUTB - p.n_out, lane);
     wave_sync();
+    MSTAMP(0)   // x and gy rows landed + staged
     f32x16 hpre[NBH];
     vec_to_acc<NBH>(hpre, b1s, lane);
-    if constexpr (B3) {
+    if constexpr (XP) {
+      gemm_tile_b3<NBH, KB>(hpre, W1im, 0, T2x, 0, lane);   // B operand straight from the planes
+    } else if constexpr (B3) {
       constexpr int XB = KB >= 2 ? 2 : 1;      // two input blocks at a time (registers)
 #pragma unroll
       for (int kb0 = 0; kb0 < KB; kb0 += XB) {
@@ -531,6 +594,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpBwdParams q) {
     for (int nb = 0; nb < NBH; ++nb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) sact[nb][r] = nlam_silu(hpre[nb][r]);
+    MSTAMP(1)   // GEMM1 + silu
     f32x16 g[NOUTB];
     tile_to_acc<NOUTB>(g, T1, ldt1, lane);
     if (HAS_LN) {
@@ -550,9 +614,10 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpBwdParams q) {
       ln_stats<NOUTB>(z, mean, rstd);
       const int hh = lane >> 5;
       float s1 = 0.f, s2 = 0.f;
-      f32x16 prod[NOUTB];
+      wave_sync();   // (the gy tile has been read: T1 takes gy * xhat block by block)
 #pragma unroll
-      for (int nb = 0; nb < NOUTB; ++nb)
+      for (int nb = 0; nb < NOUTB; ++nb) {
+        f32x16 prod[1];
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) {
           const f32x4 gm = *reinterpret_cast<const f32x4*>(gs + 32 * nb + 8 * qq + 4 * hh);
@@ -561,18 +626,18 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpBwdParams q) {
             const int r = 4 * qq + j;
             const float xh = (z[nb][r] - mean) * rstd;
             z[nb][r] = xh;
-            prod[nb][r] = g[nb][r] * xh;         // gy * xhat -> dgamma
+            prod[0][r] = g[nb][r] * xh;         // gy * xhat -> dgamma
             const float gv = g[nb][r] * gm[j];
             g[nb][r] = gv;
             s1 += gv;
             s2 += gv * xh;
           }
         }
+        acc_to_tile<1>(prod, T1 + 32 * nb, ldt1, lane);
+      }
       s1 += __shfl_xor(s1, 32, 64);
       s2 += __shfl_xor(s2, 32, 64);
       const float m1 = s1 * inv_d, m2 = s2 * inv_d;
-      wave_sync();
-      acc_to_tile<NOUTB>(prod, T1, ldt1, lane);
       wave_sync();
       tile_colsum_all<NV_O>(dgam, T1, ldt1, 0, lane);
 #pragma unroll
@@ -581,6 +646,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpBwdParams q) {
         for (int r = 0; r < 16; ++r) g[nb][r] = rstd * (g[nb][r] - m1 - z[nb][r] * m2);
     }
     // g is gz (zero on padded rows).  Publish GZ (T1); S is in T0.
+    MSTAMP(2)   // GEMM2 + LayerNorm backward (+ two column sums)
     wave_sync();
     // column sums on the matrix cores where the register budget allows (the K = 64 form
     // with both weight gradients in registers spills with it: measured 145 -> 198 us)
@@ -608,6 +674,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpBwdParams q) {
       tile_colsum_all<NV_O>(db2, T1, ldt1, 0, lane);
       outer_accum<NOUTB, NBH>(dW2, T1, ldt1, 0, T0, ldt0, 0, lane);
     }
+    MSTAMP(3)   // GZ / S planes, db2, dW2 outer product
     // ga = (W2^T gz) * silu'(h)   (registers + weights only)
     f32x16 ga[NBH];
 #pragma unroll
@@ -622,11 +689,20 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpBwdParams q) {
       for (int r = 0; r < 16; ++r) ga[nb][r] *= nlam_silu_grad(hpre[nb][r]);
     wave_sync();
     acc_to_tile<NBH>(ga, T1, ldt1, lane);           // GA
+    MSTAMP(4)   // W2^T gz, silu', GA tile
+    issue_next(tt + (int64_t)gridDim.x * 4);        // XP: next tile's rows fly from here on
     if constexpr (DEFER_DW1) {
       wave_sync();
       float* gb = q.ga_out + (b * p.rows + r0) * HID;
       auto gp = [&](int t) { return gb + (int64_t)t * HID; };
       store_rows<true>(T1, ldt1, 0, HID, nrows, lane, gp);
+    } else if constexpr (XP) {
+      wave_sync();
+      tile_colsum_all<NV_H>(db1, T1, ldt1, 0, lane);
+      wave_sync();
+      acc_to_tile_b3<NBH>(ga, T1h, 0, lane);        // GA planes over its fp32 copy
+      wave_sync();
+      outer_accum_b3<NBH, KB>(dW1, T1h, 0, T2x, 0, lane);   // X planes are still in T2
     } else {
       stage_x(b, r0, nrows);                        // X again
       wave_sync();
@@ -645,6 +721,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpBwdParams q) {
         outer_accum<NBH, KB>(dW1, T1, ldt1, 0, T0, ldt0, 0, lane);
       }
     }
+    MSTAMP(5)   // X again + db1 + dW1 outer product (or the ga store)
     const bool want_gx = q.gxa != nullptr || q.gxb != nullptr;
     if (want_gx) {
       // gx = W1^T ga, 64 input columns (2 blocks) at a time to bound the registers
@@ -690,6 +767,11 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpBwdParams q) {
       }
       wave_sync();
     }
+    MSTAMP(6)   // gx = W1^T ga + stores
+  }
+  if (q.stamp && lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) atomicAdd(&g_mlp_bwd_stamps[k], mst[k]);
   }
 
   // ---- fold the waves' partials in LDS (fixed order) and write the slab
@@ -766,18 +848,20 @@ extern "C" int nlam_reduce_slabs(const float* slab, int64_t nslabs, int64_t stri
   return 0;
 }
 
-template <int HID, int NOUTB, int KB, bool HAS_LN, bool DEFER_DW1 = false, bool B3 = false>
+template <int HID, int NOUTB, int KB, bool HAS_LN, bool DEFER_DW1 = false, bool B3 = false,
+          bool XP = false>
 static int launch_mlp_bwd(const MlpBwdParams& q, hipStream_t s) {
   constexpr int KP32 = 32 * KB;
   constexpr int ldt0 = (KP32 > HID ? KP32 : HID) + 4;
   constexpr int ldt1 = (HID > 32 * NOUTB ? HID : 32 * NOUTB) + 4;
   const size_t lds = ((size_t)HID * (KP32 + 4) + (size_t)32 * NOUTB * (HID + 4) + HID +
-                      2 * 32 * NOUTB + (size_t)4 * NLAM_TILE * (ldt0 + ldt1)) * sizeof(float);
+                      2 * 32 * NOUTB + (size_t)4 * NLAM_TILE * (ldt0 + ldt1) +
+                      (XP ? (size_t)4 * NLAM_TILE * (KP32 + 4) : 0)) * sizeof(float);
   NLAM_REQUIRE(lds <= 160 * 1024, "mlp_bwd: LDS footprint %zu B exceeds 160 KiB", lds);
   static_assert((size_t)4 * HID * KP32 * 4 <= 160 * 1024, "fold images exceed LDS");
   const size_t fold_bytes = (size_t)4 * HID * KP32 * sizeof(float);
   const size_t lds_alloc = lds > fold_bytes ? lds : fold_bytes;
-  auto kern = mlp_bwd_kernel<HID, NOUTB, KB, HAS_LN, DEFER_DW1, B3>;
+  auto kern = mlp_bwd_kernel<HID, NOUTB, KB, HAS_LN, DEFER_DW1, B3, XP>;
   NLAM_BIG_LDS(kern, __func__);
   const int64_t ntiles = ((q.f.rows + NLAM_TILE - 1) / NLAM_TILE) * q.f.B;
   kern<<<(unsigned)nlam_bwd_grid(ntiles), 256, lds_alloc, s>>>(q);
@@ -833,12 +917,18 @@ extern "C" int nlam_mlp_bwd(
   q.vec_gy = view_vec_ok(gy, gy_bstride, gy_ld, n_out);
   q.vec_gxa = gxa && view_vec_ok(gxa, gxa_bstride, gxa_ld, xa_width);
   q.vec_gxb = gxb && view_vec_ok(gxb, gxb_bstride, gxb_ld, xb_width) && (xa_width % 4 == 0);
+  static const bool mstamp = getenv("NLAM_STAMP") != nullptr;
+  q.stamp = mstamp ? 1 : 0;
   hipStream_t s = (hipStream_t)stream;
   const bool ln = gamma != nullptr;
   const int kb = (p.k_in + 31) / 32;
   const int noutb = (n_out + 31) / 32;
 #define MLP_BWD_CASE(H, NO, K, L) return launch_mlp_bwd<H, NO, K, L>(q, s)
   if (hid == 64 && nlam_mfma_b3()) {
+    // float4 views of x and gy: X staged once as planes + next-tile register prefetch
+    const bool xp = (p.vec_mask & 1) && p.nsrc == 1 && q.vec_gy && n_out == 32 * noutb;
+    if (xp && ln && kb == 1) return launch_mlp_bwd<64, 2, 1, true, false, true, true>(q, s);
+    if (xp && ln && kb == 2) return launch_mlp_bwd<64, 2, 2, true, false, true, true>(q, s);
     if (ln && kb == 1) return launch_mlp_bwd<64, 2, 1, true, false, true>(q, s);
     if (ln && kb == 2) return launch_mlp_bwd<64, 2, 2, true, false, true>(q, s);
     if (ln && kb == 4 && ga_out != nullptr) return launch_mlp_bwd<64, 2, 4, true, true, true>(q, s);
@@ -916,12 +1006,34 @@ __global__ __launch_bounds__(256) void lin_bwd_kernel(LinBwdParams q) {
   const int n_out = q.nA + q.nB;
   const int64_t tiles_per_b = (q.rows + NLAM_TILE - 1) / NLAM_TILE;
   const int64_t ntiles = tiles_per_b * q.B;
+  // B3 without the batch sum: the x / gy rows of the NEXT tile are requested as soon as the
+  // current ones have been written to LDS (same registers), and land under this tile's MFMAs
+  constexpr bool PF = B3 && !SUMGY;
+  f32x4 pvx[PF ? 4 * KB : 1], pvg[PF ? 4 * NOUTB : 1];
+  auto issue_next = [&](int64_t task) {
+    if constexpr (PF) {
+      const int64_t tq = task < ntiles ? task : ntiles - 1;
+      const int64_t bq = tq / tiles_per_b;
+      const int64_t rq = (tq - bq * tiles_per_b) * NLAM_TILE;
+      const int nq = (int)((q.rows - rq) < NLAM_TILE ? (q.rows - rq) : NLAM_TILE);
+      view_load_v<4 * KB>(pvx, q.x, bq, rq, nq, lane);
+      view_load_v<4 * NOUTB>(pvg, q.gy, bq, rq, nq, lane);
+    }
+  };
+  const bool pf = PF && q.vec_x && q.vec_gy;
+  if (pf && (int64_t)blockIdx.x * 4 + wave < ntiles) issue_next((int64_t)blockIdx.x * 4 + wave);
   for (int64_t tt = (int64_t)blockIdx.x * 4 + wave; tt < ntiles; tt += (int64_t)gridDim.x * 4) {
     const int64_t b = tt / tiles_per_b;
     const int64_t r0 = (tt - b * tiles_per_b) * NLAM_TILE;
     const int nfull = (int)((q.rows - r0) < NLAM_TILE ? (q.rows - r0) : NLAM_TILE);
     const int nrows = nfull;
-    if (q.vec_x && q.vec_gy) {
+    if (pf) {
+      if constexpr (PF) {
+        put_rows_v_b3<4 * KB>(T0p, 0, q.x.width, nrows, lane, pvx);
+        put_rows_v_b3<4 * NOUTB>(T1p, 0, n_out, nrows, lane, pvg);
+        issue_next(tt + (int64_t)gridDim.x * 4);
+      }
+    } else if (q.vec_x && q.vec_gy) {
       f32x4 vx[4 * KB], vg[4 * NOUTB];
       view_load_v<4 * KB>(vx, q.x, b, r0, nfull, lane);
       view_load_v<4 * NOUTB>(vg, q.gy, b, r0, nfull, lane);

@@ -128,3 +128,49 @@ def test_overlap_hooks_fire_during_backward_and_match_plain_path():
         assert lb_ovl == 2 * nb and lr_ovl == 0              # every bucket issued by a hook
         assert g_plain == g_ovl                               # bit for bit
     assert res[0]["overlap"][0] == res[1]["overlap"][0]
+
+
+def _gather_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from neural_lam_amd.models.ar_model import ARModel
+
+    class Shell:   # the two methods need nothing of the model but the process group
+        pass
+
+    sh = Shell()
+    sh._is_rank_zero = lambda: ARModel._is_rank_zero(sh)
+    sh.all_gather_cat = lambda t: ARModel.all_gather_cat(sh, t)
+    sh.state_std = torch.tensor([2.0, 0.5, 1.0])
+    sh.eval_results = {}
+    local = torch.full((2, 4, 3), float(rank + 1))          # (N_eval per rank, steps, d_f)
+    out = ARModel.aggregate_metrics(sh, {"mse": [local], "mae": [local]}, prefix="val")
+    gathered = ARModel.all_gather_cat(sh, local)
+    q.put((rank, gathered.tolist(), {k: v.tolist() for k, v in out.items()}))
+    dist.destroy_process_group()
+
+
+def test_all_gather_cat_and_metric_aggregation_two_ranks():
+    """Reference ar_model.py:311-320, 610-644: metrics are gathered over the ranks, averaged
+    over all evaluated samples, *mse -> *rmse, rescaled by state_std, on rank 0 only."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {r: (g, o) for r, g, o in (q.get(timeout=120) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g0 = torch.tensor(res[0][0])
+    assert g0.shape == (4, 4, 3) and torch.equal(g0[:2], torch.ones(2, 4, 3)) and \
+        torch.equal(g0[2:], torch.full((2, 4, 3), 2.0))
+    assert res[1][1] == {}                                   # only rank 0 aggregates
+    rmse = torch.tensor(res[0][1]["val_rmse"])
+    mae = torch.tensor(res[0][1]["val_mae"])
+    std = torch.tensor([2.0, 0.5, 1.0])
+    assert torch.allclose(rmse, torch.sqrt(torch.tensor(1.5)) * std.expand(4, 3))
+    assert torch.allclose(mae, 1.5 * std.expand(4, 3))
