@@ -1,0 +1,1248 @@
+// "Feature-split" fused kernels (gfx950) for hidden widths whose weight matrices do not fit the
+// LDS next to row tiles: hidden_dim 256 in bf16-mixed arithmetic (BASELINE configs[4]; reference
+// interaction_net.py:63-131, utils.py:191-214 under train_model.py's `--precision bf16-mixed`).
+//
+// One 256 x 256 bf16 image is 131 KB of the 160 KB LDS, so the weights leave LDS altogether:
+//   * a workgroup has D / 32 wavefronts; wave w keeps ITS 32 output features of the weight
+//     matrix as MFMA A-fragments in registers (32 x D bf16 = 64 registers per lane) for the
+//     life of the persistent workgroup;
+//   * the workgroup shares a tile of R = 64 rows (two 32-row blocks) as bf16 planes in LDS
+//     (the B operand, read by every wave; 50 % of the LDS bandwidth at full MFMA rate);
+//   * every wave produces the 32 x 64 block (its features, all rows) in accumulator layout;
+//     LayerNorm statistics are exchanged between the waves through LDS (two floats per row and
+//     wave); outputs go through an fp32 LDS tile so that global stores, row scatters and the
+//     receiver-aligned segment sums stay whole-row and coalesced.
+// Same entry points and semantics as fused_wide.hip (the host sequence in wide.py is shared);
+// arithmetic: plain bf16 products, fp32 accumulate, fp32 LayerNorm / residuals / aggregates
+// (NLAM_MFMA=bf16).  TERMS = 3 (split-bf16) is templated in for hidden 128 but not dispatched.
+#include <stdlib.h>
+
+#include "fused_bf16x3.h"
+#include "fused_common.h"
+#include "fused_fs.h"
+
+#define FS_R 64   // rows per workgroup tile
+
+template <int K, int TERMS>
+struct FsW {   // register-resident slice of a weight matrix: A fragments of all K / 16 steps
+  bf16x8 hi[K / 16];
+  bf16x8 lo[TERMS == 3 ? K / 16 : 1];
+};
+
+__device__ __forceinline__ void fs_cvt8(const f32x4& v0, const f32x4& v1, bf16x8& hi, bf16x8& lo,
+                                        bool want_lo) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    hi[j] = (__bf16)v0[j];
+    hi[4 + j] = (__bf16)v1[j];
+    if (want_lo) {
+      lo[j] = (__bf16)(v0[j] - (float)hi[j]);
+      lo[4 + j] = (__bf16)(v1[j] - (float)hi[4 + j]);
+    }
+  }
+}
+
+// rows [row0, row0 + 32) of W (n_out x D): the A operand of W . x for output features row0 ..
+// (fragment order of b3_row_frag: lane (n, h) holds k = 16 s + 4 h + {0..3}, 16 s + 8 + 4 h + {0..3})
+// k_in <= K columns are real (the rest of the fragment is zero); rows need not be aligned
+template <int K, int TERMS>
+__device__ __forceinline__ void fs_load_w_rows(FsW<K, TERMS>& A, const float* __restrict__ W,
+                                               int64_t ldW, int row0, int n_out, int k_in,
+                                               int lane) {
+  const int n = lane & 31, h = lane >> 5;
+  const bool ok = row0 + n < n_out;
+  const float* wr = W + (int64_t)(ok ? row0 + n : 0) * ldW;
+  const bool vec = (k_in == K) && (ldW % 4 == 0) && ((reinterpret_cast<uintptr_t>(W) & 15u) == 0);
+#pragma unroll
+  for (int s = 0; s < K / 16; ++s) {
+    f32x4 v0, v1;
+    if (vec) {
+      v0 = *reinterpret_cast<const f32x4*>(wr + 16 * s + 4 * h);
+      v1 = *reinterpret_cast<const f32x4*>(wr + 16 * s + 8 + 4 * h);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k0 = 16 * s + 4 * h + j, k1 = k0 + 8;
+        v0[j] = k0 < k_in ? wr[k0] : 0.f;
+        v1[j] = k1 < k_in ? wr[k1] : 0.f;
+      }
+    }
+    if (!ok) { v0 = f32x4{0.f, 0.f, 0.f, 0.f}; v1 = v0; }
+    fs_cvt8(v0, v1, A.hi[s], A.lo[TERMS == 3 ? s : 0], TERMS == 3);
+  }
+}
+// columns [col0, col0 + 32) of W (n_rows x >= col0 + 32): the A operand of W^T . g for output
+// (input-gradient) features col0 ..: lane (i, h) holds W[k][col0 + i] for the fragment's eight k
+template <int K, int TERMS>
+__device__ __forceinline__ void fs_load_w_cols(FsW<K, TERMS>& A, const float* __restrict__ W,
+                                               int64_t ldW, int col0, int n_rows, int lane) {
+  const int i = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int s = 0; s < K / 16; ++s) {
+    f32x4 v0, v1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k0 = 16 * s + 4 * h + j, k1 = k0 + 8;
+      v0[j] = k0 < n_rows ? W[(int64_t)k0 * ldW + col0 + i] : 0.f;
+      v1[j] = k1 < n_rows ? W[(int64_t)k1 * ldW + col0 + i] : 0.f;
+    }
+    fs_cvt8(v0, v1, A.hi[s], A.lo[TERMS == 3 ? s : 0], TERMS == 3);
+  }
+}
+
+// shared row tile as bf16 planes: hi[R][P] (| lo[R][P]), P = K + 4 elements
+template <int K, int TERMS>
+struct FsPlanes {
+  __bf16* hi;
+  __bf16* lo;
+  static constexpr int P = K + 4;
+  static constexpr size_t bytes = (size_t)(TERMS == 3 ? 2 : 1) * FS_R * (K + 4) * sizeof(__bf16);
+  __device__ __forceinline__ void init(void* base) {
+    hi = reinterpret_cast<__bf16*>(base);
+    lo = hi + (TERMS == 3 ? FS_R * P : 0);
+  }
+};
+
+// acc[rb] += A . X^T for the two 32-row blocks of the shared tile
+template <int K, int TERMS>
+__device__ __forceinline__ void fs_gemm(f32x16 (&acc)[2], const FsW<K, TERMS>& A,
+                                        const FsPlanes<K, TERMS>& X, int lane) {
+  const int t = lane & 31, h = lane >> 5;
+  constexpr int P = FsPlanes<K, TERMS>::P;
+#pragma unroll
+  for (int s = 0; s < K / 16; ++s) {
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      const int xo = (32 * rb + t) * P + 16 * s + 4 * h;
+      const bf16x8 bh = b3_join(*reinterpret_cast<const bf16x4*>(X.hi + xo),
+                                *reinterpret_cast<const bf16x4*>(X.hi + xo + 8));
+      acc[rb] = B3_MFMA(A.hi[s], bh, acc[rb]);
+      if constexpr (TERMS == 3) {
+        const bf16x8 bl = b3_join(*reinterpret_cast<const bf16x4*>(X.lo + xo),
+                                  *reinterpret_cast<const bf16x4*>(X.lo + xo + 8));
+        acc[rb] = B3_MFMA(A.hi[s], bl, acc[rb]);
+        acc[rb] = B3_MFMA(A.lo[s], bh, acc[rb]);
+      }
+    }
+    if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // bound the fragment prefetch depth
+  }
+}
+
+// ---- cooperative row staging -------------------------------------------------------------
+// The workgroup (NT = 2 D threads) moves R = 64 rows of D floats as float4 chunks: thread `tid`
+// owns chunk column c4 = tid % (D / 4) of rows rg + 8 k, rg = tid / (D / 4), k = 0..7.
+template <int D>
+struct FsMap {
+  static constexpr int CPR = D / 4;       // float4 chunks per row
+  int c4, rg;
+  __device__ __forceinline__ FsMap(int tid) : c4(tid % CPR), rg(tid / CPR) {}
+  __device__ __forceinline__ int row(int k) const { return rg + 8 * k; }
+};
+
+// sub-tile context (one 32-row block): batch item, first position, rows, receivers
+struct FsSub {
+  int64_t b;
+  int p0, ne, r0, nr;
+};
+struct FsTiling {
+  const int32_t* tiles;      // edge mode: (ntiles, 4); NULL = row mode
+  int64_t ntiles;            // 32-row sub-tiles per batch item
+  int64_t rows;              // positions per batch item
+  const int32_t* csr_rec;
+  const int32_t* csr_rowptr;
+  int B;
+};
+__device__ __forceinline__ FsSub fs_sub(const FsTiling& tl, int64_t id) {
+  FsSub s;
+  const int64_t total = tl.ntiles * tl.B;
+  if (id >= total) { s.b = 0; s.p0 = 0; s.ne = 0; s.r0 = 0; s.nr = 0; return s; }
+  s.b = id / tl.ntiles;
+  const int64_t k = id - s.b * tl.ntiles;
+  if (tl.tiles != nullptr) {
+    const int4 hdr = reinterpret_cast<const int4*>(tl.tiles)[k];
+    s.p0 = hdr.x; s.ne = hdr.y - hdr.x; s.r0 = hdr.z; s.nr = hdr.w - hdr.z;
+  } else {
+    s.p0 = (int)(k * NLAM_TILE);
+    const int64_t left = tl.rows - (int64_t)s.p0;
+    s.ne = (int)(left < NLAM_TILE ? left : NLAM_TILE);
+    s.r0 = 0; s.nr = 0;
+  }
+  return s;
+}
+
+// =========================================================================== lin_fwd ===
+// out = x W^T + bias, W: n_out (<= 256) x k_in (<= K), output features padded to 256.
+struct FsLinParams {
+  RowView x;                 // width = k_in
+  const float* W; int64_t ldW; const float* bias; int n_out;
+  float* out; int64_t out_bstride; int64_t out_ld;
+  const float* add; int64_t add_bstride; int64_t add_ld;   // optional addend of out (rows like out)
+  int64_t rows; int B;
+  int x_vec;                 // x rows float4-loadable and k_in == K
+};
+
+// rows of the workgroup tile -> bf16 planes (zero beyond nrows / k_in); float4 or scalar source
+template <int D, int K, int TERMS>
+__device__ __forceinline__ void fs_stage_x(const FsPlanes<K, TERMS>& X, const RowView& x, int64_t b,
+                                           int64_t r0, int nrows, bool vec, int tid) {
+  const float* xb = x.ptr + b * x.bstride + r0 * x.ld;
+  if (vec) {
+    // 2 D threads over K / 4 chunk columns: K == D -> 8 rows per pass, 8 passes
+    constexpr int CPR = K / 4;
+    constexpr int RPP = (2 * D) / CPR;          // rows per pass
+    constexpr int NP = FS_R / RPP;
+    const int c4 = tid % CPR, rg = tid / CPR;
+    f32x4 v[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      const int r = rg + RPP * k;
+      v[k] = reinterpret_cast<const f32x4*>(xb + (int64_t)(r < nrows ? r : nrows - 1) * x.ld)[c4];
+    }
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      const int r = rg + RPP * k;
+      f32x4 xx = v[k];
+      if (r >= nrows) xx = f32x4{0.f, 0.f, 0.f, 0.f};
+      bf16x4 hi, lo;
+      b3_split4(xx, hi, lo);
+      *reinterpret_cast<bf16x4*>(X.hi + r * X.P + 4 * c4) = hi;
+      if constexpr (TERMS == 3) *reinterpret_cast<bf16x4*>(X.lo + r * X.P + 4 * c4) = lo;
+    }
+  } else {
+    for (int idx = tid; idx < FS_R * K; idx += 2 * D) {
+      const int r = idx / K, c = idx - r * K;
+      const float v = (r < nrows && c < x.width) ? xb[(int64_t)r * x.ld + c] : 0.f;
+      const __bf16 hi = (__bf16)v;
+      X.hi[r * X.P + c] = hi;
+      if constexpr (TERMS == 3) X.lo[r * X.P + c] = (__bf16)(v - (float)hi);
+    }
+  }
+}
+
+// accumulator blocks of this wave (features 32 wave .., rows of both blocks) -> fp32 tile
+template <int LDO>
+__device__ __forceinline__ void fs_acc_to_tile(const f32x16 (&acc)[2], float* __restrict__ otile,
+                                               int wave, int lane) {
+  const int t = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 o = {acc[rb][4 * q], acc[rb][4 * q + 1], acc[rb][4 * q + 2], acc[rb][4 * q + 3]};
+      *reinterpret_cast<f32x4*>(otile + (32 * rb + t) * LDO + 32 * wave + 8 * q + 4 * h) = o;
+    }
+}
+template <int LDO>
+__device__ __forceinline__ void fs_tile_to_acc(f32x16 (&acc)[2], const float* __restrict__ otile,
+                                               int wave, int lane) {
+  const int t = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 o = *reinterpret_cast<const f32x4*>(otile + (32 * rb + t) * LDO + 32 * wave +
+                                                       8 * q + 4 * h);
+      acc[rb][4 * q] = o[0]; acc[rb][4 * q + 1] = o[1];
+      acc[rb][4 * q + 2] = o[2]; acc[rb][4 * q + 3] = o[3];
+    }
+}
+// per-feature vector (bias / gamma / beta) of this wave's block, zero beyond n
+__device__ __forceinline__ f32x16 fs_vec_block(const float* __restrict__ p, int n, int wave, int lane) {
+  const int h = lane >> 5;
+  f32x16 v;
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int f = 32 * wave + 8 * q + 4 * h + j;
+      v[4 * q + j] = (p != nullptr && f < n) ? p[f] : 0.f;
+    }
+  return v;
+}
+
+// TRANS: out = x W (+ add) with W: k_in x n_out -- the data gradient gx = gy W of a Linear
+template <int D, int K, int TERMS, bool TRANS = false>
+__global__ __launch_bounds__(2 * D) void fs_lin_fwd_kernel(FsLinParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int LDO = D + 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  FsPlanes<K, TERMS> X;
+  X.init(smem);
+  float* otile = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + FsPlanes<K, TERMS>::bytes);
+  FsW<K, TERMS> A;
+  if (TRANS) fs_load_w_cols<K, TERMS>(A, p.W, p.ldW, 32 * wave, p.x.width, lane);
+  else fs_load_w_rows<K, TERMS>(A, p.W, p.ldW, 32 * wave, p.n_out, p.x.width, lane);
+  const f32x16 bias = fs_vec_block(p.bias, p.n_out, wave, lane);
+  constexpr int CPR = D / 4;
+  const int oc4 = tid % CPR, org = tid / CPR;    // output chunk column / row group (8 per pass)
+  const int64_t tiles_per_b = (p.rows + FS_R - 1) / FS_R;
+  const int64_t ntiles = tiles_per_b * p.B;
+  for (int64_t tt = blockIdx.x; tt < ntiles; tt += gridDim.x) {
+    const int64_t b = tt / tiles_per_b;
+    const int64_t r0 = (tt - b * tiles_per_b) * FS_R;
+    const int nrows = (int)((p.rows - r0) < FS_R ? (p.rows - r0) : FS_R);
+    fs_stage_x<D, K, TERMS>(X, p.x, b, r0, nrows, p.x_vec != 0, tid);
+    __syncthreads();
+    f32x16 acc[2] = {bias, bias};
+    fs_gemm<K, TERMS>(acc, A, X, lane);
+    fs_acc_to_tile<LDO>(acc, otile, wave, lane);
+    __syncthreads();
+    {
+      float* ob = p.out + b * p.out_bstride + r0 * p.out_ld;
+      const int nc4 = p.n_out >> 2;   // (n_out % 4 == 0, checked on the host)
+      if (p.add != nullptr) {
+        const float* ab = p.add + b * p.add_bstride + r0 * p.add_ld;
+        f32x4 av[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int r = org + 8 * k;
+          av[k] = reinterpret_cast<const f32x4*>(ab + (int64_t)(r < nrows ? r : nrows - 1) * p.add_ld)
+              [oc4 < nc4 ? oc4 : 0];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int r = org + 8 * k;
+          if (r < nrows && oc4 < nc4)
+            reinterpret_cast<f32x4*>(ob + (int64_t)r * p.out_ld)[oc4] =
+                *reinterpret_cast<const f32x4*>(otile + r * LDO + 4 * oc4) + av[k];
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int r = org + 8 * k;
+          if (r < nrows && oc4 < nc4)
+            reinterpret_cast<f32x4*>(ob + (int64_t)r * p.out_ld)[oc4] =
+                *reinterpret_cast<const f32x4*>(otile + r * LDO + 4 * oc4);
+        }
+      }
+    }
+    // (the next staging overwrites the planes only after every wave passed the barrier behind
+    //  its fragment reads; the otile reads are ordered before the next tile's otile writes by
+    //  the barrier after the next staging)
+  }
+}
+
+static unsigned fs_grid(int64_t ntiles) {
+  int64_t g = ntiles;
+  if (g > 256) g = 256;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+template <int D, int K, int TERMS, bool TRANS = false>
+static int launch_fs_lin_fwd(const FsLinParams& p, hipStream_t s) {
+  const size_t lds = FsPlanes<K, TERMS>::bytes + (size_t)FS_R * (D + 4) * sizeof(float);
+  NLAM_REQUIRE(lds <= 160 * 1024, "fs_lin_fwd: LDS footprint %zu B exceeds 160 KiB", lds);
+  auto kern = fs_lin_fwd_kernel<D, K, TERMS, TRANS>;
+  NLAM_BIG_LDS(kern, "fs_lin_fwd_kernel");
+  const int64_t ntiles = ((p.rows + FS_R - 1) / FS_R) * p.B;
+  kern<<<fs_grid(ntiles), 2 * D, lds, s>>>(p);
+  NLAM_CHECK_LAUNCH("fs_lin_fwd_kernel");
+  return 0;
+}
+
+// out = x W^T + bias for x: (B, rows, k_in <= 256) fp32, W: 256 x k_in; NLAM_MFMA=bf16.
+int nlam_fs_lin_fwd_256(const float* x, int64_t x_bstride, int64_t x_ld, int k_in, const float* W,
+                        int64_t ldW, const float* bias, int n_out, float* out, int64_t out_bstride,
+                        int64_t out_ld, int64_t B, int64_t rows, void* stream) {
+  if (B <= 0 || rows <= 0) return 0;
+  NLAM_REQUIRE(nlam_mfma_terms() == 1, "hidden 256 needs NLAM_MFMA=bf16");
+  NLAM_REQUIRE(n_out >= 4 && n_out <= 256 && n_out % 4 == 0, "fs_lin_fwd: n_out %d unsupported", n_out);
+  NLAM_REQUIRE(k_in >= 1 && k_in <= 256, "fs_lin_fwd: k_in %d out of range", k_in);
+  NLAM_REQUIRE(view_vec_ok(out, out_bstride, out_ld, n_out),
+               "fs_lin_fwd: output rows must be 16-byte aligned with pitch %% 4 == 0");
+  FsLinParams p;
+  p.x = RowView{x, x_bstride, x_ld, k_in};
+  p.W = W; p.ldW = ldW; p.bias = bias; p.n_out = n_out;
+  p.out = out; p.out_bstride = out_bstride; p.out_ld = out_ld;
+  p.add = nullptr; p.add_bstride = 0; p.add_ld = 0;
+  p.rows = rows; p.B = (int)B;
+  hipStream_t s = (hipStream_t)stream;
+  if (k_in <= 32) { p.x_vec = (k_in == 32 && view_vec_ok(x, x_bstride, x_ld, 32)); return launch_fs_lin_fwd<256, 32, 1>(p, s); }
+  if (k_in <= 64) { p.x_vec = (k_in == 64 && view_vec_ok(x, x_bstride, x_ld, 64)); return launch_fs_lin_fwd<256, 64, 1>(p, s); }
+  NLAM_REQUIRE(k_in == 256 || k_in <= 256, "fs_lin_fwd: k_in %d", k_in);
+  p.x_vec = (k_in == 256 && view_vec_ok(x, x_bstride, x_ld, 256));
+  return launch_fs_lin_fwd<256, 256, 1>(p, s);
+}
+
+// gx = gy W (+ gx_add), W: 256 x 256 (data gradient of a Linear); NLAM_MFMA=bf16.
+int nlam_fs_lin_bwd_data_256(const float* gy, int64_t gy_bstride, int64_t gy_ld, const float* W,
+                             int64_t ldW, float* gx, int64_t gx_bstride, int64_t gx_ld,
+                             const float* gx_add, int64_t ga_bstride, int64_t ga_ld, int64_t B,
+                             int64_t rows, void* stream) {
+  if (B <= 0 || rows <= 0) return 0;
+  NLAM_REQUIRE(nlam_mfma_terms() == 1, "hidden 256 needs NLAM_MFMA=bf16");
+  NLAM_REQUIRE(view_vec_ok(gy, gy_bstride, gy_ld, 256) && view_vec_ok(gx, gx_bstride, gx_ld, 256) &&
+                   (gx_add == nullptr || view_vec_ok(gx_add, ga_bstride, ga_ld, 256)),
+               "fs_lin_bwd_data: operand rows must be 16-byte aligned with pitch %% 4 == 0");
+  FsLinParams p;
+  p.x = RowView{gy, gy_bstride, gy_ld, 256};
+  p.W = W; p.ldW = ldW; p.bias = nullptr; p.n_out = 256;
+  p.out = gx; p.out_bstride = gx_bstride; p.out_ld = gx_ld;
+  p.add = gx_add; p.add_bstride = ga_bstride; p.add_ld = ga_ld;
+  p.rows = rows; p.B = (int)B; p.x_vec = 1;
+  return launch_fs_lin_fwd<256, 256, 1, true>(p, (hipStream_t)stream);
+}
+
+// ========================================================================= tail forward ===
+struct FsTailFwdParams {
+  FsTiling tl;
+  RowView a; const int32_t* idx_a;
+  RowView b; const int32_t* idx_b;       // optional
+  RowView c; const int32_t* idx_c;       // optional
+  const float* W2; int64_t ldW2; const float* b2; const float* gamma; const float* beta;
+  int n_out;
+  float* h_out; int64_t h_bstride;
+  float* y; int64_t y_bstride; int64_t y_ld; const int32_t* idx_y;
+  RowView res;
+  float* agg; int64_t agg_bstride; int64_t agg_ld; const float* inv_deg;
+  int vec_y;
+};
+
+// slot r of the workgroup tile (sub-tile r >> 5, slot r & 31): its position, clamped to a valid one
+// (the two sub-tile contexts are separate variables selected by value: an indexed array of
+//  structs would live in scratch)
+struct FsSub2 {
+  FsSub s0, s1;
+  __device__ __forceinline__ int64_t b(int rb) const { return rb ? s1.b : s0.b; }
+  __device__ __forceinline__ int p0(int rb) const { return rb ? s1.p0 : s0.p0; }
+  __device__ __forceinline__ int ne(int rb) const { return rb ? s1.ne : s0.ne; }
+};
+__device__ __forceinline__ int fs_slot_pos(const FsSub2& sub, int r) {
+  const int rb = r >> 5, t = r & 31;
+  const int ne = sub.ne(rb);
+  return sub.p0(rb) + (t < ne ? t : (ne > 0 ? ne - 1 : 0));
+}
+
+// tile-local segmented sums of one sub-tile over a 64-feature column chunk (lanes = features):
+// fast path when every receiver of the tile has in-edges, row-pointer loop otherwise
+template <typename Emit>
+__device__ __forceinline__ void fs_segment_sums(const float* __restrict__ tile, int ld,
+                                                const FsSub& sb, const FsTiling& tl, int lane,
+                                                Emit emit) {
+  if (sb.ne <= 0) return;
+  const int t = lane & 31;
+  const int rcv = tl.csr_rec[sb.p0 + (t < sb.ne ? t : sb.ne - 1)];
+  const int ri = sb.r0 + (lane < sb.nr ? lane : sb.nr);
+  const int rp = tl.csr_rowptr[ri] - sb.p0;
+  const int rpn = __shfl_down(rp, 1, 64);
+  const bool dense = __all((lane >= sb.nr) || (rpn > rp));
+  if (dense) {
+    tile_segment_sums<64>(tile, ld, sb.ne, rcv, lane,
+                          [&](int r, int f0, float acc) { emit(r, acc); (void)f0; });
+  } else {
+    for (int i = 0; i < sb.nr; ++i) {
+      const int beg = __shfl(rp, i, 64), end = __shfl(rp, i + 1, 64);
+      float acc = 0.f;
+      for (int sidx = beg; sidx < end; ++sidx) acc += tile[sidx * ld + lane];
+      emit(sb.r0 + i, acc);
+    }
+  }
+}
+
+template <int D, bool HAS_LN, int TERMS>
+__global__ __launch_bounds__(2 * D) void fs_tail_fwd_kernel(FsTailFwdParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NT = 2 * D, NW = D / 32, LDO = D + 4, CPR = D / 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int t = lane & 31, h = lane >> 5;
+  FsPlanes<D, TERMS> S;
+  S.init(smem);
+  float* mtile = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + FsPlanes<D, TERMS>::bytes);
+  float* red = mtile + FS_R * LDO;                 // [2][FS_R][NW]
+  int* itab = reinterpret_cast<int*>(red + 2 * FS_R * NW);   // [4][FS_R]: a, b, c, y
+  FsW<D, TERMS> A;
+  fs_load_w_rows<D, TERMS>(A, p.W2, p.ldW2, 32 * wave, p.n_out, D, lane);
+  const f32x16 b2v = fs_vec_block(p.b2, p.n_out, wave, lane);
+  const f32x16 gav = fs_vec_block(p.gamma, p.n_out, wave, lane);
+  const f32x16 bev = fs_vec_block(p.beta, p.n_out, wave, lane);
+  const int c4 = tid % CPR, rg = tid / CPR;        // staging map: rows rg + 8 k
+  const int64_t nsub = p.tl.ntiles * p.tl.B;
+  const int64_t ntiles = (nsub + 1) / 2;
+  for (int64_t tt = blockIdx.x; tt < ntiles; tt += gridDim.x) {
+    const FsSub2 sub = {fs_sub(p.tl, 2 * tt), fs_sub(p.tl, 2 * tt + 1)};
+    if (tid < FS_R) {
+      const int pos = fs_slot_pos(sub, tid);
+      itab[tid] = p.idx_a ? p.idx_a[pos] : pos;
+      itab[FS_R + tid] = (p.b.ptr && p.idx_b) ? p.idx_b[pos] : pos;
+      itab[2 * FS_R + tid] = (p.c.ptr && p.idx_c) ? p.idx_c[pos] : pos;
+      itab[3 * FS_R + tid] = p.idx_y ? p.idx_y[pos] : pos;
+    }
+    __syncthreads();
+    // ---- h = a + b + c (row layout), keep h, s = silu(h) -> planes
+    {
+      f32x4 v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int r = rg + 8 * k;
+        const float* ab = p.a.ptr + sub.b(r >> 5) * p.a.bstride;
+        v[k] = reinterpret_cast<const f32x4*>(ab + (int64_t)itab[r] * p.a.ld)[c4];
+      }
+      if (p.b.ptr) {
+        f32x4 u[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int r = rg + 8 * k;
+          const float* bb = p.b.ptr + sub.b(r >> 5) * p.b.bstride;
+          u[k] = reinterpret_cast<const f32x4*>(bb + (int64_t)itab[FS_R + r] * p.b.ld)[c4];
+        }
+        if (p.c.ptr) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const int r = rg + 8 * k;
+            const float* cb = p.c.ptr + sub.b(r >> 5) * p.c.bstride;
+            u[k] += reinterpret_cast<const f32x4*>(cb + (int64_t)itab[2 * FS_R + r] * p.c.ld)[c4];
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += u[k];
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int r = rg + 8 * k;
+        const int rb = r >> 5;
+        const bool valid = (r & 31) < sub.ne(rb);
+        f32x4 x = v[k];
+        if (valid && p.h_out != nullptr)
+          reinterpret_cast<f32x4*>(p.h_out + sub.b(rb) * p.h_bstride +
+                                   (int64_t)(sub.p0(rb) + (r & 31)) * D)[c4] = x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[j] = valid ? nlam_silu(x[j]) : 0.f;
+        bf16x4 hi, lo;
+        b3_split4(x, hi, lo);
+        *reinterpret_cast<bf16x4*>(S.hi + r * S.P + 4 * c4) = hi;
+        if constexpr (TERMS == 3) *reinterpret_cast<bf16x4*>(S.lo + r * S.P + 4 * c4) = lo;
+      }
+    }
+    __syncthreads();
+    f32x16 z[2] = {b2v, b2v};
+    fs_gemm<D, TERMS>(z, A, S, lane);
+    if (HAS_LN) {
+      // LayerNorm over the D features of a row = over the NW waves: exchange through LDS
+      const float inv_n = 1.0f / (float)p.n_out;
+      float mean[2], rstd[2];
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        float sm = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sm += z[rb][r];
+        sm += __shfl_xor(sm, 32, 64);
+        if (h == 0) red[(32 * rb + t) * NW + wave] = sm;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        float sm = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) sm += red[(32 * rb + t) * NW + w];
+        mean[rb] = sm * inv_n;
+        float vs = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float dlt = z[rb][r] - mean[rb];
+          vs += dlt * dlt;
+        }
+        vs += __shfl_xor(vs, 32, 64);
+        if (h == 0) red[FS_R * NW + (32 * rb + t) * NW + wave] = vs;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        float vs = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) vs += red[FS_R * NW + (32 * rb + t) * NW + w];
+        rstd[rb] = rsqrtf(vs * inv_n + 1e-5f);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[rb][r] = (z[rb][r] - mean[rb]) * rstd[rb] * gav[r] + bev[r];
+      }
+    }
+    fs_acc_to_tile<LDO>(z, mtile, wave, lane);
+    __syncthreads();
+    // ---- outputs from the fp32 tile: receiver aggregation, whole-row stores
+    if (p.agg != nullptr) {
+      const int rb = wave / (NW / 2), fc = wave % (NW / 2);
+      const FsSub sb = rb ? sub.s1 : sub.s0;
+      float* aggb = p.agg + sb.b * p.agg_bstride;
+      fs_segment_sums(mtile + 32 * rb * LDO + 64 * fc, LDO, sb, p.tl, lane, [&](int r, float acc) {
+        const float sc = p.inv_deg ? p.inv_deg[r] : 1.0f;
+        aggb[(int64_t)r * p.agg_ld + 64 * fc + lane] = acc * sc;
+      });
+    }
+    if (p.y != nullptr) {
+      if (p.vec_y) {
+        const int nc4 = p.n_out >> 2;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int r = rg + 8 * k;
+          const int rb = r >> 5;
+          if ((r & 31) < sub.ne(rb) && c4 < nc4) {
+            const int64_t row = itab[3 * FS_R + r];
+            f32x4 o = *reinterpret_cast<const f32x4*>(mtile + r * LDO + 4 * c4);
+            if (p.res.ptr != nullptr)
+              o += reinterpret_cast<const f32x4*>(p.res.ptr + sub.b(rb) * p.res.bstride + row * p.res.ld)[c4];
+            reinterpret_cast<f32x4*>(p.y + sub.b(rb) * p.y_bstride + row * p.y_ld)[c4] = o;
+          }
+        }
+      } else {
+        for (int idx = tid; idx < FS_R * p.n_out; idx += NT) {
+          const int r = idx / p.n_out, cc = idx - r * p.n_out;
+          const int rb = r >> 5;
+          if ((r & 31) < sub.ne(rb)) {
+            const int64_t row = itab[3 * FS_R + r];
+            float o = mtile[r * LDO + cc];
+            if (p.res.ptr != nullptr) o += p.res.ptr[sub.b(rb) * p.res.bstride + row * p.res.ld + cc];
+            p.y[sub.b(rb) * p.y_bstride + row * p.y_ld + cc] = o;
+          }
+        }
+      }
+    }
+    __syncthreads();   // tables / tiles are rewritten by the next iteration
+  }
+}
+
+template <int D, bool HAS_LN, int TERMS>
+static int launch_fs_tail_fwd(const FsTailFwdParams& p, hipStream_t s) {
+  const size_t lds = FsPlanes<D, TERMS>::bytes + (size_t)FS_R * (D + 4) * sizeof(float) +
+                     (size_t)2 * FS_R * (D / 32) * sizeof(float) + (size_t)4 * FS_R * sizeof(int);
+  NLAM_REQUIRE(lds <= 160 * 1024, "fs_tail_fwd: LDS footprint %zu B exceeds 160 KiB", lds);
+  auto kern = fs_tail_fwd_kernel<D, HAS_LN, TERMS>;
+  NLAM_BIG_LDS(kern, "fs_tail_fwd_kernel");
+  const int64_t ntiles = (p.tl.ntiles * p.tl.B + 1) / 2;
+  kern<<<fs_grid(ntiles), 2 * D, lds, s>>>(p);
+  NLAM_CHECK_LAUNCH("fs_tail_fwd_kernel");
+  return 0;
+}
+
+int nlam_fs_tail_fwd_256(
+    const int32_t* tiles, int64_t ntiles, int64_t rows, const int32_t* csr_rec,
+    const int32_t* csr_rowptr,
+    const float* a, int64_t a_bstride, int64_t a_ld, const int32_t* idx_a,
+    const float* b, int64_t b_bstride, int64_t b_ld, const int32_t* idx_b,
+    const float* c, int64_t c_bstride, int64_t c_ld, const int32_t* idx_c,
+    const float* W2, int64_t ldW2, const float* b2, const float* gamma, const float* beta,
+    int n_out, float* h_out, int64_t h_bstride,
+    float* y, int64_t y_bstride, int64_t y_ld, const int32_t* idx_y,
+    const float* res, int64_t res_bstride, int64_t res_ld,
+    float* agg, int64_t agg_bstride, int64_t agg_ld, const float* inv_deg,
+    int64_t B, void* stream) {
+  constexpr int d = 256;
+  NLAM_REQUIRE(nlam_mfma_terms() == 1, "hidden 256 needs NLAM_MFMA=bf16");
+  NLAM_REQUIRE(n_out >= 1 && n_out <= d, "nlam_tail_fwd: n_out %d out of range", n_out);
+  NLAM_REQUIRE(gamma == nullptr || n_out == d, "nlam_tail_fwd: LayerNorm needs n_out == d");
+  NLAM_REQUIRE(view_vec_ok(a, a_bstride, a_ld, d) && (!b || view_vec_ok(b, b_bstride, b_ld, d)) &&
+                   (!c || view_vec_ok(c, c_bstride, c_ld, d)) && (!c || b),
+               "nlam_tail_fwd: sources must be 16-byte aligned rows of width d");
+  NLAM_REQUIRE(h_out == nullptr || (nlam_aligned16(h_out) && h_bstride % 4 == 0),
+               "nlam_tail_fwd: h_out misaligned");
+  NLAM_REQUIRE(agg == nullptr || (tiles != nullptr && csr_rec != nullptr && csr_rowptr != nullptr &&
+                                  agg_ld >= n_out && n_out == d),
+               "nlam_tail_fwd: aggregation needs edge tiles and n_out == d");
+  FsTailFwdParams p;
+  p.tl = FsTiling{tiles, ntiles, rows, csr_rec, csr_rowptr, (int)B};
+  p.a = RowView{a, a_bstride, a_ld, d}; p.idx_a = idx_a;
+  p.b = RowView{b, b_bstride, b_ld, d}; p.idx_b = idx_b;
+  p.c = RowView{c, c_bstride, c_ld, d}; p.idx_c = idx_c;
+  p.W2 = W2; p.ldW2 = ldW2; p.b2 = b2; p.gamma = gamma; p.beta = beta; p.n_out = n_out;
+  p.h_out = h_out; p.h_bstride = h_bstride;
+  p.y = y; p.y_bstride = y_bstride; p.y_ld = y_ld; p.idx_y = idx_y;
+  p.res = RowView{res, res_bstride, res_ld, n_out};
+  p.agg = agg; p.agg_bstride = agg_bstride; p.agg_ld = agg_ld; p.inv_deg = inv_deg;
+  p.vec_y = (y != nullptr && view_vec_ok(y, y_bstride, y_ld, n_out) &&
+             (res == nullptr || view_vec_ok(res, res_bstride, res_ld, n_out))) ? 1 : 0;
+  hipStream_t s = (hipStream_t)stream;
+  return gamma != nullptr ? launch_fs_tail_fwd<256, true, 1>(p, s)
+                          : launch_fs_tail_fwd<256, false, 1>(p, s);
+}
+
+
+template <int LDO>
+__device__ __forceinline__ void fs_acc_to_tile1(const f32x16& acc, float* __restrict__ otile, int rb,
+                                                int wave, int lane) {
+  const int t = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    f32x4 o = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+    *reinterpret_cast<f32x4*>(otile + (32 * rb + t) * LDO + 32 * wave + 8 * q + 4 * h) = o;
+  }
+}
+template <int LDO>
+__device__ __forceinline__ void fs_tile_to_acc1(f32x16& acc, const float* __restrict__ otile, int rb,
+                                                int wave, int lane) {
+  const int t = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x4 o = *reinterpret_cast<const f32x4*>(otile + (32 * rb + t) * LDO + 32 * wave + 8 * q + 4 * h);
+    acc[4 * q] = o[0]; acc[4 * q + 1] = o[1]; acc[4 * q + 2] = o[2]; acc[4 * q + 3] = o[3];
+  }
+}
+template <int D, int TERMS>
+__device__ __forceinline__ void fs_acc_to_planes1(const f32x16& acc, const FsPlanes<D, TERMS>& X, int rb,
+                                                  int wave, int lane) {
+  const int t = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    f32x4 v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+    bf16x4 hi, lo;
+    b3_split4(v, hi, lo);
+    const int off = (32 * rb + t) * X.P + 32 * wave + 8 * q + 4 * h;
+    *reinterpret_cast<bf16x4*>(X.hi + off) = hi;
+    if constexpr (TERMS == 3) *reinterpret_cast<bf16x4*>(X.lo + off) = lo;
+  }
+}
+
+// ======================================================================== tail backward ===
+// Slab per workgroup: [dgamma (D) | dbeta (D)]  (HAS_LN only).
+struct FsTailBwdParams {
+  FsTiling tl;
+  const float* h; int64_t h_bstride;
+  RowView g1; const int32_t* idx_g1; const float* scale1;
+  RowView g2; const int32_t* idx_g2;
+  const float* W2; int64_t ldW2; const float* b2; const float* gamma; int n_out;
+  float* gz_out; int64_t gz_bstride;
+  float* gh; int64_t gh_bstride; int64_t gh_ld; const int32_t* idx_gh;
+  float* gpr; int64_t gpr_bstride; int64_t gpr_ld;
+  float* slab; int64_t slab_stride;
+  int vec_g;
+};
+
+// accumulator blocks -> bf16 planes (hi only / hi + lo)
+template <int D, int TERMS>
+__device__ __forceinline__ void fs_acc_to_planes(const f32x16 (&acc)[2], const FsPlanes<D, TERMS>& X,
+                                                 int wave, int lane) {
+  const int t = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 v = {acc[rb][4 * q], acc[rb][4 * q + 1], acc[rb][4 * q + 2], acc[rb][4 * q + 3]};
+      bf16x4 hi, lo;
+      b3_split4(v, hi, lo);
+      const int off = (32 * rb + t) * X.P + 32 * wave + 8 * q + 4 * h;
+      *reinterpret_cast<bf16x4*>(X.hi + off) = hi;
+      if constexpr (TERMS == 3) *reinterpret_cast<bf16x4*>(X.lo + off) = lo;
+    }
+}
+
+template <int D, bool HAS_LN, int TERMS>
+__global__ __launch_bounds__(2 * D) void fs_tail_bwd_kernel(FsTailBwdParams q) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NT = 2 * D, NW = D / 32, LDO = D + 4, CPR = D / 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int t = lane & 31, h = lane >> 5;
+  FsPlanes<D, TERMS> S;      // silu(h), later gz
+  S.init(smem);
+  __bf16* DS = reinterpret_cast<__bf16*>(reinterpret_cast<char*>(smem) + FsPlanes<D, TERMS>::bytes);
+  constexpr int PD = D + 4;  // silu'(h) as one bf16 plane (2^-9 relative: inside the bf16-mixed budget)
+  float* gtile = reinterpret_cast<float*>(reinterpret_cast<char*>(DS) + (size_t)FS_R * PD * sizeof(__bf16));
+  float* red = gtile + FS_R * LDO;                            // [2][FS_R][NW]
+  int* itab = reinterpret_cast<int*>(red + 2 * FS_R * NW);    // [3][FS_R]: g1, g2, gh
+  float* stab = reinterpret_cast<float*>(itab + 3 * FS_R);    // [FS_R] row scales
+  FsW<D, TERMS> A1, A2;
+  fs_load_w_rows<D, TERMS>(A1, q.W2, q.ldW2, 32 * wave, q.n_out, D, lane);
+  fs_load_w_cols<D, TERMS>(A2, q.W2, q.ldW2, 32 * wave, q.n_out, lane);
+  f32x16 dgam, dbet;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dgam[r] = dbet[r] = 0.f;
+  const int c4 = tid % CPR, rg = tid / CPR;
+  const int NO = (q.n_out + 31) & ~31;
+  const int64_t nsub = q.tl.ntiles * q.tl.B;
+  const int64_t ntiles = (nsub + 1) / 2;
+  for (int64_t tt = blockIdx.x; tt < ntiles; tt += gridDim.x) {
+    const FsSub2 sub = {fs_sub(q.tl, 2 * tt), fs_sub(q.tl, 2 * tt + 1)};
+    if (tid < FS_R) {
+      const int pos = fs_slot_pos(sub, tid);
+      const int i1 = q.idx_g1 ? q.idx_g1[pos] : pos;
+      itab[tid] = i1;
+      itab[FS_R + tid] = (q.g2.ptr && q.idx_g2) ? q.idx_g2[pos] : pos;
+      itab[2 * FS_R + tid] = q.idx_gh ? q.idx_gh[pos] : pos;
+      stab[tid] = q.scale1 ? q.scale1[i1] : 1.0f;
+    }
+    __syncthreads();
+    // ---- stage: s = silu(h), silu'(h) as planes; g = scale * g1[idx] + g2[idx] as fp32 rows
+    // (four rows per thread in flight at a time: the two weight slices hold 128 registers)
+    {
+#pragma unroll 1
+      for (int k0 = 0; k0 < 8; k0 += 4) {
+        f32x4 vh[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int r = rg + 8 * (k0 + k);
+          const int pos = fs_slot_pos(sub, r);
+          vh[k] = reinterpret_cast<const f32x4*>(q.h + sub.b(r >> 5) * q.h_bstride + (int64_t)pos * D)[c4];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int r = rg + 8 * (k0 + k);
+          const bool valid = (r & 31) < sub.ne(r >> 5);
+          f32x4 sv, dv;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            sv[j] = valid ? nlam_silu(vh[k][j]) : 0.f;
+            dv[j] = valid ? nlam_silu_grad(vh[k][j]) : 0.f;
+          }
+          bf16x4 hi, lo;
+          b3_split4(sv, hi, lo);
+          *reinterpret_cast<bf16x4*>(S.hi + r * S.P + 4 * c4) = hi;
+          if constexpr (TERMS == 3) *reinterpret_cast<bf16x4*>(S.lo + r * S.P + 4 * c4) = lo;
+          bf16x4 dh;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) dh[j] = (__bf16)dv[j];
+          *reinterpret_cast<bf16x4*>(DS + r * PD + 4 * c4) = dh;
+        }
+      }
+      if (q.vec_g) {
+#pragma unroll 1
+        for (int k0 = 0; k0 < 8; k0 += 4) {
+          f32x4 vg[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int r = rg + 8 * (k0 + k);
+            const float* gb = q.g1.ptr + sub.b(r >> 5) * q.g1.bstride;
+            vg[k] = reinterpret_cast<const f32x4*>(gb + (int64_t)itab[r] * q.g1.ld)[c4];
+          }
+          if (q.g2.ptr) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const int r = rg + 8 * (k0 + k);
+              const float* gb = q.g2.ptr + sub.b(r >> 5) * q.g2.bstride;
+              const f32x4 v2 = reinterpret_cast<const f32x4*>(gb + (int64_t)itab[FS_R + r] * q.g2.ld)[c4];
+              vg[k] = vg[k] * stab[r] + v2;
+            }
+          } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) vg[k] *= stab[rg + 8 * (k0 + k)];
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int r = rg + 8 * (k0 + k);
+            f32x4 x = vg[k];
+            if ((r & 31) >= sub.ne(r >> 5)) x = f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(gtile + r * LDO + 4 * c4) = x;
+          }
+        }
+      } else {
+        for (int idx = tid; idx < FS_R * D; idx += NT) {
+          const int r = idx / D, cc = idx - r * D;
+          const int rb = r >> 5;
+          float v = 0.f;
+          if ((r & 31) < sub.ne(rb) && cc < q.n_out) {
+            v = q.g1.ptr[sub.b(rb) * q.g1.bstride + (int64_t)itab[r] * q.g1.ld + cc] * stab[r];
+            if (q.g2.ptr)
+              v += q.g2.ptr[sub.b(rb) * q.g2.bstride + (int64_t)itab[FS_R + r] * q.g2.ld + cc];
+          }
+          gtile[r * LDO + cc] = v;
+        }
+      }
+    }
+    __syncthreads();
+    // Every wave reads and writes only its own 32 columns of the g tile, so g -> gamma*g -> gz
+    // is done in place there, one row block at a time (register budget: A1 + A2 + z + dgam/dbet).
+    if (HAS_LN) {
+      const f32x16 b2v = fs_vec_block(q.b2, q.n_out, wave, lane);
+      f32x16 z[2] = {b2v, b2v};
+      fs_gemm<D, TERMS>(z, A1, S, lane);
+      const float inv_n = 1.0f / (float)q.n_out;
+      float mean[2], rstd[2];
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        float sm = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sm += z[rb][r];
+        sm += __shfl_xor(sm, 32, 64);
+        if (h == 0) red[(32 * rb + t) * NW + wave] = sm;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        float sm = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) sm += red[(32 * rb + t) * NW + w];
+        mean[rb] = sm * inv_n;
+        float vs = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float dlt = z[rb][r] - mean[rb];
+          vs += dlt * dlt;
+        }
+        vs += __shfl_xor(vs, 32, 64);
+        if (h == 0) red[FS_R * NW + (32 * rb + t) * NW + wave] = vs;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        float vs = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) vs += red[FS_R * NW + (32 * rb + t) * NW + w];
+        rstd[rb] = rsqrtf(vs * inv_n + 1e-5f);
+      }
+      __syncthreads();   // (every wave has read the statistics: red is reused for s1 / s2)
+      {
+        const f32x16 gav = fs_vec_block(q.gamma, q.n_out, wave, lane);
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+          f32x16 g;
+          fs_tile_to_acc1<LDO>(g, gtile, rb, wave, lane);
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float xh = (z[rb][r] - mean[rb]) * rstd[rb];
+            z[rb][r] = xh;
+            dbet[r] += g[r];
+            dgam[r] += g[r] * xh;
+            const float gv = g[r] * gav[r];
+            g[r] = gv;
+            s1 += gv;
+            s2 += gv * xh;
+          }
+          fs_acc_to_tile1<LDO>(g, gtile, rb, wave, lane);
+          s1 += __shfl_xor(s1, 32, 64);
+          s2 += __shfl_xor(s2, 32, 64);
+          if (h == 0) {
+            red[(32 * rb + t) * NW + wave] = s1;
+            red[FS_R * NW + (32 * rb + t) * NW + wave] = s2;
+          }
+        }
+      }
+      __syncthreads();   // s1 / s2 complete; every wave is past its z GEMM: the S planes are free
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+          s1 += red[(32 * rb + t) * NW + w];
+          s2 += red[FS_R * NW + (32 * rb + t) * NW + w];
+        }
+        const float m1 = s1 * inv_n, m2 = s2 * inv_n;
+        f32x16 g;
+        fs_tile_to_acc1<LDO>(g, gtile, rb, wave, lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) g[r] = rstd[rb] * (g[r] - m1 - z[rb][r] * m2);
+        fs_acc_to_tile1<LDO>(g, gtile, rb, wave, lane);
+        fs_acc_to_planes1<D, TERMS>(g, S, rb, wave, lane);
+      }
+    } else {
+      // gz = g: the tile already holds it; planes for W2^T gz
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        f32x16 g;
+        fs_tile_to_acc1<LDO>(g, gtile, rb, wave, lane);
+        fs_acc_to_planes1<D, TERMS>(g, S, rb, wave, lane);
+      }
+    }
+    __syncthreads();
+    {
+      const int nc4 = NO >> 2;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int r = rg + 8 * k;
+        const int rb = r >> 5;
+        if ((r & 31) < sub.ne(rb) && c4 < nc4)
+          reinterpret_cast<f32x4*>(q.gz_out + sub.b(rb) * q.gz_bstride +
+                                   (int64_t)(sub.p0(rb) + (r & 31)) * NO)[c4] =
+              *reinterpret_cast<const f32x4*>(gtile + r * LDO + 4 * c4);
+      }
+    }
+    // gh = (W2^T gz) * silu'(h)
+    f32x16 gh[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) gh[rb][r] = 0.f;
+    fs_gemm<D, TERMS>(gh, A2, S, lane);
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        const bf16x4 dv = *reinterpret_cast<const bf16x4*>(DS + (32 * rb + t) * PD + 32 * wave + 8 * qq + 4 * h);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gh[rb][4 * qq + j] *= (float)dv[j];
+      }
+    __syncthreads();   // the gz rows have been read from the tile
+    fs_acc_to_tile<LDO>(gh, gtile, wave, lane);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int r = rg + 8 * k;
+      const int rb = r >> 5;
+      if ((r & 31) < sub.ne(rb))
+        reinterpret_cast<f32x4*>(q.gh + sub.b(rb) * q.gh_bstride + (int64_t)itab[2 * FS_R + r] * q.gh_ld)[c4] =
+            *reinterpret_cast<const f32x4*>(gtile + r * LDO + 4 * c4);
+    }
+    if (q.gpr != nullptr) {
+      const int rb = wave / (NW / 2), fc = wave % (NW / 2);
+      const FsSub sb = rb ? sub.s1 : sub.s0;
+      float* gb = q.gpr + sb.b * q.gpr_bstride;
+      fs_segment_sums(gtile + 32 * rb * LDO + 64 * fc, LDO, sb, q.tl, lane, [&](int r, float acc) {
+        gb[(int64_t)r * q.gpr_ld + 64 * fc + lane] = acc;
+      });
+    }
+    __syncthreads();
+  }
+  if (HAS_LN) {
+    // per-lane (row slot) partials -> per-feature sums over the 32 slots of each lane half
+    float* slab = q.slab + (int64_t)blockIdx.x * q.slab_stride;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float a = dgam[r], bsum = dbet[r];
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) {
+        a += __shfl_xor(a, o, 64);
+        bsum += __shfl_xor(bsum, o, 64);
+      }
+      if (t == 0) {
+        const int f = 32 * wave + 8 * (r >> 2) + 4 * h + (r & 3);
+        slab[f] = a;
+        slab[D + f] = bsum;
+      }
+    }
+  }
+}
+
+template <int D, bool HAS_LN, int TERMS>
+static int launch_fs_tail_bwd(const FsTailBwdParams& q, hipStream_t s, unsigned grid) {
+  const size_t lds = FsPlanes<D, TERMS>::bytes + (size_t)FS_R * (D + 4) * sizeof(__bf16) +
+                     (size_t)FS_R * (D + 4) * sizeof(float) +
+                     (size_t)2 * FS_R * (D / 32) * sizeof(float) + (size_t)4 * FS_R * sizeof(int);
+  NLAM_REQUIRE(lds <= 160 * 1024, "fs_tail_bwd: LDS footprint %zu B exceeds 160 KiB", lds);
+  auto kern = fs_tail_bwd_kernel<D, HAS_LN, TERMS>;
+  NLAM_BIG_LDS(kern, "fs_tail_bwd_kernel");
+  kern<<<grid, 2 * D, lds, s>>>(q);
+  NLAM_CHECK_LAUNCH("fs_tail_bwd_kernel");
+  return 0;
+}
+
+// grid = the slab count the host sized its buffer for (nlam_bwd_grid(B * ntiles))
+int nlam_fs_tail_bwd_256(
+    const int32_t* tiles, int64_t ntiles, int64_t rows, const int32_t* csr_rec,
+    const int32_t* csr_rowptr, const float* h, int64_t h_bstride,
+    const float* g1, int64_t g1_bstride, int64_t g1_ld, const int32_t* idx_g1, const float* scale1,
+    const float* g2, int64_t g2_bstride, int64_t g2_ld, const int32_t* idx_g2,
+    const float* W2, int64_t ldW2, const float* b2, const float* gamma, int n_out,
+    float* gz_out, int64_t gz_bstride,
+    float* gh, int64_t gh_bstride, int64_t gh_ld, const int32_t* idx_gh,
+    float* gpr, int64_t gpr_bstride, int64_t gpr_ld,
+    float* slab, int64_t slab_stride, int64_t B, unsigned grid, void* stream) {
+  constexpr int d = 256;
+  NLAM_REQUIRE(nlam_mfma_terms() == 1, "hidden 256 needs NLAM_MFMA=bf16");
+  NLAM_REQUIRE(gamma == nullptr || n_out == d, "nlam_tail_bwd: LayerNorm needs n_out == d");
+  NLAM_REQUIRE(h != nullptr && nlam_aligned16(h) && h_bstride % 4 == 0, "nlam_tail_bwd: bad h");
+  NLAM_REQUIRE(g1 != nullptr && gz_out != nullptr && nlam_aligned16(gz_out) && gz_bstride % 4 == 0,
+               "nlam_tail_bwd: g1 / gz_out missing or misaligned");
+  NLAM_REQUIRE(gh != nullptr && view_vec_ok(gh, gh_bstride, gh_ld, d), "nlam_tail_bwd: bad gh view");
+  NLAM_REQUIRE(gamma == nullptr || (slab != nullptr && slab_stride >= 2 * d), "nlam_tail_bwd: slab too small");
+  FsTailBwdParams q;
+  q.tl = FsTiling{tiles, ntiles, rows, csr_rec, csr_rowptr, (int)B};
+  q.h = h; q.h_bstride = h_bstride;
+  q.g1 = RowView{g1, g1_bstride, g1_ld, n_out}; q.idx_g1 = idx_g1; q.scale1 = scale1;
+  q.g2 = RowView{g2, g2_bstride, g2_ld, n_out}; q.idx_g2 = idx_g2;
+  q.W2 = W2; q.ldW2 = ldW2; q.b2 = b2; q.gamma = gamma; q.n_out = n_out;
+  q.gz_out = gz_out; q.gz_bstride = gz_bstride;
+  q.gh = gh; q.gh_bstride = gh_bstride; q.gh_ld = gh_ld; q.idx_gh = idx_gh;
+  q.gpr = gpr; q.gpr_bstride = gpr_bstride; q.gpr_ld = gpr_ld;
+  q.slab = slab; q.slab_stride = slab_stride;
+  q.vec_g = (n_out == d && view_vec_ok(g1, g1_bstride, g1_ld, n_out) &&
+             (g2 == nullptr || view_vec_ok(g2, g2_bstride, g2_ld, n_out))) ? 1 : 0;
+  hipStream_t s = (hipStream_t)stream;
+  return gamma != nullptr ? launch_fs_tail_bwd<256, true, 1>(q, s, grid)
+                          : launch_fs_tail_bwd<256, false, 1>(q, s, grid);
+}
+
+// ==================================================================== weight gradients ===
+// dW (ng x nx) = sum_rows G[r]^T (x) f(X[r]),  db = colsum(G);  f = silu when silu_x (X is then
+// the kept pre-activation h).  Every wave owns a 32-feature slice of dW for the whole launch:
+//   GW == 256: wave w holds dW[32 w .. 32 w + 31][0 .. 32 NXB)   (8 NXB accumulator registers x 16)
+//   GW == 32 : wave w holds dW[0 .. 31][32 w .. 32 w + 31]        (nx = 256; the n_out <= 32 heads)
+// Slab per workgroup as nlam_wide_outer: [dW (ng x 32 NXB) | db (ng)].
+struct FsOuterParams {
+  RowView g;        // (B, rows, GW)
+  RowView x;        // (B, rows, nx); batch-invariant x (bstride 0) allowed
+  float* slab; int64_t slab_stride;
+  FsTiling tl;      // row mode
+  int silu_x;
+  int x_vec;
+};
+
+template <int GW, int NXB, int TERMS>
+__global__ __launch_bounds__(512) void fs_outer_kernel(FsOuterParams q) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NX = 32 * NXB, NT = 512;
+  constexpr int NJ = GW == 256 ? NXB : 1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  FsPlanes<GW, TERMS> G;
+  G.init(smem);
+  FsPlanes<NX, TERMS> X;
+  X.init(reinterpret_cast<char*>(smem) + FsPlanes<GW, TERMS>::bytes);
+  f32x16 dW[1][NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dW[0][j][r] = 0.f;
+  float db = 0.f;
+  // staging maps: G rows (GW / 4 chunks per row), X rows (NX / 4 chunks per row, wide form)
+  constexpr int GCPR = GW / 4, GRPP = NT / GCPR, GNV = FS_R / GRPP;   // 256: 64, 8, 8;  32: 8, 64, 1
+  constexpr int XCPR = NX / 4, XRPP = NT / XCPR, XNV = (FS_R + XRPP - 1) / XRPP;
+  const int gc4 = tid % GCPR, grg = tid / GCPR;
+  const int xc4 = tid % XCPR, xrg = tid / XCPR;
+  const int64_t nsub = q.tl.ntiles * q.tl.B;
+  const int64_t ntiles = (nsub + 1) / 2;
+  const bool silu_x = q.silu_x != 0;
+  const bool x_vec = NXB >= 8 ? true : (q.x_vec != 0);
+  f32x4 vg[GNV], vx[XNV];
+  auto issue = [&](int64_t tt) {
+    const FsSub2 sub = {fs_sub(q.tl, 2 * tt), fs_sub(q.tl, 2 * tt + 1)};
+#pragma unroll
+    for (int k = 0; k < GNV; ++k) {
+      const int r = grg + GRPP * k;
+      const int pos = fs_slot_pos(sub, r);
+      vg[k] = reinterpret_cast<const f32x4*>(q.g.ptr + sub.b(r >> 5) * q.g.bstride + (int64_t)pos * q.g.ld)[gc4];
+      if ((r & 31) >= sub.ne(r >> 5)) vg[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (x_vec) {
+#pragma unroll
+      for (int k = 0; k < XNV; ++k) {
+        const int r = (xrg + XRPP * k) & (FS_R - 1);
+        const int pos = fs_slot_pos(sub, r);
+        const int cc = (4 * xc4 < q.x.width) ? xc4 : 0;
+        vx[k] = reinterpret_cast<const f32x4*>(q.x.ptr + sub.b(r >> 5) * q.x.bstride + (int64_t)pos * q.x.ld)[cc];
+        if ((r & 31) >= sub.ne(r >> 5) || 4 * xc4 >= q.x.width) vx[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  };
+  auto put = [&](int64_t tt) {
+#pragma unroll
+    for (int k = 0; k < GNV; ++k) {
+      const int r = grg + GRPP * k;
+      bf16x4 hi, lo;
+      b3_split4(vg[k], hi, lo);
+      *reinterpret_cast<bf16x4*>(G.hi + r * G.P + 4 * gc4) = hi;
+      if constexpr (TERMS == 3) *reinterpret_cast<bf16x4*>(G.lo + r * G.P + 4 * gc4) = lo;
+    }
+    if (x_vec) {
+#pragma unroll
+      for (int k = 0; k < XNV; ++k) {
+        const int r = xrg + XRPP * k;
+        if (r < FS_R) {
+          f32x4 v = vx[k];
+          if (silu_x) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = nlam_silu(v[j]);
+          }
+          bf16x4 hi, lo;
+          b3_split4(v, hi, lo);
+          *reinterpret_cast<bf16x4*>(X.hi + r * X.P + 4 * xc4) = hi;
+          if constexpr (TERMS == 3) *reinterpret_cast<bf16x4*>(X.lo + r * X.P + 4 * xc4) = lo;
+        }
+      }
+    } else {
+      // narrow or unaligned x rows (static features of the embedders): scalar staging
+      const FsSub2 sub = {fs_sub(q.tl, 2 * tt), fs_sub(q.tl, 2 * tt + 1)};
+      for (int idx = tid; idx < FS_R * NX; idx += NT) {
+        const int r = idx / NX, cc = idx - r * NX;
+        const int rb = r >> 5;
+        float v = 0.f;
+        if ((r & 31) < sub.ne(rb) && cc < q.x.width)
+          v = q.x.ptr[sub.b(rb) * q.x.bstride + (int64_t)(sub.p0(rb) + (r & 31)) * q.x.ld + cc];
+        if (silu_x) v = nlam_silu(v);
+        const __bf16 hi = (__bf16)v;
+        X.hi[r * X.P + cc] = hi;
+        if constexpr (TERMS == 3) X.lo[r * X.P + cc] = (__bf16)(v - (float)hi);
+      }
+    }
+  };
+  int64_t tt = blockIdx.x;
+  if (tt < ntiles) issue(tt);
+  bf16x8 ones;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+  for (; tt < ntiles; tt += gridDim.x) {
+    put(tt);
+    __syncthreads();
+    if (tt + gridDim.x < ntiles) issue(tt + gridDim.x);
+    const bool active = GW == 256 || true;
+    if (active) {
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        const B3Tile Gt = {G.hi + 32 * rb * G.P, G.lo + 32 * rb * G.P, G.P};
+        const B3Tile Xt = {X.hi + 32 * rb * X.P, X.lo + 32 * rb * X.P, X.P};
+        if constexpr (GW == 256) {
+          outer_accum_b3<1, NJ, TERMS>(dW, Gt, 32 * wave, Xt, 0, lane);
+        } else {
+          outer_accum_b3<1, 1, TERMS>(dW, Gt, 0, Xt, 32 * wave, lane);
+        }
+        if (GW == 256 || wave == 0) {
+          const int gcol = GW == 256 ? 32 * wave : 0;
+          f32x16 c;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) c[r] = 0.f;
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const bf16x8 bh = b3_tr_frag_rows(Gt.hi, Gt.pitch, 16 * u, gcol, lane);
+            c = B3_MFMA(ones, bh, c);
+            if constexpr (TERMS == 3) {
+              const bf16x8 bl = b3_tr_frag_rows(Gt.lo, Gt.pitch, 16 * u, gcol, lane);
+              c = B3_MFMA(ones, bl, c);
+            }
+          }
+          db += c[0];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float* slab = q.slab + (int64_t)blockIdx.x * q.slab_stride;
+  const int h = lane >> 5, j = lane & 31;
+  if constexpr (GW == 256) {
+#pragma unroll
+    for (int jb = 0; jb < NJ; ++jb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = 8 * (r >> 2) + 4 * h + (r & 3);
+        slab[(int64_t)(32 * wave + i) * NX + 32 * jb + j] = dW[0][jb][r];
+      }
+    if (lane < 32) slab[(int64_t)GW * NX + 32 * wave + lane] = db;
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = 8 * (r >> 2) + 4 * h + (r & 3);
+      slab[(int64_t)i * NX + 32 * wave + j] = dW[0][0][r];
+    }
+    if (wave == 0 && lane < 32) slab[(int64_t)GW * NX + lane] = db;
+  }
+}
+
+template <int GW, int NXB, int TERMS>
+static int launch_fs_outer(const FsOuterParams& q, hipStream_t s, unsigned grid) {
+  const size_t lds = FsPlanes<GW, TERMS>::bytes + FsPlanes<32 * NXB, TERMS>::bytes;
+  auto kern = fs_outer_kernel<GW, NXB, TERMS>;
+  NLAM_BIG_LDS(kern, "fs_outer_kernel");
+  kern<<<grid, 512, lds, s>>>(q);
+  NLAM_CHECK_LAUNCH("fs_outer_kernel");
+  return 0;
+}
+
+// (ng, nx) in {(256, 256), (32, 256), (256, <= 64)}; grid = the slab count of the caller
+int nlam_fs_outer_256(const float* g, int64_t g_bstride, int64_t g_ld, int ng,
+                      const float* x, int64_t x_bstride, int64_t x_ld, int nx, int silu_x,
+                      float* slab, int64_t slab_stride, int64_t B, int64_t rows, unsigned grid,
+                      void* stream) {
+  NLAM_REQUIRE(nlam_mfma_terms() == 1, "hidden 256 needs NLAM_MFMA=bf16");
+  NLAM_REQUIRE((ng == 256 || ng == 32) && nx >= 1 && (nx <= 64 || nx == 256) && (ng == 256 || nx == 256),
+               "nlam_wide_outer: shape %d x %d unsupported", ng, nx);
+  NLAM_REQUIRE(view_vec_ok(g, g_bstride, g_ld, ng) && x != nullptr && x_ld >= nx,
+               "nlam_wide_outer: g rows must be 16-byte aligned with pitch %% 4 == 0");
+  const int nxp = (nx + 31) & ~31;
+  NLAM_REQUIRE(slab != nullptr && slab_stride >= (int64_t)ng * nxp + ng, "nlam_wide_outer: slab too small");
+  FsOuterParams q;
+  q.g = RowView{g, g_bstride, g_ld, ng};
+  q.x = RowView{x, x_bstride, x_ld, nx};
+  q.slab = slab; q.slab_stride = slab_stride;
+  q.tl = FsTiling{nullptr, (rows + NLAM_TILE - 1) / NLAM_TILE, rows, nullptr, nullptr, (int)B};
+  q.silu_x = silu_x;
+  q.x_vec = view_vec_ok(x, x_bstride, x_ld, nx) ? 1 : 0;
+  NLAM_REQUIRE(nx < 256 || q.x_vec, "nlam_wide_outer: 256-wide x rows must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  if (ng == 32) return launch_fs_outer<32, 8, 1>(q, s, grid);
+  if (nx <= 32) return launch_fs_outer<256, 1, 1>(q, s, grid);
+  if (nx <= 64) return launch_fs_outer<256, 2, 1>(q, s, grid);
+  return launch_fs_outer<256, 8, 1>(q, s, grid);
+}

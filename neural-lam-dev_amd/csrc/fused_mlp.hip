@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include "fused_common.h"
 #include "fused_bf16x3.h"
+#include "fused_fs.h"
 
 struct MlpParams {
   RowView src[2];
@@ -381,6 +382,10 @@ extern "C" int nlam_lin_fwd(const float* x, int64_t x_bstride, int64_t x_ld, int
   if (view_vec_ok(x, x_bstride, x_ld, k_in)) p.vec_mask |= 1;
   if (view_vec_ok(out, out_bstride, out_ld, p.nA + p.nB)) p.vec_mask |= 8;
   hipStream_t s = (hipStream_t)stream;
+  // hidden 256, bf16-mixed (fused_fs.hip): register-stationary weight slices
+  if (nlam_mfma_terms() == 1 && nA == 256 && p.nB == 0 && (p.vec_mask & 8))
+    return nlam_fs_lin_fwd_256(x, x_bstride, x_ld, k_in, WA, ldWA, bA, nA, out, out_bstride, out_ld,
+                               B, rows, stream);
   if (nlam_mfma_b3() && k_in == 64 && (p.vec_mask & 1) && (p.vec_mask & 8)) {
     if ((p.nA + p.nB) == 64) return launch_lin_fwd_b3<2, 2>(p, s);
     if ((p.nA + p.nB) == 128) return launch_lin_fwd_b3<4, 2>(p, s);

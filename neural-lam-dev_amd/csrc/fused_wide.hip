@@ -24,6 +24,7 @@
 
 #include "fused_bf16x3.h"
 #include "fused_common.h"
+#include "fused_fs.h"
 
 struct WideTiling {
   const int32_t* tiles;      // edge mode: (ntiles, 4) = p0, p1, r0, r1; NULL = row mode
@@ -296,7 +297,12 @@ extern "C" int nlam_tail_fwd(
     float* agg, int64_t agg_bstride, int64_t agg_ld, const float* inv_deg,
     int64_t B, int d, void* stream) {
   if (B <= 0 || rows <= 0) return 0;
-  NLAM_REQUIRE(d == 128, "nlam_tail_fwd: hidden width %d unsupported (128)", d);
+  if (d == 256)
+    return nlam_fs_tail_fwd_256(tiles, ntiles, rows, csr_rec, csr_rowptr, a, a_bstride, a_ld, idx_a,
+                                b, b_bstride, b_ld, idx_b, c, c_bstride, c_ld, idx_c, W2, ldW2, b2,
+                                gamma, beta, n_out, h_out, h_bstride, y, y_bstride, y_ld, idx_y, res,
+                                res_bstride, res_ld, agg, agg_bstride, agg_ld, inv_deg, B, stream);
+  NLAM_REQUIRE(d == 128, "nlam_tail_fwd: hidden width %d unsupported (128, 256)", d);
   NLAM_REQUIRE(nlam_mfma_terms() != 0, "nlam_tail_fwd: needs NLAM_MFMA=bf16x3|bf16");
   NLAM_REQUIRE(n_out >= 1 && n_out <= d, "nlam_tail_fwd: n_out %d out of range", n_out);
   NLAM_REQUIRE((gamma == nullptr) == (beta == nullptr), "nlam_tail_fwd: gamma/beta mismatch");
@@ -626,7 +632,19 @@ extern "C" int nlam_tail_bwd(
     float* gpr, int64_t gpr_bstride, int64_t gpr_ld,
     float* slab, int64_t slab_stride, int64_t B, int d, void* stream) {
   if (B <= 0 || rows <= 0) return 0;
-  NLAM_REQUIRE(d == 128, "nlam_tail_bwd: hidden width %d unsupported (128)", d);
+  if (d == 256) {
+    NLAM_REQUIRE(gpr == nullptr || (tiles != nullptr && csr_rec != nullptr && csr_rowptr != nullptr &&
+                                    gpr_ld >= d), "nlam_tail_bwd: gpr needs edge tiles");
+    NLAM_REQUIRE(tiles != nullptr || ntiles == (rows + NLAM_TILE - 1) / NLAM_TILE,
+                 "nlam_tail_bwd: row mode expects ntiles == ceil(rows / 32)");
+    NLAM_REQUIRE(n_out >= 1 && n_out <= d && (gamma != nullptr || n_out <= 32),
+                 "nlam_tail_bwd: n_out %d unsupported", n_out);
+    return nlam_fs_tail_bwd_256(tiles, ntiles, rows, csr_rec, csr_rowptr, h, h_bstride, g1, g1_bstride,
+                                g1_ld, idx_g1, scale1, g2, g2_bstride, g2_ld, idx_g2, W2, ldW2, b2,
+                                gamma, n_out, gz_out, gz_bstride, gh, gh_bstride, gh_ld, idx_gh, gpr,
+                                gpr_bstride, gpr_ld, slab, slab_stride, B, wide_grid(ntiles * B), stream);
+  }
+  NLAM_REQUIRE(d == 128, "nlam_tail_bwd: hidden width %d unsupported (128, 256)", d);
   NLAM_REQUIRE(nlam_mfma_terms() != 0, "nlam_tail_bwd: needs NLAM_MFMA=bf16x3|bf16");
   NLAM_REQUIRE(n_out >= 1 && n_out <= d, "nlam_tail_bwd: n_out out of range");
   NLAM_REQUIRE(gamma == nullptr || n_out == d, "nlam_tail_bwd: LayerNorm needs n_out == d");
@@ -799,6 +817,9 @@ extern "C" int nlam_lin_bwd_data(const float* gy, int64_t gy_bstride, int64_t gy
                                  int64_t B, int64_t rows, void* stream) {
   if (B <= 0 || rows <= 0) return 0;
   NLAM_REQUIRE(nlam_mfma_terms() != 0, "nlam_lin_bwd_data: needs NLAM_MFMA=bf16x3|bf16");
+  if (n_out == 256 && k_in == 256)
+    return nlam_fs_lin_bwd_data_256(gy, gy_bstride, gy_ld, W, ldW, gx, gx_bstride, gx_ld, gx_add,
+                                    ga_bstride, ga_ld, B, rows, stream);
   WideMulti<LinBwdDataParams> m;
   m.n = 1;
   if (lin_bwd_data_fill(m.p[0], gy, gy_bstride, gy_ld, n_out, W, ldW, k_in, gx, gx_bstride, gx_ld,
@@ -974,6 +995,9 @@ extern "C" int nlam_wide_outer(const float* g, int64_t g_bstride, int64_t g_ld, 
                                void* stream) {
   if (B <= 0 || rows <= 0) return 0;
   NLAM_REQUIRE(nlam_mfma_terms() != 0, "nlam_wide_outer: needs NLAM_MFMA=bf16x3|bf16");
+  if (ng == 256 || nx == 256)
+    return nlam_fs_outer_256(g, g_bstride, g_ld, ng, x, x_bstride, x_ld, nx, silu_x, slab, slab_stride,
+                             B, rows, wide_grid(((rows + NLAM_TILE - 1) / NLAM_TILE) * B), stream);
   WideMulti<WideOuterParams> m;
   m.n = 1;
   if (wide_outer_fill(m.p[0], g, g_bstride, g_ld, ng, x, x_bstride, x_ld, nx, silu_x, slab,

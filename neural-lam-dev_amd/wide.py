@@ -1,4 +1,4 @@
-"""hidden_dim 128 path of the fused gfx950 kernels (csrc/fused_wide.hip).
+"""hidden_dim 128 / 256 path of the fused gfx950 kernels (csrc/fused_wide.hip, fused_fs.hip).
 
 Same operators as fused.py -- the make_mlp blocks (reference utils.py:191-214) and one
 InteractionNet layer (interaction_net.py:86-131) -- but cut at the Linear boundaries: at d = 128
@@ -16,6 +16,11 @@ matrix and every weight gradient is a streaming pass of its own:
 The pre-activations h are kept by the forward (the backward neither repeats the first GEMM nor
 gathers); memory is sized for 288 GB of HBM.  Arithmetic: NLAM_MFMA=bf16x3 (default, fp32-grade)
 or bf16 (plain bf16 products, fp32 accumulate); exact-fp32 mode takes the generic kernels.
+
+hidden_dim 256 runs the same host sequence on the feature-split kernels of csrc/fused_fs.hip
+(weights register-stationary, one 64-row tile per 512-thread workgroup) and exists in bf16
+arithmetic only -- the reference's `--precision bf16-mixed` (BASELINE configs[4]); the multi-problem
+launches of the 128 path become single launches there.
 """
 import torch
 
@@ -23,11 +28,13 @@ from . import ops
 from ._lib import lib
 from .ops import _launch, _p, mat, stream
 
-WIDE_HIDDEN = (128,)
+WIDE_HIDDEN = (128, 256)
 
 
-def enabled():
-    return int(lib.nlam_mfma_mode()) != 0
+def enabled(hid=128):
+    """hidden 128: split-bf16 or bf16 arithmetic; hidden 256: bf16 only."""
+    mode = int(lib.nlam_mfma_mode())
+    return mode == 2 if hid == 256 else mode != 0
 
 
 def _empty(*shape, device):
@@ -112,7 +119,7 @@ def tail_bwd(tl, h, g1, idx_g1, scale1, g2, idx_g2, W2, b2, gamma, gz_out, gh, i
 
 
 def lin_bwd_data(gy, W, gx, gx_add=None):
-    """gx = gy W (+ gx_add); W: (128, 128) view (any row pitch)."""
+    """gx = gy W (+ gx_add); W: (d, d) view (any row pitch)."""
     n_out, k_in = W.shape
     _launch(
         "nlam_lin_bwd_data", lib.nlam_lin_bwd_data,
@@ -125,7 +132,7 @@ def lin_bwd_data(gy, W, gx, gx_add=None):
 
 
 def outer(g, x, dW, db, silu_x=False, rows_out=None):
-    """dW (rows_out x 128 view) = sum_rows g^T f(x); db = colsum(g).  g: (B, rows, 128 | 32)."""
+    """dW (rows_out x d view) = sum_rows g^T f(x); db = colsum(g).  g: (B, rows, d | 32)."""
     ng, nx = g.cols, x.cols
     nxp = (nx + 31) // 32 * 32
     B, rows = g.B, g.rows
@@ -155,6 +162,10 @@ def _parr(vals):
 def lin_fwd_multi(problems):
     """[(x Mat, W (128,128) view, bias or None, out Mat)] -> one launch (aligned 128-wide rows)."""
     import ctypes
+    if problems[0][1].shape[0] != 128:
+        for x, W, b, o in problems:
+            ops.fused_lin_fwd(x, W, b, None, None, o)
+        return
     I64 = ctypes.c_int64
     n = len(problems)
     _launch(
@@ -174,6 +185,10 @@ def lin_fwd_multi(problems):
 def lin_bwd_data_multi(problems):
     """[(gy Mat, W (128,128) view, gx Mat, gx_add Mat or None)] -> one launch."""
     import ctypes
+    if problems[0][1].shape[0] != 128:
+        for gy, W, gx, gx_add in problems:
+            lin_bwd_data(gy, W, gx, gx_add)
+        return
     I64 = ctypes.c_int64
     n = len(problems)
     _launch(
@@ -197,6 +212,10 @@ def outer_multi(problems):
     """[(g Mat (.., 128), x Mat (.., 128), dW view, db, silu_x)] -> one launch + the layer's slab
     reduction (all 128 x 128)."""
     import ctypes
+    if problems[0][0].cols != 128:
+        for g, x, dW, db, sx in problems:
+            outer(g, x, dW, db, silu_x=sx)
+        return
     I64, I32 = ctypes.c_int64, ctypes.c_int32
     n = len(problems)
     dev = problems[0][2].device
@@ -234,7 +253,7 @@ def _first_linear_bwd(x, ga, W, need_gx, gx_add, dW, db, dev):
     """Backward of out = x W^T + b given ga = dL/dout: returns gx (or None), fills dW / db."""
     k_in = W.shape[1]
     gx = None
-    wide_ok = k_in == 128 and _aligned(x)
+    wide_ok = k_in == ga.cols and _aligned(x)
     if need_gx:
         gx = _empty(ga.B, ga.rows, k_in, device=dev)
         if wide_ok:
@@ -254,7 +273,7 @@ def _first_linear_bwd(x, ga, W, need_gx, gx_add, dW, db, dev):
 def mlp_eligible(seq, x, res=None):
     from .fused import FORCE_GENERIC, _mlp_parts
 
-    if FORCE_GENERIC or not x.is_cuda or x.dtype != torch.float32 or not enabled():
+    if FORCE_GENERIC or not x.is_cuda or x.dtype != torch.float32:
         return False
     if res is not None and res is not x and res.shape[:-1] != x.shape[:-1]:
         return False
@@ -263,7 +282,7 @@ def mlp_eligible(seq, x, res=None):
         return False
     hid, k_in = lin[0].weight.shape
     n_out = lin[1].weight.shape[0]
-    if hid not in WIDE_HIDDEN or lin[1].weight.shape[1] != hid or k_in > 128:
+    if hid not in WIDE_HIDDEN or not enabled(hid) or lin[1].weight.shape[1] != hid or k_in > hid:
         return False
     if ln is not None:
         return n_out == hid
@@ -271,7 +290,7 @@ def mlp_eligible(seq, x, res=None):
 
 
 class WideMLPFunction(torch.autograd.Function):
-    """y = [res +] [LN](W2 silu(W1 x + b1) + b2), x: (..., rows, k_in), hidden 128."""
+    """y = [res +] [LN](W2 silu(W1 x + b1) + b2), x: (..., rows, k_in), hidden 128 / 256."""
 
     @staticmethod
     def forward(ctx, x, res, W1, b1, W2, b2, gamma, beta):
@@ -338,13 +357,13 @@ def inet_eligible(net, send_rep, rec_rep, edge_rep):
     from .fused import FORCE_GENERIC
     from .interaction_net import SplitMLPs
 
-    if FORCE_GENERIC or not edge_rep.is_cuda or edge_rep.dtype != torch.float32 or not enabled():
+    if FORCE_GENERIC or not edge_rep.is_cuda or edge_rep.dtype != torch.float32:
         return False
     if isinstance(net.edge_mlp, SplitMLPs) or isinstance(net.aggr_mlp, SplitMLPs):
         return False
     if net.hidden_layers != 1 or net.input_dim != net.hidden_dim:
         return False
-    if net.hidden_dim not in WIDE_HIDDEN:
+    if net.hidden_dim not in WIDE_HIDDEN or not enabled(net.hidden_dim):
         return False
     if send_rep.dim() != 3 or rec_rep.dim() != 3 or edge_rep.dim() != 3:
         return False

@@ -45,3 +45,16 @@ def test_operator_parity_wide_widths_in_mode(mode, fwd_bar, grad_bar):
     assert {int(r[0]) for r in rows} >= {128, 256}, out.stdout
     for d, fwd, gin, gpar in rows:
         assert float(fwd) < fwd_bar and float(gin) < grad_bar and float(gpar) < grad_bar, out.stdout
+
+
+@pytest.mark.parametrize("mode,width", [("bf16", 256), ("bf16", 128)])
+def test_wide_cases_in_mode(mode, width):
+    """Every operator / MLP case of test_gpu_wide.py against the CPU oracle at hidden 256 (the
+    feature-split kernels of csrc/fused_fs.hip; bf16 arithmetic only) and at hidden 128 in bf16
+    arithmetic, bf16-mixed bars (forward 2e-2, gradients 2e-1 of max|ref|)."""
+    env = dict(os.environ, NLAM_MFMA=mode, NLAM_WIDE_D=str(width))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "parity_wide.py")],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-2500:])
+    assert f"mfma mode: {mode} width: {width}" in out.stdout
+    assert "all wide cases passed" in out.stdout

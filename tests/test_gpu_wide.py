@@ -3,11 +3,21 @@
 (shared / separate senders, sum / mean with empty receivers, update_edges on / off, stride-0
 batch-invariant inputs, narrow embedder inputs, the 17-wide output map), and proof that the wide
 kernels -- not the generic GEMM sequence -- are what runs.  fp32 bars (default bf16x3
-arithmetic): forward 1e-4, gradients 1e-3 relative to max|ref|."""
+arithmetic): forward 1e-4, gradients 1e-3 relative to max|ref|.
+
+The same cases run at hidden 256 on the feature-split kernels (csrc/fused_fs.hip) in bf16
+arithmetic -- NLAM_WIDE_D=256 NLAM_MFMA=bf16, in a process of its own (tools/parity_wide.py,
+driven by test_gpu_mfma_modes.py) -- with the bf16-mixed bars of SURVEY.md 8c (2e-2 / 2e-1)."""
+import os
+
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+
+D = int(os.environ.get("NLAM_WIDE_D", "128"))
+_BF16 = os.environ.get("NLAM_MFMA", "") == "bf16"
+FWD_BAR, GRAD_BAR = (2e-2, 2e-1) if _BF16 else (1e-4, 1e-3)
 
 
 def rel(a, b):
@@ -25,13 +35,14 @@ def _edges(gen, n_s, n_r, M, shared, empty_receivers=False):
 
 
 @pytest.mark.parametrize("shared,upd,aggr,B", [(True, True, "sum", 2), (False, False, "mean", 3),
-                                                (False, True, "mean", 1), (True, False, "sum", 2)])
+                                                (False, True, "mean", 1), (True, False, "sum", 2),
+                                                (True, True, "mean", 5)])
 def test_wide_interaction_net_vs_oracle(shared, upd, aggr, B):
     import nlam_oracle as orc
     from neural_lam_amd import wide
     from neural_lam_amd.interaction_net import InteractionNet
 
-    d = 128
+    d = D
     gen = torch.Generator().manual_seed(7 + B)
     n_s, n_r, M = (45, 45, 410) if shared else (70, 38, 333)
     ei = _edges(gen, n_s, n_r, M, shared, empty_receivers=(aggr == "mean"))
@@ -66,14 +77,14 @@ def test_wide_interaction_net_vs_oracle(shared, upd, aggr, B):
     eg = edge.cuda().requires_grad_(True)
     assert wide.inet_eligible(net, sg, rg, eg)
     g_r, g_e = run(net, sg, rg, eg, cr.cuda(), ce.cuda())
-    assert rel(g_r, w_r) < 1e-4
+    assert rel(g_r, w_r) < FWD_BAR
     if upd:
-        assert rel(g_e, w_e) < 1e-4
-    assert rel(sg.grad, sc.grad) < 1e-3 and rel(eg.grad, ec.grad) < 1e-3
+        assert rel(g_e, w_e) < FWD_BAR
+    assert rel(sg.grad, sc.grad) < GRAD_BAR and rel(eg.grad, ec.grad) < GRAD_BAR
     if not shared:
-        assert rel(rg.grad, rc.grad) < 1e-3
+        assert rel(rg.grad, rc.grad) < GRAD_BAR
     for k, p in net.named_parameters():
-        assert rel(p.grad, osd[f"n.{k}"].grad) < 1e-3, k
+        assert rel(p.grad, osd[f"n.{k}"].grad) < GRAD_BAR, k
 
 
 def test_wide_stride0_batch_inputs_match_oracle():
@@ -82,7 +93,7 @@ def test_wide_stride0_batch_inputs_match_oracle():
     from neural_lam_amd.interaction_net import InteractionNet
 
     gen = torch.Generator().manual_seed(21)
-    d, B, n_s, n_r, M = 128, 3, 60, 20, 150
+    d, B, n_s, n_r, M = D, 3, 60, 20, 150
     ei = _edges(gen, n_s, n_r, M, shared=False)
     torch.manual_seed(3)
     net = InteractionNet(ei, d, update_edges=False)
@@ -97,17 +108,22 @@ def test_wide_stride0_batch_inputs_match_oracle():
     sg, rg, eg = (t.cuda().requires_grad_(True) for t in (send, rec1, edge1))
     got = net(sg, rg.unsqueeze(0).expand(B, -1, -1), eg.unsqueeze(0).expand(B, -1, -1))
     (got ** 2).sum().backward()
-    assert rel(got, want) < 1e-4
-    assert rel(sg.grad, sc.grad) < 1e-3 and rel(rg.grad, rc.grad) < 1e-3 and rel(eg.grad, ec.grad) < 1e-3
+    assert rel(got, want) < FWD_BAR
+    assert (rel(sg.grad, sc.grad) < GRAD_BAR and rel(rg.grad, rc.grad) < GRAD_BAR
+            and rel(eg.grad, ec.grad) < GRAD_BAR)
 
 
-@pytest.mark.parametrize("blueprint,ln,res,rows,B", [
-    ([3, 128, 128], True, False, 77, 1),        # edge / mesh embedders (narrow static features)
-    ([17, 128, 128], True, False, 100, 2),      # grid embedder (unaligned 17-wide rows)
-    ([128, 128, 128], True, True, 131, 2),      # encoding_grid_mlp with fused residual
-    ([128, 128, 17], False, False, 90, 2),      # output map: no LayerNorm, 17 columns
-    ([128, 128, 5], False, False, 33, 1),
-])
+MLP_CASES = [
+    ([3, D, D], True, False, 77, 1),        # edge / mesh embedders (narrow static features)
+    ([17, D, D], True, False, 100, 2),      # grid embedder (unaligned 17-wide rows)
+    ([48, D, D], True, False, 70, 2),       # grid embedder, aligned 48-wide rows
+    ([D, D, D], True, True, 131, 2),        # encoding_grid_mlp with fused residual
+    ([D, D, 17], False, False, 90, 2),      # output map: no LayerNorm, 17 columns
+    ([D, D, 5], False, False, 33, 1),
+]
+
+
+@pytest.mark.parametrize("blueprint,ln,res,rows,B", MLP_CASES)
 def test_wide_mlp_vs_oracle(blueprint, ln, res, rows, B):
     import nlam_oracle as orc
     from neural_lam_amd import ops, utils, wide
@@ -139,12 +155,17 @@ def test_wide_mlp_vs_oracle(blueprint, ln, res, rows, B):
         ops.PROFILER = None
     names = {k.split("@")[0] for k in stats}
     assert {"nlam_tail_fwd", "nlam_tail_bwd", "nlam_wide_outer"} <= names
-    assert rel(got, want) < 1e-4
-    assert rel(xg.grad, xc.grad) < 1e-3
+    assert rel(got, want) < FWD_BAR
+    assert rel(xg.grad, xc.grad) < GRAD_BAR
     for k, p in mlp.named_parameters():
-        assert rel(p.grad, sd[f"m.{k}"].grad) < 1e-3, k
+        assert rel(p.grad, sd[f"m.{k}"].grad) < GRAD_BAR, k
 
 
+INET_CASES = [(True, True, "sum", 2), (False, False, "mean", 3), (False, True, "mean", 1),
+              (True, False, "sum", 2)]
+
+
+@pytest.mark.skipif(D != 128, reason="launch budget of the 128 path")
 def test_wide_paths_are_taken_at_hidden_128():
     """d = 128, hidden_layers = 1: the wide kernels must be the ones that run -- no generic GEMM
     on the 128-wide operands (narrow embedder inputs may use it for their first layer only)."""
