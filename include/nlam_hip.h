@@ -347,7 +347,12 @@ int nlam_wmse_bwd(const float* pred, const float* target, const float* keep,
  *   h_out[p] = h[p]                       (optional; (B, rows, d) contiguous rows, kept for backward)
  *   y[idx_y[p]] = m[p] (+ res[idx_y[p]])  (optional)
  *   agg[i] = inv_deg[i] * sum_{p: csr_rec[p] = i} m[p]          (optional, edge mode)
- * i.e. edge_mlp / aggr_mlp / embedder blocks after their first Linear (nlam_lin_fwd). */
+ * i.e. edge_mlp / aggr_mlp / embedder blocks after their first Linear (nlam_lin_fwd).
+ * d = 256 (NLAM_MFMA=bf16 only; csrc/fused_fs.hip): W2 silu(h) + b2 is rounded to bf16 before the
+ * LayerNorm -- the Linear output dtype under the reference's `--precision bf16-mixed` autocast
+ * (train_model.py:73-76) -- and z_keep (optional; (B, rows, d) bf16 rows, position order, batch
+ * pitch z_bstride elements) receives those rows for nlam_tail_bwd, which then needs no second
+ * GEMM.  d = 128 ignores z_keep (its backward repeats the GEMM from h). */
 int nlam_tail_fwd(const int32_t* tiles, int64_t ntiles, int64_t rows, const int32_t* csr_rec,
                   const int32_t* csr_rowptr,
                   const float* a, int64_t a_bstride, int64_t a_ld, const int32_t* idx_a,
@@ -355,6 +360,7 @@ int nlam_tail_fwd(const int32_t* tiles, int64_t ntiles, int64_t rows, const int3
                   const float* c, int64_t c_bstride, int64_t c_ld, const int32_t* idx_c,
                   const float* W2, int64_t ldW2, const float* b2, const float* gamma,
                   const float* beta, int n_out, float* h_out, int64_t h_bstride,
+                  void* z_keep, int64_t z_bstride,
                   float* y, int64_t y_bstride, int64_t y_ld, const int32_t* idx_y,
                   const float* res, int64_t res_bstride, int64_t res_ld,
                   float* agg, int64_t agg_bstride, int64_t agg_ld, const float* inv_deg,
@@ -364,10 +370,12 @@ int nlam_tail_fwd(const int32_t* tiles, int64_t ntiles, int64_t rows, const int3
  * gz_out (B, rows, ceil32(n_out)) for the weight-gradient pass;  gh[idx_gh[p]] =
  * (W2^T gz[p]) * silu'(h[p]);  gpr[i] = sum_{p: csr_rec[p] = i} gh[p] (optional, edge mode);
  * dgamma / dbeta as per-workgroup slabs [dgamma | dbeta] (count nlam_bwd_grid(B * ntiles),
- * pitch >= nlam_tail_bwd_slab_stride).  dW2 = gz^T silu(h), db2 = colsum(gz): nlam_wide_outer. */
+ * pitch >= nlam_tail_bwd_slab_stride).  dW2 = gz^T silu(h), db2 = colsum(gz): nlam_wide_outer.
+ * d = 256 with LayerNorm: z_keep = the rows nlam_tail_fwd kept (required). */
 int64_t nlam_tail_bwd_slab_stride(int n_out);
 int nlam_tail_bwd(const int32_t* tiles, int64_t ntiles, int64_t rows, const int32_t* csr_rec,
                   const int32_t* csr_rowptr, const float* h, int64_t h_bstride,
+                  const void* z_keep, int64_t z_bstride,
                   const float* g1, int64_t g1_bstride, int64_t g1_ld, const int32_t* idx_g1,
                   const float* scale1,
                   const float* g2, int64_t g2_bstride, int64_t g2_ld, const int32_t* idx_g2,
@@ -394,19 +402,20 @@ int nlam_wide_outer(const float* g, int64_t g_bstride, int64_t g_ld, int ng,
 /* Several INDEPENDENT problems of one kind in one launch (n <= 8; arrays of n entries): the small
  * mesh levels of Hi-LAM (reference hi_lam.py:82-207: 10 InteractionNets per processor layer on
  * 81 ... 6,561-node levels) are bound by the latency of their launches, not by their work.
- * nlam_lin_fwd_multi: out_k = x_k W_k^T + bias_k (bias_k may be NULL), all 128 -> 128.
- * nlam_lin_bwd_data_multi / nlam_wide_outer_multi: as the single forms, all 128 x 128. */
-int nlam_lin_fwd_multi(int n, const float* const* x, const int64_t* x_bstride, const int64_t* x_ld,
+ * nlam_lin_fwd_multi: out_k = x_k W_k^T + bias_k (bias_k may be NULL), all d -> d.
+ * nlam_lin_bwd_data_multi / nlam_wide_outer_multi: as the single forms, all d x d.
+ * d = 128, or 256 (NLAM_MFMA=bf16 only). */
+int nlam_lin_fwd_multi(int n, int d, const float* const* x, const int64_t* x_bstride, const int64_t* x_ld,
                        const float* const* W, const int64_t* ldW, const float* const* bias,
                        float* const* out, const int64_t* out_bstride, const int64_t* out_ld,
                        const int64_t* B, const int64_t* rows, void* stream);
-int nlam_lin_bwd_data_multi(int n, const float* const* gy, const int64_t* gy_bstride,
+int nlam_lin_bwd_data_multi(int n, int d, const float* const* gy, const int64_t* gy_bstride,
                             const int64_t* gy_ld, const float* const* W, const int64_t* ldW,
                             float* const* gx, const int64_t* gx_bstride, const int64_t* gx_ld,
                             const float* const* gx_add, const int64_t* ga_bstride,
                             const int64_t* ga_ld, const int64_t* B, const int64_t* rows,
                             void* stream);
-int nlam_wide_outer_multi(int n, const float* const* g, const int64_t* g_bstride,
+int nlam_wide_outer_multi(int n, int d, const float* const* g, const int64_t* g_bstride,
                           const int64_t* g_ld, const float* const* x, const int64_t* x_bstride,
                           const int64_t* x_ld, const int32_t* silu_x, float* const* slab,
                           const int64_t* slab_stride, const int64_t* B, const int64_t* rows,

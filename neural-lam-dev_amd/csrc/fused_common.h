@@ -646,3 +646,21 @@ __device__ __forceinline__ void fold_vec_lds(const float (&v)[NV], float* __rest
     __syncthreads();
   }
 }
+
+// Up to NLAM_WIDE_MAXP independent problems of one kernel type in ONE launch: Hi-LAM's small
+// mesh levels are bound by the latency of their ~24 launches per InteractionNet, not by work.
+// Workgroup b serves problem k with first[k] <= b < first[k + 1] as block b - first[k] of
+// first[k + 1] - first[k].
+#define NLAM_WIDE_MAXP 8
+template <typename P>
+struct WideMulti {
+  int n;
+  int first[NLAM_WIDE_MAXP + 1];
+  P p[NLAM_WIDE_MAXP];
+};
+template <typename P>
+__device__ __forceinline__ int wide_multi_find(const WideMulti<P>& m, int b) {
+  int k = 0;
+  while (k + 1 < m.n && b >= m.first[k + 1]) ++k;
+  return k;
+}

@@ -19,7 +19,7 @@ int nlam_fs_tail_fwd_256(
     const float* b, int64_t b_bstride, int64_t b_ld, const int32_t* idx_b,
     const float* c, int64_t c_bstride, int64_t c_ld, const int32_t* idx_c,
     const float* W2, int64_t ldW2, const float* b2, const float* gamma, const float* beta,
-    int n_out, float* h_out, int64_t h_bstride,
+    int n_out, float* h_out, int64_t h_bstride, void* z_keep, int64_t z_bstride,
     float* y, int64_t y_bstride, int64_t y_ld, const int32_t* idx_y,
     const float* res, int64_t res_bstride, int64_t res_ld,
     float* agg, int64_t agg_bstride, int64_t agg_ld, const float* inv_deg,
@@ -27,6 +27,7 @@ int nlam_fs_tail_fwd_256(
 int nlam_fs_tail_bwd_256(
     const int32_t* tiles, int64_t ntiles, int64_t rows, const int32_t* csr_rec,
     const int32_t* csr_rowptr, const float* h, int64_t h_bstride,
+    const void* z_keep, int64_t z_bstride,
     const float* g1, int64_t g1_bstride, int64_t g1_ld, const int32_t* idx_g1, const float* scale1,
     const float* g2, int64_t g2_bstride, int64_t g2_ld, const int32_t* idx_g2,
     const float* W2, int64_t ldW2, const float* b2, const float* gamma, int n_out,
@@ -38,3 +39,19 @@ int nlam_fs_outer_256(const float* g, int64_t g_bstride, int64_t g_ld, int ng,
                       const float* x, int64_t x_bstride, int64_t x_ld, int nx, int silu_x,
                       float* slab, int64_t slab_stride, int64_t B, int64_t rows, unsigned grid,
                       void* stream);
+int nlam_fs_lin_fwd_multi_256(int n, const float* const* x, const int64_t* x_bstride,
+                              const int64_t* x_ld, const float* const* W, const int64_t* ldW,
+                              const float* const* bias, float* const* out,
+                              const int64_t* out_bstride, const int64_t* out_ld, const int64_t* B,
+                              const int64_t* rows, void* stream);
+int nlam_fs_lin_bwd_data_multi_256(int n, const float* const* gy, const int64_t* gy_bstride,
+                                   const int64_t* gy_ld, const float* const* W, const int64_t* ldW,
+                                   float* const* gx, const int64_t* gx_bstride, const int64_t* gx_ld,
+                                   const float* const* gx_add, const int64_t* ga_bstride,
+                                   const int64_t* ga_ld, const int64_t* B, const int64_t* rows,
+                                   void* stream);
+int nlam_fs_outer_multi_256(int n, const float* const* g, const int64_t* g_bstride,
+                            const int64_t* g_ld, const float* const* x, const int64_t* x_bstride,
+                            const int64_t* x_ld, const int32_t* silu_x, float* const* slab,
+                            const int64_t* slab_stride, const int64_t* B, const int64_t* rows,
+                            const unsigned* grid, void* stream);

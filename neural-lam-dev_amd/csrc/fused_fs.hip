@@ -90,6 +90,52 @@ __device__ __forceinline__ void fs_load_w_cols(FsW<K, TERMS>& A, const float* __
   }
 }
 
+// The same slice, loaded by the whole workgroup through LDS: 64 rows of W at a time are read
+// with coalesced float4 loads, written TRANSPOSED as bf16 (T[col][k], pitch 68) and picked up as
+// fragments.  (The per-lane column walk above issues 128 strided dword loads per lane: ~50 us of
+// prologue, which is the whole run time on the small mesh levels of Hi-LAM.)  scratch: >= 256 *
+// 68 bf16; every thread of the 512-thread workgroup must call; ends with a barrier.
+template <int K, int TERMS>
+__device__ __forceinline__ void fs_load_w_cols_lds(FsW<K, TERMS>& A, const float* __restrict__ W,
+                                                   int64_t ldW, int col0, int n_rows,
+                                                   void* scratch, int tid) {
+  static_assert(K == 256 && TERMS == 1, "fs_load_w_cols_lds: 256-wide bf16 slices only");
+  constexpr int TP = 68;
+  __bf16* T = reinterpret_cast<__bf16*>(scratch);
+  const int lane = tid & 63;
+  const int i = lane & 31, h = lane >> 5;
+  const int c4 = tid & 63, rg = tid >> 6;   // 64 float4 chunk columns x 8 row groups
+  const bool vec = (ldW % 4 == 0) && ((reinterpret_cast<uintptr_t>(W) & 15u) == 0);
+#pragma unroll
+  for (int c = 0; c < K / 64; ++c) {   // (unrolled: A.hi must stay in registers)
+    f32x4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int row = 64 * c + rg + 8 * k;
+      const float* wr = W + (int64_t)(row < n_rows ? row : 0) * ldW + 4 * c4;
+      if (vec) {
+        v[k] = *reinterpret_cast<const f32x4*>(wr);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[k][j] = wr[j];
+      }
+      if (row >= n_rows) v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) T[(4 * c4 + j) * TP + rg + 8 * k] = (__bf16)v[k][j];
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const __bf16* tr = T + (col0 + i) * TP + 16 * u + 4 * h;
+      A.hi[4 * c + u] = b3_join(*reinterpret_cast<const bf16x4*>(tr),
+                                *reinterpret_cast<const bf16x4*>(tr + 8));
+    }
+    __syncthreads();
+  }
+}
+
 // shared row tile as bf16 planes: hi[R][P] (| lo[R][P]), P = K + 4 elements
 template <int K, int TERMS>
 struct FsPlanes {
@@ -261,44 +307,80 @@ __device__ __forceinline__ f32x16 fs_vec_block(const float* __restrict__ p, int 
 }
 
 // TRANS: out = x W (+ add) with W: k_in x n_out -- the data gradient gx = gy W of a Linear
-template <int D, int K, int TERMS, bool TRANS = false>
-__global__ __launch_bounds__(2 * D) void fs_lin_fwd_kernel(FsLinParams p) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+template <int D, int K, int TERMS, bool TRANS>
+__device__ __forceinline__ void fs_lin_fwd_body(const FsLinParams& p, const int bid, const int gdim,
+                                                float* smem) {
   constexpr int LDO = D + 4;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   FsPlanes<K, TERMS> X;
   X.init(smem);
   float* otile = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + FsPlanes<K, TERMS>::bytes);
   FsW<K, TERMS> A;
-  if (TRANS) fs_load_w_cols<K, TERMS>(A, p.W, p.ldW, 32 * wave, p.x.width, lane);
+  if constexpr (TRANS) fs_load_w_cols_lds<K, TERMS>(A, p.W, p.ldW, 32 * wave, p.x.width, otile, tid);
   else fs_load_w_rows<K, TERMS>(A, p.W, p.ldW, 32 * wave, p.n_out, p.x.width, lane);
   const f32x16 bias = fs_vec_block(p.bias, p.n_out, wave, lane);
   constexpr int CPR = D / 4;
   const int oc4 = tid % CPR, org = tid / CPR;    // output chunk column / row group (8 per pass)
   const int64_t tiles_per_b = (p.rows + FS_R - 1) / FS_R;
   const int64_t ntiles = tiles_per_b * p.B;
-  for (int64_t tt = blockIdx.x; tt < ntiles; tt += gridDim.x) {
-    const int64_t b = tt / tiles_per_b;
-    const int64_t r0 = (tt - b * tiles_per_b) * FS_R;
-    const int nrows = (int)((p.rows - r0) < FS_R ? (p.rows - r0) : FS_R);
-    fs_stage_x<D, K, TERMS>(X, p.x, b, r0, nrows, p.x_vec != 0, tid);
+  // float4 rows: the NEXT tile's rows (and addend rows) are in flight during this tile's GEMM
+  constexpr int XCPR = K / 4, XRPP = (2 * D) / XCPR, XNP = FS_R / XRPP;
+  const int xc4 = tid % XCPR, xrg = tid / XCPR;
+  const bool x_vec = p.x_vec != 0;
+  f32x4 vx[XNP];
+  auto tile_of = [&](int64_t tt, int64_t& b, int64_t& r0, int& nrows) {
+    b = tt / tiles_per_b;
+    r0 = (tt - b * tiles_per_b) * FS_R;
+    nrows = (int)((p.rows - r0) < FS_R ? (p.rows - r0) : FS_R);
+  };
+  auto issue = [&](int64_t tt) {
+    int64_t b, r0; int nrows;
+    tile_of(tt, b, r0, nrows);
+    const float* xb = p.x.ptr + b * p.x.bstride + r0 * p.x.ld;
+#pragma unroll
+    for (int k = 0; k < XNP; ++k) {
+      const int r = xrg + XRPP * k;
+      vx[k] = reinterpret_cast<const f32x4*>(xb + (int64_t)(r < nrows ? r : nrows - 1) * p.x.ld)[xc4];
+    }
+  };
+  if (x_vec && (int64_t)bid < ntiles) issue(bid);
+  for (int64_t tt = bid; tt < ntiles; tt += gdim) {
+    int64_t b, r0; int nrows;
+    tile_of(tt, b, r0, nrows);
+    if (x_vec) {
+#pragma unroll
+      for (int k = 0; k < XNP; ++k) {
+        const int r = xrg + XRPP * k;
+        f32x4 xx = vx[k];
+        if (r >= nrows) xx = f32x4{0.f, 0.f, 0.f, 0.f};
+        bf16x4 hi, lo;
+        b3_split4(xx, hi, lo);
+        *reinterpret_cast<bf16x4*>(X.hi + r * X.P + 4 * xc4) = hi;
+        if constexpr (TERMS == 3) *reinterpret_cast<bf16x4*>(X.lo + r * X.P + 4 * xc4) = lo;
+      }
+    } else {
+      fs_stage_x<D, K, TERMS>(X, p.x, b, r0, nrows, false, tid);
+    }
     __syncthreads();
+    if (x_vec && tt + gdim < ntiles) issue(tt + gdim);
+    const int nc4 = p.n_out >> 2;   // (n_out % 4 == 0, checked on the host)
+    f32x4 av[8];
+    if (p.add != nullptr) {
+      const float* ab = p.add + b * p.add_bstride + r0 * p.add_ld;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int r = org + 8 * k;
+        av[k] = reinterpret_cast<const f32x4*>(ab + (int64_t)(r < nrows ? r : nrows - 1) * p.add_ld)
+            [oc4 < nc4 ? oc4 : 0];
+      }
+    }
     f32x16 acc[2] = {bias, bias};
     fs_gemm<K, TERMS>(acc, A, X, lane);
     fs_acc_to_tile<LDO>(acc, otile, wave, lane);
     __syncthreads();
     {
       float* ob = p.out + b * p.out_bstride + r0 * p.out_ld;
-      const int nc4 = p.n_out >> 2;   // (n_out % 4 == 0, checked on the host)
       if (p.add != nullptr) {
-        const float* ab = p.add + b * p.add_bstride + r0 * p.add_ld;
-        f32x4 av[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const int r = org + 8 * k;
-          av[k] = reinterpret_cast<const f32x4*>(ab + (int64_t)(r < nrows ? r : nrows - 1) * p.add_ld)
-              [oc4 < nc4 ? oc4 : 0];
-        }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
           const int r = org + 8 * k;
@@ -322,6 +404,15 @@ __global__ __launch_bounds__(2 * D) void fs_lin_fwd_kernel(FsLinParams p) {
   }
 }
 
+// one launch, up to NLAM_WIDE_MAXP independent problems (fused_common.h: WideMulti)
+template <int D, int K, int TERMS, bool TRANS = false>
+__global__ __launch_bounds__(2 * D) void fs_lin_fwd_kernel(WideMulti<FsLinParams> m) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int k = wide_multi_find(m, blockIdx.x);
+  fs_lin_fwd_body<D, K, TERMS, TRANS>(m.p[k], blockIdx.x - m.first[k], m.first[k + 1] - m.first[k],
+                                      smem);
+}
+
 static unsigned fs_grid(int64_t ntiles) {
   int64_t g = ntiles;
   if (g > 256) g = 256;
@@ -329,16 +420,44 @@ static unsigned fs_grid(int64_t ntiles) {
   return (unsigned)g;
 }
 
+// grid shares of a multi launch: fs_grid() each, scaled down to <= 256 workgroups in all (one
+// 512-thread workgroup is resident per CU)
+template <typename P, typename TilesOf>
+static unsigned fs_multi_grid(WideMulti<P>& m, TilesOf tiles_of) {
+  int64_t want[NLAM_WIDE_MAXP], sum = 0;
+  for (int k = 0; k < m.n; ++k) {
+    want[k] = fs_grid(tiles_of(m.p[k]));
+    sum += want[k];
+  }
+  m.first[0] = 0;
+  for (int k = 0; k < m.n; ++k) {
+    int64_t g = sum > 256 ? (want[k] * 256 + sum - 1) / sum : want[k];
+    if (g < 1) g = 1;
+    m.first[k + 1] = m.first[k] + (int)g;
+  }
+  for (int k = m.n; k < NLAM_WIDE_MAXP; ++k) m.first[k + 1] = m.first[m.n];
+  return (unsigned)m.first[m.n];
+}
+
 template <int D, int K, int TERMS, bool TRANS = false>
-static int launch_fs_lin_fwd(const FsLinParams& p, hipStream_t s) {
+static int launch_fs_lin_fwd(WideMulti<FsLinParams>& m, hipStream_t s) {
   const size_t lds = FsPlanes<K, TERMS>::bytes + (size_t)FS_R * (D + 4) * sizeof(float);
   NLAM_REQUIRE(lds <= 160 * 1024, "fs_lin_fwd: LDS footprint %zu B exceeds 160 KiB", lds);
   auto kern = fs_lin_fwd_kernel<D, K, TERMS, TRANS>;
   NLAM_BIG_LDS(kern, "fs_lin_fwd_kernel");
-  const int64_t ntiles = ((p.rows + FS_R - 1) / FS_R) * p.B;
-  kern<<<fs_grid(ntiles), 2 * D, lds, s>>>(p);
+  const unsigned grid = fs_multi_grid(m, [](const FsLinParams& p) {
+    return ((p.rows + FS_R - 1) / FS_R) * p.B;
+  });
+  kern<<<grid, 2 * D, lds, s>>>(m);
   NLAM_CHECK_LAUNCH("fs_lin_fwd_kernel");
   return 0;
+}
+template <int D, int K, int TERMS, bool TRANS = false>
+static int launch_fs_lin_fwd(const FsLinParams& p, hipStream_t s) {
+  WideMulti<FsLinParams> m;
+  m.n = 1;
+  m.p[0] = p;
+  return launch_fs_lin_fwd<D, K, TERMS, TRANS>(m, s);
 }
 
 // out = x W^T + bias for x: (B, rows, k_in <= 256) fp32, W: 256 x k_in; NLAM_MFMA=bf16.
@@ -384,6 +503,75 @@ int nlam_fs_lin_bwd_data_256(const float* gy, int64_t gy_bstride, int64_t gy_ld,
   return launch_fs_lin_fwd<256, 256, 1, true>(p, (hipStream_t)stream);
 }
 
+// accumulator blocks -> bf16 planes (hi only / hi + lo)
+template <int D, int TERMS>
+__device__ __forceinline__ void fs_acc_to_planes(const f32x16 (&acc)[2], const FsPlanes<D, TERMS>& X,
+                                                 int wave, int lane) {
+  const int t = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 v = {acc[rb][4 * q], acc[rb][4 * q + 1], acc[rb][4 * q + 2], acc[rb][4 * q + 3]};
+      bf16x4 hi, lo;
+      b3_split4(v, hi, lo);
+      const int off = (32 * rb + t) * X.P + 32 * wave + 8 * q + 4 * h;
+      *reinterpret_cast<bf16x4*>(X.hi + off) = hi;
+      if constexpr (TERMS == 3) *reinterpret_cast<bf16x4*>(X.lo + off) = lo;
+    }
+}
+
+// n <= NLAM_WIDE_MAXP independent 256 -> 256 problems in one launch (aligned 256-wide rows)
+int nlam_fs_lin_fwd_multi_256(int n, const float* const* x, const int64_t* x_bstride,
+                              const int64_t* x_ld, const float* const* W, const int64_t* ldW,
+                              const float* const* bias, float* const* out,
+                              const int64_t* out_bstride, const int64_t* out_ld, const int64_t* B,
+                              const int64_t* rows, void* stream) {
+  NLAM_REQUIRE(nlam_mfma_terms() == 1, "hidden 256 needs NLAM_MFMA=bf16");
+  WideMulti<FsLinParams> m;
+  m.n = 0;
+  for (int k = 0; k < n; ++k) {
+    if (B[k] <= 0 || rows[k] <= 0) continue;
+    NLAM_REQUIRE(view_vec_ok(x[k], x_bstride[k], x_ld[k], 256) &&
+                     view_vec_ok(out[k], out_bstride[k], out_ld[k], 256),
+                 "nlam_lin_fwd_multi: operand rows must be 16-byte aligned, width 256");
+    FsLinParams& p = m.p[m.n++];
+    p.x = RowView{x[k], x_bstride[k], x_ld[k], 256};
+    p.W = W[k]; p.ldW = ldW[k]; p.bias = bias[k]; p.n_out = 256;
+    p.out = out[k]; p.out_bstride = out_bstride[k]; p.out_ld = out_ld[k];
+    p.add = nullptr; p.add_bstride = 0; p.add_ld = 0;
+    p.rows = rows[k]; p.B = (int)B[k]; p.x_vec = 1;
+  }
+  if (m.n == 0) return 0;
+  return launch_fs_lin_fwd<256, 256, 1>(m, (hipStream_t)stream);
+}
+
+int nlam_fs_lin_bwd_data_multi_256(int n, const float* const* gy, const int64_t* gy_bstride,
+                                   const int64_t* gy_ld, const float* const* W, const int64_t* ldW,
+                                   float* const* gx, const int64_t* gx_bstride, const int64_t* gx_ld,
+                                   const float* const* gx_add, const int64_t* ga_bstride,
+                                   const int64_t* ga_ld, const int64_t* B, const int64_t* rows,
+                                   void* stream) {
+  NLAM_REQUIRE(nlam_mfma_terms() == 1, "hidden 256 needs NLAM_MFMA=bf16");
+  WideMulti<FsLinParams> m;
+  m.n = 0;
+  for (int k = 0; k < n; ++k) {
+    if (B[k] <= 0 || rows[k] <= 0) continue;
+    NLAM_REQUIRE(view_vec_ok(gy[k], gy_bstride[k], gy_ld[k], 256) &&
+                     view_vec_ok(gx[k], gx_bstride[k], gx_ld[k], 256) &&
+                     (gx_add[k] == nullptr || view_vec_ok(gx_add[k], ga_bstride[k], ga_ld[k], 256)),
+                 "nlam_lin_bwd_data_multi: operand rows must be 16-byte aligned, width 256");
+    FsLinParams& p = m.p[m.n++];
+    p.x = RowView{gy[k], gy_bstride[k], gy_ld[k], 256};
+    p.W = W[k]; p.ldW = ldW[k]; p.bias = nullptr; p.n_out = 256;
+    p.out = gx[k]; p.out_bstride = gx_bstride[k]; p.out_ld = gx_ld[k];
+    p.add = gx_add[k]; p.add_bstride = ga_bstride[k]; p.add_ld = ga_ld[k];
+    p.rows = rows[k]; p.B = (int)B[k]; p.x_vec = 1;
+  }
+  if (m.n == 0) return 0;
+  return launch_fs_lin_fwd<256, 256, 1, true>(m, (hipStream_t)stream);
+}
+
 // ========================================================================= tail forward ===
 struct FsTailFwdParams {
   FsTiling tl;
@@ -393,6 +581,7 @@ struct FsTailFwdParams {
   const float* W2; int64_t ldW2; const float* b2; const float* gamma; const float* beta;
   int n_out;
   float* h_out; int64_t h_bstride;
+  __bf16* z_keep; int64_t z_bstride;     // optional (HAS_LN): the pre-LayerNorm rows, bf16, position order
   float* y; int64_t y_bstride; int64_t y_ld; const int32_t* idx_y;
   RowView res;
   float* agg; int64_t agg_bstride; int64_t agg_ld; const float* inv_deg;
@@ -450,25 +639,39 @@ __global__ __launch_bounds__(2 * D) void fs_tail_fwd_kernel(FsTailFwdParams p) {
   S.init(smem);
   float* mtile = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + FsPlanes<D, TERMS>::bytes);
   float* red = mtile + FS_R * LDO;                 // [2][FS_R][NW]
-  int* itab = reinterpret_cast<int*>(red + 2 * FS_R * NW);   // [4][FS_R]: a, b, c, y
+  int* itab0 = reinterpret_cast<int*>(red + 2 * FS_R * NW);   // [2][4][FS_R]: a, b, c, y
   FsW<D, TERMS> A;
   fs_load_w_rows<D, TERMS>(A, p.W2, p.ldW2, 32 * wave, p.n_out, D, lane);
-  const f32x16 b2v = fs_vec_block(p.b2, p.n_out, wave, lane);
-  const f32x16 gav = fs_vec_block(p.gamma, p.n_out, wave, lane);
-  const f32x16 bev = fs_vec_block(p.beta, p.n_out, wave, lane);
   const int c4 = tid % CPR, rg = tid / CPR;        // staging map: rows rg + 8 k
   const int64_t nsub = p.tl.ntiles * p.tl.B;
   const int64_t ntiles = (nsub + 1) / 2;
-  for (int64_t tt = blockIdx.x; tt < ntiles; tt += gridDim.x) {
+  // slot -> row tables, double buffered: the NEXT tile's indices are fetched while this tile
+  // computes (a dependent global load per tile would otherwise sit on the critical path of the
+  // lock-stepped workgroup)
+  int nidx[4];
+  auto fetch_idx = [&](int64_t tt) {
     const FsSub2 sub = {fs_sub(p.tl, 2 * tt), fs_sub(p.tl, 2 * tt + 1)};
-    if (tid < FS_R) {
-      const int pos = fs_slot_pos(sub, tid);
-      itab[tid] = p.idx_a ? p.idx_a[pos] : pos;
-      itab[FS_R + tid] = (p.b.ptr && p.idx_b) ? p.idx_b[pos] : pos;
-      itab[2 * FS_R + tid] = (p.c.ptr && p.idx_c) ? p.idx_c[pos] : pos;
-      itab[3 * FS_R + tid] = p.idx_y ? p.idx_y[pos] : pos;
-    }
-    __syncthreads();
+    const int pos = fs_slot_pos(sub, tid & (FS_R - 1));
+    nidx[0] = p.idx_a ? p.idx_a[pos] : pos;
+    nidx[1] = (p.b.ptr && p.idx_b) ? p.idx_b[pos] : pos;
+    nidx[2] = (p.c.ptr && p.idx_c) ? p.idx_c[pos] : pos;
+    nidx[3] = p.idx_y ? p.idx_y[pos] : pos;
+  };
+  auto put_idx = [&](int* tab) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) tab[k * FS_R + tid] = nidx[k];
+  };
+  int par = 0;
+  if (tid < FS_R && (int64_t)blockIdx.x < ntiles) {
+    fetch_idx(blockIdx.x);
+    put_idx(itab0);
+  }
+  __syncthreads();
+  for (int64_t tt = blockIdx.x; tt < ntiles; tt += gridDim.x, par ^= 1) {
+    const FsSub2 sub = {fs_sub(p.tl, 2 * tt), fs_sub(p.tl, 2 * tt + 1)};
+    const int* itab = itab0 + par * 4 * FS_R;
+    const bool more = tt + gridDim.x < ntiles;
+    if (tid < FS_R && more) fetch_idx(tt + gridDim.x);
     // ---- h = a + b + c (row layout), keep h, s = silu(h) -> planes
     {
       f32x4 v[8];
@@ -515,9 +718,30 @@ __global__ __launch_bounds__(2 * D) void fs_tail_fwd_kernel(FsTailFwdParams p) {
       }
     }
     __syncthreads();
-    f32x16 z[2] = {b2v, b2v};
+    // residual rows: in flight during the GEMM and the LayerNorm exchange
+    f32x4 rv[8];
+    const bool res_vec = p.y != nullptr && p.vec_y && p.res.ptr != nullptr;
+    if (res_vec) {
+      const int cc = c4 < (p.n_out >> 2) ? c4 : 0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int r = rg + 8 * k;
+        rv[k] = reinterpret_cast<const f32x4*>(p.res.ptr + sub.b(r >> 5) * p.res.bstride +
+                                               (int64_t)itab[3 * FS_R + r] * p.res.ld)[cc];
+      }
+    }
+    f32x16 z[2];
+    z[0] = fs_vec_block(p.b2, p.n_out, wave, lane);
+    z[1] = z[0];
     fs_gemm<D, TERMS>(z, A, S, lane);
     if (HAS_LN) {
+      // The Linear output is a bf16 tensor, as under the reference's autocast (LayerNorm then
+      // works in fp32 on those bf16 values): the backward reads the kept bf16 rows instead of
+      // repeating this GEMM, and sees exactly the values normalised here.
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[rb][r] = (float)(__bf16)z[rb][r];
       // LayerNorm over the D features of a row = over the NW waves: exchange through LDS
       const float inv_n = 1.0f / (float)p.n_out;
       float mean[2], rstd[2];
@@ -530,6 +754,7 @@ __global__ __launch_bounds__(2 * D) void fs_tail_fwd_kernel(FsTailFwdParams p) {
         if (h == 0) red[(32 * rb + t) * NW + wave] = sm;
       }
       __syncthreads();
+      if (p.z_keep != nullptr) fs_acc_to_planes<D, TERMS>(z, S, wave, lane);   // (every GEMM is done)
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb) {
         float sm = 0.f;
@@ -552,11 +777,27 @@ __global__ __launch_bounds__(2 * D) void fs_tail_fwd_kernel(FsTailFwdParams p) {
 #pragma unroll
         for (int w = 0; w < NW; ++w) vs += red[FS_R * NW + (32 * rb + t) * NW + w];
         rstd[rb] = rsqrtf(vs * inv_n + 1e-5f);
+      }
+      if (p.z_keep != nullptr) {   // whole bf16 rows, coalesced (the planes are complete: barrier above)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int r = rg + 8 * k;
+          const int rb = r >> 5;
+          if ((r & 31) < sub.ne(rb))
+            reinterpret_cast<bf16x4*>(p.z_keep + sub.b(rb) * p.z_bstride +
+                                      (int64_t)(sub.p0(rb) + (r & 31)) * D)[c4] =
+                *reinterpret_cast<const bf16x4*>(S.hi + r * S.P + 4 * c4);
+        }
+      }
+      const f32x16 gav = fs_vec_block(p.gamma, p.n_out, wave, lane);
+      const f32x16 bev = fs_vec_block(p.beta, p.n_out, wave, lane);
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) z[rb][r] = (z[rb][r] - mean[rb]) * rstd[rb] * gav[r] + bev[r];
-      }
     }
     fs_acc_to_tile<LDO>(z, mtile, wave, lane);
+    if (tid < FS_R && more) put_idx(itab0 + (par ^ 1) * 4 * FS_R);
     __syncthreads();
     // ---- outputs from the fp32 tile: receiver aggregation, whole-row stores
     if (p.agg != nullptr) {
@@ -578,8 +819,7 @@ __global__ __launch_bounds__(2 * D) void fs_tail_fwd_kernel(FsTailFwdParams p) {
           if ((r & 31) < sub.ne(rb) && c4 < nc4) {
             const int64_t row = itab[3 * FS_R + r];
             f32x4 o = *reinterpret_cast<const f32x4*>(mtile + r * LDO + 4 * c4);
-            if (p.res.ptr != nullptr)
-              o += reinterpret_cast<const f32x4*>(p.res.ptr + sub.b(rb) * p.res.bstride + row * p.res.ld)[c4];
+            if (p.res.ptr != nullptr) o += rv[k];
             reinterpret_cast<f32x4*>(p.y + sub.b(rb) * p.y_bstride + row * p.y_ld)[c4] = o;
           }
         }
@@ -596,14 +836,16 @@ __global__ __launch_bounds__(2 * D) void fs_tail_fwd_kernel(FsTailFwdParams p) {
         }
       }
     }
-    __syncthreads();   // tables / tiles are rewritten by the next iteration
+    // (no barrier here: the next iteration writes the S planes -- free since every wave passed
+    //  the barriers behind its GEMM -- and touches the output tile, the LayerNorm exchange
+    //  and this tile's index table only behind its own first barrier)
   }
 }
 
 template <int D, bool HAS_LN, int TERMS>
 static int launch_fs_tail_fwd(const FsTailFwdParams& p, hipStream_t s) {
   const size_t lds = FsPlanes<D, TERMS>::bytes + (size_t)FS_R * (D + 4) * sizeof(float) +
-                     (size_t)2 * FS_R * (D / 32) * sizeof(float) + (size_t)4 * FS_R * sizeof(int);
+                     (size_t)2 * FS_R * (D / 32) * sizeof(float) + (size_t)8 * FS_R * sizeof(int);
   NLAM_REQUIRE(lds <= 160 * 1024, "fs_tail_fwd: LDS footprint %zu B exceeds 160 KiB", lds);
   auto kern = fs_tail_fwd_kernel<D, HAS_LN, TERMS>;
   NLAM_BIG_LDS(kern, "fs_tail_fwd_kernel");
@@ -620,12 +862,15 @@ int nlam_fs_tail_fwd_256(
     const float* b, int64_t b_bstride, int64_t b_ld, const int32_t* idx_b,
     const float* c, int64_t c_bstride, int64_t c_ld, const int32_t* idx_c,
     const float* W2, int64_t ldW2, const float* b2, const float* gamma, const float* beta,
-    int n_out, float* h_out, int64_t h_bstride,
+    int n_out, float* h_out, int64_t h_bstride, void* z_keep, int64_t z_bstride,
     float* y, int64_t y_bstride, int64_t y_ld, const int32_t* idx_y,
     const float* res, int64_t res_bstride, int64_t res_ld,
     float* agg, int64_t agg_bstride, int64_t agg_ld, const float* inv_deg,
     int64_t B, void* stream) {
   constexpr int d = 256;
+  NLAM_REQUIRE(z_keep == nullptr || (gamma != nullptr && (reinterpret_cast<uintptr_t>(z_keep) & 7u) == 0 &&
+                                     z_bstride % 4 == 0),
+               "nlam_tail_fwd: z_keep needs the LayerNorm form and 8-byte aligned rows");
   NLAM_REQUIRE(nlam_mfma_terms() == 1, "hidden 256 needs NLAM_MFMA=bf16");
   NLAM_REQUIRE(n_out >= 1 && n_out <= d, "nlam_tail_fwd: n_out %d out of range", n_out);
   NLAM_REQUIRE(gamma == nullptr || n_out == d, "nlam_tail_fwd: LayerNorm needs n_out == d");
@@ -644,6 +889,7 @@ int nlam_fs_tail_fwd_256(
   p.c = RowView{c, c_bstride, c_ld, d}; p.idx_c = idx_c;
   p.W2 = W2; p.ldW2 = ldW2; p.b2 = b2; p.gamma = gamma; p.beta = beta; p.n_out = n_out;
   p.h_out = h_out; p.h_bstride = h_bstride;
+  p.z_keep = reinterpret_cast<__bf16*>(z_keep); p.z_bstride = z_bstride;
   p.y = y; p.y_bstride = y_bstride; p.y_ld = y_ld; p.idx_y = idx_y;
   p.res = RowView{res, res_bstride, res_ld, n_out};
   p.agg = agg; p.agg_bstride = agg_bstride; p.agg_ld = agg_ld; p.inv_deg = inv_deg;
@@ -695,6 +941,7 @@ __device__ __forceinline__ void fs_acc_to_planes1(const f32x16& acc, const FsPla
 struct FsTailBwdParams {
   FsTiling tl;
   const float* h; int64_t h_bstride;
+  const __bf16* z_keep; int64_t z_bstride;   // HAS_LN: the bf16 pre-LayerNorm rows kept by the forward
   RowView g1; const int32_t* idx_g1; const float* scale1;
   RowView g2; const int32_t* idx_g2;
   const float* W2; int64_t ldW2; const float* b2; const float* gamma; int n_out;
@@ -705,41 +952,21 @@ struct FsTailBwdParams {
   int vec_g;
 };
 
-// accumulator blocks -> bf16 planes (hi only / hi + lo)
-template <int D, int TERMS>
-__device__ __forceinline__ void fs_acc_to_planes(const f32x16 (&acc)[2], const FsPlanes<D, TERMS>& X,
-                                                 int wave, int lane) {
-  const int t = lane & 31, h = lane >> 5;
-#pragma unroll
-  for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      f32x4 v = {acc[rb][4 * q], acc[rb][4 * q + 1], acc[rb][4 * q + 2], acc[rb][4 * q + 3]};
-      bf16x4 hi, lo;
-      b3_split4(v, hi, lo);
-      const int off = (32 * rb + t) * X.P + 32 * wave + 8 * q + 4 * h;
-      *reinterpret_cast<bf16x4*>(X.hi + off) = hi;
-      if constexpr (TERMS == 3) *reinterpret_cast<bf16x4*>(X.lo + off) = lo;
-    }
-}
-
 template <int D, bool HAS_LN, int TERMS>
 __global__ __launch_bounds__(2 * D) void fs_tail_bwd_kernel(FsTailBwdParams q) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NT = 2 * D, NW = D / 32, LDO = D + 4, CPR = D / 4;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int t = lane & 31, h = lane >> 5;
-  FsPlanes<D, TERMS> S;      // silu(h), later gz
+  FsPlanes<D, TERMS> S;      // kept z rows (bf16), later gz
   S.init(smem);
   __bf16* DS = reinterpret_cast<__bf16*>(reinterpret_cast<char*>(smem) + FsPlanes<D, TERMS>::bytes);
   constexpr int PD = D + 4;  // silu'(h) as one bf16 plane (2^-9 relative: inside the bf16-mixed budget)
   float* gtile = reinterpret_cast<float*>(reinterpret_cast<char*>(DS) + (size_t)FS_R * PD * sizeof(__bf16));
   float* red = gtile + FS_R * LDO;                            // [2][FS_R][NW]
-  int* itab = reinterpret_cast<int*>(red + 2 * FS_R * NW);    // [3][FS_R]: g1, g2, gh
-  float* stab = reinterpret_cast<float*>(itab + 3 * FS_R);    // [FS_R] row scales
-  FsW<D, TERMS> A1, A2;
-  fs_load_w_rows<D, TERMS>(A1, q.W2, q.ldW2, 32 * wave, q.n_out, D, lane);
-  fs_load_w_cols<D, TERMS>(A2, q.W2, q.ldW2, 32 * wave, q.n_out, lane);
+  int* itab0 = reinterpret_cast<int*>(red + 2 * FS_R * NW);   // [2][4][FS_R]: g1, g2, gh, scale
+  FsW<D, TERMS> A2;
+  fs_load_w_cols_lds<D, TERMS>(A2, q.W2, q.ldW2, 32 * wave, q.n_out, gtile, tid);
   f32x16 dgam, dbet;
 #pragma unroll
   for (int r = 0; r < 16; ++r) dgam[r] = dbet[r] = 0.f;
@@ -747,48 +974,55 @@ __global__ __launch_bounds__(2 * D) void fs_tail_bwd_kernel(FsTailBwdParams q) {
   const int NO = (q.n_out + 31) & ~31;
   const int64_t nsub = q.tl.ntiles * q.tl.B;
   const int64_t ntiles = (nsub + 1) / 2;
-  for (int64_t tt = blockIdx.x; tt < ntiles; tt += gridDim.x) {
+  // double-buffered slot tables (see fs_tail_fwd_kernel): next tile's indices fetched early, its
+  // row scales (a dependent load) once the indices have arrived
+  int nidx[3];
+  auto fetch_idx = [&](int64_t tt) {
     const FsSub2 sub = {fs_sub(q.tl, 2 * tt), fs_sub(q.tl, 2 * tt + 1)};
-    if (tid < FS_R) {
-      const int pos = fs_slot_pos(sub, tid);
-      const int i1 = q.idx_g1 ? q.idx_g1[pos] : pos;
-      itab[tid] = i1;
-      itab[FS_R + tid] = (q.g2.ptr && q.idx_g2) ? q.idx_g2[pos] : pos;
-      itab[2 * FS_R + tid] = q.idx_gh ? q.idx_gh[pos] : pos;
-      stab[tid] = q.scale1 ? q.scale1[i1] : 1.0f;
-    }
-    __syncthreads();
-    // ---- stage: s = silu(h), silu'(h) as planes; g = scale * g1[idx] + g2[idx] as fp32 rows
-    // (four rows per thread in flight at a time: the two weight slices hold 128 registers)
+    const int pos = fs_slot_pos(sub, tid & (FS_R - 1));
+    nidx[0] = q.idx_g1 ? q.idx_g1[pos] : pos;
+    nidx[1] = (q.g2.ptr && q.idx_g2) ? q.idx_g2[pos] : pos;
+    nidx[2] = q.idx_gh ? q.idx_gh[pos] : pos;
+  };
+  auto put_idx = [&](int* tab) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) tab[k * FS_R + tid] = nidx[k];
+    reinterpret_cast<float*>(tab)[3 * FS_R + tid] = q.scale1 ? q.scale1[nidx[0]] : 1.0f;
+  };
+  int par = 0;
+  if (tid < FS_R && (int64_t)blockIdx.x < ntiles) {
+    fetch_idx(blockIdx.x);
+    put_idx(itab0);
+  }
+  __syncthreads();
+  for (int64_t tt = blockIdx.x; tt < ntiles; tt += gridDim.x, par ^= 1) {
+    const FsSub2 sub = {fs_sub(q.tl, 2 * tt), fs_sub(q.tl, 2 * tt + 1)};
+    const int* itab = itab0 + par * 4 * FS_R;
+    const float* stab = reinterpret_cast<const float*>(itab + 3 * FS_R);
+    const bool more = tt + gridDim.x < ntiles;
+    if (tid < FS_R && more) fetch_idx(tt + gridDim.x);
+    // ---- stage: silu'(h) as a bf16 plane, the kept z rows (already bf16) into the S planes,
+    //      g = scale * g1[idx] + g2[idx] as fp32 rows
     {
-#pragma unroll 1
-      for (int k0 = 0; k0 < 8; k0 += 4) {
-        f32x4 vh[4];
+      f32x4 vh[8];
+      bf16x4 vz[8];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int r = rg + 8 * (k0 + k);
-          const int pos = fs_slot_pos(sub, r);
-          vh[k] = reinterpret_cast<const f32x4*>(q.h + sub.b(r >> 5) * q.h_bstride + (int64_t)pos * D)[c4];
-        }
+      for (int k = 0; k < 8; ++k) {
+        const int r = rg + 8 * k;
+        const int pos = fs_slot_pos(sub, r);
+        vh[k] = reinterpret_cast<const f32x4*>(q.h + sub.b(r >> 5) * q.h_bstride + (int64_t)pos * D)[c4];
+        if (HAS_LN)
+          vz[k] = reinterpret_cast<const bf16x4*>(q.z_keep + sub.b(r >> 5) * q.z_bstride + (int64_t)pos * D)[c4];
+      }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int r = rg + 8 * (k0 + k);
-          const bool valid = (r & 31) < sub.ne(r >> 5);
-          f32x4 sv, dv;
+      for (int k = 0; k < 8; ++k) {
+        const int r = rg + 8 * k;
+        const bool valid = (r & 31) < sub.ne(r >> 5);
+        bf16x4 dh;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            sv[j] = valid ? nlam_silu(vh[k][j]) : 0.f;
-            dv[j] = valid ? nlam_silu_grad(vh[k][j]) : 0.f;
-          }
-          bf16x4 hi, lo;
-          b3_split4(sv, hi, lo);
-          *reinterpret_cast<bf16x4*>(S.hi + r * S.P + 4 * c4) = hi;
-          if constexpr (TERMS == 3) *reinterpret_cast<bf16x4*>(S.lo + r * S.P + 4 * c4) = lo;
-          bf16x4 dh;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) dh[j] = (__bf16)dv[j];
-          *reinterpret_cast<bf16x4*>(DS + r * PD + 4 * c4) = dh;
-        }
+        for (int j = 0; j < 4; ++j) dh[j] = (__bf16)(valid ? nlam_silu_grad(vh[k][j]) : 0.f);
+        *reinterpret_cast<bf16x4*>(DS + r * PD + 4 * c4) = dh;
+        if (HAS_LN) *reinterpret_cast<bf16x4*>(S.hi + r * S.P + 4 * c4) = vz[k];
       }
       if (q.vec_g) {
 #pragma unroll 1
@@ -836,11 +1070,18 @@ __global__ __launch_bounds__(2 * D) void fs_tail_bwd_kernel(FsTailBwdParams q) {
     }
     __syncthreads();
     // Every wave reads and writes only its own 32 columns of the g tile, so g -> gamma*g -> gz
-    // is done in place there, one row block at a time (register budget: A1 + A2 + z + dgam/dbet).
+    // is done in place there, one row block at a time; likewise z -> gz in the S planes.
     if (HAS_LN) {
-      const f32x16 b2v = fs_vec_block(q.b2, q.n_out, wave, lane);
-      f32x16 z[2] = {b2v, b2v};
-      fs_gemm<D, TERMS>(z, A1, S, lane);
+      // z: the forward's bf16 rows (its LayerNorm input), this wave's 32 features
+      f32x16 z[2];
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+          const bf16x4 zv = *reinterpret_cast<const bf16x4*>(S.hi + (32 * rb + t) * S.P + 32 * wave + 8 * qq + 4 * h);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) z[rb][4 * qq + j] = (float)zv[j];
+        }
       const float inv_n = 1.0f / (float)q.n_out;
       float mean[2], rstd[2];
 #pragma unroll
@@ -903,7 +1144,7 @@ __global__ __launch_bounds__(2 * D) void fs_tail_bwd_kernel(FsTailBwdParams q) {
           }
         }
       }
-      __syncthreads();   // s1 / s2 complete; every wave is past its z GEMM: the S planes are free
+      __syncthreads();   // s1 / s2 complete
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb) {
         float s1 = 0.f, s2 = 0.f;
@@ -957,6 +1198,7 @@ __global__ __launch_bounds__(2 * D) void fs_tail_bwd_kernel(FsTailBwdParams q) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) gh[rb][4 * qq + j] *= (float)dv[j];
       }
+    if (tid < FS_R && more) put_idx(itab0 + (par ^ 1) * 4 * FS_R);
     __syncthreads();   // the gz rows have been read from the tile
     fs_acc_to_tile<LDO>(gh, gtile, wave, lane);
     __syncthreads();
@@ -1002,7 +1244,7 @@ template <int D, bool HAS_LN, int TERMS>
 static int launch_fs_tail_bwd(const FsTailBwdParams& q, hipStream_t s, unsigned grid) {
   const size_t lds = FsPlanes<D, TERMS>::bytes + (size_t)FS_R * (D + 4) * sizeof(__bf16) +
                      (size_t)FS_R * (D + 4) * sizeof(float) +
-                     (size_t)2 * FS_R * (D / 32) * sizeof(float) + (size_t)4 * FS_R * sizeof(int);
+                     (size_t)2 * FS_R * (D / 32) * sizeof(float) + (size_t)8 * FS_R * sizeof(int);
   NLAM_REQUIRE(lds <= 160 * 1024, "fs_tail_bwd: LDS footprint %zu B exceeds 160 KiB", lds);
   auto kern = fs_tail_bwd_kernel<D, HAS_LN, TERMS>;
   NLAM_BIG_LDS(kern, "fs_tail_bwd_kernel");
@@ -1015,6 +1257,7 @@ static int launch_fs_tail_bwd(const FsTailBwdParams& q, hipStream_t s, unsigned 
 int nlam_fs_tail_bwd_256(
     const int32_t* tiles, int64_t ntiles, int64_t rows, const int32_t* csr_rec,
     const int32_t* csr_rowptr, const float* h, int64_t h_bstride,
+    const void* z_keep, int64_t z_bstride,
     const float* g1, int64_t g1_bstride, int64_t g1_ld, const int32_t* idx_g1, const float* scale1,
     const float* g2, int64_t g2_bstride, int64_t g2_ld, const int32_t* idx_g2,
     const float* W2, int64_t ldW2, const float* b2, const float* gamma, int n_out,
@@ -1023,6 +1266,9 @@ int nlam_fs_tail_bwd_256(
     float* gpr, int64_t gpr_bstride, int64_t gpr_ld,
     float* slab, int64_t slab_stride, int64_t B, unsigned grid, void* stream) {
   constexpr int d = 256;
+  NLAM_REQUIRE(gamma == nullptr || (z_keep != nullptr && (reinterpret_cast<uintptr_t>(z_keep) & 7u) == 0 &&
+                                    z_bstride % 4 == 0),
+               "nlam_tail_bwd: hidden 256 with LayerNorm needs the z_keep rows of nlam_tail_fwd");
   NLAM_REQUIRE(nlam_mfma_terms() == 1, "hidden 256 needs NLAM_MFMA=bf16");
   NLAM_REQUIRE(gamma == nullptr || n_out == d, "nlam_tail_bwd: LayerNorm needs n_out == d");
   NLAM_REQUIRE(h != nullptr && nlam_aligned16(h) && h_bstride % 4 == 0, "nlam_tail_bwd: bad h");
@@ -1033,6 +1279,7 @@ int nlam_fs_tail_bwd_256(
   FsTailBwdParams q;
   q.tl = FsTiling{tiles, ntiles, rows, csr_rec, csr_rowptr, (int)B};
   q.h = h; q.h_bstride = h_bstride;
+  q.z_keep = reinterpret_cast<const __bf16*>(z_keep); q.z_bstride = z_bstride;
   q.g1 = RowView{g1, g1_bstride, g1_ld, n_out}; q.idx_g1 = idx_g1; q.scale1 = scale1;
   q.g2 = RowView{g2, g2_bstride, g2_ld, n_out}; q.idx_g2 = idx_g2;
   q.W2 = W2; q.ldW2 = ldW2; q.b2 = b2; q.gamma = gamma; q.n_out = n_out;
@@ -1063,8 +1310,8 @@ struct FsOuterParams {
 };
 
 template <int GW, int NXB, int TERMS>
-__global__ __launch_bounds__(512) void fs_outer_kernel(FsOuterParams q) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+__device__ __forceinline__ void fs_outer_body(const FsOuterParams& q, const int bid, const int gdim,
+                                              float* smem) {
   constexpr int NX = 32 * NXB, NT = 512;
   constexpr int NJ = GW == 256 ? NXB : 1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1149,15 +1396,15 @@ __global__ __launch_bounds__(512) void fs_outer_kernel(FsOuterParams q) {
       }
     }
   };
-  int64_t tt = blockIdx.x;
+  int64_t tt = bid;
   if (tt < ntiles) issue(tt);
   bf16x8 ones;
 #pragma unroll
   for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
-  for (; tt < ntiles; tt += gridDim.x) {
+  for (; tt < ntiles; tt += gdim) {
     put(tt);
     __syncthreads();
-    if (tt + gridDim.x < ntiles) issue(tt + gridDim.x);
+    if (tt + gdim < ntiles) issue(tt + gdim);
     const bool active = GW == 256 || true;
     if (active) {
 #pragma unroll
@@ -1189,7 +1436,7 @@ __global__ __launch_bounds__(512) void fs_outer_kernel(FsOuterParams q) {
     }
     __syncthreads();
   }
-  float* slab = q.slab + (int64_t)blockIdx.x * q.slab_stride;
+  float* slab = q.slab + (int64_t)bid * q.slab_stride;
   const int h = lane >> 5, j = lane & 31;
   if constexpr (GW == 256) {
 #pragma unroll
@@ -1211,28 +1458,42 @@ __global__ __launch_bounds__(512) void fs_outer_kernel(FsOuterParams q) {
 }
 
 template <int GW, int NXB, int TERMS>
-static int launch_fs_outer(const FsOuterParams& q, hipStream_t s, unsigned grid) {
+__global__ __launch_bounds__(512) void fs_outer_kernel(WideMulti<FsOuterParams> m) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int k = wide_multi_find(m, blockIdx.x);
+  fs_outer_body<GW, NXB, TERMS>(m.p[k], blockIdx.x - m.first[k], m.first[k + 1] - m.first[k], smem);
+}
+
+// m.first[] = the slab counts the caller sized its buffers for (one workgroup per slab)
+template <int GW, int NXB, int TERMS>
+static int launch_fs_outer(const WideMulti<FsOuterParams>& m, hipStream_t s) {
   const size_t lds = FsPlanes<GW, TERMS>::bytes + FsPlanes<32 * NXB, TERMS>::bytes;
   auto kern = fs_outer_kernel<GW, NXB, TERMS>;
   NLAM_BIG_LDS(kern, "fs_outer_kernel");
-  kern<<<grid, 512, lds, s>>>(q);
+  kern<<<(unsigned)m.first[m.n], 512, lds, s>>>(m);
   NLAM_CHECK_LAUNCH("fs_outer_kernel");
   return 0;
 }
+template <int GW, int NXB, int TERMS>
+static int launch_fs_outer(const FsOuterParams& q, hipStream_t s, unsigned grid) {
+  WideMulti<FsOuterParams> m;
+  m.n = 1;
+  m.p[0] = q;
+  m.first[0] = 0;
+  for (int k = 0; k < NLAM_WIDE_MAXP; ++k) m.first[k + 1] = (int)grid;
+  return launch_fs_outer<GW, NXB, TERMS>(m, s);
+}
 
 // (ng, nx) in {(256, 256), (32, 256), (256, <= 64)}; grid = the slab count of the caller
-int nlam_fs_outer_256(const float* g, int64_t g_bstride, int64_t g_ld, int ng,
-                      const float* x, int64_t x_bstride, int64_t x_ld, int nx, int silu_x,
-                      float* slab, int64_t slab_stride, int64_t B, int64_t rows, unsigned grid,
-                      void* stream) {
-  NLAM_REQUIRE(nlam_mfma_terms() == 1, "hidden 256 needs NLAM_MFMA=bf16");
+static int fs_outer_fill(FsOuterParams& q, const float* g, int64_t g_bstride, int64_t g_ld, int ng,
+                         const float* x, int64_t x_bstride, int64_t x_ld, int nx, int silu_x,
+                         float* slab, int64_t slab_stride, int64_t B, int64_t rows) {
   NLAM_REQUIRE((ng == 256 || ng == 32) && nx >= 1 && (nx <= 64 || nx == 256) && (ng == 256 || nx == 256),
                "nlam_wide_outer: shape %d x %d unsupported", ng, nx);
   NLAM_REQUIRE(view_vec_ok(g, g_bstride, g_ld, ng) && x != nullptr && x_ld >= nx,
                "nlam_wide_outer: g rows must be 16-byte aligned with pitch %% 4 == 0");
   const int nxp = (nx + 31) & ~31;
   NLAM_REQUIRE(slab != nullptr && slab_stride >= (int64_t)ng * nxp + ng, "nlam_wide_outer: slab too small");
-  FsOuterParams q;
   q.g = RowView{g, g_bstride, g_ld, ng};
   q.x = RowView{x, x_bstride, x_ld, nx};
   q.slab = slab; q.slab_stride = slab_stride;
@@ -1240,9 +1501,43 @@ int nlam_fs_outer_256(const float* g, int64_t g_bstride, int64_t g_ld, int ng,
   q.silu_x = silu_x;
   q.x_vec = view_vec_ok(x, x_bstride, x_ld, nx) ? 1 : 0;
   NLAM_REQUIRE(nx < 256 || q.x_vec, "nlam_wide_outer: 256-wide x rows must be 16-byte aligned");
+  return 0;
+}
+
+int nlam_fs_outer_256(const float* g, int64_t g_bstride, int64_t g_ld, int ng,
+                      const float* x, int64_t x_bstride, int64_t x_ld, int nx, int silu_x,
+                      float* slab, int64_t slab_stride, int64_t B, int64_t rows, unsigned grid,
+                      void* stream) {
+  NLAM_REQUIRE(nlam_mfma_terms() == 1, "hidden 256 needs NLAM_MFMA=bf16");
+  FsOuterParams q;
+  if (fs_outer_fill(q, g, g_bstride, g_ld, ng, x, x_bstride, x_ld, nx, silu_x, slab, slab_stride, B, rows))
+    return 1;
   hipStream_t s = (hipStream_t)stream;
   if (ng == 32) return launch_fs_outer<32, 8, 1>(q, s, grid);
   if (nx <= 32) return launch_fs_outer<256, 1, 1>(q, s, grid);
   if (nx <= 64) return launch_fs_outer<256, 2, 1>(q, s, grid);
   return launch_fs_outer<256, 8, 1>(q, s, grid);
+}
+
+// all problems 256 x 256; grid[k] = slab count of problem k
+int nlam_fs_outer_multi_256(int n, const float* const* g, const int64_t* g_bstride,
+                            const int64_t* g_ld, const float* const* x, const int64_t* x_bstride,
+                            const int64_t* x_ld, const int32_t* silu_x, float* const* slab,
+                            const int64_t* slab_stride, const int64_t* B, const int64_t* rows,
+                            const unsigned* grid, void* stream) {
+  NLAM_REQUIRE(nlam_mfma_terms() == 1, "hidden 256 needs NLAM_MFMA=bf16");
+  WideMulti<FsOuterParams> m;
+  m.n = 0;
+  m.first[0] = 0;
+  for (int k = 0; k < n; ++k) {
+    if (B[k] <= 0 || rows[k] <= 0) continue;
+    if (fs_outer_fill(m.p[m.n], g[k], g_bstride[k], g_ld[k], 256, x[k], x_bstride[k], x_ld[k], 256,
+                      silu_x[k], slab[k], slab_stride[k], B[k], rows[k]))
+      return 1;
+    m.first[m.n + 1] = m.first[m.n] + (int)grid[k];
+    ++m.n;
+  }
+  if (m.n == 0) return 0;
+  for (int k = m.n; k < NLAM_WIDE_MAXP; ++k) m.first[k + 1] = m.first[m.n];
+  return launch_fs_outer<256, 8, 1>(m, (hipStream_t)stream);
 }

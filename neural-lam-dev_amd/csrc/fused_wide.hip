@@ -291,7 +291,7 @@ extern "C" int nlam_tail_fwd(
     const float* b, int64_t b_bstride, int64_t b_ld, const int32_t* idx_b,
     const float* c, int64_t c_bstride, int64_t c_ld, const int32_t* idx_c,
     const float* W2, int64_t ldW2, const float* b2, const float* gamma, const float* beta,
-    int n_out, float* h_out, int64_t h_bstride,
+    int n_out, float* h_out, int64_t h_bstride, void* z_keep, int64_t z_bstride,
     float* y, int64_t y_bstride, int64_t y_ld, const int32_t* idx_y,
     const float* res, int64_t res_bstride, int64_t res_ld,
     float* agg, int64_t agg_bstride, int64_t agg_ld, const float* inv_deg,
@@ -300,8 +300,10 @@ extern "C" int nlam_tail_fwd(
   if (d == 256)
     return nlam_fs_tail_fwd_256(tiles, ntiles, rows, csr_rec, csr_rowptr, a, a_bstride, a_ld, idx_a,
                                 b, b_bstride, b_ld, idx_b, c, c_bstride, c_ld, idx_c, W2, ldW2, b2,
-                                gamma, beta, n_out, h_out, h_bstride, y, y_bstride, y_ld, idx_y, res,
-                                res_bstride, res_ld, agg, agg_bstride, agg_ld, inv_deg, B, stream);
+                                gamma, beta, n_out, h_out, h_bstride, z_keep, z_bstride, y, y_bstride,
+                                y_ld, idx_y, res, res_bstride, res_ld, agg, agg_bstride, agg_ld,
+                                inv_deg, B, stream);
+  (void)z_keep; (void)z_bstride;   // hidden 128 repeats the GEMM in its backward instead
   NLAM_REQUIRE(d == 128, "nlam_tail_fwd: hidden width %d unsupported (128, 256)", d);
   NLAM_REQUIRE(nlam_mfma_terms() != 0, "nlam_tail_fwd: needs NLAM_MFMA=bf16x3|bf16");
   NLAM_REQUIRE(n_out >= 1 && n_out <= d, "nlam_tail_fwd: n_out %d out of range", n_out);
@@ -624,6 +626,7 @@ extern "C" int64_t nlam_tail_bwd_slab_stride(int n_out) { return 2 * (int64_t)((
 extern "C" int nlam_tail_bwd(
     const int32_t* tiles, int64_t ntiles, int64_t rows, const int32_t* csr_rec,
     const int32_t* csr_rowptr, const float* h, int64_t h_bstride,
+    const void* z_keep, int64_t z_bstride,
     const float* g1, int64_t g1_bstride, int64_t g1_ld, const int32_t* idx_g1, const float* scale1,
     const float* g2, int64_t g2_bstride, int64_t g2_ld, const int32_t* idx_g2,
     const float* W2, int64_t ldW2, const float* b2, const float* gamma, int n_out,
@@ -639,8 +642,8 @@ extern "C" int nlam_tail_bwd(
                  "nlam_tail_bwd: row mode expects ntiles == ceil(rows / 32)");
     NLAM_REQUIRE(n_out >= 1 && n_out <= d && (gamma != nullptr || n_out <= 32),
                  "nlam_tail_bwd: n_out %d unsupported", n_out);
-    return nlam_fs_tail_bwd_256(tiles, ntiles, rows, csr_rec, csr_rowptr, h, h_bstride, g1, g1_bstride,
-                                g1_ld, idx_g1, scale1, g2, g2_bstride, g2_ld, idx_g2, W2, ldW2, b2,
+    return nlam_fs_tail_bwd_256(tiles, ntiles, rows, csr_rec, csr_rowptr, h, h_bstride, z_keep,
+                                z_bstride, g1, g1_bstride, g1_ld, idx_g1, scale1, g2, g2_bstride, g2_ld, idx_g2, W2, ldW2, b2,
                                 gamma, n_out, gz_out, gz_bstride, gh, gh_bstride, gh_ld, idx_gh, gpr,
                                 gpr_bstride, gpr_ld, slab, slab_stride, B, wide_grid(ntiles * B), stream);
   }
@@ -733,24 +736,6 @@ __device__ __forceinline__ void lin_bwd_data_body(const LinBwdDataParams& q, int
   }
 }
 
-// Up to NLAM_WIDE_MAXP independent problems of one kernel type in ONE launch: Hi-LAM's small
-// mesh levels are bound by the latency of their ~24 launches per InteractionNet, not by work.
-// Workgroup b serves problem k with first[k] <= b < first[k + 1] as block b - first[k] of
-// first[k + 1] - first[k].
-#define NLAM_WIDE_MAXP 8
-template <typename P>
-struct WideMulti {
-  int n;
-  int first[NLAM_WIDE_MAXP + 1];
-  P p[NLAM_WIDE_MAXP];
-};
-template <typename P>
-__device__ __forceinline__ int wide_multi_find(const WideMulti<P>& m, int b) {
-  int k = 0;
-  while (k + 1 < m.n && b >= m.first[k + 1]) ++k;
-  return k;
-}
-
 template <int NOUTB, int KB, int TERMS>
 __global__ __launch_bounds__(256) void lin_bwd_data_kernel(WideMulti<LinBwdDataParams> m) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -830,7 +815,7 @@ extern "C" int nlam_lin_bwd_data(const float* gy, int64_t gy_bstride, int64_t gy
                                 : launch_lin_bwd_data<4, 4, 1>(m, s);
 }
 
-extern "C" int nlam_lin_bwd_data_multi(int n, const float* const* gy, const int64_t* gy_bstride,
+extern "C" int nlam_lin_bwd_data_multi(int n, int d, const float* const* gy, const int64_t* gy_bstride,
                                        const int64_t* gy_ld, const float* const* W,
                                        const int64_t* ldW, float* const* gx,
                                        const int64_t* gx_bstride, const int64_t* gx_ld,
@@ -840,6 +825,10 @@ extern "C" int nlam_lin_bwd_data_multi(int n, const float* const* gy, const int6
   NLAM_REQUIRE(n >= 1 && n <= NLAM_WIDE_MAXP, "nlam_lin_bwd_data_multi: n %d out of [1, %d]", n,
                NLAM_WIDE_MAXP);
   NLAM_REQUIRE(nlam_mfma_terms() != 0, "nlam_lin_bwd_data_multi: needs NLAM_MFMA=bf16x3|bf16");
+  if (d == 256)
+    return nlam_fs_lin_bwd_data_multi_256(n, gy, gy_bstride, gy_ld, W, ldW, gx, gx_bstride, gx_ld,
+                                          gx_add, ga_bstride, ga_ld, B, rows, stream);
+  NLAM_REQUIRE(d == 128, "nlam_lin_bwd_data_multi: width %d unsupported (128, 256)", d);
   WideMulti<LinBwdDataParams> m;
   m.n = 0;
   for (int k = 0; k < n; ++k) {
@@ -1012,7 +1001,7 @@ extern "C" int nlam_wide_outer(const float* g, int64_t g_bstride, int64_t g_ld, 
 }
 
 // all problems 128 x 128
-extern "C" int nlam_wide_outer_multi(int n, const float* const* g, const int64_t* g_bstride,
+extern "C" int nlam_wide_outer_multi(int n, int d, const float* const* g, const int64_t* g_bstride,
                                      const int64_t* g_ld, const float* const* x,
                                      const int64_t* x_bstride, const int64_t* x_ld,
                                      const int32_t* silu_x, float* const* slab,
@@ -1021,6 +1010,14 @@ extern "C" int nlam_wide_outer_multi(int n, const float* const* g, const int64_t
   NLAM_REQUIRE(n >= 1 && n <= NLAM_WIDE_MAXP, "nlam_wide_outer_multi: n %d out of [1, %d]", n,
                NLAM_WIDE_MAXP);
   NLAM_REQUIRE(nlam_mfma_terms() != 0, "nlam_wide_outer_multi: needs NLAM_MFMA=bf16x3|bf16");
+  if (d == 256) {
+    unsigned grid[NLAM_WIDE_MAXP];
+    for (int k = 0; k < n; ++k)
+      grid[k] = wide_grid(((rows[k] + NLAM_TILE - 1) / NLAM_TILE) * B[k]);
+    return nlam_fs_outer_multi_256(n, g, g_bstride, g_ld, x, x_bstride, x_ld, silu_x, slab,
+                                   slab_stride, B, rows, grid, stream);
+  }
+  NLAM_REQUIRE(d == 128, "nlam_wide_outer_multi: width %d unsupported (128, 256)", d);
   WideMulti<WideOuterParams> m;
   m.n = 0;
   for (int k = 0; k < n; ++k) {
@@ -1101,7 +1098,7 @@ static int launch_wide_lin_fwd(WideMulti<WideLinParams>& m, hipStream_t s) {
   return 0;
 }
 
-extern "C" int nlam_lin_fwd_multi(int n, const float* const* x, const int64_t* x_bstride,
+extern "C" int nlam_lin_fwd_multi(int n, int d, const float* const* x, const int64_t* x_bstride,
                                   const int64_t* x_ld, const float* const* W, const int64_t* ldW,
                                   const float* const* bias, float* const* out,
                                   const int64_t* out_bstride, const int64_t* out_ld,
@@ -1109,6 +1106,10 @@ extern "C" int nlam_lin_fwd_multi(int n, const float* const* x, const int64_t* x
   NLAM_REQUIRE(n >= 1 && n <= NLAM_WIDE_MAXP, "nlam_lin_fwd_multi: n %d out of [1, %d]", n,
                NLAM_WIDE_MAXP);
   NLAM_REQUIRE(nlam_mfma_terms() != 0, "nlam_lin_fwd_multi: needs NLAM_MFMA=bf16x3|bf16");
+  if (d == 256)
+    return nlam_fs_lin_fwd_multi_256(n, x, x_bstride, x_ld, W, ldW, bias, out, out_bstride, out_ld, B,
+                                     rows, stream);
+  NLAM_REQUIRE(d == 128, "nlam_lin_fwd_multi: width %d unsupported (128, 256)", d);
   WideMulti<WideLinParams> m;
   m.n = 0;
   for (int k = 0; k < n; ++k) {

@@ -417,6 +417,57 @@ class slab_batch:
         return False
 
 
+class WeightGradLane:
+    """Second HIP stream for the weight-gradient passes of a small layer's backward.
+
+    On the small mesh levels of Hi-LAM (reference hi_lam.py:82-207: 81 ... 6,561-node levels) every
+    kernel of an InteractionNet backward is a handful of workgroups on a 256-CU device, so the
+    backward is a chain of launch / memory latencies.  The weight gradients (nlam_wide_outer and
+    their slab reductions) feed nothing inside that chain: they are issued on this lane, after the
+    lane has waited for the main stream at the point where their operands exist, and the main
+    stream waits for the lane once, before the backward returns.  Inside a HIP-graph capture the
+    fork / join become graph edges.  `with lane:` = fork + launches on the lane (slab reductions
+    collected); `lane.finish()` = flush the reductions on the lane and join.  Disabled lane: the
+    block runs on the current stream and finish() only flushes."""
+
+    _streams = {}
+
+    def __init__(self, enabled, device):
+        self.enabled = bool(enabled)
+        self.pending = []
+        self.ctx = None
+        if self.enabled:
+            key = torch.device(device).index
+            if key not in WeightGradLane._streams:
+                WeightGradLane._streams[key] = torch.cuda.Stream(device=device)
+            self.side = WeightGradLane._streams[key]
+            self.main = torch.cuda.current_stream(device)
+
+    def __enter__(self):
+        if self.enabled:
+            self.side.wait_stream(self.main)
+            self.ctx = torch.cuda.stream(self.side)
+            self.ctx.__enter__()
+        _SLAB_BATCH.append(self.pending)
+        return self
+
+    def __exit__(self, et, ev, tb):
+        _SLAB_BATCH.pop()
+        if self.enabled:
+            self.ctx.__exit__(et, ev, tb)
+            self.ctx = None
+        return False
+
+    def finish(self):
+        if self.enabled:
+            with torch.cuda.stream(self.side):
+                _flush_segments(self.pending)
+            self.main.wait_stream(self.side)
+        else:
+            _flush_segments(self.pending)
+        self.pending = []
+
+
 def _flush_segments(entries):
     for i in range(0, len(entries), MAX_SEGS):
         part = entries[i : i + MAX_SEGS]

@@ -37,6 +37,16 @@ def enabled(hid=128):
     return mode == 2 if hid == 256 else mode != 0
 
 
+import os
+
+# Layers with at most this many edge rows (B * M) issue their weight-gradient passes on a second
+# stream (ops.WeightGradLane).  Measured on Hi-LAM (MI355X, HIP-graph replay): hidden 256 with one
+# launch per weight gradient 48.96 -> 46.09 ms / step, hidden 128 (whose weight gradients are ONE
+# multi-problem launch already) 22.64 -> 23.21 ms: splitting that launch costs more than the
+# overlap returns.  With multi-problem launches at both widths the lane is off by default.
+SIDE_LANE_ROWS = int(os.environ.get("NLAM_SIDE_ROWS", "0"))
+
+
 def _empty(*shape, device):
     return torch.empty(*shape, dtype=torch.float32, device=device)
 
@@ -69,15 +79,24 @@ def _src(m, idx=None):
     return (m.ptr, m.bstride, m.ld, idx.data_ptr() if idx is not None else None)
 
 
+def keep_z(B, rows, d, gamma, device):
+    """bf16 (B, rows, d) buffer for the pre-LayerNorm rows the hidden-256 backward reads back."""
+    if d != 256 or gamma is None:
+        return None
+    return torch.empty(B, rows, d, dtype=torch.bfloat16, device=device)
+
+
 def tail_fwd(tl, a, idx_a, b, idx_b, c, idx_c, W2, b2, gamma, beta, h_out, y, idx_y, res, agg,
-             inv_deg, B, d):
+             inv_deg, B, d, z_keep=None):
     n_out = W2.shape[0]
     _launch(
         "nlam_tail_fwd", lib.nlam_tail_fwd,
         tl.args + _src(a, idx_a) + _src(b, idx_b) + _src(c, idx_c)
         + (W2.data_ptr(), W2.stride(0), _p(b2), _p(gamma), _p(beta), n_out,
            h_out.data_ptr() if h_out is not None else None,
-           h_out.stride(0) if h_out is not None else 0)
+           h_out.stride(0) if h_out is not None else 0,
+           z_keep.data_ptr() if z_keep is not None else None,
+           z_keep.stride(0) if z_keep is not None else 0)
         + ((y.ptr, y.bstride, y.ld) if y is not None else (None, 0, 0))
         + (idx_y.data_ptr() if idx_y is not None else None,)
         + ((res.ptr, res.bstride, res.ld) if res is not None else (None, 0, 0))
@@ -91,7 +110,7 @@ def tail_fwd(tl, a, idx_a, b, idx_b, c, idx_c, W2, b2, gamma, beta, h_out, y, id
 
 
 def tail_bwd(tl, h, g1, idx_g1, scale1, g2, idx_g2, W2, b2, gamma, gz_out, gh, idx_gh, gpr, B, d,
-             dgamma, dbeta):
+             dgamma, dbeta, z_keep=None):
     n_out = W2.shape[0]
     dev = W2.device
     stride = int(lib.nlam_tail_bwd_slab_stride(n_out))
@@ -99,7 +118,9 @@ def tail_bwd(tl, h, g1, idx_g1, scale1, g2, idx_g2, W2, b2, gamma, gz_out, gh, i
     slab = torch.empty(nslabs * stride, dtype=torch.float32, device=dev) if gamma is not None else None
     _launch(
         "nlam_tail_bwd", lib.nlam_tail_bwd,
-        tl.args + (h.data_ptr(), h.stride(0))
+        tl.args + (h.data_ptr(), h.stride(0),
+                   z_keep.data_ptr() if z_keep is not None else None,
+                   z_keep.stride(0) if z_keep is not None else 0)
         + (g1.ptr, g1.bstride, g1.ld, idx_g1.data_ptr() if idx_g1 is not None else None,
            scale1.data_ptr() if scale1 is not None else None)
         + ((g2.ptr, g2.bstride, g2.ld, idx_g2.data_ptr() if idx_g2 is not None else None)
@@ -160,40 +181,34 @@ def _parr(vals):
 
 
 def lin_fwd_multi(problems):
-    """[(x Mat, W (128,128) view, bias or None, out Mat)] -> one launch (aligned 128-wide rows)."""
+    """[(x Mat, W (d, d) view, bias or None, out Mat)] -> one launch (aligned d-wide rows)."""
     import ctypes
-    if problems[0][1].shape[0] != 128:
-        for x, W, b, o in problems:
-            ops.fused_lin_fwd(x, W, b, None, None, o)
-        return
+    d = problems[0][1].shape[0]
     I64 = ctypes.c_int64
     n = len(problems)
     _launch(
         "nlam_lin_fwd_multi", lib.nlam_lin_fwd_multi,
-        (n, _parr([x.ptr for x, _, _, _ in problems]), _arr(I64, [x.bstride for x, _, _, _ in problems]),
+        (n, d, _parr([x.ptr for x, _, _, _ in problems]), _arr(I64, [x.bstride for x, _, _, _ in problems]),
          _arr(I64, [x.ld for x, _, _, _ in problems]), _parr([W.data_ptr() for _, W, _, _ in problems]),
          _arr(I64, [W.stride(0) for _, W, _, _ in problems]),
          _parr([_p(b) for _, _, b, _ in problems]), _parr([o.ptr for _, _, _, o in problems]),
          _arr(I64, [o.bstride for _, _, _, o in problems]), _arr(I64, [o.ld for _, _, _, o in problems]),
          _arr(I64, [o.B for _, _, _, o in problems]), _arr(I64, [o.rows for _, _, _, o in problems]),
          stream()),
-        flops=sum(2.0 * o.B * o.rows * 128 * 128 for _, _, _, o in problems),
-        nbytes=sum(8.0 * o.B * o.rows * 128 for _, _, _, o in problems),
+        flops=sum(2.0 * o.B * o.rows * d * d for _, _, _, o in problems),
+        nbytes=sum(8.0 * o.B * o.rows * d for _, _, _, o in problems),
     )
 
 
 def lin_bwd_data_multi(problems):
-    """[(gy Mat, W (128,128) view, gx Mat, gx_add Mat or None)] -> one launch."""
+    """[(gy Mat, W (d, d) view, gx Mat, gx_add Mat or None)] -> one launch."""
     import ctypes
-    if problems[0][1].shape[0] != 128:
-        for gy, W, gx, gx_add in problems:
-            lin_bwd_data(gy, W, gx, gx_add)
-        return
+    d = problems[0][1].shape[0]
     I64 = ctypes.c_int64
     n = len(problems)
     _launch(
         "nlam_lin_bwd_data_multi", lib.nlam_lin_bwd_data_multi,
-        (n, _parr([g.ptr for g, _, _, _ in problems]), _arr(I64, [g.bstride for g, _, _, _ in problems]),
+        (n, d, _parr([g.ptr for g, _, _, _ in problems]), _arr(I64, [g.bstride for g, _, _, _ in problems]),
          _arr(I64, [g.ld for g, _, _, _ in problems]), _parr([W.data_ptr() for _, W, _, _ in problems]),
          _arr(I64, [W.stride(0) for _, W, _, _ in problems]),
          _parr([x.ptr for _, _, x, _ in problems]), _arr(I64, [x.bstride for _, _, x, _ in problems]),
@@ -203,23 +218,20 @@ def lin_bwd_data_multi(problems):
          _arr(I64, [a.ld if a is not None else 0 for _, _, _, a in problems]),
          _arr(I64, [x.B for _, _, x, _ in problems]), _arr(I64, [x.rows for _, _, x, _ in problems]),
          stream()),
-        flops=sum(2.0 * x.B * x.rows * 128 * 128 for _, _, x, _ in problems),
-        nbytes=sum(4.0 * x.B * x.rows * 128 * (2 + (a is not None)) for _, _, x, a in problems),
+        flops=sum(2.0 * x.B * x.rows * d * d for _, _, x, _ in problems),
+        nbytes=sum(4.0 * x.B * x.rows * d * (2 + (a is not None)) for _, _, x, a in problems),
     )
 
 
 def outer_multi(problems):
-    """[(g Mat (.., 128), x Mat (.., 128), dW view, db, silu_x)] -> one launch + the layer's slab
-    reduction (all 128 x 128)."""
+    """[(g Mat (.., d), x Mat (.., d), dW view, db, silu_x)] -> one launch + the layer's slab
+    reduction (all d x d)."""
     import ctypes
-    if problems[0][0].cols != 128:
-        for g, x, dW, db, sx in problems:
-            outer(g, x, dW, db, silu_x=sx)
-        return
+    d = problems[0][0].cols
     I64, I32 = ctypes.c_int64, ctypes.c_int32
     n = len(problems)
     dev = problems[0][2].device
-    stride = 128 * 128 + 128
+    stride = d * d + d
     slabs, ns = [], []
     for g, x, dW, db, sx in problems:
         nsl = int(lib.nlam_bwd_grid(g.B * ((g.rows + 31) // 32)))
@@ -227,7 +239,7 @@ def outer_multi(problems):
         slabs.append(torch.empty(nsl * stride, dtype=torch.float32, device=dev))
     _launch(
         "nlam_wide_outer_multi", lib.nlam_wide_outer_multi,
-        (n, _parr([g.ptr for g, _, _, _, _ in problems]),
+        (n, d, _parr([g.ptr for g, _, _, _, _ in problems]),
          _arr(I64, [g.bstride for g, _, _, _, _ in problems]),
          _arr(I64, [g.ld for g, _, _, _, _ in problems]),
          _parr([x.ptr for _, x, _, _, _ in problems]),
@@ -237,11 +249,11 @@ def outer_multi(problems):
          _parr([sl.data_ptr() for sl in slabs]), _arr(I64, [stride] * n),
          _arr(I64, [g.B for g, _, _, _, _ in problems]),
          _arr(I64, [g.rows for g, _, _, _, _ in problems]), stream()),
-        flops=sum(2.0 * g.B * g.rows * 128 * 128 for g, _, _, _, _ in problems),
-        nbytes=sum(8.0 * g.B * g.rows * 128 for g, _, _, _, _ in problems),
+        flops=sum(2.0 * g.B * g.rows * d * d for g, _, _, _, _ in problems),
+        nbytes=sum(8.0 * g.B * g.rows * d for g, _, _, _, _ in problems),
     )
     for (g, x, dW, db, sx), sl, nsl in zip(problems, slabs, ns):
-        ops.reduce_segments(sl, nsl, stride, [(0, 128, 128, 128, dW), (128 * 128, 1, 128, 128, db)])
+        ops.reduce_segments(sl, nsl, stride, [(0, d, d, d, dW), (d * d, 1, d, d, db)])
 
 
 def _first_linear(x, W, b, out):
@@ -304,9 +316,10 @@ class WideMLPFunction(torch.autograd.Function):
         h = _empty(B, rows, hid, device=dev)
         _first_linear(xm, W1, b1, mat(h))
         out = _empty(B, rows, n_out, device=dev)
+        zk = keep_z(B, rows, hid, gamma, dev)
         tail_fwd(Tiling(rows), mat(h), None, None, None, None, None, W2, b2, gamma, beta, None,
-                 mat(out), None, rm, None, None, B, hid)
-        ctx.save_for_backward(W1, b1, W2, b2, gamma, h)
+                 mat(out), None, rm, None, None, B, hid, zk)
+        ctx.save_for_backward(W1, b1, W2, b2, gamma, h, zk)
         ctx.xm, ctx.x_shape = xm, x.shape
         ctx.res_mode = 0 if res is None else (1 if res_is_x else 2)
         ctx.B = B
@@ -314,7 +327,7 @@ class WideMLPFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy):
-        W1, b1, W2, b2, gamma, h = ctx.saved_tensors
+        W1, b1, W2, b2, gamma, h, zk = ctx.saved_tensors
         hid, k_in = W1.shape
         n_out = W2.shape[0]
         xm, B = ctx.xm, ctx.B
@@ -333,7 +346,7 @@ class WideMLPFunction(torch.autograd.Function):
             gz = _empty(B, rows, no, device=dev)
             ga = _empty(B, rows, hid, device=dev)
             tail_bwd(Tiling(rows), h, gym, None, None, None, None, W2, b2, gamma, gz, mat(ga),
-                     None, None, B, hid, dg, dbt)
+                     None, None, B, hid, dg, dbt, zk)
             outer(mat(gz), mat(h), dW2, db2, silu_x=True, rows_out=n_out)
             gx_add = gym if (ctx.res_mode == 1 and need_gx) else None
             gx = _first_linear_bwd(xm, mat(ga), W1, need_gx, gx_add, dW1, db1, dev)
@@ -395,19 +408,21 @@ class WideInteractionNetFunction(torch.autograd.Function):
             agg = _empty(B, N_r, d, device=dev)
             e_out = _empty(B, M, d, device=dev) if update_edges else None
             tl = Tiling(M, g)
+            z_e = keep_z(B, M, d, gam, dev)
             tail_fwd(tl, mat(Pe), g.csr_eid, mat(Ps), g.csr_send, mat(Pr), g.csr_rec, W2, b2, gam,
                      bet, h_e, mat(e_out) if update_edges else None,
                      g.csr_eid if update_edges else None, em if update_edges else None,
-                     mat(agg), g.inv_deg if mean else None, B, d)
+                     mat(agg), g.inv_deg if mean else None, B, d, z_e)
             del Pe, Ps, Pr
             # node update x_r + LN(V2 silu(V1 [x_r | agg] + c1) + c2)
             hn2 = _empty(B, N_r, d, device=dev)
             _first_linear(mat(agg), V1[:, d:], None, mat(hn2))
             h_n = _empty(B, N_r, d, device=dev)
             rec_out = _empty(B, N_r, d, device=dev)
+            z_n = keep_z(B, N_r, d, gam2, dev)
             tail_fwd(Tiling(N_r), mat(hn1), None, mat(hn2), None, None, None, V2, c2, gam2, bet2,
-                     h_n, mat(rec_out), None, rm, None, None, B, d)
-            ctx.save_for_backward(W1, b1, W2, b2, gam, V1, c1, V2, c2, gam2, h_e, h_n, agg)
+                     h_n, mat(rec_out), None, rm, None, None, B, d, z_n)
+            ctx.save_for_backward(W1, b1, W2, b2, gam, V1, c1, V2, c2, gam2, h_e, h_n, agg, z_e, z_n)
             ctx.set_materialize_grads(False)
             ctx.g, ctx.same, ctx.update_edges, ctx.mean = g, same, update_edges, mean
             ctx.mats = (sm, rm, em)
@@ -419,7 +434,7 @@ class WideInteractionNetFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_rec_out, g_edge_out=None):
         with ops.tag(ctx.g.tag), ops.slab_batch():
-            W1, b1, W2, b2, gam, V1, c1, V2, c2, gam2, h_e, h_n, agg = ctx.saved_tensors
+            W1, b1, W2, b2, gam, V1, c1, V2, c2, gam2, h_e, h_n, agg, z_e, z_n = ctx.saved_tensors
             g = ctx.g
             sm, rm, em = ctx.mats
             B, N_s, N_r, M, d = ctx.dims
@@ -436,11 +451,12 @@ class WideInteractionNetFunction(torch.autograd.Function):
             dV1, dc1 = torch.empty_like(V1), _empty(d, device=dev)
             dV2, dc2 = torch.empty_like(V2), _empty(d, device=dev)
             dg2, db2n = _empty(d, device=dev), _empty(d, device=dev)
+            lane = ops.WeightGradLane(B * M <= SIDE_LANE_ROWS, dev)   # (default: off, see above)
             # 1. node update backward
             gz_n = _empty(B, N_r, d, device=dev)
             ga_n = _empty(B, N_r, d, device=dev)
             tail_bwd(Tiling(N_r), h_n, mat(g_rec_out), None, None, None, None, V2, c2, gam2, gz_n,
-                     mat(ga_n), None, None, B, d, dg2, db2n)
+                     mat(ga_n), None, None, B, d, dg2, db2n, z_n)
             g_rec = _empty(B, N_r, d, device=dev)       # node-update part + residual
             g_agg = _empty(B, N_r, d, device=dev)
             lin_bwd_data_multi([(mat(ga_n), V1[:, :d], mat(g_rec), mat(g_rec_out)),
@@ -448,6 +464,10 @@ class WideInteractionNetFunction(torch.autograd.Function):
             dummy = [_empty(d, device=dev) for _ in range(4)]
             outers = [(mat(gz_n), mat(h_n), dV2, dc2, True), (mat(ga_n), rm, dV1[:, :d], dc1, False),
                       (mat(ga_n), mat(agg), dV1[:, d:], dummy[0], False)]
+            if lane.enabled:
+                with lane:
+                    outer_multi(outers)
+                outers = []
             if rm.B == 1 and B > 1:
                 t3 = _empty(1, N_r, d, device=dev)
                 ops.sum_batch(g_rec, t3)
@@ -461,7 +481,7 @@ class WideInteractionNetFunction(torch.autograd.Function):
                 geo = mat(g_edge_out.contiguous())
             tail_bwd(Tiling(M, g), h_e, mat(g_agg), g.csr_rec, g.inv_deg if ctx.mean else None,
                      geo, g.csr_eid if geo is not None else None, W2, b2, gam, gz_e, mat(gh),
-                     g.csr_eid, mat(gPr), B, d, dgam, dbet)
+                     g.csr_eid, mat(gPr), B, d, dgam, dbet, z_e)
             outers.append((mat(gz_e), mat(h_e), dW2, db2, True))
             # 3. sender-side reduction of gh (edge order; sender lists of edge ids)
             gPs = (torch.zeros if N_s > g.n_send else torch.empty)(
@@ -480,6 +500,10 @@ class WideInteractionNetFunction(torch.autograd.Function):
             outers += [(gps_m, sm, dW1[:, d : 2 * d], dummy[1], False),
                        (gpr_m, rm, dW1[:, 2 * d :], db1, False),
                        (mat(gh), em, dW1[:, :d], dummy[2], False)]
+            if lane.enabled:   # the remaining weight gradients run next to step 5
+                with lane:
+                    outer_multi(outers)
+                outers = []
             # 5. data gradients of the three projections (e' = e + m adds g_e' to the edge one)
             dPe = mat(gh)
             if not ctx.update_edges and em.B == 1 and B > 1:
@@ -503,8 +527,12 @@ class WideInteractionNetFunction(torch.autograd.Function):
                 t5 = _empty(1, M, d, device=dev)
                 ops.sum_batch(g_e, t5)
                 g_edge = t5
-            # 6. every weight / bias gradient of the layer: one streaming launch
-            outer_multi(outers)
+            # 6. every weight / bias gradient of the layer: one streaming launch (small layers
+            #    have issued theirs on the weight-gradient lane already: only the join is left)
+            if outers:
+                with lane:
+                    outer_multi(outers)
+            lane.finish()
         return (g_send, g_rec_total, g_edge, None, None, None, None,
                 dW1, db1, dW2, db2, dgam, dbet, dV1, dc1, dV2, dc2, dg2, db2n)
 
