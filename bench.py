@@ -269,9 +269,22 @@ def main():
         opt.step(grad_scale=gscale)
         return loss
 
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
     graphed = None
-    if not args.no_graph and world == 1:   # multi-rank runs launch eagerly (the gain is <1 %)
+    launch = {"mode": "eager"}
+    # Multi-rank runs launch eagerly by default (gradient buckets go out from backward hooks).
+    # NLAM_BENCH_MULTIRANK_GRAPH=probe additionally captures the step and takes the faster of the
+    # two schedules -- worth it when eager launching is host-bound (Hi-LAM at hidden 64: ~40 us
+    # of host time per launch); opt-in because it could only be rehearsed with two gloo ranks
+    # stacked on one GPU, where a captured-but-unused graph slowed later eager steps.
+    multirank_graph = os.environ.get("NLAM_BENCH_MULTIRANK_GRAPH", "off") == "probe"
+    if not args.no_graph and (world == 1 or multirank_graph):
+        reducer.hooks_enabled = False      # no collectives inside the capture
         graphed = parallel.GraphedTrainStep(model, flat, batch)
+        reducer.hooks_enabled = True
 
         def gstep():
             loss = graphed()
@@ -279,11 +292,35 @@ def main():
             opt.step(grad_scale=gscale)
             return loss
 
-    timed_step = gstep if (graphed is not None and graphed.graph is not None) else step
+    use_graph = graphed is not None and graphed.graph is not None
+    if use_graph and world > 1:
+        # Two schedules for a multi-rank step: (a) eager launches, gradient buckets all-reduced
+        # from backward hooks (overlap, but ~40 us of host time per launch: Hi-LAM at hidden 64
+        # is then host-bound), (b) HIP-graph replay of forward + backward + packing, buckets
+        # all-reduced after it.  Probe both, take the slower rank's view, use the faster one.
+        def probe(fn, hooks, n=3):
+            reducer.hooks_enabled = hooks
+            fn()
+            torch.cuda.synchronize()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
+        t_pair = torch.tensor([probe(step, True), probe(gstep, False)], device=dev,
+                              dtype=torch.float64)
+        dist.all_reduce(t_pair, op=dist.ReduceOp.MAX)
+        use_graph = bool(t_pair[1] < t_pair[0])
+        launch["probe_ms"] = {"eager_overlap": float(t_pair[0]) * 1e3,
+                              "hip_graph_trailing_allreduce": float(t_pair[1]) * 1e3}
+    reducer.hooks_enabled = not use_graph
+    if use_graph:
+        launch["mode"] = "hip_graph" if world == 1 else "hip_graph+trailing_allreduce"
+    elif world > 1 and reducer.overlap:
+        launch["mode"] = "eager+overlapped_allreduce"
+    timed_step = gstep if use_graph else step
 
     for _ in range(args.warmup):
         timed_step()
@@ -311,6 +348,7 @@ def main():
     from neural_lam_amd._lib import lib as _nlam_lib
     mfma_mode = MFMA_MODES[int(_nlam_lib.nlam_mfma_mode())]
     nprof = max(1, min(3, args.steps))
+    reducer.hooks_enabled = True   # the per-kernel pass below launches eagerly
     if not args.no_kernel_timing and rank != 0:
         for _ in range(nprof):   # every rank takes part in the steps' collective
             step()
@@ -433,7 +471,7 @@ def main():
             # [+ Hi-LAM init/read-out sweeps] per AR step
             "all_receiver_updates_per_s": world * B * T * all_receiver_updates(args, info)
             / (elapsed / args.steps),
-            "hip_graph": bool(graphed is not None and graphed.graph is not None),
+            "hip_graph": bool(use_graph), "launch": launch,
             "rccl_ranks": dist.get_world_size() if world > 1 else 1,
             "backend": (dist.get_backend() if world > 1 else None),
             "grad_allreduce": reducer.describe(),

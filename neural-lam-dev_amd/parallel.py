@@ -124,6 +124,9 @@ class GradAllReduce:
         self._launched = set()
         self._dirty = set()
         self.stats = {"launched_in_backward": 0, "launched_in_reduce": 0}
+        # False while a HIP graph of the step is captured / replayed: the hooks must not issue
+        # collectives then (reduce(packed=True) issues every bucket after the replay instead)
+        self.hooks_enabled = True
         if self.overlap:
             self._bucket_of = {}
             self._pending = []
@@ -147,6 +150,8 @@ class GradAllReduce:
     # ---- overlap machinery ---------------------------------------------------
     def _make_hook(self, i):
         def hook(_param):
+            if not self.hooks_enabled:
+                return
             bi = self._bucket_of[i]
             if bi in self._launched:
                 # a second gradient contribution after the bucket went out (a re-entrant
