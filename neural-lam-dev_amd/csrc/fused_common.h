@@ -275,12 +275,71 @@ __device__ __forceinline__ void view_load_v(f32x4 (&v)[NV], const RowView& src, 
   auto rp = [&](int t) { return base + (int64_t)(t < last ? t : last) * src.ld; };
   load_rows_v<NV>(v, src.width, lane, rp);
 }
+// Narrow / unaligned rows (static features of the embedders, the 17-wide output map): dword
+// loads over the 32 x width elements of the tile, in TWO phases per chunk of 12 per lane -- all
+// loads of the chunk are issued, then written to LDS.  (The plain load -> store loop paid one
+// global round trip per 64 elements: 9 serialized round trips = 15.6 k cycles, 49 % of the tile
+// time, for the 17-wide gy of the output map's backward.)  The (row, column) of an element
+// advances incrementally: no per-element integer division by the run-time width.
 __device__ __forceinline__ void view_stage_s(float* __restrict__ tile, int ld, int col0,
                                              const RowView& src, int64_t b, int64_t r0, int nrows,
                                              int lane) {
   const float* base = src.ptr + b * src.bstride + r0 * src.ld;
-  auto rp = [&](int t) { return base + (int64_t)t * src.ld; };
-  stage_rows<false, false>(tile, ld, col0, src.width, nrows, lane, rp);
+  const int width = src.width;
+  const int total = NLAM_TILE * width;
+  const int dq = 64 / width, dr = 64 - dq * width;   // (row, column) step of idx += 64
+  constexpr int CH = 12;
+  int t = lane / width, c = lane - t * width;
+  const int last = nrows - 1;
+  for (int i0 = lane; i0 < total; i0 += 64 * CH) {
+    float v[CH];
+    int tt = t, cc = c;
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      const int tr = tt < last ? tt : last;          // (slots past the tile read a valid row)
+      v[k] = base[(int64_t)tr * src.ld + cc];
+      cc += dr; tt += dq;
+      if (cc >= width) { cc -= width; tt += 1; }
+    }
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      if (i0 + 64 * k < total) tile[t * ld + col0 + c] = (t < nrows) ? v[k] : 0.f;
+      c += dr; t += dq;
+      if (c >= width) { c -= width; t += 1; }
+    }
+  }
+}
+
+// The same in two separate calls (register prefetch of a narrow source one tile ahead):
+// NS >= ceil(32 * width / 64) values per lane.
+template <int NS>
+__device__ __forceinline__ void view_load_s(float (&v)[NS], const RowView& src, int64_t b,
+                                            int64_t r0, int nrows, int lane) {
+  const float* base = src.ptr + b * src.bstride + r0 * src.ld;
+  const int width = src.width;
+  const int dq = 64 / width, dr = 64 - dq * width;
+  int t = lane / width, c = lane - t * width;
+  const int last = nrows - 1;
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    const int tr = t < last ? t : last;
+    v[k] = base[(int64_t)tr * src.ld + c];
+    c += dr; t += dq;
+    if (c >= width) { c -= width; t += 1; }
+  }
+}
+template <int NS>
+__device__ __forceinline__ void view_put_s(float* __restrict__ tile, int ld, int col0, int width,
+                                           int nrows, int lane, const float (&v)[NS]) {
+  const int total = NLAM_TILE * width;
+  const int dq = 64 / width, dr = 64 - dq * width;
+  int t = lane / width, c = lane - t * width;
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    if (lane + 64 * k < total) tile[t * ld + col0 + c] = (t < nrows) ? v[k] : 0.f;
+    c += dr; t += dq;
+    if (c >= width) { c -= width; t += 1; }
+  }
 }
 
 // zero columns [col0, col0+width) of the tile (K padding)
