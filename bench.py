@@ -243,6 +243,11 @@ def cpu_baseline(args, tmp, info, model):
 
 def main():
     args = parse()
+    if args.hidden_dim == 256:
+        # BASELINE configs[4] is "hidden_dim=256, bf16": the feature-split kernels of that width
+        # exist in bf16-mixed arithmetic only (NLAM_MFMA is read once, when the library loads;
+        # an explicit setting -- e.g. fp32 for the generic exact kernels -- is respected)
+        os.environ.setdefault("NLAM_MFMA", "bf16")
     if args.gpus > 1 and "RANK" not in os.environ:
         spawn_ranks(args)   # never returns
     rank, world, local = setup_dist(args)

@@ -404,7 +404,10 @@ int nlam_wide_outer(const float* g, int64_t g_bstride, int64_t g_ld, int ng,
  * 81 ... 6,561-node levels) are bound by the latency of their launches, not by their work.
  * nlam_lin_fwd_multi: out_k = x_k W_k^T + bias_k (bias_k may be NULL), all d -> d.
  * nlam_lin_bwd_data_multi / nlam_wide_outer_multi: as the single forms, all d x d.
- * d = 128, or 256 (NLAM_MFMA=bf16 only). */
+ * d = 128, or 256 (NLAM_MFMA=bf16 only).  nlam_wide_outer_multi: nslabs[k] = slabs (= workgroups)
+ * of problem k, chosen by the caller -- proportional to the problems' row counts with ~512 in
+ * all, so that the slab traffic of a layer's seven weight gradients stays a fraction of what
+ * 7 x nlam_bwd_grid() slabs would be; slab[k] holds nslabs[k] * slab_stride[k] floats. */
 int nlam_lin_fwd_multi(int n, int d, const float* const* x, const int64_t* x_bstride, const int64_t* x_ld,
                        const float* const* W, const int64_t* ldW, const float* const* bias,
                        float* const* out, const int64_t* out_bstride, const int64_t* out_ld,
@@ -419,7 +422,7 @@ int nlam_wide_outer_multi(int n, int d, const float* const* g, const int64_t* g_
                           const int64_t* g_ld, const float* const* x, const int64_t* x_bstride,
                           const int64_t* x_ld, const int32_t* silu_x, float* const* slab,
                           const int64_t* slab_stride, const int64_t* B, const int64_t* rows,
-                          void* stream);
+                          const int32_t* nslabs, void* stream);
 
 /* Grid feature rows of predict_step (reference base_graph_model.py:116-124): out (B, N, sum w) =
  * concatenation of up to four (B | 1, N, w_k) sources along the feature axis (bstride 0 =

@@ -942,8 +942,10 @@ __global__ __launch_bounds__(256) void wide_outer_kernel(WideMulti<WideOuterPara
                                    smem);
 }
 
+// counts: slabs (= workgroups) per problem; NULL = nlam_bwd_grid(tiles) each (single launches)
 template <int NGB, int NXB, int TERMS>
-static int launch_wide_outer(WideMulti<WideOuterParams>& m, hipStream_t s) {
+static int launch_wide_outer(WideMulti<WideOuterParams>& m, hipStream_t s,
+                             const int* counts = nullptr) {
   constexpr int NG = 32 * NGB, NX = 32 * NXB;
   size_t lds = (size_t)4 * NLAM_TILE * (NG + 4 + NX + 4) * sizeof(float);
   const size_t fold = (size_t)4 * 32 * NX * sizeof(float);
@@ -951,10 +953,10 @@ static int launch_wide_outer(WideMulti<WideOuterParams>& m, hipStream_t s) {
   NLAM_REQUIRE(lds <= 160 * 1024, "wide_outer: LDS footprint %zu B exceeds 160 KiB", lds);
   auto kern = wide_outer_kernel<NGB, NXB, TERMS>;
   NLAM_BIG_LDS(kern, "wide_outer_kernel");
-  // every problem's slab count is what the host sized its slab buffer for: nlam_bwd_grid(tiles)
+  // every problem's slab count is what the host sized its slab buffer for
   m.first[0] = 0;
   for (int k = 0; k < m.n; ++k)
-    m.first[k + 1] = m.first[k] + (int)wide_grid(((m.p[k].rows + NLAM_TILE - 1) / NLAM_TILE) * m.p[k].B);
+    m.first[k + 1] = m.first[k] + (counts ? counts[k] : (int)wide_grid(((m.p[k].rows + NLAM_TILE - 1) / NLAM_TILE) * m.p[k].B));
   for (int k = m.n; k < NLAM_WIDE_MAXP; ++k) m.first[k + 1] = m.first[m.n];
   kern<<<(unsigned)m.first[m.n], 256, lds, s>>>(m);
   NLAM_CHECK_LAUNCH("wide_outer_kernel");
@@ -1006,30 +1008,35 @@ extern "C" int nlam_wide_outer_multi(int n, int d, const float* const* g, const 
                                      const int64_t* x_bstride, const int64_t* x_ld,
                                      const int32_t* silu_x, float* const* slab,
                                      const int64_t* slab_stride, const int64_t* B,
-                                     const int64_t* rows, void* stream) {
+                                     const int64_t* rows, const int32_t* nslabs, void* stream) {
   NLAM_REQUIRE(n >= 1 && n <= NLAM_WIDE_MAXP, "nlam_wide_outer_multi: n %d out of [1, %d]", n,
                NLAM_WIDE_MAXP);
   NLAM_REQUIRE(nlam_mfma_terms() != 0, "nlam_wide_outer_multi: needs NLAM_MFMA=bf16x3|bf16");
+  for (int k = 0; k < n; ++k)
+    NLAM_REQUIRE(nslabs != nullptr && nslabs[k] >= 1 && nslabs[k] <= 1024,
+                 "nlam_wide_outer_multi: nslabs[%d] out of [1, 1024]", k);
   if (d == 256) {
     unsigned grid[NLAM_WIDE_MAXP];
-    for (int k = 0; k < n; ++k)
-      grid[k] = wide_grid(((rows[k] + NLAM_TILE - 1) / NLAM_TILE) * B[k]);
+    for (int k = 0; k < n; ++k) grid[k] = (unsigned)nslabs[k];
     return nlam_fs_outer_multi_256(n, g, g_bstride, g_ld, x, x_bstride, x_ld, silu_x, slab,
                                    slab_stride, B, rows, grid, stream);
   }
   NLAM_REQUIRE(d == 128, "nlam_wide_outer_multi: width %d unsupported (128, 256)", d);
   WideMulti<WideOuterParams> m;
+  int counts[NLAM_WIDE_MAXP];
   m.n = 0;
   for (int k = 0; k < n; ++k) {
     if (B[k] <= 0 || rows[k] <= 0) continue;
     if (wide_outer_fill(m.p[m.n], g[k], g_bstride[k], g_ld[k], 128, x[k], x_bstride[k], x_ld[k], 128,
                         silu_x[k], slab[k], slab_stride[k], B[k], rows[k]))
       return 1;
+    counts[m.n] = nslabs[k];
     ++m.n;
   }
   if (m.n == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
-  return nlam_mfma_terms() == 3 ? launch_wide_outer<4, 4, 3>(m, s) : launch_wide_outer<4, 4, 1>(m, s);
+  return nlam_mfma_terms() == 3 ? launch_wide_outer<4, 4, 3>(m, s, counts)
+                                : launch_wide_outer<4, 4, 1>(m, s, counts);
 }
 
 // ===================================== projections (first Linear), several per launch ===

@@ -232,9 +232,14 @@ def outer_multi(problems):
     n = len(problems)
     dev = problems[0][2].device
     stride = d * d + d
+    # slabs (= workgroups) per problem: proportional to the row counts, ~512 in all -- every slab
+    # is d*d floats written and read back, so 7 x 256 of them would out-weigh the operands
+    tiles = [g.B * ((g.rows + 31) // 32) for g, _, _, _, _ in problems]
+    total = max(1, sum(tiles))
+    budget = max(512, 64 * n)
     slabs, ns = [], []
-    for g, x, dW, db, sx in problems:
-        nsl = int(lib.nlam_bwd_grid(g.B * ((g.rows + 31) // 32)))
+    for t in tiles:
+        nsl = max(1, min(int(lib.nlam_bwd_grid(t)), -(-budget * t // total)))
         ns.append(nsl)
         slabs.append(torch.empty(nsl * stride, dtype=torch.float32, device=dev))
     _launch(
@@ -248,7 +253,7 @@ def outer_multi(problems):
          _arr(I32, [int(sx) for _, _, _, _, sx in problems]),
          _parr([sl.data_ptr() for sl in slabs]), _arr(I64, [stride] * n),
          _arr(I64, [g.B for g, _, _, _, _ in problems]),
-         _arr(I64, [g.rows for g, _, _, _, _ in problems]), stream()),
+         _arr(I64, [g.rows for g, _, _, _, _ in problems]), _arr(I32, ns), stream()),
         flops=sum(2.0 * g.B * g.rows * d * d for g, _, _, _, _ in problems),
         nbytes=sum(8.0 * g.B * g.rows * d for g, _, _, _, _ in problems),
     )

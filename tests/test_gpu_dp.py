@@ -39,13 +39,15 @@ def _build(tmp):
     return model, n
 
 
-def _worker(rank, world, port, tmp, q):
+def _worker(rank, world, port, tmp, q, backend="gloo"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # gloo: both ranks share the one visible card; nccl (= RCCL): one card per rank
+    torch.cuda.set_device(rank if backend == "nccl" else 0)
+    dist.init_process_group(backend, rank=rank, world_size=world)
     from neural_lam_amd import parallel, synthetic
 
-    torch.cuda.set_device(0)
     model, n = _build(tmp)
     model = model.cuda()
     flat = parallel.FlatParams(model)
@@ -62,14 +64,19 @@ def _worker(rank, world, port, tmp, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_gradients_match_single_process():
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_two_rank_gradients_match_single_process(backend):
+    """gloo: rehearsal on the one card of the test box; nccl: the RCCL path itself, on boxes
+    with at least two cards (skipped otherwise)."""
     from neural_lam_amd import parallel, synthetic
 
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("RCCL needs one GPU per rank (it refuses two ranks on one device)")
     with tempfile.TemporaryDirectory() as tmp:
         ctx = mp.get_context("spawn")
         q = ctx.Queue()
         port = _free_port()
-        procs = [ctx.Process(target=_worker, args=(r, 2, port, tmp, q)) for r in range(2)]
+        procs = [ctx.Process(target=_worker, args=(r, 2, port, tmp, q, backend)) for r in range(2)]
         for p in procs:
             p.start()
         res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
