@@ -20,4 +20,50 @@ print("ok inet stride-0 inputs", flush=True)
 for blueprint, ln, res, rows, B in T.MLP_CASES:
     T.test_wide_mlp_vs_oracle(blueprint, ln, res, rows, B)
     print(f"ok mlp {blueprint} ln={ln} res={res} rows={rows} B={B}", flush=True)
+
+
+def model_case(kind, hierarchical, levels):
+    """One training step of a small model at hidden T.D against the CPU oracle: loss and every
+    parameter gradient (the model wiring is pinned by the reference goldens at hidden 64 / 128;
+    this is the same check at this width, in this process's arithmetic)."""
+    import tempfile
+    import numpy as np
+    import torch
+    import nlam_oracle as orc
+    from neural_lam_amd import graphgen, synthetic, models
+
+    gen = torch.Generator().manual_seed(11)
+    with tempfile.TemporaryDirectory() as tmp:
+        info = graphgen.create_graph(tmp + "/graph/g", graphgen.make_xy(30, 28, 5000.0), levels,
+                                     hierarchical)
+        ng = info["num_grid"]
+        ds = synthetic.SyntheticDatastore(
+            tmp, torch.randn(ng, 1, generator=gen).numpy(), np.zeros(5), np.ones(5), np.zeros(5),
+            np.ones(5), (torch.rand(ng, generator=gen) < 0.2).float().numpy(), n_forcing=2)
+        torch.manual_seed(2)
+        cls = {"graph_lam": models.GraphLAM, "hi_lam": models.HiLAM}[kind]
+        model = cls(synthetic.model_args(graph="g", hidden_dim=T.D, processor_layers=1),
+                    config=None, datastore=ds)
+        _, graph = orc.load_graph(tmp + "/graph/g")
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()
+          if v.dtype.is_floating_point}
+    data = {k: getattr(model, k).detach().clone() for k in
+            ("grid_static_features", "diff_mean", "diff_std", "boundary_mask", "per_var_std")}
+    model = model.cuda()
+    batch = synthetic.random_batch(2, 1, ng, n_state=5, n_forcing_window=6, seed=5)
+    loss = model.training_step(tuple(t.cuda() if t is not None else None for t in batch))
+    loss.backward()
+    cfg = {"model": kind, "hidden_layers": 1, "processor_layers": 1, "mesh_aggr": "sum",
+           "loss": "wmse"}
+    want, _ = orc.training_loss(sd, graph, cfg, data, batch[0], batch[1], batch[2])
+    names = [k for k, _ in model.named_parameters()]
+    grads = torch.autograd.grad(want, [sd[k] for k in names])
+    lerr = abs(float(loss) - float(want)) / abs(float(want))
+    gerr = max(T.rel(p.grad, g) for (k, p), g in zip(model.named_parameters(), grads))
+    print(f"ok model {kind} d{T.D}: loss rel {lerr:.2e}  worst param grad {gerr:.2e}", flush=True)
+    assert lerr < T.FWD_BAR and gerr < T.GRAD_BAR, (lerr, gerr)
+
+
+model_case("graph_lam", False, None)
+model_case("hi_lam", True, None)
 print("all wide cases passed")
