@@ -458,6 +458,8 @@ int nlam_debug_edge_bwd_stamps(unsigned long long* out, int reset);
 /* Same for nlam_mlp_bwd: out[0..6] = staging, GEMM1 + silu, GEMM2 + LN backward, planes + dW2,
  * W2^T gz, X again + dW1 (or the ga store), W1^T ga + stores. */
 int nlam_debug_mlp_bwd_stamps(unsigned long long* out, int reset);
+/* The same for the hidden-256 tail kernels (16 values: forward phases 0..7, backward 8..15). */
+int nlam_debug_fs_stamps(unsigned long long* out, int reset);
 /* Diagnostic (NLAM_TIMELINE=1 in the environment of the process): nlam_lin_fwd records
  * s_memrealtime (100 MHz) per workgroup at start / after the weight prologue / at exit;
  * out: host array of 3 * 1024 values (first 1024 workgroups of the last launch). */

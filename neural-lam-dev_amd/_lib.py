@@ -91,6 +91,7 @@ SIGNATURES = {
     "nlam_nll_bwd": [_p, _p, _p, _p, _p, _f, _p, _p, _i64, _i64, _i32, _p],
     "nlam_debug_edge_bwd_stamps": [_p, _i32],
     "nlam_debug_mlp_bwd_stamps": [_p, _i32],
+    "nlam_debug_fs_stamps": [_p, _i32],
     "nlam_debug_lin_fwd_timeline": [_p],
     "nlam_mfma_probe": [_p, _p],
 }

@@ -572,6 +572,32 @@ int nlam_fs_lin_bwd_data_multi_256(int n, const float* const* gy, const int64_t*
   return launch_fs_lin_fwd<256, 256, 1, true>(m, (hipStream_t)stream);
 }
 
+// Diagnostic (NLAM_STAMP=1): wave 0 of every workgroup of fs_tail_fwd adds the s_memtime cycles
+// of each phase of each tile to g_fs_stamps (tools/stamp_fs.py).
+__device__ unsigned long long g_fs_stamps[16];
+extern "C" int nlam_debug_fs_stamps(unsigned long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fs_stamps), sizeof(unsigned long long) * 16) != hipSuccess)
+    return 1;
+  if (reset) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_fs_stamps), z, sizeof(z)) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#define FSSTAMP(k)                                                  \
+  if (stamp) {                                                      \
+    __builtin_amdgcn_sched_barrier(0);                              \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();   \
+    __builtin_amdgcn_s_waitcnt(0xC07F);                             \
+    __builtin_amdgcn_sched_barrier(0);                              \
+    fst[k] += now_ - fprev;                                         \
+    fprev = now_;                                                   \
+  }
+static int fs_stamp_flag() {
+  static const int f = getenv("NLAM_STAMP") != nullptr ? 1 : 0;
+  return f;
+}
+
 // ========================================================================= tail forward ===
 struct FsTailFwdParams {
   FsTiling tl;
@@ -586,6 +612,7 @@ struct FsTailFwdParams {
   RowView res;
   float* agg; int64_t agg_bstride; int64_t agg_ld; const float* inv_deg;
   int vec_y;
+  int stamp;
 };
 
 // slot r of the workgroup tile (sub-tile r >> 5, slot r & 31): its position, clamped to a valid one
@@ -662,6 +689,9 @@ __global__ __launch_bounds__(2 * D) void fs_tail_fwd_kernel(FsTailFwdParams p) {
     for (int k = 0; k < 4; ++k) tab[k * FS_R + tid] = nidx[k];
   };
   int par = 0;
+  const bool stamp = p.stamp != 0;
+  unsigned long long fst[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long fprev = stamp ? __builtin_amdgcn_s_memtime() : 0;
   if (tid < FS_R && (int64_t)blockIdx.x < ntiles) {
     fetch_idx(blockIdx.x);
     put_idx(itab0);
@@ -717,7 +747,9 @@ __global__ __launch_bounds__(2 * D) void fs_tail_fwd_kernel(FsTailFwdParams p) {
         if constexpr (TERMS == 3) *reinterpret_cast<bf16x4*>(S.lo + r * S.P + 4 * c4) = lo;
       }
     }
+    FSSTAMP(0)   // issue + landing of the gathered rows, h store, silu -> planes
     __syncthreads();
+    FSSTAMP(1)   // barrier (the slowest wave's rows)
     // residual rows: in flight during the GEMM and the LayerNorm exchange
     f32x4 rv[8];
     const bool res_vec = p.y != nullptr && p.vec_y && p.res.ptr != nullptr;
@@ -734,6 +766,7 @@ __global__ __launch_bounds__(2 * D) void fs_tail_fwd_kernel(FsTailFwdParams p) {
     z[0] = fs_vec_block(p.b2, p.n_out, wave, lane);
     z[1] = z[0];
     fs_gemm<D, TERMS>(z, A, S, lane);
+    FSSTAMP(2)   // residual issue + GEMM
     if (HAS_LN) {
       // The Linear output is a bf16 tensor, as under the reference's autocast (LayerNorm then
       // works in fp32 on those bf16 values): the backward reads the kept bf16 rows instead of
@@ -796,9 +829,11 @@ __global__ __launch_bounds__(2 * D) void fs_tail_fwd_kernel(FsTailFwdParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) z[rb][r] = (z[rb][r] - mean[rb]) * rstd[rb] * gav[r] + bev[r];
     }
+    FSSTAMP(3)   // LayerNorm: statistics exchange (2 barriers), z_keep store, normalise
     fs_acc_to_tile<LDO>(z, mtile, wave, lane);
     if (tid < FS_R && more) put_idx(itab0 + (par ^ 1) * 4 * FS_R);
     __syncthreads();
+    FSSTAMP(4)   // output tile + next tables + barrier
     // ---- outputs from the fp32 tile: receiver aggregation, whole-row stores
     if (p.agg != nullptr) {
       const int rb = wave / (NW / 2), fc = wave % (NW / 2);
@@ -839,6 +874,11 @@ __global__ __launch_bounds__(2 * D) void fs_tail_fwd_kernel(FsTailFwdParams p) {
     // (no barrier here: the next iteration writes the S planes -- free since every wave passed
     //  the barriers behind its GEMM -- and touches the output tile, the LayerNorm exchange
     //  and this tile's index table only behind its own first barrier)
+    FSSTAMP(5)   // aggregation + row stores
+  }
+  if (stamp && tid == 0) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) atomicAdd(&g_fs_stamps[k], fst[k]);
   }
 }
 
@@ -895,6 +935,7 @@ int nlam_fs_tail_fwd_256(
   p.agg = agg; p.agg_bstride = agg_bstride; p.agg_ld = agg_ld; p.inv_deg = inv_deg;
   p.vec_y = (y != nullptr && view_vec_ok(y, y_bstride, y_ld, n_out) &&
              (res == nullptr || view_vec_ok(res, res_bstride, res_ld, n_out))) ? 1 : 0;
+  p.stamp = fs_stamp_flag();
   hipStream_t s = (hipStream_t)stream;
   return gamma != nullptr ? launch_fs_tail_fwd<256, true, 1>(p, s)
                           : launch_fs_tail_fwd<256, false, 1>(p, s);
