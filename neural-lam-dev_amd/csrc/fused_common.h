@@ -237,6 +237,47 @@ __device__ __forceinline__ void store_rows_i(const float* __restrict__ tile, int
   }
 }
 
+// The receivers of a receiver-aligned tile are CONSECUTIVE rows r0 .. r0 + nr - 1 (nr <= 32, ~4-9
+// on the mesh graphs): their rows are loaded once (ceil(nr / rows-per-instruction) wave-wide
+// loads instead of the 32-row gather that fetched every receiver row deg times) and expanded to
+// the edge slots from LDS.  A CU issues a wave-wide 16-byte access every ~40 cycles whatever it
+// hits, so the gathers are priced by their NUMBER.  NV loads cover NV * rows-per-instruction
+// receivers (d = 64: 4 per load); callers prefetch NV = 4 and fetch the rest, if a tile has
+// more than 16 receivers, when they stage.
+template <int NV>
+__device__ __forceinline__ void load_rows_c(f32x4 (&v)[NV], const float* __restrict__ base,
+                                            int64_t ld, int r0, int nr, int width, int lane) {
+  const int lpr = width >> 2;
+  const int rpi = 64 / lpr;
+  const int sub = lane / lpr;
+  const int c4 = sub < rpi ? lane - sub * lpr : 0;
+  const int last = nr - 1;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {   // unconditional (slots past nr re-read the last row): no branches
+    const int t = sub + k * rpi;
+    v[k] = reinterpret_cast<const f32x4*>(base + (int64_t)(r0 + (t < last ? t : last)) * ld)[c4];
+  }
+}
+// accumulator layout (lane = slot t, half h) <- tile row `row` of that slot (its receiver's row)
+template <int NB, bool ADD>
+__device__ __forceinline__ void tile_rows_to_acc(f32x16 (&acc)[NB], const float* __restrict__ tile,
+                                                 int ld, int row, bool valid, int lane) {
+  const int h = lane >> 5;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(tile + row * ld + 32 * nb + 8 * q + 4 * h);
+      if (!valid) v = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (ADD) acc[nb][4 * q + j] += v[j];
+        else acc[nb][4 * q + j] = v[j];
+      }
+    }
+  }
+}
+
 // scalar form for narrow / unaligned sources (width <= 2 NS)
 template <int NS, typename RowPtr>
 __device__ __forceinline__ void load_rows_s(float (&v)[NS], int width, int lane, RowPtr row_ptr) {

@@ -358,7 +358,9 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
   // The five row gathers of a tile (e, ps, pr, g_agg, g_eout) are issued ONE TILE AHEAD,
   // at the start of the previous tile's last phase, and land while its MFMAs run: with
   // one wave per SIMD nothing else hides their latency (stamps: 16 % of the tile time).
-  f32x4 vE[NVR], vS[NVR], vR[NVR], vG[NVR], vO[NVR];
+  constexpr int NVC = 4;                      // receiver rows prefetched: 4 loads = 16 rows at d = 64
+  constexpr int RC = NVC * (64 / (D / 4));    // rows those cover
+  f32x4 vE[NVR], vS[NVR], vR[NVC], vG[NVC], vO[NVR];
   auto issue_rows = [&](const TileCtx& c, unsigned task, int par) {
     const unsigned tq = task < total ? task : total - 1;
     const unsigned b = tq / (unsigned)p.ntiles;
@@ -375,14 +377,13 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
     stash_slot_index(tab + NLAM_TILE, snd, lane);
     stash_slot_index(tab + 2 * NLAM_TILE, rcv, lane);
     wave_sync();
-    int ie[NVR], is[NVR], ir[NVR];
+    int ie[NVR], is[NVR];
     lane_row_index<NVR>(ie, tab, D, lane);
     lane_row_index<NVR>(is, tab + NLAM_TILE, D, lane);
-    lane_row_index<NVR>(ir, tab + 2 * NLAM_TILE, D, lane);
     load_rows_i<NVR>(vE, eb, p.e.ld, ie, D, lane);
     load_rows_i<NVR>(vS, psb, p.ps.ld, is, D, lane);
-    load_rows_i<NVR>(vR, prb, p.pr.ld, ir, D, lane);
-    load_rows_i<NVR>(vG, gab, q.g_agg.ld, ir, D, lane);
+    load_rows_c<NVC>(vR, prb, p.pr.ld, c.r0, c.nr, D, lane);       // the tile's receiver rows, once
+    load_rows_c<NVC>(vG, gab, q.g_agg.ld, c.r0, c.nr, D, lane);
     if (has_geo) load_rows_i<NVR>(vO, gob, gold, ie, D, lane);
   };
   int par = 0;
@@ -397,8 +398,6 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
     const int4 hdr_nn = load_tile_hdr(p, tt + 2 * stride, total);
 
     // ---- recompute forward: hpre, sact, xhat
-#pragma unroll
-    for (int k = 0; k < NVR; ++k) vS[k] += vR[k];
     f32x16 hpre[NB];
     if (HAS_EGEMM) {
       if constexpr (B3) put_rows_v_b3<NVR>(T0p, 0, D, ne, lane, vE);   // E stays in T0 (planes)
@@ -408,12 +407,28 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
       for (int k = 0; k < NVR; ++k) vS[k] += vE[k];              // Pe + Ps + Pr
     }
     put_rows_v<NVR, false>(T1, LDT, 0, D, ne, lane, vS);
-    put_rows_v<NVR, false>(T2, LDT, 0, D, ne, lane, vG);         // g_agg rows
+    put_rows_v<NVC, false>(T2, LDT, 0, D, nr, lane, vR);         // Pr rows of the tile's receivers
+    if (nr > RC) {   // (rare: more than 16 receivers in a 32-edge tile) the rest, fetched now
+      f32x4 xr[NVC];
+      load_rows_c<NVC>(xr, p.pr.ptr + (int64_t)b * p.pr.bstride, p.pr.ld, r0 + RC, nr - RC, D, lane);
+      put_rows_v<NVC, false>(T2 + RC * LDT, LDT, 0, D, nr - RC, lane, xr);
+    }
     wave_sync();
     STAMP_AT(0)   // gathers landed + staged
+    const int roff = (t < ne) ? rcv - r0 : 0;                    // this slot's receiver row in T2
     tile_to_acc<NB>(hpre, T1, LDT, lane);
+    tile_rows_to_acc<NB, true>(hpre, T2, LDT, roff, t < ne, lane);
+    wave_sync();
+    put_rows_v<NVC, false>(T2, LDT, 0, D, nr, lane, vG);         // g_agg rows of the receivers
+    if (nr > RC) {
+      f32x4 xg[NVC];
+      load_rows_c<NVC>(xg, q.g_agg.ptr + (int64_t)b * q.g_agg.bstride, q.g_agg.ld, r0 + RC, nr - RC, D,
+                       lane);
+      put_rows_v<NVC, false>(T2 + RC * LDT, LDT, 0, D, nr - RC, lane, xg);
+    }
+    wave_sync();
     f32x16 g[NB];
-    tile_to_acc<NB>(g, T2, LDT, lane);
+    tile_rows_to_acc<NB, false>(g, T2, LDT, roff, t < ne, lane);
     if (p.inv_deg != nullptr) {
       const float sc = (t < ne) ? p.inv_deg[rcv] : 0.f;
 #pragma unroll
