@@ -229,7 +229,7 @@ int nlam_lin_fwd(const float* x, int64_t x_bstride, int64_t x_ld, int k_in,
                  const float* WA, int64_t ldWA, const float* bA, int nA,
                  const float* WB, int64_t ldWB, const float* bB, int nB,
                  float* out, int64_t out_bstride, int64_t out_ld,
-                 int64_t B, int64_t rows, void* stream);
+                 int64_t B, int64_t rows, int out_bf16, void* stream);
 
 /* Fused edge update + aggregation of one InteractionNet layer
  * (interaction_net.py:102-105,117-131):
@@ -352,7 +352,17 @@ int nlam_wmse_bwd(const float* pred, const float* target, const float* keep,
  * LayerNorm -- the Linear output dtype under the reference's `--precision bf16-mixed` autocast
  * (train_model.py:73-76) -- and z_keep (optional; (B, rows, d) bf16 rows, position order, batch
  * pitch z_bstride elements) receives those rows for nlam_tail_bwd, which then needs no second
- * GEMM.  d = 128 ignores z_keep (its backward repeats the GEMM from h). */
+ * GEMM.  d = 128 ignores z_keep (its backward repeats the GEMM from h).
+ *
+ * bf16 STORAGE of intermediates (hidden 256 only; the dtype the reference's autocast gives the
+ * outputs of nn.Linear and their gradients): `out_bf16` / `io_bf16` say which row operands are
+ * bf16 instead of fp32 -- the pointer is then a bf16 pointer passed as float*, its pitches count
+ * bf16 elements (multiples of 8: a lane moves 16 bytes) and the rows are 256 wide.
+ *   nlam_lin_fwd: out_bf16 (nlam_lin_fwd_multi: bit k = problem k);
+ *   nlam_tail_fwd: io_bf16 != 0 = a, b, c AND h_out are bf16 (h is rounded to bf16 before the SiLU);
+ *   nlam_tail_bwd: io_bf16 != 0 = h AND gz_out are bf16 (LayerNorm form);
+ *   nlam_wide_outer[_multi]: bit 0 = g, bit 1 = x.
+ * 0 everywhere = all fp32 (the only form at hidden 64 / 128). */
 int nlam_tail_fwd(const int32_t* tiles, int64_t ntiles, int64_t rows, const int32_t* csr_rec,
                   const int32_t* csr_rowptr,
                   const float* a, int64_t a_bstride, int64_t a_ld, const int32_t* idx_a,
@@ -364,7 +374,7 @@ int nlam_tail_fwd(const int32_t* tiles, int64_t ntiles, int64_t rows, const int3
                   float* y, int64_t y_bstride, int64_t y_ld, const int32_t* idx_y,
                   const float* res, int64_t res_bstride, int64_t res_ld,
                   float* agg, int64_t agg_bstride, int64_t agg_ld, const float* inv_deg,
-                  int64_t B, int d, void* stream);
+                  int64_t B, int d, int io_bf16, void* stream);
 /* Backward of nlam_tail_fwd from the kept h:  g[p] = scale1[idx_g1[p]] * g1[idx_g1[p]] +
  * g2[idx_g2[p]] is the gradient of m[p];  gz = LN'(z; g) (= g without LayerNorm) is written to
  * gz_out (B, rows, ceil32(n_out)) for the weight-gradient pass;  gh[idx_gh[p]] =
@@ -383,7 +393,7 @@ int nlam_tail_bwd(const int32_t* tiles, int64_t ntiles, int64_t rows, const int3
                   float* gz_out, int64_t gz_bstride,
                   float* gh, int64_t gh_bstride, int64_t gh_ld, const int32_t* idx_gh,
                   float* gpr, int64_t gpr_bstride, int64_t gpr_ld,
-                  float* slab, int64_t slab_stride, int64_t B, int d, void* stream);
+                  float* slab, int64_t slab_stride, int64_t B, int d, int io_bf16, void* stream);
 /* gx = gy W [+ gx_add]: data gradient of a Linear (W: n_out x k_in = 128 x 128). */
 int nlam_lin_bwd_data(const float* gy, int64_t gy_bstride, int64_t gy_ld, int n_out,
                       const float* W, int64_t ldW, int k_in,
@@ -397,7 +407,8 @@ int nlam_lin_bwd_data(const float* gy, int64_t gy_bstride, int64_t gy_ld, int n_
  * unaligned x rows (static features of the embedders) are staged by scalar loads. */
 int nlam_wide_outer(const float* g, int64_t g_bstride, int64_t g_ld, int ng,
                     const float* x, int64_t x_bstride, int64_t x_ld, int nx, int silu_x,
-                    float* slab, int64_t slab_stride, int64_t B, int64_t rows, void* stream);
+                    float* slab, int64_t slab_stride, int64_t B, int64_t rows, int io_bf16,
+                    void* stream);
 
 /* Several INDEPENDENT problems of one kind in one launch (n <= 8; arrays of n entries): the small
  * mesh levels of Hi-LAM (reference hi_lam.py:82-207: 10 InteractionNets per processor layer on
@@ -411,7 +422,7 @@ int nlam_wide_outer(const float* g, int64_t g_bstride, int64_t g_ld, int ng,
 int nlam_lin_fwd_multi(int n, int d, const float* const* x, const int64_t* x_bstride, const int64_t* x_ld,
                        const float* const* W, const int64_t* ldW, const float* const* bias,
                        float* const* out, const int64_t* out_bstride, const int64_t* out_ld,
-                       const int64_t* B, const int64_t* rows, void* stream);
+                       const int64_t* B, const int64_t* rows, int out_bf16_mask, void* stream);
 int nlam_lin_bwd_data_multi(int n, int d, const float* const* gy, const int64_t* gy_bstride,
                             const int64_t* gy_ld, const float* const* W, const int64_t* ldW,
                             float* const* gx, const int64_t* gx_bstride, const int64_t* gx_ld,
@@ -422,7 +433,8 @@ int nlam_wide_outer_multi(int n, int d, const float* const* g, const int64_t* g_
                           const int64_t* g_ld, const float* const* x, const int64_t* x_bstride,
                           const int64_t* x_ld, const int32_t* silu_x, float* const* slab,
                           const int64_t* slab_stride, const int64_t* B, const int64_t* rows,
-                          const int32_t* nslabs, void* stream);
+                          const int32_t* nslabs, const int32_t* io_bf16,
+                          void* stream);
 
 /* Grid feature rows of predict_step (reference base_graph_model.py:116-124): out (B, N, sum w) =
  * concatenation of up to four (B | 1, N, w_k) sources along the feature axis (bstride 0 =

@@ -48,7 +48,7 @@ SIGNATURES = {
     "nlam_reduce_slabs_multi": [_p, _i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p],
     "nlam_reduce_slabs_batch": [_i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     "nlam_lin_fwd": [_p, _i64, _i64, _i32, _p, _i64, _p, _i32, _p, _i64, _p, _i32, _p, _i64, _i64,
-                     _i64, _i64, _p],
+                     _i64, _i64, _i32, _p],
     "nlam_edge_fwd": [_p, _i64, _p, _p, _p, _p, _p, _p, _i64, _i64, _i32, _p, _i64, _i64, _p, _i64,
                       _i64, _p, _i64, _p, _i64, _p, _p, _p, _p, _i64, _i64, _p, _i64, _i64, _i64,
                       _i32, _p],
@@ -71,19 +71,20 @@ SIGNATURES = {
                       _p, _i64, _i64, _p, _p, _i64, _i64, _p, _p, _i64, _i64, _p,
                       _p, _i64, _p, _p, _p, _i32, _p, _i64, _p, _i64,
                       _p, _i64, _i64, _p, _p, _i64, _i64,
-                      _p, _i64, _i64, _p, _i64, _i32, _p],
+                      _p, _i64, _i64, _p, _i64, _i32, _i32, _p],
     "nlam_tail_bwd_slab_stride": [_i32],
     "nlam_tail_bwd": [_p, _i64, _i64, _p, _p, _p, _i64, _p, _i64,
                       _p, _i64, _i64, _p, _p, _p, _i64, _i64, _p,
                       _p, _i64, _p, _p, _i32, _p, _i64,
                       _p, _i64, _i64, _p, _p, _i64, _i64,
-                      _p, _i64, _i64, _i32, _p],
+                      _p, _i64, _i64, _i32, _i32, _p],
     "nlam_lin_bwd_data": [_p, _i64, _i64, _i32, _p, _i64, _i32, _p, _i64, _i64, _p, _i64, _i64,
                           _i64, _i64, _p],
-    "nlam_wide_outer": [_p, _i64, _i64, _i32, _p, _i64, _i64, _i32, _i32, _p, _i64, _i64, _i64, _p],
-    "nlam_lin_fwd_multi": [_i32, _i32] + [_p] * 11 + [_p],
+    "nlam_wide_outer": [_p, _i64, _i64, _i32, _p, _i64, _i64, _i32, _i32, _p, _i64, _i64, _i64, _i32,
+                        _p],
+    "nlam_lin_fwd_multi": [_i32, _i32] + [_p] * 11 + [_i32, _p],
     "nlam_lin_bwd_data_multi": [_i32, _i32] + [_p] * 13 + [_p],
-    "nlam_wide_outer_multi": [_i32, _i32] + [_p] * 12 + [_p],
+    "nlam_wide_outer_multi": [_i32, _i32] + [_p] * 13 + [_p],
     "nlam_concat_rows": [_i32, _p, _p, _p, _p, _p, _i64, _i64, _p],
     "nlam_std_head_fwd": [_p, _p, _p, _p, _p, _p, _i64, _i32, _p],
     "nlam_std_head_bwd": [_p, _p, _p, _p, _p, _i64, _i32, _p],

@@ -218,6 +218,36 @@ __device__ __forceinline__ FsSub fs_sub(const FsTiling& tl, int64_t id) {
 
 // =========================================================================== lin_fwd ===
 // out = x W^T + bias, W: n_out (<= 256) x k_in (<= K), output features padded to 256.
+// bf16 STORAGE of row operands (hidden 256; the dtype the reference's autocast gives Linear
+// outputs and their gradients).  A lane moves 8 elements = 16 bytes, so a 256-wide row is 32
+// lanes and the 512 threads of a workgroup cover 16 rows per pass (4 passes per 64-row tile):
+// HALF the vector-memory instructions of the fp32 form -- which is what these kernels are bound
+// by (an 8-byte-per-lane form with the fp32 thread map was slower than fp32 storage).
+// Pointers to such operands are bf16 pointers passed as float*; pitches count bf16 elements.
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 fs_bf16x8;
+__device__ __forceinline__ void fs_cvt8f(const fs_bf16x8& v, float (&x)[8]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) x[j] = (float)v[j];
+}
+__device__ __forceinline__ fs_bf16x8 fs_cvt8b(const float (&x)[8]) {
+  fs_bf16x8 v;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = (__bf16)x[j];
+  return v;
+}
+__device__ __forceinline__ fs_bf16x8 fs_ld8(const float* ptr, int64_t idx, int c8) {
+  return reinterpret_cast<const fs_bf16x8*>(reinterpret_cast<const __bf16*>(ptr) + idx)[c8];
+}
+__device__ __forceinline__ void fs_st8(float* ptr, int64_t idx, int c8, const fs_bf16x8& v) {
+  reinterpret_cast<fs_bf16x8*>(reinterpret_cast<__bf16*>(ptr) + idx)[c8] = v;
+}
+// 8 bf16 -> a plane row (two 8-byte LDS writes: plane rows are only 8-byte aligned)
+__device__ __forceinline__ void fs_plane_put8(__bf16* plane, int off, const fs_bf16x8& v) {
+  const bf16x4 lo = {v[0], v[1], v[2], v[3]}, hi = {v[4], v[5], v[6], v[7]};
+  *reinterpret_cast<bf16x4*>(plane + off) = lo;
+  *reinterpret_cast<bf16x4*>(plane + off + 4) = hi;
+}
+
 struct FsLinParams {
   RowView x;                 // width = k_in
   const float* W; int64_t ldW; const float* bias; int n_out;
@@ -225,6 +255,7 @@ struct FsLinParams {
   const float* add; int64_t add_bstride; int64_t add_ld;   // optional addend of out (rows like out)
   int64_t rows; int B;
   int x_vec;                 // x rows float4-loadable and k_in == K
+  int out_bf16;              // out rows stored as bf16 (n_out == D; pitches in bf16 elements)
 };
 
 // rows of the workgroup tile -> bf16 planes (zero beyond nrows / k_in); float4 or scalar source
@@ -388,6 +419,19 @@ __device__ __forceinline__ void fs_lin_fwd_body(const FsLinParams& p, const int 
             reinterpret_cast<f32x4*>(ob + (int64_t)r * p.out_ld)[oc4] =
                 *reinterpret_cast<const f32x4*>(otile + r * LDO + 4 * oc4) + av[k];
         }
+      } else if (p.out_bf16) {
+        const int oc8 = tid % (D / 8), orh = tid / (D / 8);     // 16 rows per pass
+        const int64_t o0 = b * p.out_bstride + r0 * p.out_ld;
+#pragma unroll
+        for (int k = 0; k < FS_R / 16; ++k) {
+          const int r = orh + 16 * k;
+          if (r < nrows) {
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(otile + r * LDO + 8 * oc8);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(otile + r * LDO + 8 * oc8 + 4);
+            const float x[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            fs_st8(p.out, o0 + (int64_t)r * p.out_ld, oc8, fs_cvt8b(x));
+          }
+        }
       } else {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -463,7 +507,9 @@ static int launch_fs_lin_fwd(const FsLinParams& p, hipStream_t s) {
 // out = x W^T + bias for x: (B, rows, k_in <= 256) fp32, W: 256 x k_in; NLAM_MFMA=bf16.
 int nlam_fs_lin_fwd_256(const float* x, int64_t x_bstride, int64_t x_ld, int k_in, const float* W,
                         int64_t ldW, const float* bias, int n_out, float* out, int64_t out_bstride,
-                        int64_t out_ld, int64_t B, int64_t rows, void* stream) {
+                        int64_t out_ld, int64_t B, int64_t rows, int out_bf16, void* stream) {
+  NLAM_REQUIRE(!out_bf16 || (n_out == 256 && out_ld % 8 == 0 && out_bstride % 8 == 0),
+               "fs_lin_fwd: bf16 output rows are 256 wide with pitches %% 8 == 0");
   if (B <= 0 || rows <= 0) return 0;
   NLAM_REQUIRE(nlam_mfma_terms() == 1, "hidden 256 needs NLAM_MFMA=bf16");
   NLAM_REQUIRE(n_out >= 4 && n_out <= 256 && n_out % 4 == 0, "fs_lin_fwd: n_out %d unsupported", n_out);
@@ -475,7 +521,7 @@ int nlam_fs_lin_fwd_256(const float* x, int64_t x_bstride, int64_t x_ld, int k_i
   p.W = W; p.ldW = ldW; p.bias = bias; p.n_out = n_out;
   p.out = out; p.out_bstride = out_bstride; p.out_ld = out_ld;
   p.add = nullptr; p.add_bstride = 0; p.add_ld = 0;
-  p.rows = rows; p.B = (int)B;
+  p.rows = rows; p.B = (int)B; p.out_bf16 = out_bf16;
   hipStream_t s = (hipStream_t)stream;
   if (k_in <= 32) { p.x_vec = (k_in == 32 && view_vec_ok(x, x_bstride, x_ld, 32)); return launch_fs_lin_fwd<256, 32, 1>(p, s); }
   if (k_in <= 64) { p.x_vec = (k_in == 64 && view_vec_ok(x, x_bstride, x_ld, 64)); return launch_fs_lin_fwd<256, 64, 1>(p, s); }
@@ -499,7 +545,7 @@ int nlam_fs_lin_bwd_data_256(const float* gy, int64_t gy_bstride, int64_t gy_ld,
   p.W = W; p.ldW = ldW; p.bias = nullptr; p.n_out = 256;
   p.out = gx; p.out_bstride = gx_bstride; p.out_ld = gx_ld;
   p.add = gx_add; p.add_bstride = ga_bstride; p.add_ld = ga_ld;
-  p.rows = rows; p.B = (int)B; p.x_vec = 1;
+  p.rows = rows; p.B = (int)B; p.x_vec = 1; p.out_bf16 = 0;
   return launch_fs_lin_fwd<256, 256, 1, true>(p, (hipStream_t)stream);
 }
 
@@ -526,7 +572,7 @@ int nlam_fs_lin_fwd_multi_256(int n, const float* const* x, const int64_t* x_bst
                               const int64_t* x_ld, const float* const* W, const int64_t* ldW,
                               const float* const* bias, float* const* out,
                               const int64_t* out_bstride, const int64_t* out_ld, const int64_t* B,
-                              const int64_t* rows, void* stream) {
+                              const int64_t* rows, int out_bf16_mask, void* stream) {
   NLAM_REQUIRE(nlam_mfma_terms() == 1, "hidden 256 needs NLAM_MFMA=bf16");
   WideMulti<FsLinParams> m;
   m.n = 0;
@@ -540,7 +586,9 @@ int nlam_fs_lin_fwd_multi_256(int n, const float* const* x, const int64_t* x_bst
     p.W = W[k]; p.ldW = ldW[k]; p.bias = bias[k]; p.n_out = 256;
     p.out = out[k]; p.out_bstride = out_bstride[k]; p.out_ld = out_ld[k];
     p.add = nullptr; p.add_bstride = 0; p.add_ld = 0;
-    p.rows = rows[k]; p.B = (int)B[k]; p.x_vec = 1;
+    p.rows = rows[k]; p.B = (int)B[k]; p.x_vec = 1; p.out_bf16 = (out_bf16_mask >> k) & 1;
+    NLAM_REQUIRE(!p.out_bf16 || (out_ld[k] % 8 == 0 && out_bstride[k] % 8 == 0),
+                 "nlam_lin_fwd_multi: bf16 output pitches must be multiples of 8");
   }
   if (m.n == 0) return 0;
   return launch_fs_lin_fwd<256, 256, 1>(m, (hipStream_t)stream);
@@ -566,7 +614,7 @@ int nlam_fs_lin_bwd_data_multi_256(int n, const float* const* gy, const int64_t*
     p.W = W[k]; p.ldW = ldW[k]; p.bias = nullptr; p.n_out = 256;
     p.out = gx[k]; p.out_bstride = gx_bstride[k]; p.out_ld = gx_ld[k];
     p.add = gx_add[k]; p.add_bstride = ga_bstride[k]; p.add_ld = ga_ld[k];
-    p.rows = rows[k]; p.B = (int)B[k]; p.x_vec = 1;
+    p.rows = rows[k]; p.B = (int)B[k]; p.x_vec = 1; p.out_bf16 = 0;
   }
   if (m.n == 0) return 0;
   return launch_fs_lin_fwd<256, 256, 1, true>(m, (hipStream_t)stream);
@@ -656,7 +704,9 @@ __device__ __forceinline__ void fs_segment_sums(const float* __restrict__ tile, 
   }
 }
 
-template <int D, bool HAS_LN, int TERMS>
+// IO16: the sources a / b / c and h_out are bf16 rows (16-byte lanes, 16 rows per pass); h is then
+// rounded to bf16 before the SiLU (it IS a bf16 tensor: the backward reads the stored value).
+template <int D, bool HAS_LN, int TERMS, bool IO16 = false>
 __global__ __launch_bounds__(2 * D) void fs_tail_fwd_kernel(FsTailFwdParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NT = 2 * D, NW = D / 32, LDO = D + 4, CPR = D / 4;
@@ -703,6 +753,44 @@ __global__ __launch_bounds__(2 * D) void fs_tail_fwd_kernel(FsTailFwdParams p) {
     const bool more = tt + gridDim.x < ntiles;
     if (tid < FS_R && more) fetch_idx(tt + gridDim.x);
     // ---- h = a + b + c (row layout), keep h, s = silu(h) -> planes
+    if constexpr (IO16) {
+      const int c8 = tid % (D / 8), rh = tid / (D / 8);
+      fs_bf16x8 va[4], vb[4], vc[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int r = rh + 16 * k, rb = r >> 5;
+        va[k] = fs_ld8(p.a.ptr, sub.b(rb) * p.a.bstride + (int64_t)itab[r] * p.a.ld, c8);
+        if (p.b.ptr)
+          vb[k] = fs_ld8(p.b.ptr, sub.b(rb) * p.b.bstride + (int64_t)itab[FS_R + r] * p.b.ld, c8);
+        if (p.c.ptr)
+          vc[k] = fs_ld8(p.c.ptr, sub.b(rb) * p.c.bstride + (int64_t)itab[2 * FS_R + r] * p.c.ld, c8);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int r = rh + 16 * k, rb = r >> 5;
+        const bool valid = (r & 31) < sub.ne(rb);
+        float x[8], y[8];
+        fs_cvt8f(va[k], x);
+        if (p.b.ptr) {
+          fs_cvt8f(vb[k], y);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) x[j] += y[j];
+        }
+        if (p.c.ptr) {
+          fs_cvt8f(vc[k], y);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) x[j] += y[j];
+        }
+        const fs_bf16x8 hb = fs_cvt8b(x);          // h as stored
+        if (valid && p.h_out != nullptr)
+          fs_st8(p.h_out, sub.b(rb) * p.h_bstride + (int64_t)(sub.p0(rb) + (r & 31)) * D, c8, hb);
+        fs_cvt8f(hb, x);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = valid ? nlam_silu(x[j]) : 0.f;
+        fs_plane_put8(S.hi, r * S.P + 8 * c8, fs_cvt8b(x));
+        __builtin_amdgcn_sched_barrier(0);   // (one row block's temporaries at a time)
+      }
+    } else
     {
       f32x4 v[8];
 #pragma unroll
@@ -882,12 +970,12 @@ __global__ __launch_bounds__(2 * D) void fs_tail_fwd_kernel(FsTailFwdParams p) {
   }
 }
 
-template <int D, bool HAS_LN, int TERMS>
+template <int D, bool HAS_LN, int TERMS, bool IO16 = false>
 static int launch_fs_tail_fwd(const FsTailFwdParams& p, hipStream_t s) {
   const size_t lds = FsPlanes<D, TERMS>::bytes + (size_t)FS_R * (D + 4) * sizeof(float) +
                      (size_t)2 * FS_R * (D / 32) * sizeof(float) + (size_t)8 * FS_R * sizeof(int);
   NLAM_REQUIRE(lds <= 160 * 1024, "fs_tail_fwd: LDS footprint %zu B exceeds 160 KiB", lds);
-  auto kern = fs_tail_fwd_kernel<D, HAS_LN, TERMS>;
+  auto kern = fs_tail_fwd_kernel<D, HAS_LN, TERMS, IO16>;
   NLAM_BIG_LDS(kern, "fs_tail_fwd_kernel");
   const int64_t ntiles = (p.tl.ntiles * p.tl.B + 1) / 2;
   kern<<<fs_grid(ntiles), 2 * D, lds, s>>>(p);
@@ -906,8 +994,12 @@ int nlam_fs_tail_fwd_256(
     float* y, int64_t y_bstride, int64_t y_ld, const int32_t* idx_y,
     const float* res, int64_t res_bstride, int64_t res_ld,
     float* agg, int64_t agg_bstride, int64_t agg_ld, const float* inv_deg,
-    int64_t B, void* stream) {
+    int64_t B, int io_bf16, void* stream) {
   constexpr int d = 256;
+  NLAM_REQUIRE(!io_bf16 || (a_ld % 8 == 0 && a_bstride % 8 == 0 &&
+                            (!b || (b_ld % 8 == 0 && b_bstride % 8 == 0)) &&
+                            (!c || (c_ld % 8 == 0 && c_bstride % 8 == 0)) && h_bstride % 8 == 0),
+               "nlam_tail_fwd: bf16 rows need pitches %% 8 == 0");
   NLAM_REQUIRE(z_keep == nullptr || (gamma != nullptr && (reinterpret_cast<uintptr_t>(z_keep) & 7u) == 0 &&
                                      z_bstride % 4 == 0),
                "nlam_tail_fwd: z_keep needs the LayerNorm form and 8-byte aligned rows");
@@ -937,6 +1029,9 @@ int nlam_fs_tail_fwd_256(
              (res == nullptr || view_vec_ok(res, res_bstride, res_ld, n_out))) ? 1 : 0;
   p.stamp = fs_stamp_flag();
   hipStream_t s = (hipStream_t)stream;
+  if (io_bf16)
+    return gamma != nullptr ? launch_fs_tail_fwd<256, true, 1, true>(p, s)
+                            : launch_fs_tail_fwd<256, false, 1, true>(p, s);
   return gamma != nullptr ? launch_fs_tail_fwd<256, true, 1>(p, s)
                           : launch_fs_tail_fwd<256, false, 1>(p, s);
 }
@@ -993,7 +1088,8 @@ struct FsTailBwdParams {
   int vec_g;
 };
 
-template <int D, bool HAS_LN, int TERMS>
+// IO16: h and gz_out are bf16 rows (16-byte lanes; z_keep always is)
+template <int D, bool HAS_LN, int TERMS, bool IO16 = false>
 __global__ __launch_bounds__(2 * D) void fs_tail_bwd_kernel(FsTailBwdParams q) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NT = 2 * D, NW = D / 32, LDO = D + 4, CPR = D / 4;
@@ -1045,6 +1141,29 @@ __global__ __launch_bounds__(2 * D) void fs_tail_bwd_kernel(FsTailBwdParams q) {
     // ---- stage: silu'(h) as a bf16 plane, the kept z rows (already bf16) into the S planes,
     //      g = scale * g1[idx] + g2[idx] as fp32 rows
     {
+      if constexpr (IO16) {
+        const int c8 = tid % (D / 8), rh = tid / (D / 8);
+        fs_bf16x8 vh[4], vz[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int r = rh + 16 * k;
+          const int pos = fs_slot_pos(sub, r);
+          vh[k] = fs_ld8(q.h, sub.b(r >> 5) * q.h_bstride + (int64_t)pos * D, c8);
+          if (HAS_LN)
+            vz[k] = reinterpret_cast<const fs_bf16x8*>(q.z_keep + sub.b(r >> 5) * q.z_bstride + (int64_t)pos * D)[c8];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int r = rh + 16 * k;
+          const bool valid = (r & 31) < sub.ne(r >> 5);
+          float x[8];
+          fs_cvt8f(vh[k], x);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) x[j] = valid ? nlam_silu_grad(x[j]) : 0.f;
+          fs_plane_put8(DS, r * PD + 8 * c8, fs_cvt8b(x));
+          if (HAS_LN) fs_plane_put8(S.hi, r * S.P + 8 * c8, vz[k]);
+        }
+      } else {
       f32x4 vh[8];
       bf16x4 vz[8];
 #pragma unroll
@@ -1064,6 +1183,7 @@ __global__ __launch_bounds__(2 * D) void fs_tail_bwd_kernel(FsTailBwdParams q) {
         for (int j = 0; j < 4; ++j) dh[j] = (__bf16)(valid ? nlam_silu_grad(vh[k][j]) : 0.f);
         *reinterpret_cast<bf16x4*>(DS + r * PD + 4 * c4) = dh;
         if (HAS_LN) *reinterpret_cast<bf16x4*>(S.hi + r * S.P + 4 * c4) = vz[k];
+      }
       }
       if (q.vec_g) {
 #pragma unroll 1
@@ -1212,7 +1332,20 @@ __global__ __launch_bounds__(2 * D) void fs_tail_bwd_kernel(FsTailBwdParams q) {
       }
     }
     __syncthreads();
-    {
+    if constexpr (IO16) {   // (NO == D here: checked on the host)
+      const int c8 = tid % (D / 8), rh = tid / (D / 8);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int r = rh + 16 * k;
+        const int rb = r >> 5;
+        if ((r & 31) < sub.ne(rb)) {
+          const f32x4 lo = *reinterpret_cast<const f32x4*>(gtile + r * LDO + 8 * c8);
+          const f32x4 hi = *reinterpret_cast<const f32x4*>(gtile + r * LDO + 8 * c8 + 4);
+          const float x[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          fs_st8(q.gz_out, sub.b(rb) * q.gz_bstride + (int64_t)(sub.p0(rb) + (r & 31)) * D, c8, fs_cvt8b(x));
+        }
+      }
+    } else {
       const int nc4 = NO >> 2;
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
@@ -1281,13 +1414,13 @@ __global__ __launch_bounds__(2 * D) void fs_tail_bwd_kernel(FsTailBwdParams q) {
   }
 }
 
-template <int D, bool HAS_LN, int TERMS>
+template <int D, bool HAS_LN, int TERMS, bool IO16 = false>
 static int launch_fs_tail_bwd(const FsTailBwdParams& q, hipStream_t s, unsigned grid) {
   const size_t lds = FsPlanes<D, TERMS>::bytes + (size_t)FS_R * (D + 4) * sizeof(__bf16) +
                      (size_t)FS_R * (D + 4) * sizeof(float) +
                      (size_t)2 * FS_R * (D / 32) * sizeof(float) + (size_t)8 * FS_R * sizeof(int);
   NLAM_REQUIRE(lds <= 160 * 1024, "fs_tail_bwd: LDS footprint %zu B exceeds 160 KiB", lds);
-  auto kern = fs_tail_bwd_kernel<D, HAS_LN, TERMS>;
+  auto kern = fs_tail_bwd_kernel<D, HAS_LN, TERMS, IO16>;
   NLAM_BIG_LDS(kern, "fs_tail_bwd_kernel");
   kern<<<grid, 2 * D, lds, s>>>(q);
   NLAM_CHECK_LAUNCH("fs_tail_bwd_kernel");
@@ -1305,8 +1438,10 @@ int nlam_fs_tail_bwd_256(
     float* gz_out, int64_t gz_bstride,
     float* gh, int64_t gh_bstride, int64_t gh_ld, const int32_t* idx_gh,
     float* gpr, int64_t gpr_bstride, int64_t gpr_ld,
-    float* slab, int64_t slab_stride, int64_t B, unsigned grid, void* stream) {
+    float* slab, int64_t slab_stride, int64_t B, unsigned grid, int io_bf16, void* stream) {
   constexpr int d = 256;
+  NLAM_REQUIRE(!io_bf16 || (gamma != nullptr && n_out == d && h_bstride % 8 == 0 && gz_bstride % 8 == 0),
+               "nlam_tail_bwd: bf16 h / gz rows exist for the LayerNorm form (n_out == d) only");
   NLAM_REQUIRE(gamma == nullptr || (z_keep != nullptr && (reinterpret_cast<uintptr_t>(z_keep) & 7u) == 0 &&
                                     z_bstride % 4 == 0),
                "nlam_tail_bwd: hidden 256 with LayerNorm needs the z_keep rows of nlam_tail_fwd");
@@ -1331,6 +1466,7 @@ int nlam_fs_tail_bwd_256(
   q.vec_g = (n_out == d && view_vec_ok(g1, g1_bstride, g1_ld, n_out) &&
              (g2 == nullptr || view_vec_ok(g2, g2_bstride, g2_ld, n_out))) ? 1 : 0;
   hipStream_t s = (hipStream_t)stream;
+  if (io_bf16) return launch_fs_tail_bwd<256, true, 1, true>(q, s, grid);
   return gamma != nullptr ? launch_fs_tail_bwd<256, true, 1>(q, s, grid)
                           : launch_fs_tail_bwd<256, false, 1>(q, s, grid);
 }
@@ -1348,6 +1484,7 @@ struct FsOuterParams {
   FsTiling tl;      // row mode
   int silu_x;
   int x_vec;
+  int io_bf16;      // bit 0: g rows are bf16, bit 1: x rows are bf16 (256-wide operands only)
 };
 
 template <int GW, int NXB, int TERMS>
@@ -1375,9 +1512,23 @@ __device__ __forceinline__ void fs_outer_body(const FsOuterParams& q, const int 
   const int64_t ntiles = (nsub + 1) / 2;
   const bool silu_x = q.silu_x != 0;
   const bool x_vec = NXB >= 8 ? true : (q.x_vec != 0);
+  const bool g16 = GW == 256 && (q.io_bf16 & 1), x16 = NXB == 8 && (q.io_bf16 & 2);
+  const int c8 = tid % 32, rh = tid / 32;     // 16-byte-lane map of 256-wide bf16 rows
   f32x4 vg[GNV], vx[XNV];
   auto issue = [&](int64_t tt) {
     const FsSub2 sub = {fs_sub(q.tl, 2 * tt), fs_sub(q.tl, 2 * tt + 1)};
+    if (g16) {   // bf16 rows: 16-byte lanes, 16 rows per pass; the 16 bytes ride in vg[k] as they are
+      if constexpr (GW == 256) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int r = rh + 16 * k;
+          const int pos = fs_slot_pos(sub, r);
+          fs_bf16x8 v = fs_ld8(q.g.ptr, sub.b(r >> 5) * q.g.bstride + (int64_t)pos * q.g.ld, c8);
+          if ((r & 31) >= sub.ne(r >> 5)) v = fs_bf16x8{};
+          vg[k] = __builtin_bit_cast(f32x4, v);
+        }
+      }
+    } else {
 #pragma unroll
     for (int k = 0; k < GNV; ++k) {
       const int r = grg + GRPP * k;
@@ -1385,7 +1536,19 @@ __device__ __forceinline__ void fs_outer_body(const FsOuterParams& q, const int 
       vg[k] = reinterpret_cast<const f32x4*>(q.g.ptr + sub.b(r >> 5) * q.g.bstride + (int64_t)pos * q.g.ld)[gc4];
       if ((r & 31) >= sub.ne(r >> 5)) vg[k] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    if (x_vec) {
+    }
+    if (x16) {
+      if constexpr (NXB == 8) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int r = rh + 16 * k;
+          const int pos = fs_slot_pos(sub, r);
+          fs_bf16x8 v = fs_ld8(q.x.ptr, sub.b(r >> 5) * q.x.bstride + (int64_t)pos * q.x.ld, c8);
+          if ((r & 31) >= sub.ne(r >> 5)) v = fs_bf16x8{};
+          vx[k] = __builtin_bit_cast(f32x4, v);
+        }
+      }
+    } else if (x_vec) {
 #pragma unroll
       for (int k = 0; k < XNV; ++k) {
         const int r = (xrg + XRPP * k) & (FS_R - 1);
@@ -1397,6 +1560,13 @@ __device__ __forceinline__ void fs_outer_body(const FsOuterParams& q, const int 
     }
   };
   auto put = [&](int64_t tt) {
+    if (g16) {
+      if constexpr (GW == 256) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          fs_plane_put8(G.hi, (rh + 16 * k) * G.P + 8 * c8, __builtin_bit_cast(fs_bf16x8, vg[k]));
+      }
+    } else {
 #pragma unroll
     for (int k = 0; k < GNV; ++k) {
       const int r = grg + GRPP * k;
@@ -1405,7 +1575,23 @@ __device__ __forceinline__ void fs_outer_body(const FsOuterParams& q, const int 
       *reinterpret_cast<bf16x4*>(G.hi + r * G.P + 4 * gc4) = hi;
       if constexpr (TERMS == 3) *reinterpret_cast<bf16x4*>(G.lo + r * G.P + 4 * gc4) = lo;
     }
-    if (x_vec) {
+    }
+    if (x16) {
+      if constexpr (NXB == 8) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          fs_bf16x8 v = __builtin_bit_cast(fs_bf16x8, vx[k]);
+          if (silu_x) {
+            float x[8];
+            fs_cvt8f(v, x);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = nlam_silu(x[j]);
+            v = fs_cvt8b(x);
+          }
+          fs_plane_put8(X.hi, (rh + 16 * k) * X.P + 8 * c8, v);
+        }
+      }
+    } else if (x_vec) {
 #pragma unroll
       for (int k = 0; k < XNV; ++k) {
         const int r = xrg + XRPP * k;
@@ -1528,7 +1714,12 @@ static int launch_fs_outer(const FsOuterParams& q, hipStream_t s, unsigned grid)
 // (ng, nx) in {(256, 256), (32, 256), (256, <= 64)}; grid = the slab count of the caller
 static int fs_outer_fill(FsOuterParams& q, const float* g, int64_t g_bstride, int64_t g_ld, int ng,
                          const float* x, int64_t x_bstride, int64_t x_ld, int nx, int silu_x,
-                         float* slab, int64_t slab_stride, int64_t B, int64_t rows) {
+                         float* slab, int64_t slab_stride, int64_t B, int64_t rows, int io_bf16) {
+  q.io_bf16 = io_bf16;
+  NLAM_REQUIRE(!(io_bf16 & 1) || (ng == 256 && g_ld % 8 == 0 && g_bstride % 8 == 0),
+               "nlam_wide_outer: bf16 g rows must be 256 wide, pitches %% 8 == 0");
+  NLAM_REQUIRE(!(io_bf16 & 2) || (nx == 256 && x_ld % 8 == 0 && x_bstride % 8 == 0),
+               "nlam_wide_outer: bf16 x rows must be 256 wide, pitches %% 8 == 0");
   NLAM_REQUIRE((ng == 256 || ng == 32) && nx >= 1 && (nx <= 64 || nx == 256) && (ng == 256 || nx == 256),
                "nlam_wide_outer: shape %d x %d unsupported", ng, nx);
   NLAM_REQUIRE(view_vec_ok(g, g_bstride, g_ld, ng) && x != nullptr && x_ld >= nx,
@@ -1548,10 +1739,11 @@ static int fs_outer_fill(FsOuterParams& q, const float* g, int64_t g_bstride, in
 int nlam_fs_outer_256(const float* g, int64_t g_bstride, int64_t g_ld, int ng,
                       const float* x, int64_t x_bstride, int64_t x_ld, int nx, int silu_x,
                       float* slab, int64_t slab_stride, int64_t B, int64_t rows, unsigned grid,
-                      void* stream) {
+                      int io_bf16, void* stream) {
   NLAM_REQUIRE(nlam_mfma_terms() == 1, "hidden 256 needs NLAM_MFMA=bf16");
   FsOuterParams q;
-  if (fs_outer_fill(q, g, g_bstride, g_ld, ng, x, x_bstride, x_ld, nx, silu_x, slab, slab_stride, B, rows))
+  if (fs_outer_fill(q, g, g_bstride, g_ld, ng, x, x_bstride, x_ld, nx, silu_x, slab, slab_stride, B, rows,
+                    io_bf16))
     return 1;
   hipStream_t s = (hipStream_t)stream;
   if (ng == 32) return launch_fs_outer<32, 8, 1>(q, s, grid);
@@ -1565,7 +1757,7 @@ int nlam_fs_outer_multi_256(int n, const float* const* g, const int64_t* g_bstri
                             const int64_t* g_ld, const float* const* x, const int64_t* x_bstride,
                             const int64_t* x_ld, const int32_t* silu_x, float* const* slab,
                             const int64_t* slab_stride, const int64_t* B, const int64_t* rows,
-                            const unsigned* grid, void* stream) {
+                            const unsigned* grid, const int32_t* io_bf16, void* stream) {
   NLAM_REQUIRE(nlam_mfma_terms() == 1, "hidden 256 needs NLAM_MFMA=bf16");
   WideMulti<FsOuterParams> m;
   m.n = 0;
@@ -1573,7 +1765,7 @@ int nlam_fs_outer_multi_256(int n, const float* const* g, const int64_t* g_bstri
   for (int k = 0; k < n; ++k) {
     if (B[k] <= 0 || rows[k] <= 0) continue;
     if (fs_outer_fill(m.p[m.n], g[k], g_bstride[k], g_ld[k], 256, x[k], x_bstride[k], x_ld[k], 256,
-                      silu_x[k], slab[k], slab_stride[k], B[k], rows[k]))
+                      silu_x[k], slab[k], slab_stride[k], B[k], rows[k], io_bf16 ? io_bf16[k] : 0))
       return 1;
     m.first[m.n + 1] = m.first[m.n] + (int)grid[k];
     ++m.n;

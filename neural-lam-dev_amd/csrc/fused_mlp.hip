@@ -364,8 +364,10 @@ extern "C" int nlam_lin_fwd(const float* x, int64_t x_bstride, int64_t x_ld, int
                             const float* WA, int64_t ldWA, const float* bA, int nA,
                             const float* WB, int64_t ldWB, const float* bB, int nB,
                             float* out, int64_t out_bstride, int64_t out_ld, int64_t B,
-                            int64_t rows, void* stream) {
+                            int64_t rows, int out_bf16, void* stream) {
   if (B <= 0 || rows <= 0) return 0;
+  NLAM_REQUIRE(!out_bf16 || (nlam_mfma_terms() == 1 && nA == 256 && (WB == nullptr || nB == 0)),
+               "nlam_lin_fwd: bf16 output rows exist for the hidden-256 bf16 path only");
   NLAM_REQUIRE(nA > 0 && nA % 32 == 0 && nB >= 0 && nB % 32 == 0,
                "nlam_lin_fwd: output block widths must be multiples of 32 (got %d, %d)", nA, nB);
   NLAM_REQUIRE(k_in >= 1 && k_in <= 256, "nlam_lin_fwd: k_in %d out of range", k_in);
@@ -385,7 +387,8 @@ extern "C" int nlam_lin_fwd(const float* x, int64_t x_bstride, int64_t x_ld, int
   // hidden 256, bf16-mixed (fused_fs.hip): register-stationary weight slices
   if (nlam_mfma_terms() == 1 && nA == 256 && p.nB == 0 && (p.vec_mask & 8))
     return nlam_fs_lin_fwd_256(x, x_bstride, x_ld, k_in, WA, ldWA, bA, nA, out, out_bstride, out_ld,
-                               B, rows, stream);
+                               B, rows, out_bf16, stream);
+  NLAM_REQUIRE(!out_bf16, "nlam_lin_fwd: bf16 output rows need 16-byte aligned rows, pitch %% 8 == 0");
   if (nlam_mfma_b3() && k_in == 64 && (p.vec_mask & 1) && (p.vec_mask & 8)) {
     if ((p.nA + p.nB) == 64) return launch_lin_fwd_b3<2, 2>(p, s);
     if ((p.nA + p.nB) == 128) return launch_lin_fwd_b3<4, 2>(p, s);

@@ -295,14 +295,15 @@ extern "C" int nlam_tail_fwd(
     float* y, int64_t y_bstride, int64_t y_ld, const int32_t* idx_y,
     const float* res, int64_t res_bstride, int64_t res_ld,
     float* agg, int64_t agg_bstride, int64_t agg_ld, const float* inv_deg,
-    int64_t B, int d, void* stream) {
+    int64_t B, int d, int io_bf16, void* stream) {
   if (B <= 0 || rows <= 0) return 0;
+  NLAM_REQUIRE(io_bf16 == 0 || d == 256, "nlam_tail_fwd: bf16 rows exist at hidden 256 only");
   if (d == 256)
     return nlam_fs_tail_fwd_256(tiles, ntiles, rows, csr_rec, csr_rowptr, a, a_bstride, a_ld, idx_a,
                                 b, b_bstride, b_ld, idx_b, c, c_bstride, c_ld, idx_c, W2, ldW2, b2,
                                 gamma, beta, n_out, h_out, h_bstride, z_keep, z_bstride, y, y_bstride,
                                 y_ld, idx_y, res, res_bstride, res_ld, agg, agg_bstride, agg_ld,
-                                inv_deg, B, stream);
+                                inv_deg, B, io_bf16, stream);
   (void)z_keep; (void)z_bstride;   // hidden 128 repeats the GEMM in its backward instead
   NLAM_REQUIRE(d == 128, "nlam_tail_fwd: hidden width %d unsupported (128, 256)", d);
   NLAM_REQUIRE(nlam_mfma_terms() != 0, "nlam_tail_fwd: needs NLAM_MFMA=bf16x3|bf16");
@@ -633,8 +634,9 @@ extern "C" int nlam_tail_bwd(
     float* gz_out, int64_t gz_bstride,
     float* gh, int64_t gh_bstride, int64_t gh_ld, const int32_t* idx_gh,
     float* gpr, int64_t gpr_bstride, int64_t gpr_ld,
-    float* slab, int64_t slab_stride, int64_t B, int d, void* stream) {
+    float* slab, int64_t slab_stride, int64_t B, int d, int io_bf16, void* stream) {
   if (B <= 0 || rows <= 0) return 0;
+  NLAM_REQUIRE(io_bf16 == 0 || d == 256, "nlam_tail_bwd: bf16 rows exist at hidden 256 only");
   if (d == 256) {
     NLAM_REQUIRE(gpr == nullptr || (tiles != nullptr && csr_rec != nullptr && csr_rowptr != nullptr &&
                                     gpr_ld >= d), "nlam_tail_bwd: gpr needs edge tiles");
@@ -645,7 +647,8 @@ extern "C" int nlam_tail_bwd(
     return nlam_fs_tail_bwd_256(tiles, ntiles, rows, csr_rec, csr_rowptr, h, h_bstride, z_keep,
                                 z_bstride, g1, g1_bstride, g1_ld, idx_g1, scale1, g2, g2_bstride, g2_ld, idx_g2, W2, ldW2, b2,
                                 gamma, n_out, gz_out, gz_bstride, gh, gh_bstride, gh_ld, idx_gh, gpr,
-                                gpr_bstride, gpr_ld, slab, slab_stride, B, wide_grid(ntiles * B), stream);
+                                gpr_bstride, gpr_ld, slab, slab_stride, B, wide_grid(ntiles * B), io_bf16,
+                                stream);
   }
   NLAM_REQUIRE(d == 128, "nlam_tail_bwd: hidden width %d unsupported (128, 256)", d);
   NLAM_REQUIRE(nlam_mfma_terms() != 0, "nlam_tail_bwd: needs NLAM_MFMA=bf16x3|bf16");
@@ -983,12 +986,14 @@ static int wide_outer_fill(WideOuterParams& q, const float* g, int64_t g_bstride
 extern "C" int nlam_wide_outer(const float* g, int64_t g_bstride, int64_t g_ld, int ng,
                                const float* x, int64_t x_bstride, int64_t x_ld, int nx, int silu_x,
                                float* slab, int64_t slab_stride, int64_t B, int64_t rows,
-                               void* stream) {
+                               int io_bf16, void* stream) {
   if (B <= 0 || rows <= 0) return 0;
   NLAM_REQUIRE(nlam_mfma_terms() != 0, "nlam_wide_outer: needs NLAM_MFMA=bf16x3|bf16");
   if (ng == 256 || nx == 256)
     return nlam_fs_outer_256(g, g_bstride, g_ld, ng, x, x_bstride, x_ld, nx, silu_x, slab, slab_stride,
-                             B, rows, wide_grid(((rows + NLAM_TILE - 1) / NLAM_TILE) * B), stream);
+                             B, rows, wide_grid(((rows + NLAM_TILE - 1) / NLAM_TILE) * B), io_bf16,
+                             stream);
+  NLAM_REQUIRE(io_bf16 == 0, "nlam_wide_outer: bf16 rows exist at hidden 256 only");
   WideMulti<WideOuterParams> m;
   m.n = 1;
   if (wide_outer_fill(m.p[0], g, g_bstride, g_ld, ng, x, x_bstride, x_ld, nx, silu_x, slab,
@@ -1008,7 +1013,8 @@ extern "C" int nlam_wide_outer_multi(int n, int d, const float* const* g, const 
                                      const int64_t* x_bstride, const int64_t* x_ld,
                                      const int32_t* silu_x, float* const* slab,
                                      const int64_t* slab_stride, const int64_t* B,
-                                     const int64_t* rows, const int32_t* nslabs, void* stream) {
+                                     const int64_t* rows, const int32_t* nslabs,
+                                     const int32_t* io_bf16, void* stream) {
   NLAM_REQUIRE(n >= 1 && n <= NLAM_WIDE_MAXP, "nlam_wide_outer_multi: n %d out of [1, %d]", n,
                NLAM_WIDE_MAXP);
   NLAM_REQUIRE(nlam_mfma_terms() != 0, "nlam_wide_outer_multi: needs NLAM_MFMA=bf16x3|bf16");
@@ -1019,8 +1025,11 @@ extern "C" int nlam_wide_outer_multi(int n, int d, const float* const* g, const 
     unsigned grid[NLAM_WIDE_MAXP];
     for (int k = 0; k < n; ++k) grid[k] = (unsigned)nslabs[k];
     return nlam_fs_outer_multi_256(n, g, g_bstride, g_ld, x, x_bstride, x_ld, silu_x, slab,
-                                   slab_stride, B, rows, grid, stream);
+                                   slab_stride, B, rows, grid, io_bf16, stream);
   }
+  for (int k = 0; k < n; ++k)
+    NLAM_REQUIRE(io_bf16 == nullptr || io_bf16[k] == 0,
+                 "nlam_wide_outer_multi: bf16 rows exist at hidden 256 only");
   NLAM_REQUIRE(d == 128, "nlam_wide_outer_multi: width %d unsupported (128, 256)", d);
   WideMulti<WideOuterParams> m;
   int counts[NLAM_WIDE_MAXP];
@@ -1109,13 +1118,15 @@ extern "C" int nlam_lin_fwd_multi(int n, int d, const float* const* x, const int
                                   const int64_t* x_ld, const float* const* W, const int64_t* ldW,
                                   const float* const* bias, float* const* out,
                                   const int64_t* out_bstride, const int64_t* out_ld,
-                                  const int64_t* B, const int64_t* rows, void* stream) {
+                                  const int64_t* B, const int64_t* rows, int out_bf16_mask,
+                                  void* stream) {
   NLAM_REQUIRE(n >= 1 && n <= NLAM_WIDE_MAXP, "nlam_lin_fwd_multi: n %d out of [1, %d]", n,
                NLAM_WIDE_MAXP);
+  NLAM_REQUIRE(out_bf16_mask == 0 || d == 256, "nlam_lin_fwd_multi: bf16 rows exist at hidden 256 only");
   NLAM_REQUIRE(nlam_mfma_terms() != 0, "nlam_lin_fwd_multi: needs NLAM_MFMA=bf16x3|bf16");
   if (d == 256)
     return nlam_fs_lin_fwd_multi_256(n, x, x_bstride, x_ld, W, ldW, bias, out, out_bstride, out_ld, B,
-                                     rows, stream);
+                                     rows, out_bf16_mask, stream);
   NLAM_REQUIRE(d == 128, "nlam_lin_fwd_multi: width %d unsupported (128, 256)", d);
   WideMulti<WideLinParams> m;
   m.n = 0;

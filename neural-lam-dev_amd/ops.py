@@ -124,6 +124,18 @@ def mat(t, col_off=0, cols=None):
     return Mat(t.data_ptr() + 4 * col_off, B, rows, cols, bs, ld, t)
 
 
+def mat16(t):
+    """Mat of a contiguous bf16 (B, rows, c) tensor: a row operand stored in bf16 (hidden 256;
+    pitches in bf16 elements; see include/nlam_hip.h 'bf16 STORAGE')."""
+    assert t.dtype == torch.bfloat16 and t.is_cuda and t.dim() == 3 and t.is_contiguous()
+    B, rows, c = t.shape
+    return Mat(t.data_ptr(), B, rows, c, rows * c if B > 1 else 0, c, t)
+
+
+def is_bf16(m):
+    return m is not None and m.keep is not None and m.keep.dtype == torch.bfloat16
+
+
 def flat(m):
     """(B, rows) -> one (B*rows)-row matrix if the batch pitch allows it."""
     if m.B == 1:
@@ -360,7 +372,7 @@ def fused_lin_fwd(x, WA, bA, WB, bB, out):
         "nlam_lin_fwd", lib.nlam_lin_fwd,
         (x.ptr, x.bstride, x.ld, x.cols, WA.data_ptr(), WA.stride(0), _p(bA), nA,
          _p(WB), WB.stride(0) if WB is not None else 0, _p(bB), nB,
-         out.ptr, out.bstride, out.ld, out.B, out.rows, stream()),
+         out.ptr, out.bstride, out.ld, out.B, out.rows, int(is_bf16(out)), stream()),
         flops=2.0 * out.B * out.rows * x.cols * (nA + nB),
         nbytes=4.0 * out.B * out.rows * (x.cols + nA + nB),
     )

@@ -26,7 +26,7 @@ import torch
 
 from . import ops
 from ._lib import lib
-from .ops import _launch, _p, mat, stream
+from .ops import _launch, _p, is_bf16, mat, mat16, stream
 
 WIDE_HIDDEN = (128, 256)
 
@@ -49,6 +49,19 @@ SIDE_LANE_ROWS = int(os.environ.get("NLAM_SIDE_ROWS", "0"))
 
 def _empty(*shape, device):
     return torch.empty(*shape, dtype=torch.float32, device=device)
+
+
+def _inter(d, *shape, device):
+    """An edge- / node-sized intermediate that is the output of a Linear (projection, pre-activation)
+    or the gradient of one (gz): bf16 at hidden 256 -- the dtype the reference's autocast gives
+    them, and half the vector-memory instructions of kernels that are bound by those -- fp32
+    otherwise."""
+    dt = torch.bfloat16 if d == 256 else torch.float32
+    return torch.empty(*shape, dtype=dt, device=device)
+
+
+def _m(t):
+    return mat16(t) if t.dtype == torch.bfloat16 else mat(t)
 
 
 def _aligned(m, width=None):
@@ -89,6 +102,9 @@ def keep_z(B, rows, d, gamma, device):
 def tail_fwd(tl, a, idx_a, b, idx_b, c, idx_c, W2, b2, gamma, beta, h_out, y, idx_y, res, agg,
              inv_deg, B, d, z_keep=None):
     n_out = W2.shape[0]
+    if is_bf16(a):   # all-or-nothing: every source and the kept h are bf16 rows
+        assert all(is_bf16(t) for t in (b, c) if t is not None)
+        assert h_out is None or h_out.dtype == torch.bfloat16
     _launch(
         "nlam_tail_fwd", lib.nlam_tail_fwd,
         tl.args + _src(a, idx_a) + _src(b, idx_b) + _src(c, idx_c)
@@ -101,7 +117,7 @@ def tail_fwd(tl, a, idx_a, b, idx_b, c, idx_c, W2, b2, gamma, beta, h_out, y, id
         + (idx_y.data_ptr() if idx_y is not None else None,)
         + ((res.ptr, res.bstride, res.ld) if res is not None else (None, 0, 0))
         + ((agg.ptr, agg.bstride, agg.ld) if agg is not None else (None, 0, 0))
-        + (inv_deg.data_ptr() if inv_deg is not None else None, B, d, stream()),
+        + (inv_deg.data_ptr() if inv_deg is not None else None, B, d, int(is_bf16(a)), stream()),
         flops=2.0 * B * tl.rows * d * n_out,
         nbytes=4.0 * B * tl.rows * (d * (1 + (h_out is not None)) + n_out * (y is not None)
                                     * (1 + (res is not None)))
@@ -113,6 +129,7 @@ def tail_bwd(tl, h, g1, idx_g1, scale1, g2, idx_g2, W2, b2, gamma, gz_out, gh, i
              dgamma, dbeta, z_keep=None):
     n_out = W2.shape[0]
     dev = W2.device
+    assert (h.dtype == torch.bfloat16) == (gz_out.dtype == torch.bfloat16)
     stride = int(lib.nlam_tail_bwd_slab_stride(n_out))
     nslabs = int(lib.nlam_bwd_grid(B * tl.ntiles))
     slab = torch.empty(nslabs * stride, dtype=torch.float32, device=dev) if gamma is not None else None
@@ -129,7 +146,8 @@ def tail_bwd(tl, h, g1, idx_g1, scale1, g2, idx_g2, W2, b2, gamma, gz_out, gh, i
            gz_out.stride(0), gh.ptr, gh.bstride, gh.ld,
            idx_gh.data_ptr() if idx_gh is not None else None)
         + ((gpr.ptr, gpr.bstride, gpr.ld) if gpr is not None else (None, 0, 0))
-        + (slab.data_ptr() if slab is not None else None, stride, B, d, stream()),
+        + (slab.data_ptr() if slab is not None else None, stride, B, d,
+           int(h.dtype == torch.bfloat16), stream()),
         flops=2.0 * B * tl.rows * d * n_out * (2 if gamma is not None else 1),
         nbytes=4.0 * B * tl.rows * (2 * d + 2 * n_out + (n_out if g2 is not None else 0)),
     )
@@ -163,7 +181,7 @@ def outer(g, x, dW, db, silu_x=False, rows_out=None):
     _launch(
         "nlam_wide_outer", lib.nlam_wide_outer,
         (g.ptr, g.bstride, g.ld, ng, x.ptr, x.bstride, x.ld, nx, int(silu_x), slab.data_ptr(),
-         stride, B, rows, stream()),
+         stride, B, rows, int(is_bf16(g)) | 2 * int(is_bf16(x)), stream()),
         flops=2.0 * B * rows * ng * nx, nbytes=4.0 * B * rows * (ng + nx),
     )
     r = ng if rows_out is None else rows_out
@@ -194,7 +212,7 @@ def lin_fwd_multi(problems):
          _parr([_p(b) for _, _, b, _ in problems]), _parr([o.ptr for _, _, _, o in problems]),
          _arr(I64, [o.bstride for _, _, _, o in problems]), _arr(I64, [o.ld for _, _, _, o in problems]),
          _arr(I64, [o.B for _, _, _, o in problems]), _arr(I64, [o.rows for _, _, _, o in problems]),
-         stream()),
+         sum(int(is_bf16(o)) << k for k, (_, _, _, o) in enumerate(problems)), stream()),
         flops=sum(2.0 * o.B * o.rows * d * d for _, _, _, o in problems),
         nbytes=sum(8.0 * o.B * o.rows * d for _, _, _, o in problems),
     )
@@ -253,7 +271,9 @@ def outer_multi(problems):
          _arr(I32, [int(sx) for _, _, _, _, sx in problems]),
          _parr([sl.data_ptr() for sl in slabs]), _arr(I64, [stride] * n),
          _arr(I64, [g.B for g, _, _, _, _ in problems]),
-         _arr(I64, [g.rows for g, _, _, _, _ in problems]), _arr(I32, ns), stream()),
+         _arr(I64, [g.rows for g, _, _, _, _ in problems]), _arr(I32, ns),
+         _arr(I32, [int(is_bf16(g)) | 2 * int(is_bf16(x)) for g, x, _, _, _ in problems]),
+         stream()),
         flops=sum(2.0 * g.B * g.rows * d * d for g, _, _, _, _ in problems),
         nbytes=sum(8.0 * g.B * g.rows * d for g, _, _, _, _ in problems),
     )
@@ -318,11 +338,11 @@ class WideMLPFunction(torch.autograd.Function):
         res_is_x = res is x
         rm = xm if res_is_x else (mat(res.detach()) if res is not None else None)
         B, rows = xm.B, xm.rows
-        h = _empty(B, rows, hid, device=dev)
-        _first_linear(xm, W1, b1, mat(h))
+        h = _inter(hid, B, rows, hid, device=dev)
+        _first_linear(xm, W1, b1, _m(h))
         out = _empty(B, rows, n_out, device=dev)
         zk = keep_z(B, rows, hid, gamma, dev)
-        tail_fwd(Tiling(rows), mat(h), None, None, None, None, None, W2, b2, gamma, beta, None,
+        tail_fwd(Tiling(rows), _m(h), None, None, None, None, None, W2, b2, gamma, beta, None,
                  mat(out), None, rm, None, None, B, hid, zk)
         ctx.save_for_backward(W1, b1, W2, b2, gamma, h, zk)
         ctx.xm, ctx.x_shape = xm, x.shape
@@ -348,11 +368,13 @@ class WideMLPFunction(torch.autograd.Function):
         dbt = _empty(n_out, device=dev) if has_ln else None
         need_gx = ctx.needs_input_grad[0]
         with ops.tag(ctx.tag), ops.slab_batch():
-            gz = _empty(B, rows, no, device=dev)
+            if h.dtype == torch.bfloat16 and not has_ln:
+                h = h.float()     # (narrow heads, e.g. the 17-wide output map: fp32 form of the kernel)
+            gz = torch.empty(B, rows, no, dtype=h.dtype, device=dev)
             ga = _empty(B, rows, hid, device=dev)
             tail_bwd(Tiling(rows), h, gym, None, None, None, None, W2, b2, gamma, gz, mat(ga),
                      None, None, B, hid, dg, dbt, zk)
-            outer(mat(gz), mat(h), dW2, db2, silu_x=True, rows_out=n_out)
+            outer(_m(gz), _m(h), dW2, db2, silu_x=True, rows_out=n_out)
             gx_add = gym if (ctx.res_mode == 1 and need_gx) else None
             gx = _first_linear_bwd(xm, mat(ga), W1, need_gx, gx_add, dW1, db1, dev)
         gres = gy if ctx.res_mode == 2 else None
@@ -402,30 +424,30 @@ class WideInteractionNetFunction(torch.autograd.Function):
             N_s, N_r, M = send_rep.shape[1], rec_rep.shape[1], edge_rep.shape[1]
             sm, rm, em = mat(send_rep.detach()), mat(rec_rep.detach()), mat(edge_rep.detach())
             W1e, W1s, W1r = W1[:, :d], W1[:, d : 2 * d], W1[:, 2 * d :]
-            Ps = _empty(sm.B, N_s, d, device=dev)
-            Pr = _empty(rm.B, N_r, d, device=dev)
-            Pe = _empty(em.B, M, d, device=dev)
-            hn1 = _empty(rm.B, N_r, d, device=dev)
+            Ps = _inter(d, sm.B, N_s, d, device=dev)
+            Pr = _inter(d, rm.B, N_r, d, device=dev)
+            Pe = _inter(d, em.B, M, d, device=dev)
+            hn1 = _inter(d, rm.B, N_r, d, device=dev)
             # the four projections that only need the layer inputs: ONE launch
-            lin_fwd_multi([(sm, W1s, None, mat(Ps)), (rm, W1r, b1, mat(Pr)),
-                           (em, W1e, None, mat(Pe)), (rm, V1[:, :d], c1, mat(hn1))])
-            h_e = _empty(B, M, d, device=dev)
+            lin_fwd_multi([(sm, W1s, None, _m(Ps)), (rm, W1r, b1, _m(Pr)),
+                           (em, W1e, None, _m(Pe)), (rm, V1[:, :d], c1, _m(hn1))])
+            h_e = _inter(d, B, M, d, device=dev)
             agg = _empty(B, N_r, d, device=dev)
             e_out = _empty(B, M, d, device=dev) if update_edges else None
             tl = Tiling(M, g)
             z_e = keep_z(B, M, d, gam, dev)
-            tail_fwd(tl, mat(Pe), g.csr_eid, mat(Ps), g.csr_send, mat(Pr), g.csr_rec, W2, b2, gam,
+            tail_fwd(tl, _m(Pe), g.csr_eid, _m(Ps), g.csr_send, _m(Pr), g.csr_rec, W2, b2, gam,
                      bet, h_e, mat(e_out) if update_edges else None,
                      g.csr_eid if update_edges else None, em if update_edges else None,
                      mat(agg), g.inv_deg if mean else None, B, d, z_e)
             del Pe, Ps, Pr
             # node update x_r + LN(V2 silu(V1 [x_r | agg] + c1) + c2)
-            hn2 = _empty(B, N_r, d, device=dev)
-            _first_linear(mat(agg), V1[:, d:], None, mat(hn2))
-            h_n = _empty(B, N_r, d, device=dev)
+            hn2 = _inter(d, B, N_r, d, device=dev)
+            _first_linear(mat(agg), V1[:, d:], None, _m(hn2))
+            h_n = _inter(d, B, N_r, d, device=dev)
             rec_out = _empty(B, N_r, d, device=dev)
             z_n = keep_z(B, N_r, d, gam2, dev)
-            tail_fwd(Tiling(N_r), mat(hn1), None, mat(hn2), None, None, None, V2, c2, gam2, bet2,
+            tail_fwd(Tiling(N_r), _m(hn1), None, _m(hn2), None, None, None, V2, c2, gam2, bet2,
                      h_n, mat(rec_out), None, rm, None, None, B, d, z_n)
             ctx.save_for_backward(W1, b1, W2, b2, gam, V1, c1, V2, c2, gam2, h_e, h_n, agg, z_e, z_n)
             ctx.set_materialize_grads(False)
@@ -458,7 +480,7 @@ class WideInteractionNetFunction(torch.autograd.Function):
             dg2, db2n = _empty(d, device=dev), _empty(d, device=dev)
             lane = ops.WeightGradLane(B * M <= SIDE_LANE_ROWS, dev)   # (default: off, see above)
             # 1. node update backward
-            gz_n = _empty(B, N_r, d, device=dev)
+            gz_n = _inter(d, B, N_r, d, device=dev)
             ga_n = _empty(B, N_r, d, device=dev)
             tail_bwd(Tiling(N_r), h_n, mat(g_rec_out), None, None, None, None, V2, c2, gam2, gz_n,
                      mat(ga_n), None, None, B, d, dg2, db2n, z_n)
@@ -467,7 +489,7 @@ class WideInteractionNetFunction(torch.autograd.Function):
             lin_bwd_data_multi([(mat(ga_n), V1[:, :d], mat(g_rec), mat(g_rec_out)),
                                 (mat(ga_n), V1[:, d:], mat(g_agg), None)])
             dummy = [_empty(d, device=dev) for _ in range(4)]
-            outers = [(mat(gz_n), mat(h_n), dV2, dc2, True), (mat(ga_n), rm, dV1[:, :d], dc1, False),
+            outers = [(_m(gz_n), _m(h_n), dV2, dc2, True), (mat(ga_n), rm, dV1[:, :d], dc1, False),
                       (mat(ga_n), mat(agg), dV1[:, d:], dummy[0], False)]
             if lane.enabled:
                 with lane:
@@ -478,7 +500,7 @@ class WideInteractionNetFunction(torch.autograd.Function):
                 ops.sum_batch(g_rec, t3)
                 g_rec = t3
             # 2. edge backward
-            gz_e = _empty(B, M, d, device=dev)
+            gz_e = _inter(d, B, M, d, device=dev)
             gh = _empty(B, M, d, device=dev)
             gPr = _empty(B, N_r, d, device=dev)
             geo = None
@@ -487,7 +509,7 @@ class WideInteractionNetFunction(torch.autograd.Function):
             tail_bwd(Tiling(M, g), h_e, mat(g_agg), g.csr_rec, g.inv_deg if ctx.mean else None,
                      geo, g.csr_eid if geo is not None else None, W2, b2, gam, gz_e, mat(gh),
                      g.csr_eid, mat(gPr), B, d, dgam, dbet, z_e)
-            outers.append((mat(gz_e), mat(h_e), dW2, db2, True))
+            outers.append((_m(gz_e), _m(h_e), dW2, db2, True))
             # 3. sender-side reduction of gh (edge order; sender lists of edge ids)
             gPs = (torch.zeros if N_s > g.n_send else torch.empty)(
                 B, N_s, d, dtype=torch.float32, device=dev)
