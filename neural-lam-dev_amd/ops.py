@@ -374,7 +374,7 @@ def fused_lin_fwd(x, WA, bA, WB, bB, out):
          _p(WB), WB.stride(0) if WB is not None else 0, _p(bB), nB,
          out.ptr, out.bstride, out.ld, out.B, out.rows, int(is_bf16(out)), stream()),
         flops=2.0 * out.B * out.rows * x.cols * (nA + nB),
-        nbytes=4.0 * out.B * out.rows * (x.cols + nA + nB),
+        nbytes=out.B * out.rows * (4.0 * x.cols + (2.0 if is_bf16(out) else 4.0) * (nA + nB)),
     )
 
 

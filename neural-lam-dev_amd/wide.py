@@ -64,6 +64,14 @@ def _m(t):
     return mat16(t) if t.dtype == torch.bfloat16 else mat(t)
 
 
+def _esz(x):
+    """bytes per element of a row operand (Mat or tensor) in the algorithmic-byte accounting"""
+    if x is None:
+        return 0
+    dt = x.keep.dtype if hasattr(x, "keep") else x.dtype
+    return 2 if dt == torch.bfloat16 else 4
+
+
 def _aligned(m, width=None):
     width = m.cols if width is None else width
     return (m.ptr % 16 == 0 and m.ld % 4 == 0 and m.bstride % 4 == 0 and width % 4 == 0)
@@ -119,8 +127,8 @@ def tail_fwd(tl, a, idx_a, b, idx_b, c, idx_c, W2, b2, gamma, beta, h_out, y, id
         + ((agg.ptr, agg.bstride, agg.ld) if agg is not None else (None, 0, 0))
         + (inv_deg.data_ptr() if inv_deg is not None else None, B, d, int(is_bf16(a)), stream()),
         flops=2.0 * B * tl.rows * d * n_out,
-        nbytes=4.0 * B * tl.rows * (d * (1 + (h_out is not None)) + n_out * (y is not None)
-                                    * (1 + (res is not None)))
+        nbytes=1.0 * B * tl.rows * (d * (_esz(a) + _esz(h_out) + _esz(z_keep))
+                                    + 4 * n_out * (y is not None) * (1 + (res is not None)))
         + 4.0 * d * B * (agg.rows if agg is not None else 0),
     )
 
@@ -149,7 +157,8 @@ def tail_bwd(tl, h, g1, idx_g1, scale1, g2, idx_g2, W2, b2, gamma, gz_out, gh, i
         + (slab.data_ptr() if slab is not None else None, stride, B, d,
            int(h.dtype == torch.bfloat16), stream()),
         flops=2.0 * B * tl.rows * d * n_out * (2 if gamma is not None else 1),
-        nbytes=4.0 * B * tl.rows * (2 * d + 2 * n_out + (n_out if g2 is not None else 0)),
+        nbytes=1.0 * B * tl.rows * (d * (_esz(h) + 4 + _esz(z_keep)) + n_out * (4 + _esz(gz_out))
+                                    + (4 * n_out if g2 is not None else 0)),
     )
     if gamma is not None:
         no = (n_out + 31) // 32 * 32
@@ -182,7 +191,7 @@ def outer(g, x, dW, db, silu_x=False, rows_out=None):
         "nlam_wide_outer", lib.nlam_wide_outer,
         (g.ptr, g.bstride, g.ld, ng, x.ptr, x.bstride, x.ld, nx, int(silu_x), slab.data_ptr(),
          stride, B, rows, int(is_bf16(g)) | 2 * int(is_bf16(x)), stream()),
-        flops=2.0 * B * rows * ng * nx, nbytes=4.0 * B * rows * (ng + nx),
+        flops=2.0 * B * rows * ng * nx, nbytes=1.0 * B * rows * (ng * _esz(g) + nx * _esz(x)),
     )
     r = ng if rows_out is None else rows_out
     ops.reduce_segments(slab, nslabs, stride,
@@ -214,7 +223,7 @@ def lin_fwd_multi(problems):
          _arr(I64, [o.B for _, _, _, o in problems]), _arr(I64, [o.rows for _, _, _, o in problems]),
          sum(int(is_bf16(o)) << k for k, (_, _, _, o) in enumerate(problems)), stream()),
         flops=sum(2.0 * o.B * o.rows * d * d for _, _, _, o in problems),
-        nbytes=sum(8.0 * o.B * o.rows * d for _, _, _, o in problems),
+        nbytes=sum(1.0 * o.B * o.rows * d * (4 + _esz(o)) for _, _, _, o in problems),
     )
 
 
@@ -275,7 +284,7 @@ def outer_multi(problems):
          _arr(I32, [int(is_bf16(g)) | 2 * int(is_bf16(x)) for g, x, _, _, _ in problems]),
          stream()),
         flops=sum(2.0 * g.B * g.rows * d * d for g, _, _, _, _ in problems),
-        nbytes=sum(8.0 * g.B * g.rows * d for g, _, _, _, _ in problems),
+        nbytes=sum(1.0 * g.B * g.rows * d * (_esz(g) + _esz(x)) for g, x, _, _, _ in problems),
     )
     for (g, x, dW, db, sx), sl, nsl in zip(problems, slabs, ns):
         ops.reduce_segments(sl, nsl, stride, [(0, d, d, d, dW), (d * d, 1, d, d, db)])
