@@ -137,12 +137,17 @@ __device__ __forceinline__ void fs_load_w_cols_lds(FsW<K, TERMS>& A, const float
 }
 
 // shared row tile as bf16 planes: hi[R][P] (| lo[R][P]), P = K + 4 elements
-template <int K, int TERMS>
+// PAD = 4 (pitch = 2 banks mod 64): conflict-free for the row-fragment reads of fs_gemm (lane t
+// reads row t).  The weight-gradient pass reads its planes TRANSPOSED (ds_read_b64_tr_b16: the
+// 16 lanes of a group touch 4 rows x 4 eight-byte chunks), where that pitch put 69 % of the LDS
+// cycles into bank conflicts (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE); PAD = 16 (pitch = 8
+// banks mod 64) makes those 16 accesses hit 16 distinct bank pairs.
+template <int K, int TERMS, int PAD = 4>
 struct FsPlanes {
   __bf16* hi;
   __bf16* lo;
-  static constexpr int P = K + 4;
-  static constexpr size_t bytes = (size_t)(TERMS == 3 ? 2 : 1) * FS_R * (K + 4) * sizeof(__bf16);
+  static constexpr int P = K + PAD;
+  static constexpr size_t bytes = (size_t)(TERMS == 3 ? 2 : 1) * FS_R * (K + PAD) * sizeof(__bf16);
   __device__ __forceinline__ void init(void* base) {
     hi = reinterpret_cast<__bf16*>(base);
     lo = hi + (TERMS == 3 ? FS_R * P : 0);
@@ -1493,10 +1498,10 @@ __device__ __forceinline__ void fs_outer_body(const FsOuterParams& q, const int 
   constexpr int NX = 32 * NXB, NT = 512;
   constexpr int NJ = GW == 256 ? NXB : 1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  FsPlanes<GW, TERMS> G;
+  FsPlanes<GW, TERMS, 16> G;
   G.init(smem);
-  FsPlanes<NX, TERMS> X;
-  X.init(reinterpret_cast<char*>(smem) + FsPlanes<GW, TERMS>::bytes);
+  FsPlanes<NX, TERMS, 16> X;
+  X.init(reinterpret_cast<char*>(smem) + FsPlanes<GW, TERMS, 16>::bytes);
   f32x16 dW[1][NJ];
 #pragma unroll
   for (int j = 0; j < NJ; ++j)
@@ -1694,7 +1699,7 @@ __global__ __launch_bounds__(512) void fs_outer_kernel(WideMulti<FsOuterParams> 
 // m.first[] = the slab counts the caller sized its buffers for (one workgroup per slab)
 template <int GW, int NXB, int TERMS>
 static int launch_fs_outer(const WideMulti<FsOuterParams>& m, hipStream_t s) {
-  const size_t lds = FsPlanes<GW, TERMS>::bytes + FsPlanes<32 * NXB, TERMS>::bytes;
+  const size_t lds = FsPlanes<GW, TERMS, 16>::bytes + FsPlanes<32 * NXB, TERMS, 16>::bytes;
   auto kern = fs_outer_kernel<GW, NXB, TERMS>;
   NLAM_BIG_LDS(kern, "fs_outer_kernel");
   kern<<<(unsigned)m.first[m.n], 512, lds, s>>>(m);

@@ -864,7 +864,9 @@ __device__ __forceinline__ void wide_outer_body(const WideOuterParams& q, int bi
                                                 float* smem) {
   constexpr int NG = 32 * NGB, NX = 32 * NXB;
   constexpr int NV = (NG + 63) / 64;
-  constexpr int ldg = NG + 4, ldx = NX + 4;
+  // plane pitch + 16 (8 banks mod 64): both operands are read TRANSPOSED here; with the usual
+  // + 4 the 16 lanes of a ds_read_b64_tr_b16 group collide (fused_fs.hip, FsPlanes)
+  constexpr int ldg = NG + 16, ldx = NX + 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float* TG = smem + wave * (NLAM_TILE * (ldg + ldx));
   float* TX = TG + NLAM_TILE * ldg;
@@ -880,7 +882,9 @@ __device__ __forceinline__ void wide_outer_body(const WideOuterParams& q, int bi
   for (int j = 0; j < NV; ++j) db[j] = 0.f;
   const int64_t tiles_per_b = (q.rows + NLAM_TILE - 1) / NLAM_TILE;
   const int64_t ntiles = tiles_per_b * q.B;
-  const B3Tile TGp = b3_tile(TG, NG), TXp = b3_tile(TX, NX);
+  B3Tile TGp, TXp;
+  TGp.pitch = ldg; TGp.hi = reinterpret_cast<__bf16*>(TG); TGp.lo = TGp.hi + NLAM_TILE * ldg;
+  TXp.pitch = ldx; TXp.hi = reinterpret_cast<__bf16*>(TX); TXp.lo = TXp.hi + NLAM_TILE * ldx;
   const bool silu_x = q.silu_x != 0;
   for (int64_t tt = (int64_t)bid * 4 + wave; tt < ntiles; tt += (int64_t)gdim * 4) {
     const int64_t b = tt / tiles_per_b;
@@ -950,7 +954,7 @@ template <int NGB, int NXB, int TERMS>
 static int launch_wide_outer(WideMulti<WideOuterParams>& m, hipStream_t s,
                              const int* counts = nullptr) {
   constexpr int NG = 32 * NGB, NX = 32 * NXB;
-  size_t lds = (size_t)4 * NLAM_TILE * (NG + 4 + NX + 4) * sizeof(float);
+  size_t lds = (size_t)4 * NLAM_TILE * (NG + 16 + NX + 16) * sizeof(float);
   const size_t fold = (size_t)4 * 32 * NX * sizeof(float);
   if (fold > lds) lds = fold;
   NLAM_REQUIRE(lds <= 160 * 1024, "wide_outer: LDS footprint %zu B exceeds 160 KiB", lds);
