@@ -106,25 +106,38 @@ __device__ __forceinline__ void fs_load_w_cols_lds(FsW<K, TERMS>& A, const float
   const int i = lane & 31, h = lane >> 5;
   const int c4 = tid & 63, rg = tid >> 6;   // 64 float4 chunk columns x 8 row groups
   const bool vec = (ldW % 4 == 0) && ((reinterpret_cast<uintptr_t>(W) & 15u) == 0);
+  // all K / 64 chunks' rows are requested up front (one round trip, not four); a thread takes 8
+  // CONSECUTIVE rows of its 16-byte column chunk, so that the transposed image gets 8-byte
+  // stores (8 per chunk and thread) instead of 2-byte ones (32)
+  f32x4 v[K / 64][8];
 #pragma unroll
-  for (int c = 0; c < K / 64; ++c) {   // (unrolled: A.hi must stay in registers)
-    f32x4 v[8];
+  for (int c = 0; c < K / 64; ++c)
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const int row = 64 * c + rg + 8 * k;
+      const int row = 64 * c + 8 * rg + k;
       const float* wr = W + (int64_t)(row < n_rows ? row : 0) * ldW + 4 * c4;
       if (vec) {
-        v[k] = *reinterpret_cast<const f32x4*>(wr);
+        v[c][k] = *reinterpret_cast<const f32x4*>(wr);
       } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[k][j] = wr[j];
+        for (int j = 0; j < 4; ++j) v[c][k][j] = wr[j];
       }
-      if (row >= n_rows) v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (row >= n_rows) v[c][k] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
+  for (int c = 0; c < K / 64; ++c) {   // (unrolled: A.hi must stay in registers)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) T[(4 * c4 + j) * TP + rg + 8 * k] = (__bf16)v[k][j];
+    for (int j = 0; j < 4; ++j) {
+      bf16x4 lo, hi;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        lo[k] = (__bf16)v[c][k][j];
+        hi[k] = (__bf16)v[c][4 + k][j];
+      }
+      __bf16* dst = T + (4 * c4 + j) * TP + 8 * rg;
+      *reinterpret_cast<bf16x4*>(dst) = lo;
+      *reinterpret_cast<bf16x4*>(dst + 4) = hi;
+    }
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
