@@ -1384,11 +1384,16 @@ struct ReduceSegs {
   int64_t first[NLAM_MAX_SEGS + 1];   // prefix sums of rows*cols
 };
 
-__global__ __launch_bounds__(1024) void reduce_slabs_multi_kernel(ReduceSegs q) {
-  // 64 consecutive outputs per workgroup (256-byte rows of every slab), 16 sub-groups that
+// G sub-groups per workgroup split the slabs (G = 16 for the 100-256 slabs of a large layer; 4 or
+// 1 when a small layer has a handful: a 256 x 256 gradient is 1,024 workgroups per matrix, and
+// 16-wave workgroups of which 15 waves had no slab made the reduction of an 81-node level of
+// Hi-LAM-256 take 57 us).
+template <int G>
+__global__ __launch_bounds__(64 * G) void reduce_slabs_multi_kernel(ReduceSegs q) {
+  // 64 consecutive outputs per workgroup (256-byte rows of every slab), G sub-groups that
   // split the slabs; eight slab loads in flight per thread (clamped + masked, so they issue
   // back to back); the summation order is fixed by the launch shape
-  __shared__ float red[16][65];
+  __shared__ float red[G][65];
   const int e = threadIdx.x & 63, gsub = threadIdx.x >> 6;
   const int64_t i = (int64_t)blockIdx.x * 64 + e;
   const int64_t n = q.first[q.nseg];
@@ -1401,25 +1406,29 @@ __global__ __launch_bounds__(1024) void reduce_slabs_multi_kernel(ReduceSegs q) 
   const int64_t nslabs = q.nslabs[k], stride = q.stride[k];
   float s = 0.f;
   if (i < n) {
-    for (int64_t sl = gsub; sl < nslabs; sl += 16 * 8) {
+    for (int64_t sl = gsub; sl < nslabs; sl += G * 8) {
       float v[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int64_t su = sl + 16 * u;
+        const int64_t su = sl + G * u;
         v[u] = slab[(su < nslabs ? su : sl) * stride];
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u)
-        if (sl + 16 * u < nslabs) s += v[u];
+        if (sl + G * u < nslabs) s += v[u];
     }
   }
-  red[gsub][e] = s;
-  __syncthreads();
-  if (gsub == 0 && i < n) {
-    float v = 0.f;
+  if constexpr (G == 1) {
+    if (i < n) q.dst[k][r * q.dst_ld[k] + c] = s;
+  } else {
+    red[gsub][e] = s;
+    __syncthreads();
+    if (gsub == 0 && i < n) {
+      float v = 0.f;
 #pragma unroll
-    for (int g = 0; g < 16; ++g) v += red[g][e];
-    q.dst[k][r * q.dst_ld[k] + c] = v;
+      for (int g = 0; g < G; ++g) v += red[g][e];
+      q.dst[k][r * q.dst_ld[k] + c] = v;
+    }
   }
 }
 
@@ -1430,7 +1439,12 @@ static int launch_reduce_segs(ReduceSegs& q, hipStream_t s) {
   }
   const int64_t n = q.first[q.nseg];
   if (n <= 0) return 0;
-  reduce_slabs_multi_kernel<<<(unsigned)((n + 63) / 64), 1024, 0, s>>>(q);
+  int maxn = 1;
+  for (int k = 0; k < q.nseg; ++k) maxn = q.nslabs[k] > maxn ? q.nslabs[k] : maxn;
+  const unsigned grid = (unsigned)((n + 63) / 64);
+  if (maxn <= 8) reduce_slabs_multi_kernel<1><<<grid, 64, 0, s>>>(q);
+  else if (maxn <= 32) reduce_slabs_multi_kernel<4><<<grid, 256, 0, s>>>(q);
+  else reduce_slabs_multi_kernel<16><<<grid, 1024, 0, s>>>(q);
   NLAM_CHECK_LAUNCH("reduce_slabs_multi");
   return 0;
 }
