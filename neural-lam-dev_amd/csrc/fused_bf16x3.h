@@ -77,12 +77,29 @@ __device__ __forceinline__ void load_weight_lds_b3(const B3Image& im, int row0,
       }
     }
   } else {
-    for (int idx = tid; idx < n_pad * k_pad32; idx += nthreads) {
-      const int i = idx / k_pad32, k = idx - i * k_pad32;
-      const float v = (i < n_out && k < k_in) ? W[(int64_t)i * ldW + k] : 0.f;
-      const __bf16 h = (__bf16)v;
-      im.hi[(row0 + i) * im.pitch + k] = h;
-      im.lo[(row0 + i) * im.pitch + k] = (__bf16)(v - (float)h);
+    // narrow / unaligned rows (the 2-3 wide static features of the embedders): eight loads in
+    // flight per thread, then the stores -- not one global round trip per element
+    const int total = n_pad * k_pad32;
+    for (int base = 0; base < total; base += 8 * nthreads) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = base + u * nthreads + tid;
+        const int i = idx / k_pad32, k = idx - i * k_pad32;
+        const bool ok = idx < total && i < n_out && k < k_in;
+        v[u] = W[ok ? (int64_t)i * ldW + k : 0];
+        if (!ok) v[u] = 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = base + u * nthreads + tid;
+        if (idx < total) {
+          const int i = idx / k_pad32, k = idx - i * k_pad32;
+          const __bf16 h = (__bf16)v[u];
+          im.hi[(row0 + i) * im.pitch + k] = h;
+          im.lo[(row0 + i) * im.pitch + k] = (__bf16)(v[u] - (float)h);
+        }
+      }
     }
   }
 }
