@@ -701,8 +701,15 @@ __device__ __forceinline__ void lin_bwd_data_body(const LinBwdDataParams& q, int
   constexpr int NO = 32 * NOUTB, K = 32 * KB;
   constexpr int LDT = (NO > K ? NO : K) + 4;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const B3Image Wim = b3_image(smem, NO, K);
-  float* tile = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + b3_image_bytes(NO, K)) +
+  // the weight image is read TRANSPOSED only here (gx = W^T gy): pitch K + 16 (8 banks mod 64)
+  // instead of K + 4 -- SQ counters: 50 % of this kernel's LDS cycles were bank conflicts
+  constexpr int WP = K + 16;
+  B3Image Wim;
+  Wim.pitch = WP;
+  Wim.hi = reinterpret_cast<__bf16*>(smem);
+  Wim.lo = Wim.hi + NO * WP;
+  float* tile = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) +
+                                         (size_t)2 * NO * WP * sizeof(__bf16)) +
                 wave * (NLAM_TILE * LDT);
   load_weight_lds_b3(Wim, 0, q.W, q.ldW, q.n_out, q.k_in, NO, K, tid, 256);
   __syncthreads();
@@ -769,7 +776,7 @@ template <int NOUTB, int KB, int TERMS>
 static int launch_lin_bwd_data(WideMulti<LinBwdDataParams>& m, hipStream_t s) {
   constexpr int NO = 32 * NOUTB, K = 32 * KB;
   constexpr int LDT = (NO > K ? NO : K) + 4;
-  const size_t lds = b3_image_bytes(NO, K) + (size_t)4 * NLAM_TILE * LDT * sizeof(float);
+  const size_t lds = (size_t)2 * NO * (K + 16) * sizeof(__bf16) + (size_t)4 * NLAM_TILE * LDT * sizeof(float);
   NLAM_REQUIRE(lds <= 160 * 1024, "lin_bwd_data: LDS footprint %zu B exceeds 160 KiB", lds);
   auto kern = lin_bwd_data_kernel<NOUTB, KB, TERMS>;
   NLAM_BIG_LDS(kern, "lin_bwd_data_kernel");
