@@ -54,10 +54,14 @@ __device__ __forceinline__ void load_weight_lds_b3(const B3Image& im, int row0,
   if (vec) {
     const int cpr = k_pad32 >> 2;
     const int total = n_pad * cpr;
-    for (int base = 0; base < total; base += 8 * nthreads) {
-      f32x4 v[8];
+    // 16 loads in flight per thread: a 128 x 128 image (16 float4 per thread of a 256-thread
+    // workgroup) arrives in ONE global round trip (the prologue is a fixed cost of every launch,
+    // and most launches of the hierarchical models are small)
+    constexpr int NB = 16;
+    for (int base = 0; base < total; base += NB * nthreads) {
+      f32x4 v[NB];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < NB; ++u) {
         const int idx = base + u * nthreads + tid;
         const int i = idx / cpr, c = idx - i * cpr;
         const bool ok = idx < total && i < n_out && 4 * c < k_in;
@@ -65,7 +69,7 @@ __device__ __forceinline__ void load_weight_lds_b3(const B3Image& im, int row0,
                   : f32x4{0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < NB; ++u) {
         const int idx = base + u * nthreads + tid;
         if (idx < total) {
           const int i = idx / cpr, c = idx - i * cpr;
