@@ -482,6 +482,17 @@ int nlam_debug_lin_fwd_timeline(unsigned long long* out);
  * for the integer test pattern documented in csrc/mfma_probe.hip. */
 int nlam_mfma_probe(float* out, void* stream);
 
+/* Tuning hook: which hidden-64 kernel families run in their 16-row, two-waves-per-SIMD form
+ * (csrc/fused16_*.hip) instead of the 32-row, one-wave-per-SIMD form.  Bit mask: 1 nlam_mlp_bwd,
+ * 2 nlam_lin_bwd, 4 nlam_outer_bwd, 8 nlam_edge_bwd, 16 nlam_mlp_fwd, 32 nlam_lin_fwd,
+ * 64 nlam_edge_fwd.  Default: all (or NLAM_K16 in the environment).  Same entry points, slab
+ * layouts and results (to rounding) either way; used to time both forms in one process. */
+int nlam_set_k16(int mask);
+/* 1 when nlam_edge_bwd (update_edges form, hidden width d) leaves the dW1e slot of its slabs
+ * unwritten: the caller then forms dW1e = gh_out^T e with nlam_outer_bwd (gh_out and e are both
+ * in the original edge order, so that pass streams linearly).  0: dW1e comes from the slabs. */
+int nlam_edge_bwd_defers_dw1e(int d);
+
 #ifdef __cplusplus
 }
 #endif

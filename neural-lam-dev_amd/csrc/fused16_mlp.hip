@@ -1,0 +1,513 @@
+// 16-row, two-waves-per-SIMD forms of the row-MLP backward kernels (gfx950): the make_mlp
+// blocks of the reference (utils.py:191-214, hidden_layers == 1, hidden width 64), the
+// projection Linear of the split first edge-MLP layer (interaction_net.py:121) and the deferred
+// first-layer weight gradient.  Same parameter blocks, slab layouts, grids and C entry points
+// as the 32-row kernels of fused_mlp.hip (which remain for exact-fp32 arithmetic and for the
+// shapes listed as unsupported below); building blocks and layout: fused16.h.
+//
+// Workgroup = 512 threads = 8 wavefronts (two per SIMD) that share ONE copy of the weight
+// images in LDS; every wavefront walks its own 16-row tiles.  Rows move between global memory
+// and registers directly in accumulator layout; LDS carries only the weight images and the
+// bf16 planes of the products that contract over rows (weight / bias / LayerNorm gradients).
+#include <cstdlib>
+
+#include "fused16.h"
+#include "fused_params.h"
+
+#define K16_NW 8
+#define K16_THREADS 512
+
+static int g_k16_mask = -2;
+bool nlam_k16_on(int family) {
+  if (g_k16_mask == -2) {
+    const char* e = getenv("NLAM_K16");
+    g_k16_mask = e ? atoi(e) : K16_DEFAULT;
+  }
+  return (g_k16_mask & family) != 0;
+}
+extern "C" int nlam_set_k16(int mask) {
+  g_k16_mask = mask;
+  return 0;
+}
+
+// this lane's slice of a row [xa | xb] (column c0 = 16 fb + 4 g): unconditional loads from a
+// clamped valid address, zeroed past the end (no branches around loads)
+template <int KF>
+__device__ __forceinline__ void load_cat16(f32x4* __restrict__ x, const float* __restrict__ ra,
+                                           int wa, const float* __restrict__ rb, int wb, int lane) {
+  const int g = lane >> 4;
+#pragma unroll
+  for (int fb = 0; fb < KF; ++fb) {
+    const int c0 = 16 * fb + 4 * g;
+    const bool in_a = c0 < wa, in_b = !in_a && (c0 - wa) < wb;
+    const float* p = in_a ? ra + c0 : (in_b ? rb + (c0 - wa) : ra);
+    f32x4 v = *reinterpret_cast<const f32x4*>(p);
+    if (!(in_a || in_b)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+    x[fb] = v;
+  }
+}
+template <int KF>
+__device__ __forceinline__ void store_cols16(float* __restrict__ row, const f32x4* __restrict__ a,
+                                             int fb0, int width, int lane) {
+  const int g = lane >> 4;
+#pragma unroll
+  for (int fb = 0; fb < KF; ++fb) {
+    const int c0 = 16 * fb + 4 * g;
+    if (c0 < width) *reinterpret_cast<f32x4*>(row + c0) = a[fb0 + fb];
+  }
+}
+// narrow / unaligned rows: element loads from clamped addresses
+template <int NF>
+__device__ __forceinline__ void load_narrow16(f32x4* __restrict__ a, const float* __restrict__ row,
+                                              int width, int lane) {
+  const int g = lane >> 4;
+#pragma unroll
+  for (int fb = 0; fb < NF; ++fb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int f = 16 * fb + 4 * g + r;
+      const float v = row[f < width ? f : 0];
+      a[fb][r] = f < width ? v : 0.f;
+    }
+}
+
+// ================================================================ MLP backward
+// KB: input blocks of 32 (k_in <= 32 KB); NOB: output blocks of 32; DEFER: the first layer's
+// weight gradient is left to nlam_outer_bwd (ga_out written) -- the K = 128 node update.
+// Sources: KB == 1: one source, any width <= 32 and alignment (element loads);
+//          KB == 2: one source, 16-byte aligned rows, width % 4 == 0;
+//          KB == 4: two sources of 64 columns each, 16-byte aligned.
+// gy: NOB == 2: 64 columns, 16-byte aligned; NOB == 1: any width <= 32 (element loads).
+template <int KB, int NOB, bool HAS_LN, bool DEFER, int TERMS>
+__global__ __launch_bounds__(K16_THREADS, 2) void mlp_bwd16_kernel(MlpBwdParams q) {
+  extern __shared__ __attribute__((aligned(16))) char smem16[];
+  constexpr int HID = 64, NFH = 4, KF = 2 * KB, NFO = 2 * NOB, NO = 32 * NOB, KP32 = 32 * KB;
+  constexpr int KBA = DEFER ? 1 : KB;
+  const MlpParams& p = q.f;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
+  const int t = lane & 15;
+  char* cur = smem16;
+  const B3Image W1im = w16_image(cur, HID, KP32);
+  cur += w16_image_bytes(HID, KP32);
+  const B3Image W2im = w16_image(cur, NO, HID);
+  cur += w16_image_bytes(NO, HID);
+  float* b1s = reinterpret_cast<float*>(cur);
+  float* b2s = b1s + HID;
+  float* gs = b2s + NO;
+  cur += (HID + 2 * NO) * sizeof(float);
+  constexpr int PW0 = (!DEFER && KP32 > HID) ? KP32 : HID;   // S planes, later X planes
+  constexpr int PW1 = HID > NO ? HID : NO;                   // g / prod / GZ planes, later GA
+  constexpr size_t HST = DEFER ? 0 : (size_t)NLAM_T16 * (HID + 4) * sizeof(float);   // h stash
+  char* mine = cur + wave * (p16_bytes(PW0) + p16_bytes(PW1) + HST);
+  void* R0 = mine;
+  void* R1 = mine + p16_bytes(PW0);
+  float* HS = reinterpret_cast<float*>(mine + p16_bytes(PW0) + p16_bytes(PW1));
+
+  load_weight_lds_b3(W1im, 0, p.W1, p.ldW1, HID, p.k_in, HID, KP32, tid, K16_THREADS);
+  load_weight_lds_b3(W2im, 0, p.W2, p.ldW2, p.n_out, HID, NO, HID, tid, K16_THREADS);
+  load_vec_lds(b1s, p.b1, HID, HID, tid, K16_THREADS);
+  load_vec_lds(b2s, p.b2, p.n_out, NO, tid, K16_THREADS);
+  load_vec_lds(gs, p.gamma, p.n_out, NO, tid, K16_THREADS);
+  __syncthreads();
+
+  f32x16 dW1[2][KBA], dW2[NOB][2];
+  if constexpr (!DEFER) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < KBA; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dW1[i][j][r] = 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < NOB; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dW2[i][j][r] = 0.f;
+  float db1[1] = {0.f}, db2[1] = {0.f}, dgam[1] = {0.f}, dbet[1] = {0.f};
+
+  const int64_t tiles_per_b = (p.rows + NLAM_T16 - 1) / NLAM_T16;
+  const int64_t ntiles = tiles_per_b * p.B;
+  const bool want_gx = q.gxa != nullptr || q.gxb != nullptr;
+  for (int64_t tt = (int64_t)blockIdx.x * K16_NW + wave; tt < ntiles;
+       tt += (int64_t)gridDim.x * K16_NW) {
+    const int64_t b = tt / tiles_per_b;
+    const int64_t r0 = (tt - b * tiles_per_b) * NLAM_T16;
+    const int nrows = (int)((p.rows - r0) < NLAM_T16 ? (p.rows - r0) : NLAM_T16);
+    const bool valid = t < nrows;
+    const int64_t row = r0 + (valid ? t : nrows - 1);   // padded slots re-read a valid row
+
+    // ---- this lane's slices of the x rows; recompute the forward: h, s = silu(h)
+    auto load_x = [&](f32x4* x) {
+      const int64_t rw = opaque(row);
+      const float* ra = p.src[0].ptr + b * p.src[0].bstride + rw * p.src[0].ld;
+      const float* rb = KB == 4 ? p.src[1].ptr + b * p.src[1].bstride + rw * p.src[1].ld : ra;
+      if constexpr (KB == 1) load_narrow16<KF>(x, ra, p.src[0].width, lane);
+      else if constexpr (KB == 4) load_cat16<KF>(x, ra, 64, rb, 64, lane);
+      else load_cat16<KF>(x, ra, p.src[0].width, ra, 0, lane);
+    };
+    const B3Tile Ts = p16_tile(R0, HID), Tz = p16_tile(R1, NO);
+    f32x4 hkeep[DEFER ? NFH : 1];   // DEFER: h stays in registers (no weight-gradient blocks of W1)
+    f32x4 g[NFO];
+    {
+      f32x4 hpre[NFH];
+      {
+        f32x4 x[KF];
+        load_x(x);
+        vec_to_acc16<NFH>(hpre, b1s, lane);
+        gemm_acc16<NFH, KB, TERMS>(hpre, W1im, 0, 0, x, lane);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (DEFER) {
+#pragma unroll
+        for (int fb = 0; fb < NFH; ++fb) hkeep[fb] = hpre[fb];
+      } else {
+        acc16_to_tile<NFH>(hpre, HS, HID + 4, lane);          // h: back from LDS for silu'
+      }
+      f32x4 sact[NFH];
+#pragma unroll
+      for (int fb = 0; fb < NFH; ++fb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sact[fb][r] = nlam_silu(hpre[fb][r]);
+      acc16_to_planes<NFH, TERMS>(sact, Ts, 0, lane);         // S stays in R0 until dW2 is formed
+      const float* rg = q.gy.ptr + b * q.gy.bstride + opaque(row) * q.gy.ld;
+      if constexpr (HAS_LN) {
+        f32x4 z[NFO];
+        vec_to_acc16<NFO>(z, b2s, lane);
+        gemm_acc16<NFO, 2, TERMS>(z, W2im, 0, 0, sact, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        load_row16<NFO>(g, rg, lane);
+        mask16<NFO>(g, valid);   // padded rows carry a zero gradient: every sum below ignores them
+        acc16_to_planes<NFO, TERMS>(g, Tz, 0, lane);          // dbeta summand: gy
+        wave_sync();
+        colsum16<1, TERMS>(dbet, Tz, 0, lane);
+        wave_sync();
+        ln16_bwd<NFO, TERMS>(z, g, Tz, gs, lane);             // g: gy -> gz; gy * xhat -> planes
+        wave_sync();
+        colsum16<1, TERMS>(dgam, Tz, 0, lane);
+        wave_sync();
+      } else {
+        if constexpr (NOB == 1) load_narrow16<NFO>(g, rg, p.n_out, lane);
+        else load_row16<NFO>(g, rg, lane);
+        mask16<NFO>(g, valid);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- second layer's weight gradient: dW2 += gz (x) s, db2 += gz
+    acc16_to_planes<NFO, TERMS>(g, Tz, 0, lane);
+    wave_sync();
+    if constexpr (NOB == 1) colsum16_32<TERMS>(db2[0], Tz, 0, lane);
+    else colsum16<1, TERMS>(db2, Tz, 0, lane);
+    outer_accum16<NOB, 2, TERMS>(dW2, Tz, 0, Ts, 0, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- ga = (W2^T gz) * silu'(h)
+    f32x4 ga[NFH];
+    zero16<NFH>(ga);
+    gemm_acc16_wt<NFH, NOB, TERMS>(ga, W2im, 0, 0, g, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      const int gq4 = lane >> 4;
+#pragma unroll
+      for (int fb = 0; fb < NFH; ++fb) {
+        f32x4 h4;
+        if constexpr (DEFER) h4 = hkeep[fb];
+        else h4 = *reinterpret_cast<const f32x4*>(HS + t * (HID + 4) + 16 * fb + 4 * gq4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ga[fb][r] *= nlam_silu_grad(h4[r]);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (DEFER) {
+      if (valid) store_row16<NFH>(q.ga_out + (b * p.rows + r0 + t) * HID, ga, lane);
+    } else {
+      // ---- first layer's weight gradient: dW1 += ga (x) x, db1 += ga (x re-read: L2-hot)
+      wave_sync();
+      const B3Tile Ta = p16_tile(R1, HID), Tx = p16_tile(R0, KP32);
+      acc16_to_planes<NFH, TERMS>(ga, Ta, 0, lane);
+      {
+        f32x4 x[KF];
+        load_x(x);
+        acc16_to_planes<KF, TERMS>(x, Tx, 0, lane);
+      }
+      wave_sync();
+      colsum16<1, TERMS>(db1, Ta, 0, lane);
+      outer_accum16<2, KB, TERMS>(dW1, Ta, 0, Tx, 0, lane);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- input gradient gx = W1^T ga (+ gy: the residual taken from source a)
+    if (want_gx) {
+      f32x4 gx[KF];
+      zero16<KF>(gx);
+      gemm_acc16_wt<KF, 2, TERMS>(gx, W1im, 0, 0, ga, lane);
+      const int wa = p.src[0].width;
+      if (q.gxa != nullptr) {
+        if (q.add_gy_to_gxa) {   // n_out == wa == 64 (checked by the host side)
+          f32x4 gy2[4];
+          load_row16<4>(gy2, q.gy.ptr + b * q.gy.bstride + opaque(row) * q.gy.ld, lane);
+#pragma unroll
+          for (int fb = 0; fb < 4 && fb < KF; ++fb) gx[fb] += gy2[fb];
+        }
+        float* o = q.gxa + b * q.gxa_bstride + (r0 + t) * q.gxa_ld;
+        if (valid) {
+          if constexpr (KB == 1) store_row16_s<KF>(o, gx, wa, lane);
+          else if constexpr (KB == 4) store_cols16<4>(o, gx, 0, 64, lane);
+          else store_cols16<KF>(o, gx, 0, wa, lane);
+        }
+      }
+      if constexpr (KB == 4) {
+        if (q.gxb != nullptr && valid)
+          store_cols16<4>(q.gxb + b * q.gxb_bstride + (r0 + t) * q.gxb_ld, gx, 4, 64, lane);
+      }
+    }
+    wave_sync();   // the planes are rewritten by the next tile
+  }
+
+  // ---- fold the eight waves' partials in LDS (fixed order) and write the slab
+  __syncthreads();
+  float* img = reinterpret_cast<float*>(smem16);   // weights and planes are dead
+  float* slab = q.slab + (int64_t)blockIdx.x * q.slab_stride;
+  constexpr int n1 = HID * KP32, n2 = NO * HID;
+  if constexpr (!DEFER) {
+    fold_blocks_to_slab16<2, KBA, KBA, K16_NW>(&dW1[0][0], img, KP32, slab, tid, wave, lane);
+    fold_vec_to_slab16<1, K16_NW>(db1, img, slab + n1, HID, tid, wave, lane);
+  }
+  fold_blocks_to_slab16<NOB, 2, 2, K16_NW>(&dW2[0][0], img, HID, slab + n1 + HID, tid, wave, lane);
+  float* vbase = slab + n1 + HID + n2;
+  fold_vec_to_slab16<1, K16_NW>(db2, img, vbase, NO, tid, wave, lane);
+  if constexpr (HAS_LN) {
+    fold_vec_to_slab16<1, K16_NW>(dgam, img, vbase + NO, NO, tid, wave, lane);
+    fold_vec_to_slab16<1, K16_NW>(dbet, img, vbase + 2 * NO, NO, tid, wave, lane);
+  }
+}
+
+template <int KB, int NOB, bool HAS_LN, bool DEFER>
+static int launch_mlp_bwd16(const MlpBwdParams& q, hipStream_t s) {
+  constexpr int HID = 64, NO = 32 * NOB, KP32 = 32 * KB;
+  constexpr int PW0 = (!DEFER && KP32 > HID) ? KP32 : HID;
+  constexpr int PW1 = HID > NO ? HID : NO;
+  size_t lds = w16_image_bytes(HID, KP32) + w16_image_bytes(NO, HID) + (HID + 2 * NO) * sizeof(float) +
+               K16_NW * (p16_bytes(PW0) + p16_bytes(PW1) +
+                         (DEFER ? 0 : (size_t)NLAM_T16 * (HID + 4) * sizeof(float)));
+  size_t fold = (size_t)K16_NW * HID * HID * sizeof(float);          // dW2 images
+  if (!DEFER && (size_t)K16_NW * HID * KP32 * sizeof(float) > fold)
+    fold = (size_t)K16_NW * HID * KP32 * sizeof(float);
+  if (fold > lds) lds = fold;
+  NLAM_REQUIRE(lds <= 160 * 1024, "mlp_bwd16: LDS footprint %zu B exceeds 160 KiB", lds);
+  auto kern = mlp_bwd16_kernel<KB, NOB, HAS_LN, DEFER, 3>;
+  NLAM_BIG_LDS(kern, __func__);
+  const int64_t ntiles32 = ((q.f.rows + 31) / 32) * q.f.B;
+  kern<<<(unsigned)nlam_bwd_grid(ntiles32), K16_THREADS, lds, s>>>(q);
+  NLAM_CHECK_LAUNCH("mlp_bwd16_kernel");
+  return 0;
+}
+
+int nlam_k16_mlp_bwd(const MlpBwdParams& q, hipStream_t s) {
+  if (!nlam_k16_on(K16_MLP_BWD) || !nlam_mfma_b3() || q.stamp) return -1;
+  const MlpParams& p = q.f;
+  const bool ln = p.gamma != nullptr;
+  const int kb = (p.k_in + 31) / 32;
+  const bool a_vec = (p.vec_mask & 1) != 0;
+  // gy as 64 aligned columns / anything narrow
+  const bool gy64 = p.n_out == 64 && q.vec_gy;
+  if (ln && !gy64) return -1;
+  if (q.gxa != nullptr && !(q.vec_gxa || kb == 1)) return -1;
+  if (q.gxb != nullptr && !q.vec_gxb) return -1;
+  if (q.add_gy_to_gxa && !(gy64 && p.src[0].width == 64)) return -1;
+  if (ln && p.nsrc == 1 && kb == 1) return launch_mlp_bwd16<1, 2, true, false>(q, s);
+  if (ln && p.nsrc == 1 && kb == 2 && a_vec) return launch_mlp_bwd16<2, 2, true, false>(q, s);
+  if (ln && p.nsrc == 2 && kb == 4 && q.ga_out != nullptr && a_vec && (p.vec_mask & 2) &&
+      p.src[0].width == 64 && p.src[1].width == 64)
+    return launch_mlp_bwd16<4, 2, true, true>(q, s);
+  if (!ln && p.nsrc == 1 && kb == 2 && a_vec && p.n_out <= 32)
+    return launch_mlp_bwd16<2, 1, false, false>(q, s);
+  return -1;
+}
+
+// ====================================================== projection backward
+// y = x [WA; WB]^T (+ b): gx = gy [WA; WB] (+ gx_add), dW = gy^T x, db = colsum(gy); k_in = 64,
+// n_out = 32 NOB in {64, 128}, 16-byte aligned views.  SUMGY: x is batch-invariant and gy is
+// summed over its gy_nsum batch slices while it is loaded (fixed order).
+template <int NOB, bool SUMGY, int TERMS>
+__global__ __launch_bounds__(K16_THREADS, 2) void lin_bwd16_kernel(LinBwdParams q) {
+  extern __shared__ __attribute__((aligned(16))) char smem16[];
+  constexpr int K = 64, KF = 4, NO = 32 * NOB, NFO = 2 * NOB, NV = NOB / 2;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
+  const int t = lane & 15;
+  const B3Image Wim = w16_image(smem16, NO, K);
+  char* mine = smem16 + w16_image_bytes(NO, K) + wave * (p16_bytes(NO) + p16_bytes(K));
+  const B3Tile Tg = p16_tile(mine, NO), Tx = p16_tile(mine + p16_bytes(NO), K);
+  load_weight_lds_b3(Wim, 0, q.WA, q.ldWA, q.nA, K, q.nA, K, tid, K16_THREADS);
+  if (q.nB > 0) load_weight_lds_b3(Wim, q.nA, q.WB, q.ldWB, q.nB, K, NO - q.nA, K, tid, K16_THREADS);
+  __syncthreads();
+  f32x16 dW[NOB][2];
+#pragma unroll
+  for (int i = 0; i < NOB; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dW[i][j][r] = 0.f;
+  float db[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) db[j] = 0.f;
+
+  const int64_t tiles_per_b = (q.rows + NLAM_T16 - 1) / NLAM_T16;
+  const int64_t ntiles = tiles_per_b * q.B;
+  for (int64_t tt = (int64_t)blockIdx.x * K16_NW + wave; tt < ntiles;
+       tt += (int64_t)gridDim.x * K16_NW) {
+    const int64_t b = tt / tiles_per_b;
+    const int64_t r0 = (tt - b * tiles_per_b) * NLAM_T16;
+    const int nrows = (int)((q.rows - r0) < NLAM_T16 ? (q.rows - r0) : NLAM_T16);
+    const bool valid = t < nrows;
+    const int64_t row = r0 + (valid ? t : nrows - 1);
+    f32x4 x[KF], g[NFO];
+    load_row16<KF>(x, q.x.ptr + b * q.x.bstride + row * q.x.ld, lane);
+    const float* rg = q.gy.ptr + b * q.gy.bstride + row * q.gy.ld;
+    load_row16<NFO>(g, rg, lane);
+    if constexpr (SUMGY) {
+      for (int sl = 1; sl < q.gy_nsum; ++sl) {
+        f32x4 tv[NFO];
+        load_row16<NFO>(tv, rg + (int64_t)sl * q.gy_sum_stride, lane);
+#pragma unroll
+        for (int fb = 0; fb < NFO; ++fb) g[fb] += tv[fb];
+      }
+    }
+    mask16<NFO>(g, valid);
+    acc16_to_planes<NFO, TERMS>(g, Tg, 0, lane);
+    acc16_to_planes<KF, TERMS>(x, Tx, 0, lane);
+    wave_sync();
+    colsum16<NV, TERMS>(db, Tg, 0, lane);
+    outer_accum16<NOB, 2, TERMS>(dW, Tg, 0, Tx, 0, lane);
+    if (q.gx != nullptr) {
+      f32x4 gx[KF];
+      zero16<KF>(gx);
+      gemm_acc16_wt<KF, NOB, TERMS>(gx, Wim, 0, 0, g, lane);
+      if (q.gx_add != nullptr) {
+        f32x4 ad[KF];
+        load_row16<KF>(ad, q.gx_add + b * q.ga_bstride + row * q.ga_ld, lane);
+#pragma unroll
+        for (int fb = 0; fb < KF; ++fb) gx[fb] += ad[fb];
+      }
+      if (valid) store_row16<KF>(q.gx + b * q.gx_bstride + (r0 + t) * q.gx_ld, gx, lane);
+    }
+    wave_sync();
+  }
+  __syncthreads();
+  float* img = reinterpret_cast<float*>(smem16);
+  float* slab = q.slab + (int64_t)blockIdx.x * q.slab_stride;
+  // 64 output rows at a time (8 x 64 x 64 floats = 128 KB of images)
+#pragma unroll
+  for (int h2 = 0; h2 < NOB / 2; ++h2)
+    fold_blocks_to_slab16<2, 2, 2, K16_NW>(&dW[2 * h2][0], img, K, slab + 64 * h2 * K, tid, wave, lane);
+  fold_vec_to_slab16<NV, K16_NW>(db, img, slab + NO * K, NO, tid, wave, lane);
+}
+
+template <int NOB, bool SUMGY>
+static int launch_lin_bwd16(const LinBwdParams& q, hipStream_t s) {
+  constexpr int K = 64, NO = 32 * NOB;
+  size_t lds = w16_image_bytes(NO, K) + K16_NW * (p16_bytes(NO) + p16_bytes(K));
+  const size_t fold = (size_t)K16_NW * 64 * K * sizeof(float);
+  if (fold > lds) lds = fold;
+  NLAM_REQUIRE(lds <= 160 * 1024, "lin_bwd16: LDS footprint %zu B exceeds 160 KiB", lds);
+  auto kern = lin_bwd16_kernel<NOB, SUMGY, 3>;
+  NLAM_BIG_LDS(kern, __func__);
+  const int64_t ntiles32 = ((q.rows + 31) / 32) * q.B;
+  kern<<<(unsigned)nlam_bwd_grid(ntiles32), K16_THREADS, lds, s>>>(q);
+  NLAM_CHECK_LAUNCH("lin_bwd16_kernel");
+  return 0;
+}
+
+int nlam_k16_lin_bwd(const LinBwdParams& q, hipStream_t s) {
+  if (!nlam_k16_on(K16_LIN_BWD) || !nlam_mfma_b3()) return -1;
+  const int n_out = q.nA + q.nB;
+  if (q.x.width != 64 || !q.vec_x || !q.vec_gy) return -1;
+  if (q.gx != nullptr && !q.vec_gx) return -1;
+  if (q.gy_nsum > 1) {
+    if (n_out == 64) return launch_lin_bwd16<2, true>(q, s);
+    if (n_out == 128) return launch_lin_bwd16<4, true>(q, s);
+    return -1;
+  }
+  if (n_out == 64) return launch_lin_bwd16<2, false>(q, s);
+  if (n_out == 128) return launch_lin_bwd16<4, false>(q, s);
+  return -1;
+}
+
+// ================================================ deferred weight gradients
+// dW (64 x 32 NXB) = sum_rows G[r]^T (x) [xa | xb][r], db = colsum(G); x rows optionally
+// gathered by x_index.  Slab: [dW | db] as nlam_outer_bwd.
+template <int NXB, int TERMS>
+__global__ __launch_bounds__(K16_THREADS, 2) void outer_bwd16_kernel(OuterParams q) {
+  extern __shared__ __attribute__((aligned(16))) char smem16[];
+  constexpr int NG = 64, NX = 32 * NXB, KF = 2 * NXB;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
+  const int t = lane & 15;
+  char* mine = smem16 + wave * (p16_bytes(NG) + p16_bytes(NX));
+  const B3Tile Tg = p16_tile(mine, NG), Tx = p16_tile(mine + p16_bytes(NG), NX);
+  f32x16 dW[2][NXB];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NXB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dW[i][j][r] = 0.f;
+  float db[1] = {0.f};
+  const int wa = q.xa.width, wb = q.xb.ptr ? q.xb.width : 0;
+  const int64_t tiles_per_b = (q.rows + NLAM_T16 - 1) / NLAM_T16;
+  const int64_t ntiles = tiles_per_b * q.B;
+  for (int64_t tt = (int64_t)blockIdx.x * K16_NW + wave; tt < ntiles;
+       tt += (int64_t)gridDim.x * K16_NW) {
+    const int64_t b = tt / tiles_per_b;
+    const int64_t r0 = (tt - b * tiles_per_b) * NLAM_T16;
+    const int nrows = (int)((q.rows - r0) < NLAM_T16 ? (q.rows - r0) : NLAM_T16);
+    const bool valid = t < nrows;
+    const int64_t row = r0 + (valid ? t : nrows - 1);
+    const int64_t xrow = q.x_index ? (int64_t)q.x_index[row] : row;
+    f32x4 g[4], x[KF];
+    load_row16<4>(g, q.g.ptr + b * q.g.bstride + row * q.g.ld, lane);
+    const float* ra = q.xa.ptr + b * q.xa.bstride + xrow * q.xa.ld;
+    const float* rb = q.xb.ptr ? q.xb.ptr + b * q.xb.bstride + xrow * q.xb.ld : ra;
+    load_cat16<KF>(x, ra, wa, rb, wb, lane);
+    mask16<4>(g, valid);
+    acc16_to_planes<4, TERMS>(g, Tg, 0, lane);
+    acc16_to_planes<KF, TERMS>(x, Tx, 0, lane);
+    wave_sync();
+    colsum16<1, TERMS>(db, Tg, 0, lane);
+    outer_accum16<2, NXB, TERMS>(dW, Tg, 0, Tx, 0, lane);
+    wave_sync();
+  }
+  __syncthreads();
+  float* img = reinterpret_cast<float*>(smem16);
+  float* slab = q.slab + (int64_t)blockIdx.x * q.slab_stride;
+  // one 32-row block of dW at a time: 8 x 32 x NX floats of images (<= 128 KB)
+#pragma unroll
+  for (int ib = 0; ib < 2; ++ib)
+    fold_blocks_to_slab16<1, NXB, NXB, K16_NW>(&dW[ib][0], img, NX, slab + 32 * ib * NX, tid, wave, lane);
+  fold_vec_to_slab16<1, K16_NW>(db, img, slab + NG * NX, NG, tid, wave, lane);
+}
+
+template <int NXB>
+static int launch_outer_bwd16(const OuterParams& q, hipStream_t s) {
+  constexpr int NG = 64, NX = 32 * NXB;
+  size_t lds = K16_NW * (p16_bytes(NG) + p16_bytes(NX));
+  const size_t fold = (size_t)K16_NW * 32 * NX * sizeof(float);
+  if (fold > lds) lds = fold;
+  NLAM_REQUIRE(lds <= 160 * 1024, "outer_bwd16: LDS footprint %zu B exceeds 160 KiB", lds);
+  auto kern = outer_bwd16_kernel<NXB, 3>;
+  NLAM_BIG_LDS(kern, __func__);
+  const int64_t ntiles32 = ((q.rows + 31) / 32) * q.B;
+  kern<<<(unsigned)nlam_bwd_grid(ntiles32), K16_THREADS, lds, s>>>(q);
+  NLAM_CHECK_LAUNCH("outer_bwd16_kernel");
+  return 0;
+}
+
+int nlam_k16_outer_bwd(const OuterParams& q, hipStream_t s) {
+  if (!nlam_k16_on(K16_OUTER_BWD) || !nlam_mfma_b3()) return -1;
+  const int kx = q.xa.width + (q.xb.ptr ? q.xb.width : 0);
+  if (q.g.width != 64 || q.xa.width % 4 != 0) return -1;
+  if (kx == 64) return launch_outer_bwd16<2>(q, s);
+  if (kx == 128) return launch_outer_bwd16<4>(q, s);
+  return -1;
+}

@@ -17,28 +17,8 @@
 
 #include "fused_common.h"
 #include "fused_bf16x3.h"
+#include "fused_params.h"
 
-struct EdgeFwdParams {
-  // graph tables (device)
-  const int32_t* tiles;       // (ntiles, 4): p0, p1, r0, r1
-  int64_t ntiles;
-  const int32_t* csr_rowptr;  // n_rec + 1
-  const int32_t* csr_eid;     // original edge id at CSR position
-  const int32_t* csr_send;
-  const int32_t* csr_rec;
-  const float* inv_deg;       // n_rec or NULL
-  // operands
-  RowView e;                  // HAS_EGEMM: edge reps (B, M, d) in original order;
-                              // else: Pe (1 or B, M, d) in original order
-  RowView ps;                 // (B, N_s, d)
-  RowView pr;                 // (B, N_r, d)
-  const float* W1e; int64_t ldW1e;
-  const float* W2; int64_t ldW2; const float* b2;
-  const float* gamma; const float* beta;
-  float* agg; int64_t agg_bstride; int64_t agg_ld;
-  float* e_out; int64_t eo_bstride; int64_t eo_ld;   // HAS_EGEMM only
-  int B;
-};
 
 
 // Per-tile indices, loaded unconditionally (padded slots use CSR position 0, whose
@@ -256,6 +236,10 @@ extern "C" int nlam_edge_fwd(
   p.e_out = e_out; p.eo_bstride = eo_bstride; p.eo_ld = eo_ld;
   p.B = (int)B;
   hipStream_t s = (hipStream_t)stream;
+  if (d == 64) {   // 16-row, two-waves-per-SIMD form (fused16_edge.hip)
+    const int r16 = nlam_k16_edge_fwd(p, has_egemm, s);
+    if (r16 >= 0) return r16;
+  }
   if (d == 64 && nlam_mfma_b3())   // (unaligned weights take the scalar image loader)
     return has_egemm ? launch_edge_fwd<64, true, true>(p, s) : launch_edge_fwd<64, false, true>(p, s);
   if (d == 64) return has_egemm ? launch_edge_fwd<64, true>(p, s) : launch_edge_fwd<64, false>(p, s);
@@ -292,15 +276,6 @@ extern "C" int nlam_debug_edge_bwd_stamps(unsigned long long* out, int reset) {
 //   gh   = (W2^T gz) * silu'(h)       -> gh_out (original edge order), gPr_i = sum_{rec=i} gh
 //   dW1e += gh (x) e ;  g_e = g_eout + W1e^T gh                 (has_egemm)
 // Slab per workgroup: [dW1e (D x D) | dW2 (D x D) | db2 | dgamma | dbeta].
-struct EdgeBwdParams {
-  EdgeFwdParams f;              // forward operands (agg / e_out unused)
-  RowView g_agg;                // (B, N_r, d)
-  const float* g_eout; int64_t geo_bstride; int64_t geo_ld;   // (B, M, d) original order, may be NULL
-  float* gh_out; int64_t gh_bstride;                          // (B, M, d) original edge order, pitch d
-  float* gpr; int64_t gpr_bstride; int64_t gpr_ld;            // (B, N_r, d)
-  float* g_e; int64_t ge_bstride; int64_t ge_ld;              // (B, M, d) original order (has_egemm)
-  float* slab; int64_t slab_stride;
-};
 
 template <int D, bool HAS_EGEMM, bool STAMP = false, bool B3 = false>
 __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
@@ -714,6 +689,10 @@ extern "C" int nlam_edge_bwd(
   q.g_e = g_e; q.ge_bstride = ge_bstride; q.ge_ld = ge_ld;
   q.slab = slab; q.slab_stride = slab_stride;
   hipStream_t s = (hipStream_t)stream;
+  {
+    const int r16 = nlam_k16_edge_bwd(q, has_egemm, s);
+    if (r16 >= 0) return r16;
+  }
   static const bool stamp = getenv("NLAM_STAMP") != nullptr;
   if (stamp && has_egemm && nlam_mfma_b3()) return launch_edge_bwd<64, true, true, true>(q, s);
   if (stamp && has_egemm) return launch_edge_bwd<64, true, true>(q, s);

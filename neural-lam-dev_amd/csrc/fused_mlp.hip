@@ -11,22 +11,8 @@
 #include "fused_common.h"
 #include "fused_bf16x3.h"
 #include "fused_fs.h"
+#include "fused_params.h"
 
-struct MlpParams {
-  RowView src[2];
-  int nsrc;
-  int k_in;             // sum of source widths (W1 is hid x k_in)
-  int k_pad;            // k_in rounded up to a multiple of 8
-  int n_out;            // true output width (<= 32 * NOUTB)
-  const float* W1; int64_t ldW1; const float* b1;
-  const float* W2; int64_t ldW2; const float* b2;
-  const float* gamma; const float* beta;
-  const float* res; int64_t res_bstride; int64_t res_ld;  // optional residual
-  float* out; int64_t out_bstride; int64_t out_ld;
-  int64_t rows;         // rows per batch item
-  int B;
-  int vec_mask;         // bit s: source s may use float4 loads; bit 2: res; bit 3: out
-};
 
 // LDS layout (floats): W1s[HID][k_pad+4] | W2s[32*NOUTB][HID+4] | b1s[HID] | b2s | gs | bs |
 //                      tiles[4][32][ldt],  ldt = max(k_pad, HID, 32*NOUTB) + 4
@@ -216,15 +202,6 @@ extern "C" int nlam_mlp_fwd(
 
 // ------------------------------------------------------------- projection
 // out[:, 0:nA] = x WA^T + bA ; out[:, nA:nA+nB] = x WB^T + bB  (WB optional).
-struct LinParams {
-  RowView x;
-  int k_pad;
-  const float* WA; int64_t ldWA; const float* bA; int nA;
-  const float* WB; int64_t ldWB; const float* bB; int nB;
-  float* out; int64_t out_bstride; int64_t out_ld;
-  int64_t rows; int B; int vec_mask;  // bit0: x, bit3: out
-  int timeline;                       // NLAM_TIMELINE=1: per-workgroup 100 MHz stamps
-};
 
 // Diagnostic (NLAM_TIMELINE=1): s_memrealtime (100 MHz, chip-wide) at workgroup start,
 // after the weight prologue and after the tile loop, for up to 1024 workgroups.
@@ -413,17 +390,6 @@ extern "C" int nlam_lin_fwd(const float* x, int64_t x_bstride, int64_t x_ld, int
 //   [dW1 (HID x KP32) | db1 (HID) | dW2 (32 NOUTB x HID) | db2 | dgamma | dbeta]
 // (KP32 = k_in rounded up to 32); nlam_reduce_slabs sums the slabs in a fixed
 // order.  Activations are recomputed from the inputs (nothing saved in forward).
-struct MlpBwdParams {
-  MlpParams f;                 // forward operands (out/res unused)
-  RowView gy;                  // (B, rows, n_out)
-  float* gxa; int64_t gxa_bstride; int64_t gxa_ld;   // optional grads of the sources
-  float* gxb; int64_t gxb_bstride; int64_t gxb_ld;
-  int add_gy_to_gxa;           // residual taken from source a: gxa += gy
-  float* slab; int64_t slab_stride;
-  float* ga_out;               // DEFER_DW1: (B, rows, HID) gradient of the hidden pre-activation
-  int vec_gy, vec_gxa, vec_gxb;
-  int stamp;                   // NLAM_STAMP=1: per-phase s_memtime sums (diagnostic)
-};
 
 __device__ unsigned long long g_mlp_bwd_stamps[8];
 extern "C" int nlam_debug_mlp_bwd_stamps(unsigned long long* out, int reset) {
@@ -937,6 +903,10 @@ extern "C" int nlam_mlp_bwd(
   static const bool mstamp = getenv("NLAM_STAMP") != nullptr;
   q.stamp = mstamp ? 1 : 0;
   hipStream_t s = (hipStream_t)stream;
+  if (hid == 64) {   // 16-row, two-waves-per-SIMD form (fused16_mlp.hip) where it applies
+    const int r16 = nlam_k16_mlp_bwd(q, s);
+    if (r16 >= 0) return r16;
+  }
   const bool ln = gamma != nullptr;
   const int kb = (p.k_in + 31) / 32;
   const int noutb = (n_out + 31) / 32;
@@ -973,18 +943,6 @@ extern "C" int nlam_mlp_bwd(
 // ---------------------------------------------------- projection backward
 // y = x [WA; WB]^T + [bA; bB]:  gx = gy [WA; WB],  dW = gy^T x,  db = colsum(gy).
 // Slab per workgroup: [dW (32 NOUTB x KP32) | db (32 NOUTB)].
-struct LinBwdParams {
-  RowView x;                   // (B, rows, k_in)
-  RowView gy;                  // (B, rows, n_out)
-  const float* WA; int64_t ldWA; int nA;
-  const float* WB; int64_t ldWB; int nB;
-  float* gx; int64_t gx_bstride; int64_t gx_ld;   // optional
-  const float* gx_add; int64_t ga_bstride; int64_t ga_ld;   // optional addend of gx
-  float* slab; int64_t slab_stride;
-  int64_t rows; int B;
-  int gy_nsum; int64_t gy_sum_stride;   // gy[b] := sum_{s < gy_nsum} gy[b][s * gy_sum_stride + ...]
-  int vec_x, vec_gy, vec_gx;
-};
 
 // B3: split-bf16 MFMAs (needs the float4 views and k_in == 32 KB, n_out == 32 NOUTB).
 template <int NOUTB, int KB, bool SUMGY = false, bool B3 = false>
@@ -1203,6 +1161,10 @@ extern "C" int nlam_lin_bwd(const float* x, int64_t x_bstride, int64_t x_ld, int
   NLAM_REQUIRE(q.gy_nsum == 1 || (q.vec_x && q.vec_gy && gy_sum_stride % 4 == 0),
                "nlam_lin_bwd: gy_nsum > 1 needs 16-byte aligned x / gy rows and slices");
   hipStream_t s = (hipStream_t)stream;
+  {
+    const int r16 = nlam_k16_lin_bwd(q, s);
+    if (r16 >= 0) return r16;
+  }
   const int noutb = (q.nA + q.nB) / 32, kb = (k_in + 31) / 32;
   const bool b3 = nlam_mfma_b3() && q.vec_x && q.vec_gy && k_in == 32 * kb &&
                   (q.nA + q.nB) == 32 * noutb;
@@ -1230,13 +1192,6 @@ extern "C" int nlam_lin_bwd(const float* x, int64_t x_bstride, int64_t x_ld, int
 // dW (32 NGB x 32 NXB) = sum_rows G[r]^T (x) [xa | xb][r],  db = colsum(G).
 // A lean streaming pass: no weights in LDS, every register for the accumulators.
 // Slab per workgroup: [dW (32 NGB x 32 NXB) | db (32 NGB)].
-struct OuterParams {
-  RowView g;                   // (B, rows, 32 NGB)
-  RowView xa, xb;              // widths sum to <= 32 NXB; xb.ptr may be NULL
-  const int32_t* x_index;      // optional: x row of (batch-local) row r is x_index[r]
-  float* slab; int64_t slab_stride;
-  int64_t rows; int B;
-};
 
 template <int NGB, int NXB, bool B3 = false>
 __global__ __launch_bounds__(256) void outer_bwd_kernel(OuterParams q) {
@@ -1352,6 +1307,10 @@ extern "C" int nlam_outer_bwd(const float* g, int64_t g_bstride, int64_t g_ld, i
   q.xb = RowView{xb, xb_bstride, xb_ld, xb ? xb_width : 0};
   q.x_index = x_index; q.slab = slab; q.slab_stride = slab_stride; q.rows = rows; q.B = (int)B;
   hipStream_t s = (hipStream_t)stream;
+  {
+    const int r16 = nlam_k16_outer_bwd(q, s);
+    if (r16 >= 0) return r16;
+  }
   const int nxb = (kx + 31) / 32;
   if (nlam_mfma_b3() && kx == 32 * nxb) {
     if (nxb == 2) return launch_outer_bwd<2, 2, true>(q, s);

@@ -1,0 +1,113 @@
+// Parameter blocks of the fused hidden-64 kernels, shared by the 32-row kernels
+// (fused_mlp.hip, fused_edge.hip) and the 16-row, two-waves-per-SIMD kernels (fused16_*.hip).
+#pragma once
+#include "fused_common.h"
+
+struct MlpParams {
+  RowView src[2];
+  int nsrc;
+  int k_in;             // sum of source widths (W1 is hid x k_in)
+  int k_pad;            // k_in rounded up to a multiple of 8
+  int n_out;            // true output width (<= 32 * NOUTB)
+  const float* W1; int64_t ldW1; const float* b1;
+  const float* W2; int64_t ldW2; const float* b2;
+  const float* gamma; const float* beta;
+  const float* res; int64_t res_bstride; int64_t res_ld;  // optional residual
+  float* out; int64_t out_bstride; int64_t out_ld;
+  int64_t rows;         // rows per batch item
+  int B;
+  int vec_mask;         // bit s: source s may use float4 loads; bit 2: res; bit 3: out
+};
+
+struct LinParams {
+  RowView x;
+  int k_pad;
+  const float* WA; int64_t ldWA; const float* bA; int nA;
+  const float* WB; int64_t ldWB; const float* bB; int nB;
+  float* out; int64_t out_bstride; int64_t out_ld;
+  int64_t rows; int B; int vec_mask;  // bit0: x, bit3: out
+  int timeline;                       // NLAM_TIMELINE=1: per-workgroup 100 MHz stamps
+};
+
+struct MlpBwdParams {
+  MlpParams f;                 // forward operands (out/res unused)
+  RowView gy;                  // (B, rows, n_out)
+  float* gxa; int64_t gxa_bstride; int64_t gxa_ld;   // optional grads of the sources
+  float* gxb; int64_t gxb_bstride; int64_t gxb_ld;
+  int add_gy_to_gxa;           // residual taken from source a: gxa += gy
+  float* slab; int64_t slab_stride;
+  float* ga_out;               // DEFER_DW1: (B, rows, HID) gradient of the hidden pre-activation
+  int vec_gy, vec_gxa, vec_gxb;
+  int stamp;                   // NLAM_STAMP=1: per-phase s_memtime sums (diagnostic)
+};
+
+struct LinBwdParams {
+  RowView x;                   // (B, rows, k_in)
+  RowView gy;                  // (B, rows, n_out)
+  const float* WA; int64_t ldWA; int nA;
+  const float* WB; int64_t ldWB; int nB;
+  float* gx; int64_t gx_bstride; int64_t gx_ld;   // optional
+  const float* gx_add; int64_t ga_bstride; int64_t ga_ld;   // optional addend of gx
+  float* slab; int64_t slab_stride;
+  int64_t rows; int B;
+  int gy_nsum; int64_t gy_sum_stride;   // gy[b] := sum_{s < gy_nsum} gy[b][s * gy_sum_stride + ...]
+  int vec_x, vec_gy, vec_gx;
+};
+
+struct OuterParams {
+  RowView g;                   // (B, rows, 32 NGB)
+  RowView xa, xb;              // widths sum to <= 32 NXB; xb.ptr may be NULL
+  const int32_t* x_index;      // optional: x row of (batch-local) row r is x_index[r]
+  float* slab; int64_t slab_stride;
+  int64_t rows; int B;
+};
+
+struct EdgeFwdParams {
+  // graph tables (device)
+  const int32_t* tiles;       // (ntiles, 4): p0, p1, r0, r1
+  int64_t ntiles;
+  const int32_t* csr_rowptr;  // n_rec + 1
+  const int32_t* csr_eid;     // original edge id at CSR position
+  const int32_t* csr_send;
+  const int32_t* csr_rec;
+  const float* inv_deg;       // n_rec or NULL
+  // operands
+  RowView e;                  // HAS_EGEMM: edge reps (B, M, d) in original order;
+                              // else: Pe (1 or B, M, d) in original order
+  RowView ps;                 // (B, N_s, d)
+  RowView pr;                 // (B, N_r, d)
+  const float* W1e; int64_t ldW1e;
+  const float* W2; int64_t ldW2; const float* b2;
+  const float* gamma; const float* beta;
+  float* agg; int64_t agg_bstride; int64_t agg_ld;
+  float* e_out; int64_t eo_bstride; int64_t eo_ld;   // HAS_EGEMM only
+  int B;
+};
+
+struct EdgeBwdParams {
+  EdgeFwdParams f;              // forward operands (agg / e_out unused)
+  RowView g_agg;                // (B, N_r, d)
+  const float* g_eout; int64_t geo_bstride; int64_t geo_ld;   // (B, M, d) original order, may be NULL
+  float* gh_out; int64_t gh_bstride;                          // (B, M, d) original edge order, pitch d
+  float* gpr; int64_t gpr_bstride; int64_t gpr_ld;            // (B, N_r, d)
+  float* g_e; int64_t ge_bstride; int64_t ge_ld;              // (B, M, d) original order (has_egemm)
+  float* slab; int64_t slab_stride;
+};
+
+// ---- 16-row kernels (fused16_*.hip): same parameter blocks, same slab layouts and grids.
+// Each returns -1 when the shape / alignment is not one it handles (the caller then continues
+// with the 32-row kernel), 0 on success, > 0 on error.
+int nlam_k16_mlp_bwd(const MlpBwdParams& q, hipStream_t s);
+int nlam_k16_lin_bwd(const LinBwdParams& q, hipStream_t s);
+int nlam_k16_outer_bwd(const OuterParams& q, hipStream_t s);
+int nlam_k16_mlp_fwd(const MlpParams& p, hipStream_t s);
+int nlam_k16_lin_fwd(const LinParams& p, hipStream_t s);
+int nlam_k16_edge_fwd(const EdgeFwdParams& p, int has_egemm, hipStream_t s);
+int nlam_k16_edge_bwd(const EdgeBwdParams& q, int has_egemm, hipStream_t s);
+// bit mask of the kernel families that take the 16-row form (NLAM_K16 in the environment,
+// default all; nlam_set_k16 changes it at run time for A/B timing in one process)
+enum { K16_MLP_BWD = 1, K16_LIN_BWD = 2, K16_OUTER_BWD = 4, K16_EDGE_BWD = 8, K16_MLP_FWD = 16,
+       K16_LIN_FWD = 32, K16_EDGE_FWD = 64, K16_EDGE_BWD_UPD = 128 };
+// default: the families whose 16-row form is the faster one on MI355X (profiles/r03_*)
+#define K16_DEFAULT (K16_MLP_BWD | K16_LIN_BWD | K16_OUTER_BWD | K16_EDGE_BWD)
+bool nlam_k16_on(int family);
