@@ -484,8 +484,9 @@ int nlam_mfma_probe(float* out, void* stream);
 
 /* Tuning hook: which hidden-64 kernel families run in their 16-row, two-waves-per-SIMD form
  * (csrc/fused16_*.hip) instead of the 32-row, one-wave-per-SIMD form.  Bit mask: 1 nlam_mlp_bwd,
- * 2 nlam_lin_bwd, 4 nlam_outer_bwd, 8 nlam_edge_bwd, 16 nlam_mlp_fwd, 32 nlam_lin_fwd,
- * 64 nlam_edge_fwd.  Default: all (or NLAM_K16 in the environment).  Same entry points, slab
+ * 2 nlam_lin_bwd, 4 nlam_outer_bwd, 8 nlam_edge_bwd (no edge update), 16 nlam_mlp_fwd,
+ * 32 nlam_lin_fwd, 64 nlam_edge_fwd, 128 nlam_edge_bwd (update_edges).  Default: the families
+ * whose 16-row form measured faster (or NLAM_K16 in the environment).  Same entry points, slab
  * layouts and results (to rounding) either way; used to time both forms in one process. */
 int nlam_set_k16(int mask);
 /* 1 when nlam_edge_bwd (update_edges form, hidden width d) leaves the dW1e slot of its slabs
