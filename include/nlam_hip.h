@@ -472,6 +472,10 @@ int nlam_debug_edge_bwd_stamps(unsigned long long* out, int reset);
 int nlam_debug_mlp_bwd_stamps(unsigned long long* out, int reset);
 /* The same for the hidden-256 tail kernels (16 values: forward phases 0..7, backward 8..15). */
 int nlam_debug_fs_stamps(unsigned long long* out, int reset);
+/* The same for the 16-row per-wave nlam_edge_bwd (NLAM_STAMP16=1): out[0..10] = prefetched rows
+ * landed + transposed, next prefetch + first GEMM, Ps / Pr landed, silu + second GEMM, LayerNorm
+ * backward + column sums, dW2, W2^T gz, gh tile / stores / receiver sums, g_e, loop overhead, tail. */
+int nlam_debug_k16_stamps(unsigned long long* out, int reset);
 /* Diagnostic (NLAM_TIMELINE=1 in the environment of the process): nlam_lin_fwd records
  * s_memrealtime (100 MHz) per workgroup at start / after the weight prologue / at exit;
  * out: host array of 3 * 1024 values (first 1024 workgroups of the last launch). */
@@ -489,10 +493,6 @@ int nlam_mfma_probe(float* out, void* stream);
  * whose 16-row form measured faster (or NLAM_K16 in the environment).  Same entry points, slab
  * layouts and results (to rounding) either way; used to time both forms in one process. */
 int nlam_set_k16(int mask);
-/* 1 when nlam_edge_bwd (update_edges form, hidden width d) leaves the dW1e slot of its slabs
- * unwritten: the caller then forms dW1e = gh_out^T e with nlam_outer_bwd (gh_out and e are both
- * in the original edge order, so that pass streams linearly).  0: dW1e comes from the slabs. */
-int nlam_edge_bwd_defers_dw1e(int d);
 
 #ifdef __cplusplus
 }

@@ -93,10 +93,10 @@ SIGNATURES = {
     "nlam_debug_edge_bwd_stamps": [_p, _i32],
     "nlam_debug_mlp_bwd_stamps": [_p, _i32],
     "nlam_debug_fs_stamps": [_p, _i32],
+    "nlam_debug_k16_stamps": [_p, _i32],
     "nlam_debug_lin_fwd_timeline": [_p],
     "nlam_mfma_probe": [_p, _p],
     "nlam_set_k16": [_i32],
-    "nlam_edge_bwd_defers_dw1e": [_i32],
 }
 _RESTYPES = {
     "nlam_last_error": ctypes.c_char_p,

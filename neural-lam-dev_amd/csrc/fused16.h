@@ -124,6 +124,9 @@ __device__ __forceinline__ void gemm_acc16(f32x4 (&out)[NO], const B3Image& W, i
         out[fb] = MFMA16(al, bh[s], out[fb]);
       }
     }
+    // deep products: keep the scheduler from hoisting every fragment read of the unrolled
+    // product to the front (4 K steps x 4 blocks x 8 registers: spills)
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -157,6 +160,7 @@ __device__ __forceinline__ void gemm_acc16_wt(f32x4 (&out)[KO], const B3Image& W
         out[kb] = MFMA16(al, bh[s], out[kb]);
       }
     }
+    __builtin_amdgcn_sched_barrier(0);   // (bounds the hoisting of fragment reads)
   }
 }
 
@@ -197,6 +201,7 @@ __device__ __forceinline__ void gemm_frag16(f32x4 (&out)[NO], const B3Image& W, 
         out[fb] = MFMA16(al, f.h[s], out[fb]);
       }
     }
+    __builtin_amdgcn_sched_barrier(0);   // (bounds the hoisting of fragment reads)
   }
 }
 template <int KO, int NS, int TERMS = 3>
@@ -221,6 +226,7 @@ __device__ __forceinline__ void gemm_frag16_wt(f32x4 (&out)[KO], const B3Image& 
         out[kb] = MFMA16(al, f.h[s], out[kb]);
       }
     }
+    __builtin_amdgcn_sched_barrier(0);   // (bounds the hoisting of fragment reads)
   }
 }
 // fragments -> planes: elements 0..3 of step s are features 32 s + 4 g + {0..3}, elements 4..7
@@ -382,6 +388,71 @@ __device__ __forceinline__ void mask16(f32x4* __restrict__ a, bool keep) {
 #pragma unroll
     for (int fb = 0; fb < NF; ++fb) a[fb] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
+}
+
+// ---- whole-row ("row-shaped") global access -------------------------------------------------
+// Lane (r4 = l >> 4, c = l & 15) moves the 16-byte chunk c of row 4 k + r4 (k = 0..3): one
+// wave-instruction = 4 whole 256-byte rows.  The fragment-shaped form above (16 rows x 64 bytes per
+// instruction) makes 2.8 x the L1 accesses per instruction (TCP_TOTAL_CACHE_ACCESSES, profiles/
+// r03_pmc_*): the gathered / scattered edge and sender rows therefore move row-shaped and change
+// shape through this wave's fp32 LDS tile (4 x ds_write_b128 + 4 x ds_read_b128 per tensor).
+// ridx[k] = row index of slot 4 k + r4: from the slot-arranged index (lanes 0..15) by 4 shuffles.
+__device__ __forceinline__ void rs_index(int (&ridx)[4], int idx_t, int lane) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) ridx[k] = __shfl(idx_t, 4 * k + (lane >> 4), 64);
+}
+__device__ __forceinline__ void rs_load(f32x4 (&v)[4], const float* __restrict__ base, int64_t ld,
+                                        const int (&ridx)[4], int lane) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    v[k] = *reinterpret_cast<const f32x4*>(base + (int64_t)ridx[k] * ld + 4 * (lane & 15));
+}
+__device__ __forceinline__ void rs_store(float* __restrict__ base, int64_t ld, const int (&ridx)[4],
+                                         const f32x4 (&v)[4], int nrows, int lane) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (4 * k + (lane >> 4) < nrows)
+      *reinterpret_cast<f32x4*>(base + (int64_t)ridx[k] * ld + 4 * (lane & 15)) = v[k];
+}
+__device__ __forceinline__ void rs_to_tile(const f32x4 (&v)[4], float* __restrict__ tile, int ld,
+                                           int lane) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    *reinterpret_cast<f32x4*>(tile + (4 * k + (lane >> 4)) * ld + 4 * (lane & 15)) = v[k];
+}
+__device__ __forceinline__ void tile_to_rs(f32x4 (&v)[4], const float* __restrict__ tile, int ld,
+                                           int lane) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    v[k] = *reinterpret_cast<const f32x4*>(tile + (4 * k + (lane >> 4)) * ld + 4 * (lane & 15));
+}
+template <int NF>
+__device__ __forceinline__ void tile_to_acc16(f32x4* __restrict__ a, const float* __restrict__ tile,
+                                              int ld, int lane) {
+  const int t = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int fb = 0; fb < NF; ++fb)
+    a[fb] = *reinterpret_cast<const f32x4*>(tile + t * ld + 16 * fb + 4 * g);
+}
+
+// row-shaped registers -> accumulator layout through this wave's fp32 tile (DS operations of one
+// wave execute in order, so back-to-back conversions through the same tile need no waits)
+__device__ __forceinline__ void rs_to_acc16(f32x4 (&a)[4], const f32x4 (&v)[4],
+                                            float* __restrict__ tile, int ld, int lane) {
+  rs_to_tile(v, tile, ld, lane);
+  wave_sync();
+  tile_to_acc16<4>(a, tile, ld, lane);
+  wave_sync();
+}
+// tile (accumulator-layout rows already written) -> whole-row stores at base + idx[slot] * gld
+__device__ __forceinline__ void tile_store_rs(const float* __restrict__ tile, int ld,
+                                              float* __restrict__ base, int64_t gld, int idx_t,
+                                              int nrows, int lane) {
+  f32x4 v[4];
+  int r[4];
+  tile_to_rs(v, tile, ld, lane);
+  rs_index(r, idx_t, lane);
+  rs_store(base, gld, r, v, nrows, lane);
 }
 
 // ---- registers -> LDS ------------------------------------------------------------------

@@ -511,3 +511,174 @@ int nlam_k16_outer_bwd(const OuterParams& q, hipStream_t s) {
   if (kx == 128) return launch_outer_bwd16<4>(q, s);
   return -1;
 }
+
+// ================================================================== forward
+// y = [res +] [LayerNorm](W2 silu(W1 [x_a | x_b] + b1) + b2): no row-contracting product, so no
+// LDS besides the weight images and ~100 registers: four or more waves per SIMD.  Sources as in
+// mlp_bwd16_kernel; NOB == 2: 64 outputs, 16-byte aligned (res, out); NOB == 1: any width <= 32.
+template <int KB, int NOB, bool HAS_LN, int TERMS>
+__global__ __launch_bounds__(K16_THREADS, 2) void mlp_fwd16_kernel(MlpParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem16[];
+  constexpr int HID = 64, NFH = 4, KF = 2 * KB, NFO = 2 * NOB, NO = 32 * NOB, KP32 = 32 * KB;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int t = lane & 15;
+  char* cur = smem16;
+  const B3Image W1im = w16_image(cur, HID, KP32);
+  cur += w16_image_bytes(HID, KP32);
+  const B3Image W2im = w16_image(cur, NO, HID);
+  cur += w16_image_bytes(NO, HID);
+  float* b1s = reinterpret_cast<float*>(cur);
+  float* b2s = b1s + HID;
+  float* gs = b2s + NO;
+  float* bs = gs + NO;
+  load_weight_lds_b3(W1im, 0, p.W1, p.ldW1, HID, p.k_in, HID, KP32, tid, K16_THREADS);
+  load_weight_lds_b3(W2im, 0, p.W2, p.ldW2, p.n_out, HID, NO, HID, tid, K16_THREADS);
+  load_vec_lds(b1s, p.b1, HID, HID, tid, K16_THREADS);
+  load_vec_lds(b2s, p.b2, p.n_out, NO, tid, K16_THREADS);
+  load_vec_lds(gs, p.gamma, p.n_out, NO, tid, K16_THREADS);
+  load_vec_lds(bs, p.beta, p.n_out, NO, tid, K16_THREADS);
+  __syncthreads();
+  const int64_t tiles_per_b = (p.rows + NLAM_T16 - 1) / NLAM_T16;
+  const int64_t ntiles = tiles_per_b * p.B;
+  for (int64_t tt = (int64_t)blockIdx.x * K16_NW + wave; tt < ntiles;
+       tt += (int64_t)gridDim.x * K16_NW) {
+    const int64_t b = tt / tiles_per_b;
+    const int64_t r0 = (tt - b * tiles_per_b) * NLAM_T16;
+    const int nrows = (int)((p.rows - r0) < NLAM_T16 ? (p.rows - r0) : NLAM_T16);
+    const bool valid = t < nrows;
+    const int64_t row = r0 + (valid ? t : nrows - 1);
+    f32x4 h[NFH];
+    {
+      f32x4 x[KF];
+      const float* ra = p.src[0].ptr + b * p.src[0].bstride + row * p.src[0].ld;
+      if constexpr (KB == 1) {
+        load_narrow16<KF>(x, ra, p.src[0].width, lane);
+      } else if constexpr (KB == 4) {
+        const float* rb = p.src[1].ptr + b * p.src[1].bstride + row * p.src[1].ld;
+        load_cat16<KF>(x, ra, 64, rb, 64, lane);
+      } else {
+        load_cat16<KF>(x, ra, p.src[0].width, ra, 0, lane);
+      }
+      vec_to_acc16<NFH>(h, b1s, lane);
+      gemm_acc16<NFH, KB, TERMS>(h, W1im, 0, 0, x, lane);
+    }
+#pragma unroll
+    for (int fb = 0; fb < NFH; ++fb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h[fb][r] = nlam_silu(h[fb][r]);
+    f32x4 y[NFO];
+    vec_to_acc16<NFO>(y, b2s, lane);
+    gemm_acc16<NFO, 2, TERMS>(y, W2im, 0, 0, h, lane);
+    if constexpr (HAS_LN) ln16_apply<NFO>(y, gs, bs, lane);
+    float* orow = p.out + b * p.out_bstride + (r0 + t) * p.out_ld;
+    if constexpr (NOB == 2) {
+      if (p.res != nullptr) {
+        f32x4 rv[NFO];
+        load_row16<NFO>(rv, p.res + b * p.res_bstride + row * p.res_ld, lane);
+#pragma unroll
+        for (int fb = 0; fb < NFO; ++fb) y[fb] += rv[fb];
+      }
+      if (valid) store_row16<NFO>(orow, y, lane);
+    } else {
+      if (p.res != nullptr) {
+        f32x4 rv[NFO];
+        load_narrow16<NFO>(rv, p.res + b * p.res_bstride + row * p.res_ld, p.n_out, lane);
+#pragma unroll
+        for (int fb = 0; fb < NFO; ++fb) y[fb] += rv[fb];
+      }
+      if (valid) store_row16_s<NFO>(orow, y, p.n_out, lane);
+    }
+  }
+}
+
+template <int KB, int NOB, bool HAS_LN>
+static int launch_mlp_fwd16(const MlpParams& p, hipStream_t s) {
+  constexpr int HID = 64, NO = 32 * NOB, KP32 = 32 * KB;
+  const size_t lds = w16_image_bytes(HID, KP32) + w16_image_bytes(NO, HID) + (HID + 3 * NO) * sizeof(float);
+  auto kern = mlp_fwd16_kernel<KB, NOB, HAS_LN, 3>;
+  NLAM_BIG_LDS(kern, __func__);
+  const int64_t ntiles = ((p.rows + NLAM_T16 - 1) / NLAM_T16) * p.B;
+  int64_t g = (ntiles + K16_NW - 1) / K16_NW;
+  if (g > 512) g = 512;   // two 512-thread workgroups per CU (<= 128 registers, <= 54 KB of LDS)
+  kern<<<(unsigned)g, K16_THREADS, lds, s>>>(p);
+  NLAM_CHECK_LAUNCH("mlp_fwd16_kernel");
+  return 0;
+}
+
+int nlam_k16_mlp_fwd(const MlpParams& p, hipStream_t s) {
+  if (!nlam_k16_on(K16_MLP_FWD) || !nlam_mfma_b3()) return -1;
+  const bool ln = p.gamma != nullptr;
+  const int kb = (p.k_in + 31) / 32;
+  const bool a_vec = (p.vec_mask & 1) != 0, out_vec = (p.vec_mask & 8) != 0;
+  const bool res_ok = p.res == nullptr || (p.vec_mask & 4) != 0;
+  if (ln) {
+    if (p.n_out != 64 || !out_vec || !res_ok) return -1;
+    if (p.nsrc == 1 && kb == 1) return launch_mlp_fwd16<1, 2, true>(p, s);
+    if (p.nsrc == 1 && kb == 2 && a_vec) return launch_mlp_fwd16<2, 2, true>(p, s);
+    if (p.nsrc == 2 && kb == 4 && a_vec && (p.vec_mask & 2) && p.src[0].width == 64 &&
+        p.src[1].width == 64)
+      return launch_mlp_fwd16<4, 2, true>(p, s);
+    return -1;
+  }
+  if (p.nsrc == 1 && kb == 2 && a_vec && p.n_out <= 32) return launch_mlp_fwd16<2, 1, false>(p, s);
+  return -1;
+}
+
+// ================================================================ projection
+// out[:, 0:nA] = x WA^T + bA ; out[:, nA:nA+nB] = x WB^T + bB: k_in = 64, n_out = 32 NOB in {64, 128}
+template <int NOB, int TERMS>
+__global__ __launch_bounds__(K16_THREADS, 2) void lin_fwd16_kernel(LinParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem16[];
+  constexpr int K = 64, KF = 4, NO = 32 * NOB, NFO = 2 * NOB;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int t = lane & 15;
+  const B3Image Wim = w16_image(smem16, NO, K);
+  float* bs = reinterpret_cast<float*>(smem16 + w16_image_bytes(NO, K));
+  load_weight_lds_b3(Wim, 0, p.WA, p.ldWA, p.nA, K, p.nA, K, tid, K16_THREADS);
+  load_vec_lds(bs, p.bA, p.nA, p.nA, tid, K16_THREADS);
+  if (p.nB > 0) {
+    load_weight_lds_b3(Wim, p.nA, p.WB, p.ldWB, p.nB, K, NO - p.nA, K, tid, K16_THREADS);
+    load_vec_lds(bs + p.nA, p.bB, p.nB, NO - p.nA, tid, K16_THREADS);
+  }
+  __syncthreads();
+  const int64_t tiles_per_b = (p.rows + NLAM_T16 - 1) / NLAM_T16;
+  const int64_t ntiles = tiles_per_b * p.B;
+  for (int64_t tt = (int64_t)blockIdx.x * K16_NW + wave; tt < ntiles;
+       tt += (int64_t)gridDim.x * K16_NW) {
+    const int64_t b = tt / tiles_per_b;
+    const int64_t r0 = (tt - b * tiles_per_b) * NLAM_T16;
+    const int nrows = (int)((p.rows - r0) < NLAM_T16 ? (p.rows - r0) : NLAM_T16);
+    const bool valid = t < nrows;
+    const int64_t row = r0 + (valid ? t : nrows - 1);
+    f32x4 x[KF], y[NFO];
+    load_row16<KF>(x, p.x.ptr + b * p.x.bstride + row * p.x.ld, lane);
+    vec_to_acc16<NFO>(y, bs, lane);
+    gemm_acc16<NFO, 2, TERMS>(y, Wim, 0, 0, x, lane);
+    if (valid) store_row16<NFO>(p.out + b * p.out_bstride + (r0 + t) * p.out_ld, y, lane);
+  }
+}
+
+template <int NOB>
+static int launch_lin_fwd16(const LinParams& p, hipStream_t s) {
+  constexpr int K = 64, NO = 32 * NOB;
+  const size_t lds = w16_image_bytes(NO, K) + NO * sizeof(float);
+  auto kern = lin_fwd16_kernel<NOB, 3>;
+  NLAM_BIG_LDS(kern, __func__);
+  const int64_t ntiles = ((p.rows + NLAM_T16 - 1) / NLAM_T16) * p.B;
+  int64_t g = (ntiles + K16_NW - 1) / K16_NW;
+  if (g > 512) g = 512;
+  kern<<<(unsigned)g, K16_THREADS, lds, s>>>(p);
+  NLAM_CHECK_LAUNCH("lin_fwd16_kernel");
+  return 0;
+}
+
+int nlam_k16_lin_fwd(const LinParams& p, hipStream_t s) {
+  if (!nlam_k16_on(K16_LIN_FWD) || !nlam_mfma_b3()) return -1;
+  if (p.x.width != 64 || !(p.vec_mask & 1) || !(p.vec_mask & 8)) return -1;
+  const int n_out = p.nA + p.nB;
+  if (n_out == 64) return launch_lin_fwd16<2>(p, s);
+  if (n_out == 128) return launch_lin_fwd16<4>(p, s);
+  return -1;
+}

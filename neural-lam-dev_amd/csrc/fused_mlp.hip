@@ -180,6 +180,10 @@ extern "C" int nlam_mlp_fwd(
   if (res && view_vec_ok(res, res_bstride, res_ld, n_out)) p.vec_mask |= 4;
   if (view_vec_ok(out, out_bstride, out_ld, n_out)) p.vec_mask |= 8;
   hipStream_t s = (hipStream_t)stream;
+  if (hid == 64) {   // 16-row form (fused16_mlp.hip) where it applies
+    const int r16 = nlam_k16_mlp_fwd(p, s);
+    if (r16 >= 0) return r16;
+  }
   const bool ln = gamma != nullptr;
   const int noutb = (n_out + 31) / 32;
   if (hid == 64 && nlam_mfma_b3()) {
@@ -366,6 +370,10 @@ extern "C" int nlam_lin_fwd(const float* x, int64_t x_bstride, int64_t x_ld, int
     return nlam_fs_lin_fwd_256(x, x_bstride, x_ld, k_in, WA, ldWA, bA, nA, out, out_bstride, out_ld,
                                B, rows, out_bf16, stream);
   NLAM_REQUIRE(!out_bf16, "nlam_lin_fwd: bf16 output rows need 16-byte aligned rows, pitch %% 8 == 0");
+  {
+    const int r16 = nlam_k16_lin_fwd(p, s);
+    if (r16 >= 0) return r16;
+  }
   if (nlam_mfma_b3() && k_in == 64 && (p.vec_mask & 1) && (p.vec_mask & 8)) {
     if ((p.nA + p.nB) == 64) return launch_lin_fwd_b3<2, 2>(p, s);
     if ((p.nA + p.nB) == 128) return launch_lin_fwd_b3<4, 2>(p, s);

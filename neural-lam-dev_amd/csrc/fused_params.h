@@ -109,5 +109,5 @@ int nlam_k16_edge_bwd(const EdgeBwdParams& q, int has_egemm, hipStream_t s);
 enum { K16_MLP_BWD = 1, K16_LIN_BWD = 2, K16_OUTER_BWD = 4, K16_EDGE_BWD = 8, K16_MLP_FWD = 16,
        K16_LIN_FWD = 32, K16_EDGE_FWD = 64, K16_EDGE_BWD_UPD = 128 };
 // default: the families whose 16-row form is the faster one on MI355X (profiles/r03_*)
-#define K16_DEFAULT (K16_MLP_BWD | K16_LIN_BWD | K16_OUTER_BWD | K16_EDGE_BWD)
+#define K16_DEFAULT (K16_MLP_BWD | K16_LIN_BWD | K16_OUTER_BWD | K16_EDGE_BWD | K16_MLP_FWD | K16_LIN_FWD)
 bool nlam_k16_on(int family);

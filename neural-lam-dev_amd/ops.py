@@ -639,11 +639,6 @@ def fused_edge_bwd(g, e, has_egemm, ps, pr, W1e, W2, b2, gamma, g_agg, g_eout, g
     dev = W2.device
     slab = torch.empty(nslabs * stride, dtype=torch.float32, device=dev)
     units = 6 if has_egemm else 3
-    # the 16-row kernel leaves dW1e = gh^T e to a streaming pass over gh_out and e (both in the
-    # original edge order: linear reads) -- see csrc/fused16_edge.hip
-    defer_dw1e = bool(has_egemm and lib.nlam_edge_bwd_defers_dw1e(d))
-    if defer_dw1e:
-        units = 5
     _launch(
         "nlam_edge_bwd", lib.nlam_edge_bwd,
         (g.tiles.data_ptr(), g.ntiles, g.csr_rowptr.data_ptr(), g.csr_eid.data_ptr(),
@@ -666,8 +661,6 @@ def fused_edge_bwd(g, e, has_egemm, ps, pr, W1e, W2, b2, gamma, g_agg, g_eout, g
     dd = d * d
     segs = [(dd, d, d, d, dW2), (2 * dd, 1, d, d, db2), (2 * dd + d, 1, d, d, dgamma),
             (2 * dd + 2 * d, 1, d, d, dbeta)]
-    if has_egemm and not defer_dw1e:
+    if has_egemm:
         segs.append((0, d, d, d, dW1e))
     reduce_segments(slab, nslabs, stride, segs)
-    if defer_dw1e:
-        fused_outer_bwd(gh_out, e, None, None, dW1e, None)
