@@ -187,10 +187,9 @@ __device__ __forceinline__ void recv_gather(f32x4 (&c)[4], f32x4 (&g)[4], RecvRo
 }
 
 // ================================================================== forward
-// (without the edge GEMM the kernel fits 128 registers and 54 KB of LDS: two workgroups per CU,
-// four waves per SIMD)
+// (128 registers and <= 73 KB of LDS: two workgroups per CU, four waves per SIMD)
 template <bool HAS_EGEMM, int TERMS>
-__global__ __launch_bounds__(K16_THREADS, HAS_EGEMM ? 2 : 4) void edge_fwd16_kernel(EdgeFwdParams p) {
+__global__ __launch_bounds__(K16_THREADS, 4) void edge_fwd16_kernel(EdgeFwdParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem16[];
   constexpr int D = 64, NF = 4, LDT = D + 4;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -335,7 +334,7 @@ static int launch_edge_fwd16(const EdgeFwdParams& p, hipStream_t s) {
   auto kern = edge_fwd16_kernel<HAS_EGEMM, 3>;
   NLAM_BIG_LDS(kern, __func__);
   int64_t g = (p.ntiles * p.B + K16_NW - 1) / K16_NW;
-  const int64_t cap = HAS_EGEMM ? 256 : 512;
+  const int64_t cap = 512;   // two workgroups per CU (<= 128 registers, <= 73 KB of LDS)
   if (g > cap) g = cap;
   if (g > 8) g &= ~(int64_t)7;      // multiple of 8: XCD-chunked tasks (k16_tasks)
   kern<<<(unsigned)g, K16_THREADS, lds, s>>>(p);
@@ -380,7 +379,10 @@ extern "C" int nlam_debug_k16_stamps(unsigned long long* out, int reset) {
 // Slab per workgroup: [dW1e (D x D) | dW2 (D x D) | db2 | dgamma | dbeta].
 //
 // ---- without edge update (g2m, m2g: e is the projected Pe): dW2 per wave ---------------------
-template <int TERMS, bool STAMP = false>
+// ABL (diagnostic, NLAM_ABL16): 1 = no global row traffic (rows synthesised in registers, result
+// stores dropped), 2 = no matrix / LayerNorm / column-sum arithmetic (rows still move): which floor
+// the kernel sits on.  Results are wrong in both; only the time is read.
+template <int TERMS, bool STAMP = false, int ABL = 0>
 __global__ __launch_bounds__(K16_THREADS, 2) void edge_bwd16_kernel(EdgeBwdParams q) {
   extern __shared__ __attribute__((aligned(16))) char smem16[];
   constexpr int D = 64, NF = 4, LDT = D + 4;
@@ -463,9 +465,15 @@ __global__ __launch_bounds__(K16_THREADS, 2) void edge_bwd16_kernel(EdgeBwdParam
         RecvRows prv, gav;
         zero16<NF>(c);
         zero16<NF>(g);
-        load_ps_rs(psv, psb, p.ps.ld, ix.snd, lane);
-        recv_issue(prv, prb, p.pr.ld, ra, nrecv < 8 ? nrecv : 8, lane);
-        recv_issue(gav, gab, q.g_agg.ld, ra, nrecv < 8 ? nrecv : 8, lane);
+        if constexpr (ABL == 1) {
+#pragma unroll
+          for (int k2 = 0; k2 < 4; ++k2) psv[k2] = f32x4{(float)ix.snd, 1.f, 2.f, (float)lane};
+          prv.v[0] = prv.v[1] = gav.v[0] = gav.v[1] = f32x4{(float)ra, 0.5f, 0.25f, (float)lane};
+        } else {
+          load_ps_rs(psv, psb, p.ps.ld, ix.snd, lane);
+          recv_issue(prv, prb, p.pr.ld, ra, nrecv < 8 ? nrecv : 8, lane);
+          recv_issue(gav, gab, q.g_agg.ld, ra, nrecv < 8 ? nrecv : 8, lane);
+        }
         rs_to_acc16(h, nx.E, HS, LDT, lane);                                       // Pe
         STAMP16(0)   // prefetched Pe rows landed + transposed
         __builtin_amdgcn_sched_barrier(0);
@@ -483,8 +491,13 @@ __global__ __launch_bounds__(K16_THREADS, 2) void edge_bwd16_kernel(EdgeBwdParam
         STAMP16(1)   // Ps / Pr / g_agg rows landed, h complete
         {   // the next half's Pe rows (second half of this tile, or the next tile's first half)
           const bool more = hf == 0 && ne > NLAM_T16;
-          issue_pre16<false>(nx, more ? i1.eid : n0.eid, more ? eb : p.e.ptr + (int64_t)bn * p.e.bstride,
-                             p.e.ld, nullptr, 0, false, lane);
+          if constexpr (ABL == 1) {
+#pragma unroll
+            for (int k2 = 0; k2 < 4; ++k2) nx.E[k2] = f32x4{(float)(more ? i1.eid : n0.eid), 1.f, 2.f, 3.f};
+          } else {
+            issue_pre16<false>(nx, more ? i1.eid : n0.eid, more ? eb : p.e.ptr + (int64_t)bn * p.e.bstride,
+                               p.e.ld, nullptr, 0, false, lane);
+          }
         }
       }
       STAMP16(2)   // next prefetch issued
@@ -508,7 +521,7 @@ __global__ __launch_bounds__(K16_THREADS, 2) void edge_bwd16_kernel(EdgeBwdParam
       {
         f32x4 z[NF];
         vec_to_acc16<NF>(z, b2s, lane);
-        gemm_frag16<NF, 2, TERMS>(z, W2im, 0, 0, fr, lane);
+        if constexpr (ABL != 2) gemm_frag16<NF, 2, TERMS>(z, W2im, 0, 0, fr, lane);
         __builtin_amdgcn_sched_barrier(0);
         STAMP16(3)   // silu, S planes, second GEMM
         // ---- incoming gradient of the messages: scale * g_agg[rec]
@@ -518,14 +531,19 @@ __global__ __launch_bounds__(K16_THREADS, 2) void edge_bwd16_kernel(EdgeBwdParam
           for (int fb = 0; fb < NF; ++fb) g[fb] *= sc;
         }
         mask16<NF>(g, valid);   // padded slots carry a zero gradient: every sum below ignores them
-        acc16_to_planes<NF, TERMS>(g, TB, 0, lane);             // dbeta summand
-        wave_sync();
-        colsum16<1, TERMS>(dbet, TB, 0, lane);
-        wave_sync();
-        ln16_bwd<NF, TERMS>(z, g, TB, gs, lane);                // g -> gz; g * xhat -> planes
-        wave_sync();
-        colsum16<1, TERMS>(dgam, TB, 0, lane);
-        wave_sync();
+        if constexpr (ABL != 2) {
+          acc16_to_planes<NF, TERMS>(g, TB, 0, lane);             // dbeta summand
+          wave_sync();
+          colsum16<1, TERMS>(dbet, TB, 0, lane);
+          wave_sync();
+          ln16_bwd<NF, TERMS>(z, g, TB, gs, lane);                // g -> gz; g * xhat -> planes
+          wave_sync();
+          colsum16<1, TERMS>(dgam, TB, 0, lane);
+          wave_sync();
+        } else {
+#pragma unroll
+          for (int fb = 0; fb < NF; ++fb) g[fb] += z[fb];
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
       STAMP16(4)   // g assembled, dbeta, LayerNorm backward, dgamma
@@ -533,14 +551,20 @@ __global__ __launch_bounds__(K16_THREADS, 2) void edge_bwd16_kernel(EdgeBwdParam
       make_frag16<2, TERMS>(fr, g);
       frag16_to_planes<2, TERMS>(fr, TB, 0, lane);
       wave_sync();
-      colsum16<1, TERMS>(db2, TB, 0, lane);
-      outer_accum16<2, 2, TERMS>(dW2, TB, 0, TA, 0, lane);
+      if constexpr (ABL != 2) {
+        colsum16<1, TERMS>(db2, TB, 0, lane);
+        outer_accum16<2, 2, TERMS>(dW2, TB, 0, TA, 0, lane);
+      }
       __builtin_amdgcn_sched_barrier(0);
       STAMP16(5)   // GZ planes, db2, dW2 outer product
       // ---- gh = (W2^T gz) * silu'(h)
       f32x4 gh[NF];
       zero16<NF>(gh);
-      gemm_frag16_wt<NF, 2, TERMS>(gh, W2im, 0, 0, fr, lane);
+      if constexpr (ABL != 2) gemm_frag16_wt<NF, 2, TERMS>(gh, W2im, 0, 0, fr, lane);
+      else {
+#pragma unroll
+        for (int fb = 0; fb < NF; ++fb) gh[fb] = g[fb];
+      }
 #pragma unroll
       for (int fb = 0; fb < NF; ++fb)
         gh[fb] *= *reinterpret_cast<const f32x4*>(HS + t * LDT + 16 * fb + 4 * (lane >> 4));
@@ -549,9 +573,11 @@ __global__ __launch_bounds__(K16_THREADS, 2) void edge_bwd16_kernel(EdgeBwdParam
       wave_sync();
       acc16_to_tile<NF>(gh, HS, LDT, lane);
       wave_sync();
-      tile_store_rs(HS, LDT, q.gh_out + (int64_t)b * q.gh_bstride, D, ix.eid, nh, lane);
+      if constexpr (ABL != 1)
+        tile_store_rs(HS, LDT, q.gh_out + (int64_t)b * q.gh_bstride, D, ix.eid, nh, lane);
       half_segment_sums(HS, LDT, nh, ends, ix.rcv, lane, carry, [&](int r, float acc) {
-        gb[(int64_t)r * q.gpr_ld + lane] = acc;
+        if constexpr (ABL != 1) gb[(int64_t)r * q.gpr_ld + lane] = acc;
+        else asm volatile("" ::"v"(acc));
       });
       wave_sync();
       STAMP16(7)   // gh tile, gh_out stores, receiver-side sums
@@ -884,7 +910,10 @@ static int launch_edge_bwd16(const EdgeBwdParams& q, hipStream_t s) {
   if (fold > lds) lds = fold;
   NLAM_REQUIRE(lds <= 160 * 1024, "edge_bwd16: LDS footprint %zu B exceeds 160 KiB", lds);
   static const bool stamp = getenv("NLAM_STAMP16") != nullptr;
+  static const int abl = getenv("NLAM_ABL16") ? atoi(getenv("NLAM_ABL16")) : 0;
   auto kern = stamp ? edge_bwd16_kernel<3, true> : edge_bwd16_kernel<3, false>;
+  if (abl == 1) kern = edge_bwd16_kernel<3, false, 1>;
+  if (abl == 2) kern = edge_bwd16_kernel<3, false, 2>;
   NLAM_BIG_LDS(kern, __func__);
   // one slab per workgroup: the grid is what the host side sized the slabs for
   kern<<<(unsigned)nlam_bwd_grid(q.f.ntiles * q.f.B), K16_THREADS, lds, s>>>(q);
