@@ -59,6 +59,36 @@ def roofline_entry(name, st, mfma_mode, traffic=None):
     return ent
 
 
+def site_traffic(name, args):
+    tpath = os.path.join(ROOT, "profiles", "traffic_sites.json")
+    if not os.path.exists(tpath):
+        return None
+    try:
+        table = json.load(open(tpath))
+    except ValueError:
+        return None
+    ent = table.get(f"{args.model}-{args.hidden_dim}", {}).get(name)
+    return ent.get("hbm_bytes_per_launch") if ent else None
+
+
+def layer_roofline(stats, nprof, args, info, B, model):
+    """a fused InteractionNet layer fwd + bwd moves 20 d (N + M) bytes (+ indices)
+    per sample algorithmically; the m2m processor layers of GraphLAM are P such layers on the
+    same graph.  Sum of every kernel launched at that call site / P layers vs that figure."""
+    site = "m2m"
+    ms = sum(v["ms"] for k, v in stats.items() if k.endswith("@" + site)) / nprof
+    if ms <= 0 or args.model != "graph_lam":
+        return None
+    N, M, d, P = info["num_mesh"][0], sum(info["m2m_edges"]), args.hidden_dim, args.processor_layers
+    nbytes = B * (20.0 * d * (N + M) + 2.0 * (4 * M + 4 * N + 4))
+    us = ms * 1e3 / P
+    return {"site": site, "layers": P, "us_per_layer_fwd_bwd": us, "algorithmic_bytes_per_layer": nbytes,
+            "hbm_floor_us": nbytes / (HBM_PEAK_GBS * 1e9) * 1e6,
+            "frac_hbm": nbytes / (HBM_PEAK_GBS * 1e9) / (us * 1e-6),
+            "launches_per_layer": sum(v["calls"] for k, v in stats.items()
+                                      if k.endswith("@" + site)) / nprof / P}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -69,6 +99,8 @@ def parse():
     ap.add_argument("--hidden-dim", type=int, default=64)
     ap.add_argument("--processor-layers", type=int, default=4)
     ap.add_argument("--model", default="graph_lam", choices=["graph_lam", "hi_lam", "hi_lam_parallel"])
+    ap.add_argument("--windows", type=int, default=5,
+                    help="timed windows of --steps steps each; the median one is reported")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="skip the per-kernel HIP-event pass (roofline = null)")
@@ -329,20 +361,28 @@ def main():
 
     for _ in range(args.warmup):
         timed_step()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = timed_step()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # `--windows` timed windows of EXACTLY `--steps` steps each, every one bracketed by barrier +
+    # synchronize on both sides and reduced with MAX over ranks; the MEDIAN window is the
+    # reported one (ms_per_step, value), the others give the spread (a 20-step window of a 3 ms
+    # step is 60 ms: one window says nothing about run-to-run variation)
+    window_s = []
+    for _ in range(max(1, args.windows)):
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = timed_step()
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        w = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([w], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            w = float(t.item())
+        window_s.append(w)
+    elapsed = sorted(window_s)[len(window_s) // 2]
     loss_val = float(loss)
 
     # per-kernel HIP-event pass (same steps, events bracket every C-ABI launch on the
@@ -350,6 +390,7 @@ def main():
     roofline = None
     kernels = None
     scatter = None
+    layer = None
     from neural_lam_amd._lib import lib as _nlam_lib
     mfma_mode = MFMA_MODES[int(_nlam_lib.nlam_mfma_mode())]
     nprof = max(1, min(3, args.steps))
@@ -362,6 +403,10 @@ def main():
         ops.PROFILER = ops.KernelProfiler()
         for _ in range(nprof):
             step()
+        dump = os.environ.get("NLAM_BENCH_DUMP_ORDER")
+        if dump:   # launch order of ONE step, for tools/site_stats.py (rocprof -> call sites)
+            seq = [n for (n, _s, _e, _f, _b) in ops.PROFILER.pending]
+            json.dump(seq[: len(seq) // nprof], open(dump, "w"))
         stats = ops.PROFILER.collect()
         ops.PROFILER = None
         kernels = {
@@ -370,20 +415,15 @@ def main():
             for k, v in sorted(stats.items(), key=lambda kv: -kv[1]["ms"])
         }
         name, st = max(stats.items(), key=lambda kv: kv[1]["ms"])
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            # PMC bytes per launch of the HIP kernel behind this entry point / call site
-            base, _, site = name.partition("@")
-            flag = "true" if site == "m2m" else "false"
-            prefix = {"nlam_edge_bwd": "edge_bwd_kernel<64, %s" % flag,
-                      "nlam_edge_fwd": "edge_fwd_kernel<64, %s" % flag,
-                      "nlam_segment_sum": "segment_sum_"}.get(base)
-            table = json.load(open(tpath))
-            ent = next((v for k, v in sorted(table.items()) if prefix and k.startswith(prefix)),
-                       None)
-            traffic = ent["hbm_bytes_per_launch"] if ent else None
+        # PMC bytes per launch of exactly this entry point at exactly this call site
+        # (profiles/traffic_sites.json, written by tools/site_stats.py from rocprofv3 --pmc passes
+        # of this script); None when that site was not profiled -- never another site's number
+        traffic = site_traffic(name, args)
         roofline = roofline_entry(name, st, mfma_mode, traffic)
+        roofline["note"] = ("per-kernel times come from an EAGER pass with HIP events around every "
+                            "launch; `value` / ms_per_step from the timed windows (HIP-graph replay "
+                            "at N = 1), so the kernel times sum to slightly more than a step")
+        layer = layer_roofline(stats, nprof, args, info, B, model)
         # the scatter-add the north star names: m2m aggregate (segment-sum) launches
         agg = stats.get("nlam_segment_sum@m2m")
         if agg and agg["ms"] > 0:
@@ -435,7 +475,7 @@ def main():
                    "--warmup", str(args.warmup), "--batch", str(args.batch),
                    "--ar-steps", str(args.ar_steps), "--hidden-dim", str(args.hidden_dim),
                    "--processor-layers", str(args.processor_layers), "--model", args.model,
-                   "--no-cpu-baseline", "--no-kernel-timing", "--no-fp32-compare"]
+                   "--windows", "3", "--no-cpu-baseline", "--no-kernel-timing", "--no-fp32-compare"]
             if args.no_graph:
                 cmd.append("--no-graph")
             try:
@@ -472,6 +512,10 @@ def main():
                 "parallelism": f"dp{world}",
             },
             "steps_per_s": 1e3 / ms, "loss": loss_val,
+            "windows": {"n": len(window_s), "steps_each": args.steps,
+                        "ms_per_step": [w / args.steps * 1e3 for w in window_s],
+                        "median_ms_per_step": ms,
+                        "min_ms_per_step": min(window_s) / args.steps * 1e3},
             # processor updates + g2m (mesh receivers) + m2g (grid receivers)
             # [+ Hi-LAM init/read-out sweeps] per AR step
             "all_receiver_updates_per_s": world * B * T * all_receiver_updates(args, info)
@@ -480,7 +524,8 @@ def main():
             "rccl_ranks": dist.get_world_size() if world > 1 else 1,
             "backend": (dist.get_backend() if world > 1 else None),
             "grad_allreduce": reducer.describe(),
-            "roofline": roofline, "scatter_add_roofline": scatter, "cpu_baseline": cpu,
+            "roofline": roofline, "layer_roofline": layer, "scatter_add_roofline": scatter,
+            "cpu_baseline": cpu,
             "kernels": kernels,
         }
         if cpu:

@@ -11,6 +11,27 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def load_fixture(path):
+    """torch.load of a golden fixture.  The *_bf16 fixtures (reference run under CPU bf16
+    autocast) hold outputs only and name the fixture whose weights and inputs they used."""
+    import torch
+
+    fx = torch.load(path, weights_only=False)
+    if fx.get("base"):
+        base = torch.load(os.path.join(GOLDEN, fx["base"] + ".pt"), weights_only=False)
+        for k, v in base.items():
+            fx.setdefault(k, v)
+    return fx
+
+
+def fixture_files(pattern, autocast=False):
+    """Golden files matching `pattern`: the fp32 ones, or the bf16-autocast ones."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(GOLDEN, pattern)))
+    return [f for f in files if f.endswith("_bf16.pt") == autocast]
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 

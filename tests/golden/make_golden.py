@@ -81,14 +81,30 @@ OP_CASES = {
         dict(update_edges=False, aggr="mean", edge_chunk_sizes=[100, 200],
              aggr_chunk_sizes=[15, 25]),
     ),
+    # round 3: the same operator run by the reference under torch.autocast("cpu", bfloat16)
+    # (what Lightning's precision="bf16-mixed" wraps the step in, train_model.py:229-231 of the
+    # reference's CLI): the pin for WHERE bf16 rounding happens (Linear in/out bf16, LayerNorm
+    # and residuals fp32), compared with the bf16 kernels at a bar below the fp32 fixtures'.
+    # Same seeds, weights and inputs as the case without the suffix: only outputs are stored.
+    "op_d256_sum_upd_bf16": None,
+    "op_d128_sum_upd_bf16": None,
 }
 
 
+def base_of(name):
+    return name[:-5] if name.endswith("_bf16") else name
+
+
+def autocast_of(name):
+    """Cases named *_bf16 run reference and oracle forward passes under CPU bf16 autocast."""
+    return torch.autocast("cpu", dtype=torch.bfloat16, enabled=name.endswith("_bf16"))
+
+
 def make_op_case(ns, name):
-    d, B, n_send, n_rec, M, shared, kw = OP_CASES[name]
-    gen = torch.Generator().manual_seed(seed_of(name))
+    d, B, n_send, n_rec, M, shared, kw = OP_CASES[base_of(name)]
+    gen = torch.Generator().manual_seed(seed_of(base_of(name)))
     ei = random_edges(gen, n_send, n_rec, M, shared)
-    if name == "op_d64_mean_noupd":
+    if base_of(name) == "op_d64_mean_noupd":
         # leave some receivers without in-edges (mean clamps the count to 1)
         rec = ei[1] - 3
         rec[(rec % 7 == 3) & (torch.arange(M) > 2)] = 5
@@ -111,9 +127,10 @@ def make_op_case(ns, name):
         s = send.clone().requires_grad_(True)
         r = s if shared else rec.clone().requires_grad_(True)
         e = edge.clone().requires_grad_(True)
-        out = fn_forward(s, r, e)
+        with autocast_of(name):
+            out = fn_forward(s, r, e)
         if kw.get("update_edges", True):
-            o_rec, o_edge = out
+            o_rec, o_edge = (t.float() for t in out)
             loss = (o_rec * cot_rec).sum() + (o_edge * cot_edge).sum()
         else:
             o_rec, o_edge = out, None
@@ -139,6 +156,7 @@ def make_op_case(ns, name):
     n_in = 2 if shared else 3
     fix = {
         "kind": "operator", "name": name, "d": d, "kwargs": kw, "shared": shared,
+        "autocast": "bfloat16" if name.endswith("_bf16") else None,
         "edge_index": ei, "state_dict": sd,
         "send": send, "rec": rec, "edge": edge, "cot_rec": cot_rec, "cot_edge": cot_edge,
         "out_rec": r_rec.detach(), "out_edge": None if r_edge is None else r_edge.detach(),
@@ -146,6 +164,10 @@ def make_op_case(ns, name):
         "grad_rec": None if shared else r_g[2],
         "grad_params": {k: g for (k, _), g in zip(net.named_parameters(), r_g[n_in:])},
     }
+    if base_of(name) != name:
+        for k in ("edge_index", "state_dict", "send", "rec", "edge", "cot_rec", "cot_edge"):
+            del fix[k]
+        fix["base"] = base_of(name)
     torch.save(fix, os.path.join(HERE, f"{name}.pt"))
     print(f"{name}: ok  (oracle vs reference fwd {relerr(o_rec, r_rec):.1e})")
 
@@ -209,19 +231,23 @@ MODEL_CASES = {
     "model_graphlam_d64_T4": ("graph_lam", 30, 28, None, False, 64, 2, 1, 4, "wmse", "sum"),
     "model_graphlam_hl2": ("graph_lam", 30, 28, None, False, 16, 2, 2, 2, "mse", "sum",
                            dict(hidden_layers=2)),
+    # round 3: 3-level Hi-LAM, hidden 128, whole training step under CPU bf16 autocast (weights
+    # and inputs of the case without the suffix; only outputs are stored)
+    "model_hilam_3level_d128_bf16": None,
 }
 
 
 def make_model_case(ns, name):
-    model, nx, ny, nml, hier, hd, pl, B, T, loss, aggr = MODEL_CASES[name][:11]
-    extra = MODEL_CASES[name][11] if len(MODEL_CASES[name]) > 11 else {}
+    case = MODEL_CASES[base_of(name)]
+    model, nx, ny, nml, hier, hd, pl, B, T, loss, aggr = case[:11]
+    extra = case[11] if len(case) > 11 else {}
     hl = extra.get("hidden_layers", 1)
-    gen = torch.Generator().manual_seed(seed_of(name))
+    gen = torch.Generator().manual_seed(seed_of(base_of(name)))
     with tempfile.TemporaryDirectory() as tmp:
         gdir = os.path.join(tmp, "graph", "g")
         info = graphgen.create_graph(gdir, graphgen.make_xy(nx, ny, 5000.0), nml, hier)
         n_grid = info["num_grid"]
-        ds = FakeDatastore(tmp, n_grid, gen, unit_stats=(name == "model_graphlam_1level"))
+        ds = FakeDatastore(tmp, n_grid, gen, unit_stats=(base_of(name) == "model_graphlam_1level"))
         args = types.SimpleNamespace(
             graph="g", hidden_dim=hd, hidden_layers=hl, processor_layers=pl, mesh_aggr=aggr,
             output_std=False, loss=loss, lr=1e-3, restore_opt=False, n_example_pred=0,
@@ -242,8 +268,9 @@ def make_model_case(ns, name):
     forcing = torch.randn(B, T, n_grid, 6, generator=gen)
 
     batch = (init, target, forcing, None)
-    pred, tgt, pred_std, _ = net.common_step(batch)
-    loss_val = net.training_step(batch)
+    with autocast_of(name):
+        pred, tgt, pred_std, _ = net.common_step(batch)
+        loss_val = net.training_step(batch)
     params = dict(net.named_parameters())
     grads = torch.autograd.grad(loss_val, list(params.values()))
 
@@ -256,15 +283,24 @@ def make_model_case(ns, name):
     cfg = {"model": model, "hidden_layers": hl, "processor_layers": pl, "mesh_aggr": aggr,
            "loss": loss, "hidden_dim": hd}
     osd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
-    o_loss, o_pred = orc.training_loss(osd, graph, cfg, data, init, target, forcing)
+    with autocast_of(name):
+        o_loss, o_pred = orc.training_loss(osd, graph, cfg, data, init, target, forcing)
     o_grads = torch.autograd.grad(o_loss, [osd[k] for k in params])
     assert relerr(o_pred, pred) < 1e-5, relerr(o_pred, pred)
     assert abs(float(o_loss) - float(loss_val)) < 1e-5 * abs(float(loss_val))
     worst = max(relerr(a, b) for a, b in zip(o_grads, grads))
-    assert worst < 2e-4, worst
+    if os.environ.get("GOLDEN_VERBOSE"):
+        for k, a, b in zip(params, o_grads, grads):
+            if relerr(a, b) > 1e-4:
+                print(f"  {k}: {relerr(a, b):.2e}")
+    # under autocast the oracle's functional restatement reaches the same forward values, but
+    # its bf16 backward runs through differently shaped matmuls (e.g. F.linear on sliced
+    # weights): a cross-check at bf16 noise level only; the stored gradients are the reference's
+    assert worst < (5e-2 if name.endswith("_bf16") else 2e-4), worst
 
     fix = {
         "kind": "model", "name": name, "cfg": cfg,
+        "autocast": "bfloat16" if name.endswith("_bf16") else None,
         "graph": {"nx": nx, "ny": ny, "spacing": 5000.0, "n_max_levels": nml,
                   "hierarchical": hier, "edge_index_checksums": ei_sums},
         "data": {k: v.detach().clone() for k, v in data.items()},
@@ -272,6 +308,10 @@ def make_model_case(ns, name):
         "prediction": pred.detach(), "loss": float(loss_val),
         "grad_params": {k: g for k, g in zip(params, grads)},
     }
+    if base_of(name) != name:
+        for k in ("graph", "data", "state_dict", "init_states", "target_states", "forcing"):
+            del fix[k]
+        fix["base"] = base_of(name)
     torch.save(fix, os.path.join(HERE, f"{name}.pt"))
     print(f"{name}: ok  loss {float(loss_val):.6f}  (oracle grads worst rel {worst:.1e}, "
           f"{sum(p.numel() for p in params.values())} params)")

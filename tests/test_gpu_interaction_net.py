@@ -8,10 +8,10 @@ import os
 import pytest
 import torch
 
-from conftest import GOLDEN
+from conftest import GOLDEN, fixture_files
 
 pytestmark = pytest.mark.gpu
-OP_FILES = sorted(glob.glob(os.path.join(GOLDEN, "op_*.pt")))
+OP_FILES = fixture_files("op_*.pt")   # the bf16-autocast ones: tests/test_gpu_mfma_modes.py
 
 
 def rel(a, b):

@@ -14,10 +14,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # fp32 / bf16x3: an order of magnitude inside the 1e-4 / 2e-3 bars, at hidden 64 AND 128 (the
 # d = 128 golden runs the wide kernels in bf16x3 and the generic exact-fp32 kernels in fp32 mode).
-# bf16: plain bf16 products, fp32 accumulate -- the bf16-mixed tolerance of SURVEY.md 8c (2e-2);
-# only the d = 128 kernels change arithmetic in that mode.
+# bf16: plain bf16 products, fp32 accumulate; only the d = 128 kernels change arithmetic in that
+# mode.  Bars 1e-2 / 6e-2 (measured 2e-3 / 3e-2; SURVEY.md 8c allows 2e-2 on the forward).
 @pytest.mark.parametrize("mode,pred_bar,grad_bar",
-                         [("fp32", 2e-6, 1e-5), ("bf16x3", 2e-5, 2e-4), ("bf16", 2e-2, 2e-1)])
+                         [("fp32", 2e-6, 1e-5), ("bf16x3", 2e-5, 2e-4), ("bf16", 1e-2, 6e-2)])
 def test_model_parity_in_mode(mode, pred_bar, grad_bar):
     env = dict(os.environ, NLAM_MFMA=mode)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "parity_margin.py")],
@@ -27,15 +27,15 @@ def test_model_parity_in_mode(mode, pred_bar, grad_bar):
     rows = re.findall(r"pred (\S+)\s+loss (\S+)\s+worst grad (\S+)", out.stdout)
     assert len(rows) >= 3, out.stdout
     for pred, loss, grad in rows:
-        loss_bar = 1e-5 if mode != "bf16" else 2e-2
+        loss_bar = 1e-5 if mode != "bf16" else 1e-2
         assert float(pred) < pred_bar and float(loss) < loss_bar and float(grad) < grad_bar, out.stdout
 
 
-@pytest.mark.parametrize("mode,fwd_bar,grad_bar", [("bf16x3", 1e-4, 1e-3), ("bf16", 2e-2, 2e-1)])
+@pytest.mark.parametrize("mode,fwd_bar,grad_bar", [("bf16x3", 1e-4, 1e-3), ("bf16", 1e-2, 5e-2)])
 def test_operator_parity_wide_widths_in_mode(mode, fwd_bar, grad_bar):
     """InteractionNet at hidden 128 (wide kernels) and 256 (generic kernels; BASELINE
-    configs[4] width) against the reference goldens: fp32 bars in the default mode, the
-    bf16-mixed tolerance (2e-2) with plain bf16 products (NLAM_MFMA=bf16)."""
+    configs[4] width) against the reference's fp32 goldens: fp32 bars in the default mode;
+    forward 1e-2 / gradients 5e-2 with plain bf16 products (NLAM_MFMA=bf16; measured 4e-3 / 6e-3)."""
     env = dict(os.environ, NLAM_MFMA=mode)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "parity_op.py")],
                          env=env, capture_output=True, text=True, timeout=600)
@@ -51,10 +51,15 @@ def test_operator_parity_wide_widths_in_mode(mode, fwd_bar, grad_bar):
 def test_wide_cases_in_mode(mode, width):
     """Every operator / MLP case of test_gpu_wide.py against the CPU oracle at hidden 256 (the
     feature-split kernels of csrc/fused_fs.hip; bf16 arithmetic only) and at hidden 128 in bf16
-    arithmetic, bf16-mixed bars (forward 2e-2, gradients 2e-1 of max|ref|)."""
+    arithmetic; a GraphLAM, a 2-level and a 3-level / 2-processor-layer Hi-LAM training step
+    against the oracle; and the reference's own CPU bf16-autocast outputs (tests/golden/
+    op_d{128,256}_sum_upd_bf16.pt, model_hilam_3level_d128_bf16.pt).  Bars: forward 1e-2,
+    gradients 5e-2 of max|ref|."""
     env = dict(os.environ, NLAM_MFMA=mode, NLAM_WIDE_D=str(width))
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "parity_wide.py")],
                          env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-2500:])
     assert f"mfma mode: {mode} width: {width}" in out.stdout
     assert "all wide cases passed" in out.stdout
+    assert f"ok autocast golden op d{width}" in out.stdout
+    assert "levels=3 layers=2" in out.stdout

@@ -10,10 +10,10 @@ import tempfile
 import pytest
 import torch
 
-from conftest import GOLDEN
+from conftest import GOLDEN, fixture_files
 
 pytestmark = pytest.mark.gpu
-MODEL_FILES = sorted(glob.glob(os.path.join(GOLDEN, "model_*.pt")))
+MODEL_FILES = fixture_files("model_*.pt")   # the bf16-autocast one: tests/test_gpu_mfma_modes.py
 
 
 def rel(a, b):

@@ -7,7 +7,9 @@ arithmetic): forward 1e-4, gradients 1e-3 relative to max|ref|.
 
 The same cases run at hidden 256 on the feature-split kernels (csrc/fused_fs.hip) in bf16
 arithmetic -- NLAM_WIDE_D=256 NLAM_MFMA=bf16, in a process of its own (tools/parity_wide.py,
-driven by test_gpu_mfma_modes.py) -- with the bf16-mixed bars of SURVEY.md 8c (2e-2 / 2e-1)."""
+driven by test_gpu_mfma_modes.py) -- with bf16 bars: forward 1e-2, gradients 5e-2 of max|ref|
+(measured worst: 4e-3 forward, 2e-2 on a Hi-LAM parameter gradient; two CPU bf16-autocast runs of
+the reference that differ only in thread count are 1e-3 .. 1e-2 apart themselves)."""
 import os
 
 import pytest
@@ -17,7 +19,7 @@ pytestmark = pytest.mark.gpu
 
 D = int(os.environ.get("NLAM_WIDE_D", "128"))
 _BF16 = os.environ.get("NLAM_MFMA", "") == "bf16"
-FWD_BAR, GRAD_BAR = (2e-2, 2e-1) if _BF16 else (1e-4, 1e-3)
+FWD_BAR, GRAD_BAR = (1e-2, 5e-2) if _BF16 else (1e-4, 1e-3)
 
 
 def rel(a, b):

@@ -11,7 +11,7 @@ import torch
 
 import nlam_oracle as orc
 import neural_lam_amd.graphgen as graphgen
-from conftest import GOLDEN
+from conftest import GOLDEN, load_fixture
 
 OP_FILES = sorted(glob.glob(os.path.join(GOLDEN, "op_*.pt")))
 MODEL_FILES = sorted(glob.glob(os.path.join(GOLDEN, "model_*.pt")))
@@ -27,21 +27,44 @@ def checksum(t):
     return int(((t * w) % 1000003).sum() % 2147483647)
 
 
+def autocast_of(fx):
+    """The *_bf16 fixtures were made under CPU bf16 autocast (what bf16-mixed wraps the step in);
+    the oracle, run under the same autocast, must reproduce them (same torch calls)."""
+    return torch.autocast("cpu", dtype=torch.bfloat16, enabled=fx.get("autocast") == "bfloat16")
+
+
+def grad_bar(fx, k):
+    """2e-4; None (not comparable) for LayerNorm affine gradients of the autocast fixtures:
+    torch's CPU LayerNorm backward on bf16 input accumulates the gamma / beta gradients per
+    thread IN bf16, so the reference's own values depend on the thread count (operator fixture:
+    0 at the 4 threads make_golden.py ran with, 6e-3 at 8, 2.6e-2 at 1) and collapse once a few
+    thousand rows are summed (g2m_embedder.3.weight of the model fixture: 0.87 apart between 4
+    and 8 threads).  An artefact of that CPU kernel (GPU autocast runs layer_norm in fp32), so
+    these entries are pinned by the fp32 fixtures only."""
+    g = fx["grad_params"]
+    w = k[: k.rfind(".")] + ".weight"
+    if fx.get("autocast") and g[w].dim() == 1:
+        return None
+    # other bf16 gradients: torch's threaded bf16 GEMM reductions move them by ~1e-3 too
+    return 1e-2 if fx.get("autocast") else 2e-4
+
+
 def test_fixtures_present():
     assert len(OP_FILES) >= 5 and len(MODEL_FILES) >= 4
 
 
 @pytest.mark.parametrize("path", OP_FILES, ids=[os.path.basename(p)[:-3] for p in OP_FILES])
 def test_oracle_operator_vs_golden(path):
-    fx = torch.load(path, weights_only=False)
+    fx = load_fixture(path)
     kw, shared = fx["kwargs"], fx["shared"]
     sd = {f"net.{k}": v.clone().requires_grad_(True) for k, v in fx["state_dict"].items()}
     s = fx["send"].clone().requires_grad_(True)
     r = s if shared else fx["rec"].clone().requires_grad_(True)
     e = fx["edge"].clone().requires_grad_(True)
-    out = orc.interaction_net(sd, "net", fx["edge_index"], s, r, e, **kw)
+    with autocast_of(fx):
+        out = orc.interaction_net(sd, "net", fx["edge_index"], s, r, e, **kw)
     if kw.get("update_edges", True):
-        o_rec, o_edge = out
+        o_rec, o_edge = (t.float() for t in out)
         loss = (o_rec * fx["cot_rec"]).sum() + (o_edge * fx["cot_edge"]).sum()
         assert relerr(o_edge, fx["out_edge"]) < 1e-5
     else:
@@ -59,7 +82,7 @@ def test_oracle_operator_vs_golden(path):
         assert relerr(grads[2], fx["grad_rec"]) < 2e-4
         n_in = 3
     for k, g in zip(names, grads[n_in:]):
-        assert relerr(g, fx["grad_params"][k]) < 2e-4, k
+        assert grad_bar(fx, k) is None or relerr(g, fx["grad_params"][k]) < grad_bar(fx, k), k
 
 
 def build_graph(fx, tmp):
@@ -78,19 +101,20 @@ def build_graph(fx, tmp):
 
 @pytest.mark.parametrize("path", MODEL_FILES, ids=[os.path.basename(p)[:-3] for p in MODEL_FILES])
 def test_oracle_model_vs_golden(path):
-    fx = torch.load(path, weights_only=False)
+    fx = load_fixture(path)
     with tempfile.TemporaryDirectory() as tmp:
         _, graph = build_graph(fx, tmp)
     sd = {k: v.clone().requires_grad_(True) for k, v in fx["state_dict"].items()}
-    loss, pred = orc.training_loss(
-        sd, graph, fx["cfg"], fx["data"], fx["init_states"], fx["target_states"], fx["forcing"]
-    )
+    with autocast_of(fx):
+        loss, pred = orc.training_loss(
+            sd, graph, fx["cfg"], fx["data"], fx["init_states"], fx["target_states"], fx["forcing"]
+        )
     assert relerr(pred, fx["prediction"]) < 1e-5
     assert abs(float(loss) - fx["loss"]) < 1e-5 * abs(fx["loss"])
     names = list(fx["grad_params"])
     grads = torch.autograd.grad(loss, [sd[k] for k in names])
     for k, g in zip(names, grads):
-        assert relerr(g, fx["grad_params"][k]) < 2e-4, k
+        assert grad_bar(fx, k) is None or relerr(g, fx["grad_params"][k]) < grad_bar(fx, k), k
 
 
 def test_oracle_vs_live_reference():
