@@ -200,14 +200,70 @@ int nlam_outer_bwd(const float* g, int64_t g_bstride, int64_t g_ld, int ng,
                    const float* xb, int64_t xb_bstride, int64_t xb_ld, int xb_width,
                    const int32_t* x_index, float* slab, int64_t slab_stride,
                    int64_t B, int64_t rows, void* stream);
+/* ---- node side of a CHAIN of InteractionNets on shared nodes (hidden width 64) ----------
+ * Replaces, between two edge passes of consecutive layers of the reference's processor
+ * (models/graph_lam.py:51-57,88: pyg Sequential of m2m InteractionNets on the same mesh
+ * nodes), the per-node work of interaction_net.py:112-115 (aggregation MLP + residual of
+ * layer l-1) followed by the sender / receiver halves of interaction_net.py:121 (first
+ * edge-MLP Linear of layer l), and their autograd.  All row views: 16-byte aligned, 64
+ * columns (P / gP: 128).  1 = the process's arithmetic mode has these kernels (split-bf16). */
+int nlam_node_chain_supported(void);
+/* xout = x + LN(V2 silu(V1 [x | agg] + c1) + c2); P (may be NULL) = [xout WA^T + bA |
+ * xout WB^T + bB] with WA / WB (64 x 64) the NEXT layer's W1[:, d:2d] / W1[:, 2d:3d]. */
+int nlam_node_fwd(const float* x, int64_t x_bstride, int64_t x_ld,
+                  const float* agg, int64_t agg_bstride, int64_t agg_ld,
+                  const float* V1, int64_t ldV1, const float* c1,
+                  const float* V2, int64_t ldV2, const float* c2,
+                  const float* gamma, const float* beta,
+                  float* xout, int64_t xo_bstride, int64_t xo_ld,
+                  const float* WA, int64_t ldWA, const float* bA,
+                  const float* WB, int64_t ldWB, const float* bB,
+                  float* P, int64_t p_bstride, int64_t p_ld,
+                  int64_t B, int64_t rows, void* stream);
+/* Backward data pass.  Layer l: gP[:, :, 0:64] = sum over the node's out-edges (sender lists
+ * csc_colptr / csc_eid, nodes >= n_send have none) of gh (B, M, 64; the hidden gradient
+ * nlam_edge_bwd leaves in edge order); gP[:, :, 64:128] is read (nlam_edge_bwd's gpr);
+ * G = gP [WA; WB] + g_res.  With x == NULL: gx_out = G.  Otherwise the aggregation MLP of
+ * layer l-1 (x, agg, V1 .. gamma) is differentiated with output gradient G:
+ * gx_out = dL/dx (residual included), gagg_out = dL/dagg, ga_out (B, rows, 64 contiguous) =
+ * hidden gradient for nlam_node_outer, and per-workgroup slabs [dV2 64x64 | dc2 | dgamma |
+ * dbeta] (count nlam_node_bwd_grid(B, rows), pitch >= nlam_node_bwd_slab_stride()). */
+int64_t nlam_node_bwd_slab_stride(void);
+int64_t nlam_node_bwd_grid(int64_t B, int64_t rows);
+int nlam_node_bwd(const float* gh, int64_t gh_bstride,
+                  const int32_t* csc_colptr, const int32_t* csc_eid, int64_t n_send,
+                  float* gP, int64_t gp_bstride, int64_t gp_ld,
+                  const float* g_res, int64_t gr_bstride, int64_t gr_ld,
+                  const float* WA, int64_t ldWA, const float* WB, int64_t ldWB,
+                  const float* x, int64_t x_bstride, int64_t x_ld,
+                  const float* agg, int64_t agg_bstride, int64_t agg_ld,
+                  const float* V1, int64_t ldV1, const float* c1,
+                  const float* V2, int64_t ldV2, const float* c2, const float* gamma,
+                  float* gx_out, int64_t gx_bstride, int64_t gx_ld,
+                  float* gagg_out, int64_t gagg_bstride, int64_t gagg_ld,
+                  float* ga_out, float* slab, int64_t slab_stride,
+                  int64_t B, int64_t rows, void* stream);
+/* Weight-gradient pass of the same pair: slabs [dV1 64x128 | dc1 64 | dWp 128x64 | dbp 128]
+ * with dV1 = ga^T [xa | xb], dc1 = colsum ga (skipped when ga == NULL) and dWp = gP^T xl
+ * (rows 0..63 = dWA, 64..127 = dWB), dbp = colsum gP.  Slab count nlam_node_outer_grid(B, rows),
+ * pitch >= nlam_node_outer_slab_stride(). */
+int64_t nlam_node_outer_slab_stride(void);
+int64_t nlam_node_outer_grid(int64_t B, int64_t rows);
+int nlam_node_outer(const float* ga,
+                    const float* xa, int64_t xa_bstride, int64_t xa_ld,
+                    const float* xb, int64_t xb_bstride, int64_t xb_ld,
+                    const float* gP, int64_t gp_bstride, int64_t gp_ld,
+                    const float* xl, int64_t xl_bstride, int64_t xl_ld,
+                    float* slab, int64_t slab_stride, int64_t B, int64_t rows, void* stream);
+
 /* out[i] (+)= sum_s slab[s * stride + i], i < n (deterministic order). */
 int nlam_reduce_slabs(const float* slab, int64_t nslabs, int64_t stride, int64_t n,
                       float* out, int accumulate, void* stream);
 
-/* Sums up to 32 matrix segments of the per-workgroup slabs into (strided)
+/* Sums up to 64 matrix segments of the per-workgroup slabs into (strided)
  * destinations in ONE launch:  dst_k[r*dst_ld_k + c] = sum_s slab[s*stride +
  * src_off_k + r*src_ld_k + c], r < rows_k, c < cols_k.  Array arguments are HOST
- * arrays of length nseg (<= 32).  Fixed summation order (deterministic). */
+ * arrays of length nseg (<= 64).  Fixed summation order (deterministic). */
 int nlam_reduce_slabs_multi(const float* slab, int64_t nslabs, int64_t stride, int nseg,
                             const int64_t* src_off, const int32_t* rows,
                             const int32_t* cols, const int64_t* src_ld,
@@ -489,7 +545,8 @@ int nlam_mfma_probe(float* out, void* stream);
 /* Tuning hook: which hidden-64 kernel families run in their 16-row, two-waves-per-SIMD form
  * (csrc/fused16_*.hip) instead of the 32-row, one-wave-per-SIMD form.  Bit mask: 1 nlam_mlp_bwd,
  * 2 nlam_lin_bwd, 4 nlam_outer_bwd, 8 nlam_edge_bwd (no edge update), 16 nlam_mlp_fwd,
- * 32 nlam_lin_fwd, 64 nlam_edge_fwd, 128 nlam_edge_bwd (update_edges).  Default: the families
+ * 32 nlam_lin_fwd, 64 nlam_edge_fwd, 128 nlam_edge_bwd (update_edges), 256 the nlam_node_*
+ * chain kernels (off: nlam_node_chain_supported() returns 0).  Default: the families
  * whose 16-row form measured faster (or NLAM_K16 in the environment).  Same entry points, slab
  * layouts and results (to rounding) either way; used to time both forms in one process. */
 int nlam_set_k16(int mask);

@@ -44,6 +44,18 @@ SIGNATURES = {
     "nlam_outer_bwd_slab_stride": [_i32, _i32],
     "nlam_outer_bwd": [_p, _i64, _i64, _i32, _p, _i64, _i64, _i32, _p, _i64, _i64, _i32, _p, _p,
                        _i64, _i64, _i64, _p],
+    "nlam_node_chain_supported": [],
+    "nlam_node_fwd": [_p, _i64, _i64, _p, _i64, _i64, _p, _i64, _p, _p, _i64, _p, _p, _p,
+                      _p, _i64, _i64, _p, _i64, _p, _p, _i64, _p, _p, _i64, _i64, _i64, _i64, _p],
+    "nlam_node_bwd_slab_stride": [],
+    "nlam_node_bwd_grid": [_i64, _i64],
+    "nlam_node_bwd": [_p, _i64, _p, _p, _i64, _p, _i64, _i64, _p, _i64, _i64, _p, _i64, _p, _i64,
+                      _p, _i64, _i64, _p, _i64, _i64, _p, _i64, _p, _p, _i64, _p, _p,
+                      _p, _i64, _i64, _p, _i64, _i64, _p, _p, _i64, _i64, _i64, _p],
+    "nlam_node_outer_slab_stride": [],
+    "nlam_node_outer_grid": [_i64, _i64],
+    "nlam_node_outer": [_p, _p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64,
+                        _p, _i64, _i64, _i64, _p],
     "nlam_reduce_slabs": [_p, _i64, _i64, _i64, _p, _i32, _p],
     "nlam_reduce_slabs_multi": [_p, _i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p],
     "nlam_reduce_slabs_batch": [_i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
@@ -109,6 +121,10 @@ _RESTYPES = {
     "nlam_wmse_blocks": _i64,
     "nlam_mlp_bwd_slab_stride": _i64,
     "nlam_outer_bwd_slab_stride": _i64,
+    "nlam_node_bwd_slab_stride": _i64,
+    "nlam_node_bwd_grid": _i64,
+    "nlam_node_outer_slab_stride": _i64,
+    "nlam_node_outer_grid": _i64,
     "nlam_tail_bwd_slab_stride": _i64,
 }
 
@@ -117,7 +133,13 @@ class NlamError(RuntimeError):
     pass
 
 
+MFMA_MODE_NAMES = ("fp32", "bf16x3", "b3", "bf16")
+
+
 def _load():
+    mode = os.environ.get("NLAM_MFMA", "")
+    if mode and mode.lower() not in MFMA_MODE_NAMES:
+        raise NlamError(f"NLAM_MFMA={mode!r} is not one of fp32 | bf16x3 | bf16")
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "

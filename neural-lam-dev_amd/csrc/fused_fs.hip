@@ -693,7 +693,8 @@ struct FsSub2 {
 __device__ __forceinline__ int fs_slot_pos(const FsSub2& sub, int r) {
   const int rb = r >> 5, t = r & 31;
   const int ne = sub.ne(rb);
-  return sub.p0(rb) + (t < ne ? t : (ne > 0 ? ne - 1 : 0));
+  const int p0 = sub.p0(rb);
+  return ne > 0 ? p0 + (t < ne ? t : ne - 1) : (p0 > 0 ? p0 - 1 : 0);   // (empty sub-tile: p0 may be M)
 }
 
 // tile-local segmented sums of one sub-tile over a 64-feature column chunk (lanes = features):
@@ -702,7 +703,10 @@ template <typename Emit>
 __device__ __forceinline__ void fs_segment_sums(const float* __restrict__ tile, int ld,
                                                 const FsSub& sb, const FsTiling& tl, int lane,
                                                 Emit emit) {
-  if (sb.ne <= 0) return;
+  if (sb.ne <= 0) {   // a sub-tile of receivers without in-edges: their sums are zero
+    for (int i = 0; i < sb.nr; ++i) emit(sb.r0 + i, 0.f);
+    return;
+  }
   const int t = lane & 31;
   const int rcv = tl.csr_rec[sb.p0 + (t < sb.ne ? t : sb.ne - 1)];
   const int ri = sb.r0 + (lane < sb.nr ? lane : sb.nr);

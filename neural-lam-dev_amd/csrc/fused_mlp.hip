@@ -1338,18 +1338,25 @@ extern "C" int nlam_outer_bwd(const float* g, int64_t g_bstride, int64_t g_ld, i
 //   dst_k[r * dst_ld_k + c] = sum_{s < nslabs_k} slab_k[s * stride_k + src_off_k + r * src_ld_k + c]
 // Every segment names its own slab buffer, so ONE launch finishes all weight gradients
 // of an InteractionNet layer's backward (these reductions are launch-latency bound).
-#define NLAM_MAX_SEGS 32
+// (64 segments x 44 bytes of 32-bit fields: the block travels as a kernel argument, < 4 KB)
+#define NLAM_MAX_SEGS 64
 struct ReduceSegs {
   int nseg;
   const float* slab[NLAM_MAX_SEGS];
-  int32_t nslabs[NLAM_MAX_SEGS];
-  int64_t stride[NLAM_MAX_SEGS];
-  int64_t src_off[NLAM_MAX_SEGS];
-  int32_t cols[NLAM_MAX_SEGS];
-  int64_t src_ld[NLAM_MAX_SEGS], dst_ld[NLAM_MAX_SEGS];
   float* dst[NLAM_MAX_SEGS];
-  int64_t first[NLAM_MAX_SEGS + 1];   // prefix sums of rows*cols
+  int32_t nslabs[NLAM_MAX_SEGS];
+  int32_t stride[NLAM_MAX_SEGS];
+  int32_t src_off[NLAM_MAX_SEGS];
+  int32_t cols[NLAM_MAX_SEGS];
+  int32_t src_ld[NLAM_MAX_SEGS], dst_ld[NLAM_MAX_SEGS];
+  int32_t first[NLAM_MAX_SEGS + 1];   // prefix sums of rows*cols
 };
+static inline bool reduce_seg_fits(int64_t nslabs, int64_t stride, int64_t src_off, int64_t src_ld,
+                                   int64_t dst_ld, int64_t total) {
+  const int64_t lim = 0x7fffffff;
+  return nslabs <= lim && stride <= lim && src_off <= lim && src_ld <= lim && dst_ld <= lim &&
+         total <= lim && stride >= 0 && src_off >= 0 && src_ld >= 0 && dst_ld >= 0;
+}
 
 // G sub-groups per workgroup split the slabs (G = 16 for the 100-256 slabs of a large layer; 4 or
 // 1 when a small layer has a handful: a 256 x 256 gradient is 1,024 workgroups per matrix, and
@@ -1369,7 +1376,7 @@ __global__ __launch_bounds__(64 * G) void reduce_slabs_multi_kernel(ReduceSegs q
   const int64_t local = i - q.first[k];
   const int cols = q.cols[k] > 0 ? q.cols[k] : 1;
   const int64_t r = local / cols, c = local - r * cols;
-  const float* __restrict__ slab = q.slab[k] + q.src_off[k] + r * q.src_ld[k] + c;
+  const float* __restrict__ slab = q.slab[k] + (int64_t)q.src_off[k] + r * (int64_t)q.src_ld[k] + c;
   const int64_t nslabs = q.nslabs[k], stride = q.stride[k];
   float s = 0.f;
   if (i < n) {
@@ -1386,7 +1393,7 @@ __global__ __launch_bounds__(64 * G) void reduce_slabs_multi_kernel(ReduceSegs q
     }
   }
   if constexpr (G == 1) {
-    if (i < n) q.dst[k][r * q.dst_ld[k] + c] = s;
+    if (i < n) q.dst[k][r * (int64_t)q.dst_ld[k] + c] = s;
   } else {
     red[gsub][e] = s;
     __syncthreads();
@@ -1394,7 +1401,7 @@ __global__ __launch_bounds__(64 * G) void reduce_slabs_multi_kernel(ReduceSegs q
       float v = 0.f;
 #pragma unroll
       for (int g = 0; g < G; ++g) v += red[g][e];
-      q.dst[k][r * q.dst_ld[k] + c] = v;
+      q.dst[k][r * (int64_t)q.dst_ld[k] + c] = v;
     }
   }
 }
@@ -1428,10 +1435,13 @@ extern "C" int nlam_reduce_slabs_multi(const float* slab, int64_t nslabs, int64_
   q.first[0] = 0;
   for (int k = 0; k < nseg; ++k) {
     NLAM_REQUIRE(rows[k] >= 1 && cols[k] >= 1 && dst[k] != nullptr, "reduce_slabs_multi: bad segment");
-    q.slab[k] = slab; q.nslabs[k] = (int32_t)nslabs; q.stride[k] = stride;
-    q.src_off[k] = src_off[k]; q.cols[k] = cols[k];
-    q.src_ld[k] = src_ld[k]; q.dst_ld[k] = dst_ld[k]; q.dst[k] = dst[k];
-    q.first[k + 1] = q.first[k] + (int64_t)rows[k] * cols[k];
+    const int64_t tot = (int64_t)q.first[k] + (int64_t)rows[k] * cols[k];
+    NLAM_REQUIRE(reduce_seg_fits(nslabs, stride, src_off[k], src_ld[k], dst_ld[k], tot),
+                 "reduce_slabs_multi: segment %d exceeds the 32-bit field range", k);
+    q.slab[k] = slab; q.nslabs[k] = (int32_t)nslabs; q.stride[k] = (int32_t)stride;
+    q.src_off[k] = (int32_t)src_off[k]; q.cols[k] = cols[k];
+    q.src_ld[k] = (int32_t)src_ld[k]; q.dst_ld[k] = (int32_t)dst_ld[k]; q.dst[k] = dst[k];
+    q.first[k + 1] = (int32_t)tot;
   }
   return launch_reduce_segs(q, (hipStream_t)stream);
 }
@@ -1450,10 +1460,13 @@ extern "C" int nlam_reduce_slabs_batch(int nseg, const float* const* slab, const
     NLAM_REQUIRE(slab[k] != nullptr && nslabs[k] >= 1 && rows[k] >= 1 && cols[k] >= 1 &&
                      dst[k] != nullptr,
                  "reduce_slabs_batch: bad segment %d", k);
-    q.slab[k] = slab[k]; q.nslabs[k] = (int32_t)nslabs[k]; q.stride[k] = stride[k];
-    q.src_off[k] = src_off[k]; q.cols[k] = cols[k];
-    q.src_ld[k] = src_ld[k]; q.dst_ld[k] = dst_ld[k]; q.dst[k] = dst[k];
-    q.first[k + 1] = q.first[k] + (int64_t)rows[k] * cols[k];
+    const int64_t tot = (int64_t)q.first[k] + (int64_t)rows[k] * cols[k];
+    NLAM_REQUIRE(reduce_seg_fits(nslabs[k], stride[k], src_off[k], src_ld[k], dst_ld[k], tot),
+                 "reduce_slabs_batch: segment %d exceeds the 32-bit field range", k);
+    q.slab[k] = slab[k]; q.nslabs[k] = (int32_t)nslabs[k]; q.stride[k] = (int32_t)stride[k];
+    q.src_off[k] = (int32_t)src_off[k]; q.cols[k] = cols[k];
+    q.src_ld[k] = (int32_t)src_ld[k]; q.dst_ld[k] = (int32_t)dst_ld[k]; q.dst[k] = dst[k];
+    q.first[k + 1] = (int32_t)tot;
   }
   return launch_reduce_segs(q, (hipStream_t)stream);
 }

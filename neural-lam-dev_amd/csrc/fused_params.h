@@ -94,6 +94,44 @@ struct EdgeBwdParams {
   float* slab; int64_t slab_stride;
 };
 
+// ---- node-side kernels of a chain of InteractionNets on shared nodes (fused16_node.hip)
+struct NodeFwdParams {
+  RowView x, agg;               // (B, N, 64): layer input, aggregated messages
+  const float* V1; int64_t ldV1; const float* c1;    // aggregation MLP (64 x 128, 64 x 64)
+  const float* V2; int64_t ldV2; const float* c2;
+  const float* gamma; const float* beta;
+  float* xout; int64_t xo_bstride; int64_t xo_ld;    // x' = x + LN(...)
+  const float* WA; int64_t ldWA; const float* bA;    // NEXT layer's sender / receiver projections
+  const float* WB; int64_t ldWB; const float* bB;
+  float* P; int64_t p_bstride; int64_t p_ld;         // (B, N, 128) = [x' WA^T + bA | x' WB^T + bB]; NULL: none
+  int64_t rows; int B;
+};
+
+struct NodeBwdParams {
+  const float* gh; int64_t gh_bstride;               // (B, M, 64) edge-MLP hidden gradients, edge order
+  const int32_t* csc_colptr; const int32_t* csc_eid; // sender lists (n_send + 1, M)
+  int n_send;
+  float* gP; int64_t gp_bstride; int64_t gp_ld;      // (B, N, 128): [gPs written here | gPr read]
+  const float* g_res; int64_t gr_bstride; int64_t gr_ld;   // gradient already on x_l
+  const float* WA; int64_t ldWA; const float* WB; int64_t ldWB;
+  RowView x, agg;                                    // layer l-1 (x.ptr == NULL: no node update below)
+  const float* V1; int64_t ldV1; const float* c1;
+  const float* V2; int64_t ldV2; const float* c2;
+  const float* gamma;
+  float* gx_out; int64_t gx_bstride; int64_t gx_ld;        // gradient on x_{l-1} (or on x_l without update)
+  float* gagg_out; int64_t gagg_bstride; int64_t gagg_ld;  // gradient on agg_{l-1}
+  float* ga_out;                                     // (B, N, 64) hidden gradient of the node update
+  float* slab; int64_t slab_stride;
+  int64_t rows; int B;
+};
+
+struct NodeOuterParams {
+  RowView ga, xa, xb;           // role A: dV1 = ga^T [xa | xb]
+  RowView gP, xl;               // role B: dWp = gP^T xl
+  float* slab; int64_t slab_stride;
+  int64_t rows; int B; int has_a;
+};
+
 // ---- 16-row kernels (fused16_*.hip): same parameter blocks, same slab layouts and grids.
 // Each returns -1 when the shape / alignment is not one it handles (the caller then continues
 // with the 32-row kernel), 0 on success, > 0 on error.
@@ -107,7 +145,8 @@ int nlam_k16_edge_bwd(const EdgeBwdParams& q, int has_egemm, hipStream_t s);
 // bit mask of the kernel families that take the 16-row form (NLAM_K16 in the environment,
 // default all; nlam_set_k16 changes it at run time for A/B timing in one process)
 enum { K16_MLP_BWD = 1, K16_LIN_BWD = 2, K16_OUTER_BWD = 4, K16_EDGE_BWD = 8, K16_MLP_FWD = 16,
-       K16_LIN_FWD = 32, K16_EDGE_FWD = 64, K16_EDGE_BWD_UPD = 128 };
+       K16_LIN_FWD = 32, K16_EDGE_FWD = 64, K16_EDGE_BWD_UPD = 128, K16_NODE_CHAIN = 256 };
 // default: the families whose 16-row form is the faster one on MI355X (profiles/r03_*)
-#define K16_DEFAULT (K16_MLP_BWD | K16_LIN_BWD | K16_OUTER_BWD | K16_EDGE_BWD | K16_MLP_FWD | K16_LIN_FWD)
+#define K16_DEFAULT (K16_MLP_BWD | K16_LIN_BWD | K16_OUTER_BWD | K16_EDGE_BWD | K16_MLP_FWD | \
+                     K16_LIN_FWD | K16_NODE_CHAIN)
 bool nlam_k16_on(int family);

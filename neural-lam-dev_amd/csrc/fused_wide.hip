@@ -50,10 +50,11 @@ __device__ __forceinline__ WTile wide_tile(const WideTiling& tl, int64_t k) {
   }
   return w;
 }
-// index of tile slot t (lanes 0..31; clamped to the last valid position so every load is legal)
+// index of tile slot t (lanes 0..31; clamped to the last valid position so every load is legal;
+// a tile of receivers without in-edges -- ne == 0, p0 possibly == M -- reads the position before)
 __device__ __forceinline__ int wide_index(const int32_t* idx, const WTile& w, int lane) {
   const int t = lane & 31;
-  const int pos = w.p0 + (t < w.ne ? t : w.ne - 1);
+  const int pos = w.ne > 0 ? w.p0 + (t < w.ne ? t : w.ne - 1) : (w.p0 > 0 ? w.p0 - 1 : 0);
   return idx ? idx[pos] : pos;
 }
 
@@ -423,8 +424,8 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(TailBwdParams q) {
     // ---- h rows (contiguous) -> tile -> accumulator layout.  h is staged twice (here for
     // s = silu(h), below for silu'(h)) instead of living in 64 registers across the whole
     // tile: at d = 128 that is the difference between spilling and not (L2-hot re-read).
-    const float* hb = q.h + b * q.h_bstride + (int64_t)w.p0 * D;
-    const int last = ne - 1;
+    const float* hb = q.h + b * q.h_bstride + (int64_t)(ne > 0 ? w.p0 : (w.p0 > 0 ? w.p0 - 1 : 0)) * D;
+    const int last = ne > 0 ? ne - 1 : 0;
     auto h_row = [&](int s) { return hb + (int64_t)(s < last ? s : last) * D; };
     {
       f32x4 vH[NV];

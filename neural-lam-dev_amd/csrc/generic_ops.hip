@@ -17,6 +17,8 @@ void nlam_set_error(const char* fmt, ...) {
 }
 extern "C" const char* nlam_last_error(void) { return g_err; }
 
+#include <cctype>
+#include <string>
 #include <mutex>
 #include <utility>
 #include <vector>
@@ -46,13 +48,14 @@ static int nlam_mfma_mode_value() {
   static const int mode = [] {
     const char* e = getenv("NLAM_MFMA");
     if (e == nullptr || e[0] == 0) return NLAM_MFMA_DEFAULT_MODE;
-    if (e[0] == 'b' || e[0] == 'B') {
-      // "bf16x3" / "b3" -> 1 (split-bf16);  "bf16" -> 2 (plain bf16 products)
-      for (const char* c = e; *c; ++c)
-        if (*c == '3') return 1;
-      return 2;
-    }
-    return 0;
+    std::string v(e);
+    for (char& c : v) c = (char)tolower((unsigned char)c);
+    if (v == "fp32") return 0;
+    if (v == "bf16x3" || v == "b3") return 1;
+    if (v == "bf16") return 2;
+    // a typo must not silently select an arithmetic (it used to fall through to fp32 / bf16)
+    fprintf(stderr, "libnlam_hip: NLAM_MFMA=\"%s\" is not one of fp32 | bf16x3 | bf16\n", e);
+    abort();
   }();
   return mode;
 }

@@ -35,9 +35,11 @@ int nlam_enable_big_lds(const void* kern, const char* name);
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// GEMM arithmetic of the fused kernels: split-bf16 MFMA (default, fused_bf16x3.h) or exact
-// fp32 MFMA (NLAM_MFMA=fp32 in the environment).  Read once per process.  The generic
-// kernels (generic_ops.hip) always use the exact fp32 MFMA.
+// GEMM arithmetic of the fused kernels: NLAM_MFMA = fp32 | bf16x3 (default) | bf16 in the
+// environment, read once per process; any other value aborts the process with a message (the
+// Python binding raises before that, _lib.py).  nlam_mfma_b3(): one of the two bf16 forms
+// (fused_bf16x3.h) rather than the exact fp32 MFMA.  The generic kernels (generic_ops.hip)
+// always use the exact fp32 MFMA.
 bool nlam_mfma_b3();
 // bf16 MFMA terms per fp32 product: 0 = exact fp32 MFMA, 3 = split-bf16 (NLAM_MFMA=bf16x3, the
 // default), 1 = plain bf16 products with fp32 accumulate (NLAM_MFMA=bf16: the reference's

@@ -327,6 +327,176 @@ def apply_inet(net, send_rep, rec_rep, edge_rep):
     return out
 
 
+# ------------------------------------------ chain of InteractionNets on shared nodes
+# The reference's processor (models/graph_lam.py:51-57,88) applies processor_layers m2m
+# InteractionNets one after the other to the same mesh nodes.  Per layer the node-side work is
+# a handful of single-tile launches on 26 k rows; as a chain it is fused across the layer
+# boundary (csrc/fused16_node.hip):
+#   forward : nlam_lin_fwd (layer 0), then per layer nlam_edge_fwd + nlam_node_fwd (node update
+#             of this layer AND the next layer's projections; the last layer: nlam_mlp_fwd)
+#   backward: nlam_mlp_bwd (+ nlam_outer_bwd) of the last layer, then per layer nlam_edge_bwd +
+#             nlam_node_bwd (sender gather, projections backward, node update of the layer
+#             below backward) + nlam_node_outer (all 128-wide weight gradients of the pair);
+#             ONE slab reduction for every parameter gradient of the chain.
+CHAIN_PARAMS = 12   # per layer: W1 b1 W2 b2 gam bet V1 c1 V2 c2 gam2 bet2
+
+
+def chain_eligible(nets, mesh_rep, edge_rep):
+    if len(nets) < 2 or FORCE_GENERIC or not edge_rep.is_cuda:
+        return False
+    if mesh_rep.dim() != 3 or edge_rep.dim() != 3:
+        return False
+    if not all(inet_eligible(n, mesh_rep, mesh_rep, edge_rep) for n in nets):
+        return False
+    t0 = nets[0].tables
+    same = getattr(nets[0], "_chain_same_graph", None)
+    if same is None or same[0] != tuple(id(n) for n in nets):
+        # (decided once per module list: the comparison synchronises with the device)
+        ok = all(n.tables.M == t0.M and n.tables.n_rec == t0.n_rec and
+                 torch.equal(n.edge_index, nets[0].edge_index) for n in nets[1:])
+        same = (tuple(id(n) for n in nets), ok)
+        nets[0]._chain_same_graph = same
+    if not same[1]:
+        return False
+    if not all(n.update_edges and n.aggr == nets[0].aggr for n in nets):
+        return False
+    if _base(mesh_rep).shape[0] != mesh_rep.shape[0]:
+        return False   # batch-invariant nodes: per-layer path
+    if mesh_rep.shape[1] != t0.n_rec or t0.n_send > t0.n_rec:
+        return False
+    return ops.node_chain_supported()
+
+
+class FusedChainFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, e, g, mean, nl, *params):
+        with ops.tag(g.tag):
+            dev = x.device
+            d = x.shape[-1]
+            B, N, M = x.shape[0], x.shape[1], e.shape[1]
+            L = [params[CHAIN_PARAMS * l : CHAIN_PARAMS * (l + 1)] for l in range(nl)]
+            xs, es, Ps, aggs = [mat(x.detach())], [mat(e.detach())], [], []
+            W1, b1 = L[0][0], L[0][1]
+            P = _empty(B, N, 2 * d, device=dev)
+            ops.fused_lin_fwd(xs[0], W1[:, d : 2 * d], None, W1[:, 2 * d :], b1, mat(P))
+            for l in range(nl):
+                W1, b1, W2, b2, gam, bet, V1, c1, V2, c2, gam2, bet2 = L[l]
+                agg = _empty(B, N, d, device=dev)
+                e_out = _empty(B, M, d, device=dev)
+                ops.fused_edge_fwd(g, es[l], True, mat(P, 0, d), mat(P, d, d), W1[:, :d], W2, b2, gam,
+                                   bet, mat(agg), mat(e_out), mean, d)
+                Ps.append(P)
+                aggs.append(agg)
+                x_out = _empty(B, N, d, device=dev)
+                if l + 1 < nl:
+                    Wn, bn = L[l + 1][0], L[l + 1][1]
+                    P = _empty(B, N, 2 * d, device=dev)
+                    ops.node_fwd(xs[l], mat(agg), V1, c1, V2, c2, gam2, bet2, mat(x_out),
+                                 Wn[:, d : 2 * d], None, Wn[:, 2 * d :], bn, mat(P))
+                    xs.append(mat(x_out))
+                    es.append(mat(e_out))
+                else:
+                    ops.fused_mlp_fwd(xs[l], mat(agg), V1, c1, V2, c2, gam2, bet2, xs[l], mat(x_out),
+                                      d, d)
+            ctx.save_for_backward(*params)
+            ctx.set_materialize_grads(False)
+            ctx.g, ctx.mean, ctx.nl = g, mean, nl
+            ctx.bufs = (xs, es, Ps, aggs)
+            ctx.dims = (B, N, M, d)
+        return x_out, e_out
+
+    @staticmethod
+    def backward(ctx, g_x_out, g_e_out):
+        g, nl = ctx.g, ctx.nl
+        with ops.tag(g.tag), ops.slab_batch():
+            params = ctx.saved_tensors
+            L = [params[CHAIN_PARAMS * l : CHAIN_PARAMS * (l + 1)] for l in range(nl)]
+            xs, es, Ps, aggs = ctx.bufs
+            ctx.bufs = None
+            B, N, M, d = ctx.dims
+            dev = params[0].device
+            grads = [None] * (CHAIN_PARAMS * nl)
+
+            def new_grads(l):
+                W1, b1, W2 = L[l][0], L[l][1], L[l][2]
+                V1, V2 = L[l][6], L[l][8]
+                o = {"dW1": _empty(d, 3 * d, device=dev), "db1": _empty(d, device=dev),
+                     "dW2": torch.empty_like(W2), "db2": _empty(d, device=dev),
+                     "dgam": _empty(d, device=dev), "dbet": _empty(d, device=dev),
+                     "dV1": torch.empty_like(V1), "dc1": _empty(d, device=dev),
+                     "dV2": torch.empty_like(V2), "dc2": _empty(d, device=dev),
+                     "dgam2": _empty(d, device=dev), "dbet2": _empty(d, device=dev)}
+                grads[CHAIN_PARAMS * l : CHAIN_PARAMS * (l + 1)] = [
+                    o[k] for k in ("dW1", "db1", "dW2", "db2", "dgam", "dbet", "dV1", "dc1", "dV2",
+                                   "dc2", "dgam2", "dbet2")]
+                return o
+
+            G = [new_grads(l) for l in range(nl)]
+            # node update of the last layer
+            if g_x_out is None:
+                g_x_out = torch.zeros(B, N, d, dtype=torch.float32, device=dev)
+            g_x_out = g_x_out.contiguous()
+            top = nl - 1
+            V1, c1, V2, c2, gam2 = L[top][6], L[top][7], L[top][8], L[top][9], L[top][10]
+            g_res = _empty(B, N, d, device=dev)
+            g_agg = _empty(B, N, d, device=dev)
+            nd = {"dW1": G[top]["dV1"], "db1": G[top]["dc1"], "dW2": G[top]["dV2"],
+                  "db2": G[top]["dc2"], "dgamma": G[top]["dgam2"], "dbeta": G[top]["dbet2"]}
+            ops.fused_mlp_bwd(xs[top], mat(aggs[top]), V1, c1, V2, c2, gam2, mat(g_x_out), mat(g_res),
+                              mat(g_agg), True, d, d, nd)
+            geo = mat(g_e_out.contiguous()) if g_e_out is not None else None
+            for l in range(top, -1, -1):
+                W1, b1, W2, b2, gam = L[l][0], L[l][1], L[l][2], L[l][3], L[l][4]
+                o = G[l]
+                gh = _empty(B, M, d, device=dev)
+                gP = _empty(B, N, 2 * d, device=dev)
+                g_e = _empty(B, M, d, device=dev)
+                ops.fused_edge_bwd(
+                    g, es[l], True, mat(Ps[l], 0, d), mat(Ps[l], d, d), W1[:, :d], W2, b2, gam,
+                    mat(g_agg), geo, mat(gh), mat(gP, d, d), mat(g_e), ctx.mean, d, o["dW1"][:, :d],
+                    o["dW2"], o["db2"], o["dgam"], o["dbet"])
+                geo = mat(g_e)
+                gx = _empty(B, N, d, device=dev)
+                if l > 0:
+                    V1, c1, V2, c2, gam2 = L[l - 1][6], L[l - 1][7], L[l - 1][8], L[l - 1][9], L[l - 1][10]
+                    ob = G[l - 1]
+                    g_agg_b = _empty(B, N, d, device=dev)
+                    ga = _empty(B, N, d, device=dev)
+                    ops.node_bwd(
+                        mat(gh), g.csc_colptr, g.csc_eid, g.n_send, mat(gP), mat(g_res),
+                        W1[:, d : 2 * d], W1[:, 2 * d :],
+                        {"x": xs[l - 1], "agg": mat(aggs[l - 1]), "V1": V1, "c1": c1, "V2": V2,
+                         "c2": c2, "gamma": gam2, "gagg_out": mat(g_agg_b), "ga_out": ga,
+                         "dst": {"dW2": ob["dV2"], "db2": ob["dc2"], "dgamma": ob["dgam2"],
+                                 "dbeta": ob["dbet2"]}},
+                        mat(gx))
+                    ops.node_outer(ga, xs[l - 1], mat(aggs[l - 1]), mat(gP), xs[l], ob["dV1"],
+                                   ob["dc1"], o["dW1"][:, d : 2 * d], o["dW1"][:, 2 * d :], o["db1"])
+                    g_res, g_agg = gx, g_agg_b
+                else:
+                    ops.node_bwd(mat(gh), g.csc_colptr, g.csc_eid, g.n_send, mat(gP), mat(g_res),
+                                 W1[:, d : 2 * d], W1[:, 2 * d :], None, mat(gx))
+                    ops.node_outer(None, None, None, mat(gP), xs[0], None, None,
+                                   o["dW1"][:, d : 2 * d], o["dW1"][:, 2 * d :], o["db1"])
+            g_edge = g_e
+            if es[0].B == 1 and B > 1:   # batch-invariant first edge input: its gradient sums over B
+                t4 = _empty(1, M, d, device=dev)
+                ops.sum_batch(g_e, t4)
+                g_edge = t4
+        return (gx, g_edge, None, None, None, *grads)
+
+
+def apply_chain(nets, mesh_rep, edge_rep):
+    params = []
+    for net in nets:
+        el, al = _mlp_parts(net.edge_mlp), _mlp_parts(net.aggr_mlp)
+        params += [el[0][0].weight, el[0][0].bias, el[0][1].weight, el[0][1].bias, el[1].weight,
+                   el[1].bias, al[0][0].weight, al[0][0].bias, al[0][1].weight, al[0][1].bias,
+                   al[1].weight, al[1].bias]
+    return FusedChainFunction.apply(mesh_rep, _base(edge_rep), nets[0].tables,
+                                    nets[0].aggr == "mean", len(nets), *params)
+
+
 # ------------------------------------------- InteractionNet with SplitMLPs
 # HiLAMParallel (hi_lam_parallel.py:26-53) gives every edge set (same-level / up / down per
 # level) its own edge MLP and every mesh level its own node MLP (interaction_net.py:134-163).

@@ -2,7 +2,7 @@
 processor = processor_layers x m2m InteractionNet with send = rec = mesh."""
 from torch import nn
 
-from .. import utils
+from .. import fused, utils
 from ..interaction_net import InteractionNet
 from .base_graph_model import BaseGraphModel
 
@@ -25,6 +25,9 @@ class ProcessorSequential(nn.Module):
         return (getattr(self, f"module_{i}") for i in range(self._n))
 
     def forward(self, mesh_rep, edge_rep):
+        nets = list(self)
+        if fused.chain_eligible(nets, mesh_rep, edge_rep):
+            return fused.apply_chain(nets, mesh_rep, edge_rep)
         for net in self:
             mesh_rep, edge_rep = net(mesh_rep, mesh_rep, edge_rep)
         return mesh_rep, edge_rep

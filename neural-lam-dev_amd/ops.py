@@ -411,7 +411,7 @@ def reduce_slabs(slab, nslabs, stride, n, out, accumulate=False):
 
 
 _SLAB_BATCH = []   # stack of pending (slab, nslabs, stride, src_off, rows, cols, src_ld, dst)
-MAX_SEGS = 32
+MAX_SEGS = 64
 
 
 class slab_batch:
@@ -627,6 +627,93 @@ def fused_lin_bwd(x, gy, WA, WB, gx, dWA, dbA, dWB, dbB, gx_add=None, sum_gy_bat
     segs = [(0, nA, k_in, kp32, dWA), (n * kp32, 1, nA, nA, dbA)]
     if nB:
         segs += [(nA * kp32, nB, k_in, kp32, dWB), (n * kp32 + nA, 1, nB, nB, dbB)]
+    reduce_segments(slab, nslabs, stride, segs)
+
+
+def node_chain_supported():
+    """The fused node-side kernels of an InteractionNet chain exist in this process's arithmetic
+    mode (split-bf16 products, hidden width 64)."""
+    return bool(lib.nlam_node_chain_supported())
+
+
+def node_fwd(x, agg, V1, c1, V2, c2, gamma, beta, xout, WA, bA, WB, bB, P):
+    """xout = x + LN(V2 silu(V1 [x | agg] + c1) + c2) and (P not None) the next layer's
+    projections P = [xout WA^T + bA | xout WB^T + bB] in one launch."""
+    B, rows, d = xout.B, xout.rows, xout.cols
+    _launch(
+        "nlam_node_fwd", lib.nlam_node_fwd,
+        (x.ptr, x.bstride, x.ld, agg.ptr, agg.bstride, agg.ld, V1.data_ptr(), V1.stride(0),
+         c1.data_ptr(), V2.data_ptr(), V2.stride(0), c2.data_ptr(), gamma.data_ptr(),
+         beta.data_ptr(), xout.ptr, xout.bstride, xout.ld,
+         _p(WA), WA.stride(0) if WA is not None else 0, _p(bA),
+         _p(WB), WB.stride(0) if WB is not None else 0, _p(bB),
+         P.ptr if P is not None else None, P.bstride if P is not None else 0,
+         P.ld if P is not None else 0, B, rows, stream()),
+        flops=2.0 * B * rows * d * (3 * d + (2 * d if P is not None else 0)),
+        nbytes=4.0 * B * rows * d * (3 + (2 if P is not None else 0)),
+    )
+
+
+def node_bwd(gh, csc_colptr, csc_eid, n_send, gP, g_res, WA, WB, upd, gx_out):
+    """Backward data pass of one chain link (include/nlam_hip.h, nlam_node_bwd).  upd: None, or
+    the node update below as a dict(x, agg, V1, c1, V2, c2, gamma, gagg_out, ga_out (tensor),
+    dst=dict(dW2, db2, dgamma, dbeta) destination views)."""
+    B, rows, d = gx_out.B, gx_out.rows, gx_out.cols
+    M = gh.rows
+    if upd is None:
+        args_u = (None, 0, 0, None, 0, 0, None, 0, None, None, 0, None, None)
+        out_u = (None, 0, 0, None, None, 0)
+        slab = None
+    else:
+        x, agg = upd["x"], upd["agg"]
+        V1, V2 = upd["V1"], upd["V2"]
+        stride = lib.nlam_node_bwd_slab_stride()
+        nslabs = lib.nlam_node_bwd_grid(B, rows)
+        slab = torch.empty(nslabs * stride, dtype=torch.float32, device=V1.device)
+        args_u = (x.ptr, x.bstride, x.ld, agg.ptr, agg.bstride, agg.ld, V1.data_ptr(), V1.stride(0),
+                  upd["c1"].data_ptr(), V2.data_ptr(), V2.stride(0), upd["c2"].data_ptr(),
+                  upd["gamma"].data_ptr())
+        ga, go = upd["ga_out"], upd["gagg_out"]
+        out_u = (go.ptr, go.bstride, go.ld, ga.data_ptr(), slab.data_ptr(), stride)
+    _launch(
+        "nlam_node_bwd", lib.nlam_node_bwd,
+        (gh.ptr, gh.bstride, csc_colptr.data_ptr(), csc_eid.data_ptr(), n_send,
+         gP.ptr, gP.bstride, gP.ld, g_res.ptr, g_res.bstride, g_res.ld,
+         WA.data_ptr(), WA.stride(0), WB.data_ptr(), WB.stride(0)) + args_u
+        + (gx_out.ptr, gx_out.bstride, gx_out.ld) + out_u + (B, rows, stream()),
+        flops=2.0 * B * rows * d * (2 * d + (8 * d if upd is not None else 0)),
+        nbytes=4.0 * B * (M * d + rows * d * (5 + (5 if upd is not None else 0))) + 4.0 * (M + rows),
+    )
+    if upd is not None:
+        dst = upd["dst"]
+        reduce_segments(slab, nslabs, stride, [
+            (0, d, d, d, dst["dW2"]), (d * d, 1, d, d, dst["db2"]),
+            (d * d + d, 1, d, d, dst["dgamma"]), (d * d + 2 * d, 1, d, d, dst["dbeta"])])
+
+
+def node_outer(ga, xa, xb, gP, xl, dV1, dc1, dWA, dWB, dbB):
+    """Weight gradients of one chain link in one launch: dV1 (d, 2d) = ga^T [xa | xb], dc1 =
+    colsum ga (ga None: skipped); dWA / dWB (d, d) = gP[:, :d]^T xl / gP[:, d:]^T xl, dbB =
+    colsum gP[:, d:] (the bias rides on the receiver projection)."""
+    B, rows, d = xl.B, xl.rows, xl.cols
+    stride = lib.nlam_node_outer_slab_stride()
+    nslabs = lib.nlam_node_outer_grid(B, rows)
+    slab = torch.empty(nslabs * stride, dtype=torch.float32, device=dWA.device)
+    has_a = ga is not None
+    _launch(
+        "nlam_node_outer", lib.nlam_node_outer,
+        (ga.data_ptr() if has_a else None,
+         xa.ptr if has_a else None, xa.bstride if has_a else 0, xa.ld if has_a else 0,
+         xb.ptr if has_a else None, xb.bstride if has_a else 0, xb.ld if has_a else 0,
+         gP.ptr, gP.bstride, gP.ld, xl.ptr, xl.bstride, xl.ld, slab.data_ptr(), stride, B, rows,
+         stream()),
+        flops=2.0 * B * rows * 2 * d * d * (2 if has_a else 1),
+        nbytes=4.0 * B * rows * d * (3 + (3 if has_a else 0)),
+    )
+    o = 2 * d * d + d
+    segs = [(o, d, d, d, dWA), (o + d * d, d, d, d, dWB), (o + 2 * d * d + d, 1, d, d, dbB)]
+    if has_a:
+        segs += [(0, d, 2 * d, 2 * d, dV1), (2 * d * d, 1, d, d, dc1)]
     reduce_segments(slab, nslabs, stride, segs)
 
 

@@ -135,6 +135,7 @@ class GradAllReduce:
                 for i in range(lo, hi):
                     self._bucket_of[i] = bi
             self._left = list(self._pending)
+            self._seen = [False] * len(flat.params)
             for i, p in enumerate(flat.params):
                 p.register_post_accumulate_grad_hook(self._make_hook(i))
 
@@ -158,6 +159,9 @@ class GradAllReduce:
                 # inner backward, e.g. args.ar_checkpoint): re-reduce it in reduce()
                 self._dirty.add(bi)
                 return
+            if self._seen[i]:
+                return   # the same parameter again (re-entrant backward): counted once
+            self._seen[i] = True
             self._left[bi] -= 1
             if self._left[bi] == 0 and self.world > 1:
                 self._launch(bi, in_backward=True)
@@ -217,6 +221,7 @@ class GradAllReduce:
         self._dirty = set()
         if self.overlap:
             self._left = list(self._pending)
+            self._seen = [False] * len(self._seen)
 
 
 class FlatAdamW:

@@ -104,6 +104,14 @@ def _overlap_worker(rank, world, port, q):
             red.reduce()
         out[name] = (flat.gather(flat.grad).tolist(), launched_before_reduce,
                      red.stats["launched_in_reduce"], len(red.ranges))
+        # two backward passes accumulate into p.grad before ONE reduce (what a re-entrant
+        # checkpointed rollout does): every hook fires twice; a parameter counts once per
+        # step towards its bucket and late contributions are re-reduced
+        flat.zero_grad()
+        net(x).pow(2).sum().backward()
+        net(0.5 * x).sum().backward()
+        red.reduce()
+        out[name + "_accum"] = flat.gather(flat.grad).tolist()
     q.put((rank, out))
     dist.destroy_process_group()
 
@@ -127,6 +135,7 @@ def test_overlap_hooks_fire_during_backward_and_match_plain_path():
         assert lb_plain == 0 and lr_plain == 2 * nb          # everything issued by reduce()
         assert lb_ovl == 2 * nb and lr_ovl == 0              # every bucket issued by a hook
         assert g_plain == g_ovl                               # bit for bit
+        assert res[rank]["plain_accum"] == res[rank]["overlap_accum"]
     assert res[0]["overlap"][0] == res[1]["overlap"][0]
 
 

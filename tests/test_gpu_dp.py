@@ -95,3 +95,69 @@ def test_two_rank_gradients_match_single_process(backend):
     assert torch.equal(g0, g1)
     assert float((g0 - want).abs().max() / want.abs().max()) < 1e-4
     assert torch.equal(torch.tensor(res[0][2]), torch.tensor(res[1][2]))
+
+
+def _overlap_worker(rank, world, port, tmp, q, backend):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank if backend == "nccl" else 0)
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    from neural_lam_amd import parallel, synthetic
+
+    out = {}
+    for overlap in (False, True):
+        model, n = _build(tmp)
+        model = model.cuda()
+        flat = parallel.FlatParams(model)
+        # small buckets: several collectives per step, issued from the backward hooks on the
+        # side stream while autograd keeps launching kernels on the main stream
+        red = parallel.GradAllReduce(flat, bucket_bytes=64 << 10, overlap=overlap)
+        red.broadcast_params()
+        opt = parallel.FlatAdamW(flat, lr=1e-2)
+        grads = []
+        for step in range(3):
+            full = synthetic.random_batch(4, 2, n, n_state=5, n_forcing_window=6, seed=3 + step,
+                                          device="cuda")
+            mine = tuple(t[rank * 2 : rank * 2 + 2] if t is not None else None for t in full)
+            flat.zero_grad()
+            model.training_step(mine).backward()
+            red.reduce()
+            grads.append(flat.grad.clone())
+            opt.step(grad_scale=1.0 / world)
+        torch.cuda.synchronize()
+        out[overlap] = (torch.stack(grads).cpu(), flat.flat.cpu().clone(), dict(red.stats),
+                        len(red.ranges))
+    same_g = torch.equal(out[False][0], out[True][0])
+    same_w = torch.equal(out[False][1], out[True][1])
+    q.put((rank, same_g, same_w, out[True][2], out[True][3], out[False][2]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_overlapped_buckets_on_device_tensors_bit_identical(backend):
+    """GradAllReduce(overlap=True) with small buckets on DEVICE tensors: the hook-issued,
+    side-stream collectives (event fork from the launch stream, pack on the side stream, join
+    in reduce()) give bit-identical gradients and weights to the single trailing schedule over
+    three optimiser steps, and the hooks did issue buckets during backward.  gloo on the one
+    card of the test box; RCCL when the box has two cards."""
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("RCCL needs one GPU per rank (it refuses two ranks on one device)")
+    with tempfile.TemporaryDirectory() as tmp:
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_overlap_worker, args=(r, 2, port, tmp, q, backend))
+                 for r in range(2)]
+        for p in procs:
+            p.start()
+        res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    for rank, same_g, same_w, stats, nbuckets, stats_off in res:
+        assert same_g and same_w, f"rank {rank}: overlap changed the result"
+        assert nbuckets >= 3
+        assert stats["launched_in_backward"] > 0, stats
+        assert stats["launched_in_backward"] + stats["launched_in_reduce"] == 3 * nbuckets
+        assert stats_off["launched_in_backward"] == 0

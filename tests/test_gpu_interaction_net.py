@@ -164,3 +164,54 @@ def test_low_in_degree_tiles_match_oracle(d, deg_lo, deg_hi, upd):
     assert rel(sg.grad, sc.grad) < 1e-3 and rel(rg.grad, rc.grad) < 1e-3 and rel(eg.grad, ec.grad) < 1e-3
     for k, p in net.named_parameters():
         assert rel(p.grad, sd[f"n.{k}"].grad) < 1e-3, k
+
+
+@pytest.mark.parametrize("shared,upd", [(True, True), (False, True), (False, False)])
+def test_tiles_of_empty_receivers_d64(shared, upd):
+    """70 consecutive receivers without in-edges at hidden 64: whole receiver-aligned tiles with
+    no edge (ne == 0); aggregates / gradients of those receivers are exactly the node-update
+    of a zero aggregate, and nothing is read out of range.  Fused path, vs the CPU oracle."""
+    import nlam_oracle as orc
+    from neural_lam_amd import fused
+    from neural_lam_amd.interaction_net import InteractionNet
+
+    gen = torch.Generator().manual_seed(31)
+    d, B = 64, 2
+    n_s, n_r, M = (130, 130, 800) if shared else (90, 125, 700)
+    span = 70
+    rec = torch.randint(0, n_r, (M,), generator=gen)
+    send = torch.randint(0, n_s, (M,), generator=gen)
+    lo = torch.arange(M) % (n_r - span - 1) + span + 1
+    rec = torch.where((rec >= 1) & (rec <= span), lo, rec)
+    rec[0], rec[1], send[2] = 0, n_r - 1, 0
+    ei = torch.stack((send + (0 if shared else n_r), rec))
+    torch.manual_seed(4)
+    net = InteractionNet(ei, d, update_edges=upd, aggr="mean")
+    sd = {f"n.{k}": v.detach().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    net = net.cuda()
+    s = torch.randn(B, n_s, d, generator=gen)
+    r = s if shared else torch.randn(B, n_r, d, generator=gen)
+    e = torch.randn(B, M, d, generator=gen)
+    cr, ce = torch.randn(B, n_r, d, generator=gen), torch.randn(B, M, d, generator=gen)
+
+    def loss_of(out, cr, ce):
+        if upd:
+            return (out[0] * cr).sum() + (out[1] * ce).sum(), out[0]
+        return (out * cr).sum(), out
+
+    sc = s.clone().requires_grad_(True)
+    rc = sc if shared else r.clone().requires_grad_(True)
+    ec = e.clone().requires_grad_(True)
+    wl, w_rec = loss_of(orc.interaction_net(sd, "n", ei, sc, rc, ec, update_edges=upd, aggr="mean"), cr, ce)
+    names = [k for k, _ in net.named_parameters()]
+    want = torch.autograd.grad(wl, [sc, ec] + [sd[f"n.{k}"] for k in names])
+    sg = s.cuda().requires_grad_(True)
+    rg = sg if shared else r.cuda().requires_grad_(True)
+    eg = e.cuda().requires_grad_(True)
+    assert fused.inet_eligible(net, sg, rg, eg)
+    gl, g_rec = loss_of(net(sg, rg, eg), cr.cuda(), ce.cuda())
+    gl.backward()
+    assert rel(g_rec, w_rec.detach()) < 1e-4
+    assert rel(sg.grad, want[0]) < 1e-3 and rel(eg.grad, want[1]) < 1e-3
+    for (k, p), w in zip(net.named_parameters(), want[2:]):
+        assert rel(p.grad, w) < 1e-3, k

@@ -26,12 +26,15 @@ def rel(a, b):
     return float((a.detach().cpu() - b.detach()).abs().max() / (b.detach().abs().max() + 1e-30))
 
 
-def _edges(gen, n_s, n_r, M, shared, empty_receivers=False):
+def _edges(gen, n_s, n_r, M, shared, empty_receivers=False, empty_span=0):
     rec = torch.randint(0, n_r, (M,), generator=gen)
     send = torch.randint(0, n_s, (M,), generator=gen)
     if empty_receivers:   # (mean clamps the count to 1); in-degrees stay <= 32
         for r_empty in (7, 20, 30):
             rec[rec == r_empty] = r_empty + 1
+    if empty_span:        # receivers 1 .. empty_span without in-edges: whole tiles with no edge
+        lo = torch.arange(M) % (n_r - empty_span - 1) + empty_span + 1
+        rec = torch.where((rec >= 1) & (rec <= empty_span), lo, rec)
     rec[0], rec[1], send[2] = 0, n_r - 1, 0
     return torch.stack((send + (0 if shared else n_r), rec))
 
@@ -40,6 +43,17 @@ def _edges(gen, n_s, n_r, M, shared, empty_receivers=False):
                                                 (False, True, "mean", 1), (True, False, "sum", 2),
                                                 (True, True, "mean", 5)])
 def test_wide_interaction_net_vs_oracle(shared, upd, aggr, B):
+    _inet_case(shared, upd, aggr, B)
+
+
+@pytest.mark.parametrize("shared", [False, True])
+def test_wide_tiles_of_empty_receivers(shared):
+    """70 consecutive receivers without in-edges: receiver-aligned tiles that hold no edge at
+    all (ne == 0) must leave zero aggregates / gradients and read nothing out of range."""
+    _inet_case(shared, True, "mean", 2, empty_span=70)
+
+
+def _inet_case(shared, upd, aggr, B, empty_span=0):
     import nlam_oracle as orc
     from neural_lam_amd import wide
     from neural_lam_amd.interaction_net import InteractionNet
@@ -47,7 +61,9 @@ def test_wide_interaction_net_vs_oracle(shared, upd, aggr, B):
     d = D
     gen = torch.Generator().manual_seed(7 + B)
     n_s, n_r, M = (45, 45, 410) if shared else (70, 38, 333)
-    ei = _edges(gen, n_s, n_r, M, shared, empty_receivers=(aggr == "mean"))
+    if empty_span:
+        n_s, n_r, M = (120, 120, 700) if shared else (90, 110, 600)
+    ei = _edges(gen, n_s, n_r, M, shared, empty_receivers=(aggr == "mean"), empty_span=empty_span)
     torch.manual_seed(5)
     net = InteractionNet(ei, d, update_edges=upd, aggr=aggr)
     with torch.no_grad():
@@ -79,14 +95,15 @@ def test_wide_interaction_net_vs_oracle(shared, upd, aggr, B):
     eg = edge.cuda().requires_grad_(True)
     assert wide.inet_eligible(net, sg, rg, eg)
     g_r, g_e = run(net, sg, rg, eg, cr.cuda(), ce.cuda())
-    assert rel(g_r, w_r) < FWD_BAR
+    assert rel(g_r, w_r) < FWD_BAR, ("rec", rel(g_r, w_r))
     if upd:
-        assert rel(g_e, w_e) < FWD_BAR
-    assert rel(sg.grad, sc.grad) < GRAD_BAR and rel(eg.grad, ec.grad) < GRAD_BAR
+        assert rel(g_e, w_e) < FWD_BAR, ("edge", rel(g_e, w_e))
+    assert rel(sg.grad, sc.grad) < GRAD_BAR and rel(eg.grad, ec.grad) < GRAD_BAR, (
+        rel(sg.grad, sc.grad), rel(eg.grad, ec.grad))
     if not shared:
-        assert rel(rg.grad, rc.grad) < GRAD_BAR
+        assert rel(rg.grad, rc.grad) < GRAD_BAR, rel(rg.grad, rc.grad)
     for k, p in net.named_parameters():
-        assert rel(p.grad, osd[f"n.{k}"].grad) < GRAD_BAR, k
+        assert rel(p.grad, osd[f"n.{k}"].grad) < GRAD_BAR, (k, rel(p.grad, osd[f"n.{k}"].grad))
 
 
 def test_wide_stride0_batch_inputs_match_oracle():

@@ -15,6 +15,9 @@ print("mfma mode:", {0: "fp32", 1: "bf16x3", 2: "bf16"}[int(lib.nlam_mfma_mode()
 for shared, upd, aggr, B in T.INET_CASES + [(True, True, "mean", 5)]:
     T.test_wide_interaction_net_vs_oracle(shared, upd, aggr, B)
     print(f"ok inet shared={shared} upd={upd} aggr={aggr} B={B}", flush=True)
+for shared in (False, True):
+    T.test_wide_tiles_of_empty_receivers(shared)
+    print(f"ok inet tiles of empty receivers shared={shared}", flush=True)
 T.test_wide_stride0_batch_inputs_match_oracle()
 print("ok inet stride-0 inputs", flush=True)
 for blueprint, ln, res, rows, B in T.MLP_CASES:
