@@ -537,6 +537,11 @@ int nlam_debug_k16_stamps(unsigned long long* out, int reset);
  * out: host array of 3 * 1024 values (first 1024 workgroups of the last launch). */
 int nlam_debug_lin_fwd_timeline(unsigned long long* out);
 
+/* Diagnostic (NLAM_TIMELINE_NODE=1): s_memrealtime (100 MHz) stamps of the last nlam_node_bwd launch
+ * with a node update, 8 per workgroup (first 256): start, weights in LDS, gather done, G formed,
+ * tile loop done, slab written.  out: host array of 256 * 8 values. */
+int nlam_debug_node_timeline(unsigned long long* out);
+
 /* Debug / self-test: verifies the MFMA fp32 32x32x2 operand and accumulator
  * lane maps the fused kernels rely on.  out: 32*32 floats = A(32x64) * B(64x32)
  * for the integer test pattern documented in csrc/mfma_probe.hip. */

@@ -104,11 +104,26 @@ __global__ __launch_bounds__(K16_THREADS, 2) void mlp_bwd16_kernel(MlpBwdParams 
   void* R1 = mine + p16_bytes(PW0);
   float* HS = reinterpret_cast<float*>(mine + p16_bytes(PW0) + p16_bytes(PW1));
 
-  load_weight_lds_b3(W1im, 0, p.W1, p.ldW1, HID, p.k_in, HID, KP32, tid, K16_THREADS);
-  load_weight_lds_b3(W2im, 0, p.W2, p.ldW2, p.n_out, HID, NO, HID, tid, K16_THREADS);
-  load_vec_lds(b1s, p.b1, HID, HID, tid, K16_THREADS);
-  load_vec_lds(b2s, p.b2, p.n_out, NO, tid, K16_THREADS);
-  load_vec_lds(gs, p.gamma, p.n_out, NO, tid, K16_THREADS);
+  {   // every global load of the prologue in flight together (fused16.h, batched prologue loads)
+    VLoad16 lv;
+    const float* const vecs[8] = {p.b1, p.b2, p.gamma, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const int lens[8] = {HID, p.n_out, p.n_out, 0, 0, 0, 0, 0};
+    static_assert(NO <= 64, "vector slots are 64 floats");
+    WLoad16<KB> l1;
+    WLoad16<NOB> l2;
+    if constexpr (NO == 64) v16_issue(lv, vecs, lens, tid);
+    w16_issue(l1, p.W1, p.ldW1, HID, p.k_in, HID, KP32, tid, K16_THREADS);
+    w16_issue(l2, p.W2, p.ldW2, p.n_out, HID, NO, HID, tid, K16_THREADS);
+    if constexpr (NO == 64) {
+      v16_commit(lv, b1s, 3, tid);
+    } else {
+      load_vec_lds(b1s, p.b1, HID, HID, tid, K16_THREADS);
+      load_vec_lds(b2s, p.b2, p.n_out, NO, tid, K16_THREADS);
+      load_vec_lds(gs, p.gamma, p.n_out, NO, tid, K16_THREADS);
+    }
+    w16_commit(l1, W1im, 0, p.W1, p.ldW1, HID, p.k_in, HID, KP32, tid, K16_THREADS);
+    w16_commit(l2, W2im, 0, p.W2, p.ldW2, p.n_out, HID, NO, HID, tid, K16_THREADS);
+  }
   __syncthreads();
 
   f32x16 dW1[2][KBA], dW2[NOB][2];
@@ -339,8 +354,13 @@ __global__ __launch_bounds__(K16_THREADS, 2) void lin_bwd16_kernel(LinBwdParams 
   const B3Image Wim = w16_image(smem16, NO, K);
   char* mine = smem16 + w16_image_bytes(NO, K) + wave * (p16_bytes(NO) + p16_bytes(K));
   const B3Tile Tg = p16_tile(mine, NO), Tx = p16_tile(mine + p16_bytes(NO), K);
-  load_weight_lds_b3(Wim, 0, q.WA, q.ldWA, q.nA, K, q.nA, K, tid, K16_THREADS);
-  if (q.nB > 0) load_weight_lds_b3(Wim, q.nA, q.WB, q.ldWB, q.nB, K, NO - q.nA, K, tid, K16_THREADS);
+  {
+    WLoad16<NOB> la, lb;   // (NOB x 512 float4 cover up to 32 NOB rows of 64)
+    w16_issue(la, q.WA, q.ldWA, q.nA, K, q.nA, K, tid, K16_THREADS);
+    if (q.nB > 0) w16_issue(lb, q.WB, q.ldWB, q.nB, K, NO - q.nA, K, tid, K16_THREADS);
+    w16_commit(la, Wim, 0, q.WA, q.ldWA, q.nA, K, q.nA, K, tid, K16_THREADS);
+    if (q.nB > 0) w16_commit(lb, Wim, q.nA, q.WB, q.ldWB, q.nB, K, NO - q.nA, K, tid, K16_THREADS);
+  }
   __syncthreads();
   f32x16 dW[NOB][2];
 #pragma unroll
@@ -532,12 +552,26 @@ __global__ __launch_bounds__(K16_THREADS, 2) void mlp_fwd16_kernel(MlpParams p) 
   float* b2s = b1s + HID;
   float* gs = b2s + NO;
   float* bs = gs + NO;
-  load_weight_lds_b3(W1im, 0, p.W1, p.ldW1, HID, p.k_in, HID, KP32, tid, K16_THREADS);
-  load_weight_lds_b3(W2im, 0, p.W2, p.ldW2, p.n_out, HID, NO, HID, tid, K16_THREADS);
-  load_vec_lds(b1s, p.b1, HID, HID, tid, K16_THREADS);
-  load_vec_lds(b2s, p.b2, p.n_out, NO, tid, K16_THREADS);
-  load_vec_lds(gs, p.gamma, p.n_out, NO, tid, K16_THREADS);
-  load_vec_lds(bs, p.beta, p.n_out, NO, tid, K16_THREADS);
+  {   // every global load of the prologue in flight together (fused16.h, batched prologue loads)
+    VLoad16 lv;
+    const float* const vecs[8] = {p.b1, p.b2, p.gamma, p.beta, nullptr, nullptr, nullptr, nullptr};
+    const int lens[8] = {HID, p.n_out, p.n_out, p.n_out, 0, 0, 0, 0};
+    WLoad16<KB> l1;
+    WLoad16<NOB> l2;
+    if constexpr (NO == 64) v16_issue(lv, vecs, lens, tid);
+    w16_issue(l1, p.W1, p.ldW1, HID, p.k_in, HID, KP32, tid, K16_THREADS);
+    w16_issue(l2, p.W2, p.ldW2, p.n_out, HID, NO, HID, tid, K16_THREADS);
+    if constexpr (NO == 64) {
+      v16_commit(lv, b1s, 4, tid);
+    } else {
+      load_vec_lds(b1s, p.b1, HID, HID, tid, K16_THREADS);
+      load_vec_lds(b2s, p.b2, p.n_out, NO, tid, K16_THREADS);
+      load_vec_lds(gs, p.gamma, p.n_out, NO, tid, K16_THREADS);
+      load_vec_lds(bs, p.beta, p.n_out, NO, tid, K16_THREADS);
+    }
+    w16_commit(l1, W1im, 0, p.W1, p.ldW1, HID, p.k_in, HID, KP32, tid, K16_THREADS);
+    w16_commit(l2, W2im, 0, p.W2, p.ldW2, p.n_out, HID, NO, HID, tid, K16_THREADS);
+  }
   __syncthreads();
   const int64_t tiles_per_b = (p.rows + NLAM_T16 - 1) / NLAM_T16;
   const int64_t ntiles = tiles_per_b * p.B;
@@ -636,11 +670,14 @@ __global__ __launch_bounds__(K16_THREADS, 2) void lin_fwd16_kernel(LinParams p) 
   const int t = lane & 15;
   const B3Image Wim = w16_image(smem16, NO, K);
   float* bs = reinterpret_cast<float*>(smem16 + w16_image_bytes(NO, K));
-  load_weight_lds_b3(Wim, 0, p.WA, p.ldWA, p.nA, K, p.nA, K, tid, K16_THREADS);
-  load_vec_lds(bs, p.bA, p.nA, p.nA, tid, K16_THREADS);
-  if (p.nB > 0) {
-    load_weight_lds_b3(Wim, p.nA, p.WB, p.ldWB, p.nB, K, NO - p.nA, K, tid, K16_THREADS);
-    load_vec_lds(bs + p.nA, p.bB, p.nB, NO - p.nA, tid, K16_THREADS);
+  {
+    WLoad16<NOB> la, lb;
+    w16_issue(la, p.WA, p.ldWA, p.nA, K, p.nA, K, tid, K16_THREADS);
+    if (p.nB > 0) w16_issue(lb, p.WB, p.ldWB, p.nB, K, NO - p.nA, K, tid, K16_THREADS);
+    load_vec_lds(bs, p.bA, p.nA, p.nA, tid, K16_THREADS);
+    if (p.nB > 0) load_vec_lds(bs + p.nA, p.bB, p.nB, NO - p.nA, tid, K16_THREADS);
+    w16_commit(la, Wim, 0, p.WA, p.ldWA, p.nA, K, p.nA, K, tid, K16_THREADS);
+    if (p.nB > 0) w16_commit(lb, Wim, p.nA, p.WB, p.ldWB, p.nB, K, NO - p.nA, K, tid, K16_THREADS);
   }
   __syncthreads();
   const int64_t tiles_per_b = (p.rows + NLAM_T16 - 1) / NLAM_T16;

@@ -16,6 +16,8 @@
 //                workgroups of role A form dV1 = ga^T [x | agg] (layer l-1), role B
 //                dWp = [gPs | gPr]^T x_l (layer l).
 // hidden width 64, split-bf16 (fp32-grade) products; building blocks: fused16.h.
+#include <cstdlib>
+
 #include "fused16.h"
 #include "fused_params.h"
 
@@ -42,17 +44,27 @@ __global__ __launch_bounds__(K16_THREADS, 2) void node_fwd16_kernel(NodeFwdParam
   float* gs = c2s + D;
   float* bs = gs + D;
   float* bps = bs + D;   // 2 D
-  load_weight_lds_b3(V1im, 0, p.V1, p.ldV1, D, 2 * D, D, 2 * D, tid, K16_THREADS);
-  load_weight_lds_b3(V2im, 0, p.V2, p.ldV2, D, D, D, D, tid, K16_THREADS);
-  load_vec_lds(c1s, p.c1, D, D, tid, K16_THREADS);
-  load_vec_lds(c2s, p.c2, D, D, tid, K16_THREADS);
-  load_vec_lds(gs, p.gamma, D, D, tid, K16_THREADS);
-  load_vec_lds(bs, p.beta, D, D, tid, K16_THREADS);
-  if constexpr (HAS_PROJ) {
-    load_weight_lds_b3(Wpim, 0, p.WA, p.ldWA, D, D, D, D, tid, K16_THREADS);
-    load_weight_lds_b3(Wpim, D, p.WB, p.ldWB, D, D, D, D, tid, K16_THREADS);
-    load_vec_lds(bps, p.bA, D, D, tid, K16_THREADS);
-    load_vec_lds(bps + D, p.bB, D, D, tid, K16_THREADS);
+  {   // every global load of the prologue in flight together (fused16.h, batched prologue loads)
+    VLoad16 lv;
+    const float* const vecs[8] = {p.c1, p.c2, p.gamma, p.beta, HAS_PROJ ? p.bA : nullptr,
+                                  HAS_PROJ ? p.bB : nullptr, nullptr, nullptr};
+    const int lens[8] = {D, D, D, D, D, D, 0, 0};
+    v16_issue(lv, vecs, lens, tid);
+    WLoad16<4> l1;
+    WLoad16<2> l2, la, lb;
+    w16_issue(l1, p.V1, p.ldV1, D, 2 * D, D, 2 * D, tid, K16_THREADS);
+    w16_issue(l2, p.V2, p.ldV2, D, D, D, D, tid, K16_THREADS);
+    if constexpr (HAS_PROJ) {
+      w16_issue(la, p.WA, p.ldWA, D, D, D, D, tid, K16_THREADS);
+      w16_issue(lb, p.WB, p.ldWB, D, D, D, D, tid, K16_THREADS);
+    }
+    v16_commit(lv, c1s, 6, tid);
+    w16_commit(l1, V1im, 0, p.V1, p.ldV1, D, 2 * D, D, 2 * D, tid, K16_THREADS);
+    w16_commit(l2, V2im, 0, p.V2, p.ldV2, D, D, D, D, tid, K16_THREADS);
+    if constexpr (HAS_PROJ) {
+      w16_commit(la, Wpim, 0, p.WA, p.ldWA, D, D, D, D, tid, K16_THREADS);
+      w16_commit(lb, Wpim, D, p.WB, p.ldWB, D, D, D, D, tid, K16_THREADS);
+    }
   }
   __syncthreads();
   const int64_t tiles_per_b = (p.rows + NLAM_T16 - 1) / NLAM_T16;
@@ -161,7 +173,20 @@ __device__ __forceinline__ void gather_sender_sum16(f32x4* __restrict__ acc, con
   }
 }
 
-template <bool HAS_A, int TERMS>
+// Diagnostic (NLAM_TIMELINE_NODE=1): s_memrealtime (100 MHz) of workgroup phases of the last
+// nlam_node_bwd launch with a node update: start, weights in LDS, first tile's gather done, G
+// formed, tile loop done, slab written -- per workgroup (first 256).
+__device__ unsigned long long g_node_tl[256 * 8];
+extern "C" int nlam_debug_node_timeline(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_node_tl), sizeof(unsigned long long) * 256 * 8) ==
+                 hipSuccess ? 0 : 1;
+}
+#define NODE_TL(k)                                                                        \
+  if constexpr (TL) {                                                                     \
+    if (tid == 0 && blockIdx.x < 256) g_node_tl[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+  }
+
+template <bool HAS_A, int TERMS, bool TL = false>
 __global__ __launch_bounds__(K16_THREADS, 2) void node_bwd16_kernel(NodeBwdParams q) {
   extern __shared__ __attribute__((aligned(16))) char smem16[];
   constexpr int D = 64;
@@ -180,17 +205,32 @@ __global__ __launch_bounds__(K16_THREADS, 2) void node_bwd16_kernel(NodeBwdParam
   cur += 3 * D * sizeof(float);
   char* mine = cur + wave * (2 * p16_bytes(D));
   const B3Tile Ts = p16_tile(mine, D), Tz = p16_tile(mine + p16_bytes(D), D);
+  NODE_TL(0)
 
-  load_weight_lds_b3(Wpim, 0, q.WA, q.ldWA, D, D, D, D, tid, K16_THREADS);
-  load_weight_lds_b3(Wpim, D, q.WB, q.ldWB, D, D, D, D, tid, K16_THREADS);
-  if constexpr (HAS_A) {
-    load_weight_lds_b3(V1im, 0, q.V1, q.ldV1, D, 2 * D, D, 2 * D, tid, K16_THREADS);
-    load_weight_lds_b3(V2im, 0, q.V2, q.ldV2, D, D, D, D, tid, K16_THREADS);
-    load_vec_lds(c1s, q.c1, D, D, tid, K16_THREADS);
-    load_vec_lds(c2s, q.c2, D, D, tid, K16_THREADS);
-    load_vec_lds(gs, q.gamma, D, D, tid, K16_THREADS);
+  {   // every global load of the prologue in flight together
+    VLoad16 lv;
+    const float* const vecs[8] = {HAS_A ? q.c1 : nullptr, HAS_A ? q.c2 : nullptr,
+                                  HAS_A ? q.gamma : nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const int lens[8] = {D, D, D, 0, 0, 0, 0, 0};
+    if constexpr (HAS_A) v16_issue(lv, vecs, lens, tid);
+    WLoad16<4> l1;
+    WLoad16<2> l2, la, lb;
+    w16_issue(la, q.WA, q.ldWA, D, D, D, D, tid, K16_THREADS);
+    w16_issue(lb, q.WB, q.ldWB, D, D, D, D, tid, K16_THREADS);
+    if constexpr (HAS_A) {
+      w16_issue(l1, q.V1, q.ldV1, D, 2 * D, D, 2 * D, tid, K16_THREADS);
+      w16_issue(l2, q.V2, q.ldV2, D, D, D, D, tid, K16_THREADS);
+      v16_commit(lv, c1s, 3, tid);
+    }
+    w16_commit(la, Wpim, 0, q.WA, q.ldWA, D, D, D, D, tid, K16_THREADS);
+    w16_commit(lb, Wpim, D, q.WB, q.ldWB, D, D, D, D, tid, K16_THREADS);
+    if constexpr (HAS_A) {
+      w16_commit(l1, V1im, 0, q.V1, q.ldV1, D, 2 * D, D, 2 * D, tid, K16_THREADS);
+      w16_commit(l2, V2im, 0, q.V2, q.ldV2, D, D, D, D, tid, K16_THREADS);
+    }
   }
   __syncthreads();
+  NODE_TL(1)
 
   f32x16 dV2[2][2];
 #pragma unroll
@@ -216,6 +256,7 @@ __global__ __launch_bounds__(K16_THREADS, 2) void node_bwd16_kernel(NodeBwdParam
       f32x4 gp[8];
       gather_sender_sum16(gp, q.gh + b * q.gh_bstride, q.csc_colptr, q.csc_eid, row, q.n_send,
                           valid, lane);
+      NODE_TL(2)
       float* prow = q.gP + b * q.gp_bstride + opaque(row) * q.gp_ld;
       load_row16<4>(gp + 4, prow + D, lane);
       if (valid) store_row16<4>(prow, gp, lane);
@@ -227,6 +268,7 @@ __global__ __launch_bounds__(K16_THREADS, 2) void node_bwd16_kernel(NodeBwdParam
       for (int fb = 0; fb < 4; ++fb) G[fb] += ad[fb];
     }
     __builtin_amdgcn_sched_barrier(0);
+    NODE_TL(3)
     if constexpr (!HAS_A) {
       if (valid) store_row16<4>(q.gx_out + b * q.gx_bstride + (r0 + t) * q.gx_ld, G, lane);
     } else {
@@ -294,15 +336,16 @@ __global__ __launch_bounds__(K16_THREADS, 2) void node_bwd16_kernel(NodeBwdParam
       wave_sync();   // the planes are rewritten by the next tile
     }
   }
+  NODE_TL(4)
   if constexpr (HAS_A) {
     __syncthreads();
     float* img = reinterpret_cast<float*>(smem16);   // weights and planes are dead
     float* slab = q.slab + (int64_t)blockIdx.x * q.slab_stride;
     fold_blocks_to_slab16<2, 2, 2, K16_NW>(&dV2[0][0], img, D, slab, tid, wave, lane);
-    fold_vec_to_slab16<1, K16_NW>(dc2, img, slab + D * D, D, tid, wave, lane);
-    fold_vec_to_slab16<1, K16_NW>(dgam, img, slab + D * D + D, D, tid, wave, lane);
-    fold_vec_to_slab16<1, K16_NW>(dbet, img, slab + D * D + 2 * D, D, tid, wave, lane);
+    const float v3[3] = {dc2[0], dgam[0], dbet[0]};   // contiguous in the slab: one pass
+    fold_vec_to_slab16<3, K16_NW>(v3, img, slab + D * D, 3 * D, tid, wave, lane);
   }
+  NODE_TL(5)
 }
 
 // slab floats per workgroup: [dV2 64 x 64 | dc2 | dgamma | dbeta]
@@ -328,7 +371,12 @@ static int launch_node_bwd16(const NodeBwdParams& q, hipStream_t s) {
   if (has_a && fold > lds) lds = fold;
   NLAM_REQUIRE(lds <= 160 * 1024, "node_bwd16: LDS footprint %zu B exceeds 160 KiB", lds);
   const int64_t g = nlam_node_bwd_grid(q.B, q.rows);
-  if (has_a) {
+  static const bool tl = getenv("NLAM_TIMELINE_NODE") != nullptr;
+  if (has_a && tl) {
+    auto kern = node_bwd16_kernel<true, 3, true>;
+    NLAM_BIG_LDS(kern, __func__);
+    kern<<<(unsigned)g, K16_THREADS, lds, s>>>(q);
+  } else if (has_a) {
     auto kern = node_bwd16_kernel<true, 3>;
     NLAM_BIG_LDS(kern, __func__);
     kern<<<(unsigned)g, K16_THREADS, lds, s>>>(q);
