@@ -205,9 +205,16 @@ __global__ __launch_bounds__(K16_THREADS, 4) void edge_fwd16_kernel(EdgeFwdParam
   float* bs = gs + D;
   float* tile = bs + D + wave * (NLAM_T16 * LDT);
   if (HAS_EGEMM) load_weight_lds_b3(W1im, 0, p.W1e, p.ldW1e, D, D, D, D, tid, K16_THREADS);
-  load_weight_lds_b3(W2im, 0, p.W2, p.ldW2, D, D, D, D, tid, K16_THREADS);
-  load_vec_lds(b2s, p.b2, D, D, tid, K16_THREADS);
-  load_vec_lds(gs, p.gamma, D, D, tid, K16_THREADS);
+  {   // (batched prologue loads: one global round trip)
+    VLoad16 lv;
+    const float* const vecs[8] = {p.b2, p.gamma, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const int lens[8] = {D, D, 0, 0, 0, 0, 0, 0};
+    v16_issue(lv, vecs, lens, tid);
+    WLoad16<2> l2;
+    w16_issue(l2, p.W2, p.ldW2, D, D, D, D, tid, K16_THREADS);
+    v16_commit(lv, b2s, 2, tid);
+    w16_commit(l2, W2im, 0, p.W2, p.ldW2, D, D, D, D, tid, K16_THREADS);
+  }
   load_vec_lds(bs, p.beta, D, D, tid, K16_THREADS);
   __syncthreads();
 
@@ -402,9 +409,16 @@ __global__ __launch_bounds__(K16_THREADS, 2) void edge_bwd16_kernel(EdgeBwdParam
   static_assert(p16_bytes(D) == (size_t)NLAM_T16 * LDT * sizeof(float), "fp32 tile = plane pair");
   const B3Tile TA = p16_tile(mine, D), TB = p16_tile(mine + p16_bytes(D), D);
   float* HS = reinterpret_cast<float*>(mine + 2 * p16_bytes(D));
-  load_weight_lds_b3(W2im, 0, p.W2, p.ldW2, D, D, D, D, tid, K16_THREADS);
-  load_vec_lds(b2s, p.b2, D, D, tid, K16_THREADS);
-  load_vec_lds(gs, p.gamma, D, D, tid, K16_THREADS);
+  {   // (batched prologue loads: one global round trip)
+    VLoad16 lv;
+    const float* const vecs[8] = {p.b2, p.gamma, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const int lens[8] = {D, D, 0, 0, 0, 0, 0, 0};
+    v16_issue(lv, vecs, lens, tid);
+    WLoad16<2> l2;
+    w16_issue(l2, p.W2, p.ldW2, D, D, D, D, tid, K16_THREADS);
+    v16_commit(lv, b2s, 2, tid);
+    w16_commit(l2, W2im, 0, p.W2, p.ldW2, D, D, D, D, tid, K16_THREADS);
+  }
   __syncthreads();
 
   f32x16 dW2[2][2];

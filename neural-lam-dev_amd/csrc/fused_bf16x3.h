@@ -108,6 +108,82 @@ __device__ __forceinline__ void load_weight_lds_b3(const B3Image& im, int row0,
   }
 }
 
+// ---- batched prologue loads ---------------------------------------------------------------
+// The prologue (weights -> split -> LDS) is a fixed cost of every launch, and most launches of the
+// node side are one tile per wavefront: measured 5.3 us of a 35 us nlam_node_bwd for three images
+// loaded one after the other (tools/node_timeline.py) -- one global round trip each.  Batched
+// form: w16_issue() for EVERY image (and v16_issue() for the vectors) first, then the commits, so
+// that all global loads of the prologue are in flight together.  NU = float4 loads per thread =
+// ceil(n_pad * k_pad32 / 4 / nthreads).  Unaligned / narrow weights fall back to
+// load_weight_lds_b3 at commit time.
+template <int NU>
+struct WLoad16 {
+  f32x4 v[NU];
+  bool vec;
+};
+template <int NU>
+__device__ __forceinline__ void w16_issue(WLoad16<NU>& w, const float* __restrict__ W, int64_t ldW,
+                                          int n_out, int k_in, int n_pad, int k_pad32, int tid,
+                                          int nthreads) {
+  w.vec = (k_in % 4 == 0) && (ldW % 4 == 0) && ((reinterpret_cast<uintptr_t>(W) & 15u) == 0) &&
+          (int64_t)NU * nthreads * 4 >= (int64_t)n_pad * k_pad32;
+  if (w.vec) {
+    const int cpr = k_pad32 >> 2;
+    const int total = n_pad * cpr;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int idx = u * nthreads + tid;
+      const int i = idx / cpr, c = idx - i * cpr;
+      const bool ok = idx < total && i < n_out && 4 * c < k_in;
+      w.v[u] = ok ? *reinterpret_cast<const f32x4*>(W + (int64_t)i * ldW + 4 * c)
+                  : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+}
+template <int NU>
+__device__ __forceinline__ void w16_commit(const WLoad16<NU>& w, const B3Image& im, int row0,
+                                           const float* __restrict__ W, int64_t ldW, int n_out,
+                                           int k_in, int n_pad, int k_pad32, int tid, int nthreads) {
+  if (w.vec) {
+    const int cpr = k_pad32 >> 2;
+    const int total = n_pad * cpr;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int idx = u * nthreads + tid;
+      if (idx < total) {
+        const int i = idx / cpr, c = idx - i * cpr;
+        bf16x4 hi, lo;
+        b3_split4(w.v[u], hi, lo);
+        *reinterpret_cast<bf16x4*>(im.hi + (row0 + i) * im.pitch + 4 * c) = hi;
+        *reinterpret_cast<bf16x4*>(im.lo + (row0 + i) * im.pitch + 4 * c) = lo;
+      }
+    }
+  } else {
+    load_weight_lds_b3(im, row0, W, ldW, n_out, k_in, n_pad, k_pad32, tid, nthreads);
+  }
+}
+// up to 8 per-feature vectors of <= 64 entries (vector tid >> 6, entry tid & 63: 512 threads cover
+// 8 vectors, 256 threads 4) in ONE load instruction; a NULL vector reads as zeros.  dst: 64-float
+// slots, one per vector.
+struct VLoad16 {
+  float v;
+};
+__device__ __forceinline__ void v16_issue(VLoad16& l, const float* const (&vec)[8], const int (&len)[8],
+                                          int tid) {
+  const int j = tid >> 6, i = tid & 63;
+  const float* p = vec[0];
+  int n = len[0];
+#pragma unroll
+  for (int k = 1; k < 8; ++k) {
+    p = j == k ? vec[k] : p;
+    n = j == k ? len[k] : n;
+  }
+  l.v = (j < 8 && p != nullptr && i < n) ? p[i] : 0.f;
+}
+__device__ __forceinline__ void v16_commit(const VLoad16& l, float* __restrict__ dst, int nvec, int tid) {
+  if ((tid >> 6) < nvec) dst[tid] = l.v;
+}
+
 // eight consecutive accumulator registers -> hi / lo bf16 fragments (the B operand of the
 // K = 16 step that covers features 16 s .. 16 s + 15 of a 32-feature block: lane half h
 // holds features 16 s + 4 h + {0..3} and 16 s + 8 + 4 h + {0..3} in registers 8 s .. 8 s + 7)

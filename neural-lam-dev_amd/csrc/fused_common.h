@@ -101,6 +101,29 @@ __device__ __forceinline__ void load_vec_lds(float* __restrict__ vs, const float
   for (int i = tid; i < n_pad; i += nthreads) vs[i] = (v != nullptr && i < n) ? v[i] : 0.f;
 }
 
+// Several per-feature vectors (n_pad <= nthreads entries each) with their global loads issued
+// together -- and BEFORE the weight image's loads when vecs_issue() is called first: the prologue
+// of a launch is then one global round trip instead of one per vector (it is a fixed cost of
+// every launch, and most launches of the hierarchical models are small).
+template <int NV>
+struct VecLoads {
+  float v[NV];
+};
+template <int NV>
+__device__ __forceinline__ void vecs_issue(VecLoads<NV>& l, const float* const (&src)[NV], int n,
+                                           int tid) {
+#pragma unroll
+  for (int j = 0; j < NV; ++j) l.v[j] = (src[j] != nullptr && tid < n) ? src[j][tid] : 0.f;
+}
+template <int NV>
+__device__ __forceinline__ void vecs_commit(const VecLoads<NV>& l, float* const (&dst)[NV], int n_pad,
+                                            int tid) {
+  if (tid < n_pad) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) dst[j][tid] = l.v[j];
+  }
+}
+
 // ---- row staging: global rows -> LDS tile ------------------------------------
 // Tile row t (< nrows) comes from src + row_off(t); `width` floats are copied to
 // columns [col0, col0 + width); vectorised when width % 4 == 0 and the source

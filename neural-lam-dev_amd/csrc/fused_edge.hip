@@ -70,16 +70,30 @@ __global__ __launch_bounds__(256, 2) void edge_fwd_kernel(EdgeFwdParams p) {
   // per-wave slot-index tables [eid | send | rec] (see lane_row_index)
   int* itab = reinterpret_cast<int*>(bs + D + 4 * (NLAM_TILE * LDT)) + wave * (3 * NLAM_TILE);
   const B3Image W1im = b3_image(W1s, D, D), W2im = b3_image(W2s, D, D);
-  if (B3) {
-    if (HAS_EGEMM) load_weight_lds_b3(W1im, 0, p.W1e, p.ldW1e, D, D, D, D, tid, 256);
-    load_weight_lds_b3(W2im, 0, p.W2, p.ldW2, D, D, D, D, tid, 256);
+  if (B3 && D == 64) {
+    // every global load of the prologue in flight together (fused_bf16x3.h, batched prologue loads)
+    VLoad16 lv;
+    const float* const vecs[8] = {p.b2, p.gamma, p.beta, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const int lens[8] = {D, D, D, 0, 0, 0, 0, 0};
+    v16_issue(lv, vecs, lens, tid);
+    WLoad16<D * D / 4 / 256> l1, l2;
+    if (HAS_EGEMM) w16_issue(l1, p.W1e, p.ldW1e, D, D, D, D, tid, 256);
+    w16_issue(l2, p.W2, p.ldW2, D, D, D, D, tid, 256);
+    v16_commit(lv, b2s, 3, tid);
+    if (HAS_EGEMM) w16_commit(l1, W1im, 0, p.W1e, p.ldW1e, D, D, D, D, tid, 256);
+    w16_commit(l2, W2im, 0, p.W2, p.ldW2, D, D, D, D, tid, 256);
   } else {
-    if (HAS_EGEMM) load_weight_lds(W1s, p.W1e, p.ldW1e, D, D, D, D, tid, 256);
-    load_weight_lds(W2s, p.W2, p.ldW2, D, D, D, D, tid, 256);
+    if (B3) {
+      if (HAS_EGEMM) load_weight_lds_b3(W1im, 0, p.W1e, p.ldW1e, D, D, D, D, tid, 256);
+      load_weight_lds_b3(W2im, 0, p.W2, p.ldW2, D, D, D, D, tid, 256);
+    } else {
+      if (HAS_EGEMM) load_weight_lds(W1s, p.W1e, p.ldW1e, D, D, D, D, tid, 256);
+      load_weight_lds(W2s, p.W2, p.ldW2, D, D, D, D, tid, 256);
+    }
+    load_vec_lds(b2s, p.b2, D, D, tid, 256);
+    load_vec_lds(gs, p.gamma, D, D, tid, 256);
+    load_vec_lds(bs, p.beta, D, D, tid, 256);
   }
-  load_vec_lds(b2s, p.b2, D, D, tid, 256);
-  load_vec_lds(gs, p.gamma, D, D, tid, 256);
-  load_vec_lds(bs, p.beta, D, D, tid, 256);
   __syncthreads();
 
   constexpr int NV = D / 8;
@@ -299,15 +313,28 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
   // per-wave slot-index tables, double-buffered over tiles: [2][eid | send | rec][32]
   int* itab = reinterpret_cast<int*>(T0base + 4 * WSTRIDE) + wave * (6 * NLAM_TILE);
   const B3Image W1im = b3_image(W1s, D, D), W2im = b3_image(W2s, D, D);
-  if (B3) {
-    if (HAS_EGEMM) load_weight_lds_b3(W1im, 0, p.W1e, p.ldW1e, D, D, D, D, tid, 256);
-    load_weight_lds_b3(W2im, 0, p.W2, p.ldW2, D, D, D, D, tid, 256);
+  if (B3 && D == 64) {
+    VLoad16 lv;   // (batched prologue loads: one global round trip)
+    const float* const vecs[8] = {p.b2, p.gamma, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const int lens[8] = {D, D, 0, 0, 0, 0, 0, 0};
+    v16_issue(lv, vecs, lens, tid);
+    WLoad16<D * D / 4 / 256> l1, l2;
+    if (HAS_EGEMM) w16_issue(l1, p.W1e, p.ldW1e, D, D, D, D, tid, 256);
+    w16_issue(l2, p.W2, p.ldW2, D, D, D, D, tid, 256);
+    v16_commit(lv, b2s, 2, tid);
+    if (HAS_EGEMM) w16_commit(l1, W1im, 0, p.W1e, p.ldW1e, D, D, D, D, tid, 256);
+    w16_commit(l2, W2im, 0, p.W2, p.ldW2, D, D, D, D, tid, 256);
   } else {
-    if (HAS_EGEMM) load_weight_lds(W1s, p.W1e, p.ldW1e, D, D, D, D, tid, 256);
-    load_weight_lds(W2s, p.W2, p.ldW2, D, D, D, D, tid, 256);
+    if (B3) {
+      if (HAS_EGEMM) load_weight_lds_b3(W1im, 0, p.W1e, p.ldW1e, D, D, D, D, tid, 256);
+      load_weight_lds_b3(W2im, 0, p.W2, p.ldW2, D, D, D, D, tid, 256);
+    } else {
+      if (HAS_EGEMM) load_weight_lds(W1s, p.W1e, p.ldW1e, D, D, D, D, tid, 256);
+      load_weight_lds(W2s, p.W2, p.ldW2, D, D, D, D, tid, 256);
+    }
+    load_vec_lds(b2s, p.b2, D, D, tid, 256);
+    load_vec_lds(gs, p.gamma, D, D, tid, 256);
   }
-  load_vec_lds(b2s, p.b2, D, D, tid, 256);
-  load_vec_lds(gs, p.gamma, D, D, tid, 256);
   __syncthreads();
   const B3Tile T0p = b3_tile(T0, D), T1p = b3_tile(T1, D), T2p = b3_tile(T2, D);
 

@@ -128,10 +128,15 @@ __global__ __launch_bounds__(256) void tail_fwd_kernel(TailFwdParams p) {
   // per-wave slot-index tables [a | b | c | y] (see lane_row_index)
   int* itab = reinterpret_cast<int*>(bs + NO + 4 * (NLAM_TILE * LDT)) + wave * (4 * NLAM_TILE);
   const B3Image W2im = b3_image(W2s, NO, D);
-  load_weight_lds_b3(W2im, 0, p.W2, p.ldW2, p.n_out, D, NO, D, tid, 256);
-  load_vec_lds(b2s, p.b2, p.n_out, NO, tid, 256);
-  load_vec_lds(gs, p.gamma, p.n_out, NO, tid, 256);
-  load_vec_lds(bs, p.beta, p.n_out, NO, tid, 256);
+  {
+    static_assert(NO <= 256, "one vector entry per thread");
+    VecLoads<3> lv;
+    const float* const vsrc[3] = {p.b2, p.gamma, p.beta};
+    float* const vdst[3] = {b2s, gs, bs};
+    vecs_issue(lv, vsrc, p.n_out, tid);
+    load_weight_lds_b3(W2im, 0, p.W2, p.ldW2, p.n_out, D, NO, D, tid, 256);
+    vecs_commit(lv, vdst, NO, tid);
+  }
   __syncthreads();
 
   // slot indices of a tile (lanes 0..31), fetched ONE TILE AHEAD so that the row gathers do
@@ -374,9 +379,15 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(TailBwdParams q) {
   float* tile = gs + NO + wave * (NLAM_TILE * LDT);
   int* itab = reinterpret_cast<int*>(gs + NO + 4 * (NLAM_TILE * LDT)) + wave * (4 * NLAM_TILE);
   const B3Image W2im = b3_image(W2s, NO, D);
-  load_weight_lds_b3(W2im, 0, q.W2, q.ldW2, q.n_out, D, NO, D, tid, 256);
-  load_vec_lds(b2s, q.b2, q.n_out, NO, tid, 256);
-  load_vec_lds(gs, q.gamma, q.n_out, NO, tid, 256);
+  {
+    static_assert(NO <= 256, "one vector entry per thread");
+    VecLoads<2> lv;
+    const float* const vsrc[2] = {q.b2, q.gamma};
+    float* const vdst[2] = {b2s, gs};
+    vecs_issue(lv, vsrc, q.n_out, tid);
+    load_weight_lds_b3(W2im, 0, q.W2, q.ldW2, q.n_out, D, NO, D, tid, 256);
+    vecs_commit(lv, vdst, NO, tid);
+  }
   __syncthreads();
 
   // per-feature partial sums (lanes = features 64 j + lane), accumulated over the tiles
@@ -1078,8 +1089,15 @@ __device__ __forceinline__ void wide_lin_fwd_body(const WideLinParams& p, int bi
   const B3Image W = b3_image(smem, NO, K);
   float* bs = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + b3_image_bytes(NO, K));
   float* tile = bs + NO + wave * (NLAM_TILE * ldt);
-  load_weight_lds_b3(W, 0, p.W, p.ldW, NO, K, NO, K, tid, 256);
-  load_vec_lds(bs, p.bias, NO, NO, tid, 256);
+  {
+    static_assert(NO <= 256, "one vector entry per thread");
+    VecLoads<1> lv;
+    const float* const vsrc[1] = {p.bias};
+    float* const vdst[1] = {bs};
+    vecs_issue(lv, vsrc, NO, tid);
+    load_weight_lds_b3(W, 0, p.W, p.ldW, NO, K, NO, K, tid, 256);
+    vecs_commit(lv, vdst, NO, tid);
+  }
   __syncthreads();
   const int64_t tiles_per_b = (p.rows + NLAM_TILE - 1) / NLAM_TILE;
   const int64_t ntiles = tiles_per_b * p.B;
