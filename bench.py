@@ -312,12 +312,18 @@ def main():
 
     graphed = None
     launch = {"mode": "eager"}
-    # Multi-rank runs launch eagerly by default (gradient buckets go out from backward hooks).
-    # NLAM_BENCH_MULTIRANK_GRAPH=probe additionally captures the step and takes the faster of the
-    # two schedules -- worth it when eager launching is host-bound (Hi-LAM at hidden 64: ~40 us
-    # of host time per launch); opt-in because it could only be rehearsed with two gloo ranks
-    # stacked on one GPU, where a captured-but-unused graph slowed later eager steps.
-    multirank_graph = os.environ.get("NLAM_BENCH_MULTIRANK_GRAPH", "off") == "probe"
+    # Multi-rank runs time BOTH schedules for a few steps and keep the faster one (max over ranks):
+    # eager launches with gradient buckets all-reduced from backward hooks (overlap, but ~40 us of
+    # host time per launch: host-bound once a step is ~100 short kernels), or HIP-graph replay of
+    # forward + backward + packing with the buckets all-reduced after it.
+    # NLAM_BENCH_MULTIRANK_GRAPH=off skips the capture and stays eager; =probe forces the probe.
+    # Default: probe on RCCL (one process per GPU); off for the gloo rehearsal, where the ranks
+    # are stacked on ONE card: replaying a HIP graph there adds hardware queues per process, the
+    # card's queues become oversubscribed and every later step of both ranks (eager ones too) is
+    # time-sliced at ~100 ms granularity (measured: GraphLAM-64 14 ms eager -> 600 ms; r03 notes).
+    backend_name = os.environ.get("NLAM_BENCH_BACKEND", "nccl")
+    multirank_graph = os.environ.get(
+        "NLAM_BENCH_MULTIRANK_GRAPH", "probe" if backend_name == "nccl" else "off") == "probe"
     if not args.no_graph and (world == 1 or multirank_graph):
         reducer.hooks_enabled = False      # no collectives inside the capture
         graphed = parallel.GraphedTrainStep(model, flat, batch)
@@ -352,6 +358,9 @@ def main():
         use_graph = bool(t_pair[1] < t_pair[0])
         launch["probe_ms"] = {"eager_overlap": float(t_pair[0]) * 1e3,
                               "hip_graph_trailing_allreduce": float(t_pair[1]) * 1e3}
+        if not use_graph:   # do not keep a captured graph (and its memory pool) around unused
+            graphed = None
+            torch.cuda.empty_cache()
     reducer.hooks_enabled = not use_graph
     if use_graph:
         launch["mode"] = "hip_graph" if world == 1 else "hip_graph+trailing_allreduce"
