@@ -469,7 +469,8 @@ int nlam_wide_outer(const float* g, int64_t g_bstride, int64_t g_ld, int ng,
 /* Several INDEPENDENT problems of one kind in one launch (n <= 8; arrays of n entries): the small
  * mesh levels of Hi-LAM (reference hi_lam.py:82-207: 10 InteractionNets per processor layer on
  * 81 ... 6,561-node levels) are bound by the latency of their launches, not by their work.
- * nlam_lin_fwd_multi: out_k = x_k W_k^T + bias_k (bias_k may be NULL), all d -> d.
+ * nlam_lin_fwd_multi: out_k = x_k W_k^T + bias_k (bias_k may be NULL), all d -> d; d = 64 (n <= 4,
+ * needs nlam_lin_multi_supported()), 128, or 256.
  * nlam_lin_bwd_data_multi / nlam_wide_outer_multi: as the single forms, all d x d.
  * d = 128, or 256 (NLAM_MFMA=bf16 only).  nlam_wide_outer_multi: nslabs[k] = slabs (= workgroups)
  * of problem k, chosen by the caller -- proportional to the problems' row counts with ~512 in
@@ -479,6 +480,32 @@ int nlam_lin_fwd_multi(int n, int d, const float* const* x, const int64_t* x_bst
                        const float* const* W, const int64_t* ldW, const float* const* bias,
                        float* const* out, const int64_t* out_bstride, const int64_t* out_ld,
                        const int64_t* B, const int64_t* rows, int out_bf16_mask, void* stream);
+/* Hidden width 64: the sender / receiver / edge thirds of an InteractionNet's first edge-MLP Linear
+ * (interaction_net.py:121) differentiated in ONE launch (n <= 4 independent problems, d = 64):
+ *   gx_k = gy_k W_k (+ gx_add_k)   (gx_k may be NULL), per-workgroup slabs [dW_k 64x64 | db_k 64]
+ *   with dW_k = gy_k^T x_k, db_k = colsum gy_k: nlam_bwd_grid(B_k * ceil(rows_k / 32)) slabs of pitch
+ *   slab_stride_k >= 64*64 + 64 each.
+ * gy_nsum_k > 1: x_k is batch-invariant (B_k = 1) and gy_k is summed over gy_nsum_k slices
+ * gy_sum_stride_k apart while it is read.  gh_k != NULL: gy_k is not read but FORMED as the sum of
+ * the rows gh_k[eid] (B, M, 64; batch / slice pitch gh_bstride_k) over the row's sender list
+ * (csc_colptr_k / csc_eid_k, rows >= n_send_k have none) -- the sender-side scatter of the
+ * reference's autograd for edge_index[0], as a gather.
+ * xb_k != NULL: problem k is instead the DEFERRED first-layer weight gradient of a node update
+ * (what nlam_mlp_bwd leaves to nlam_outer_bwd): W_k = gx_k = gh_k = NULL, gy_k = the stored hidden
+ * gradient, slabs [dW_k 64x128 | db_k 64] with dW_k = gy_k^T [x_k | xb_k] (pitch >= 64*128 + 64).
+ * nlam_lin_multi_supported(): 1 = available in this process's arithmetic mode. */
+int nlam_lin_multi_supported(void);
+int nlam_lin_bwd_multi(int n, int d, const float* const* x, const int64_t* x_bstride, const int64_t* x_ld,
+                       const float* const* xb, const int64_t* xb_bstride, const int64_t* xb_ld,
+                       const float* const* gy, const int64_t* gy_bstride, const int64_t* gy_ld,
+                       const float* const* W, const int64_t* ldW,
+                       float* const* gx, const int64_t* gx_bstride, const int64_t* gx_ld,
+                       const float* const* gx_add, const int64_t* ga_bstride, const int64_t* ga_ld,
+                       const int64_t* gy_nsum, const int64_t* gy_sum_stride,
+                       const float* const* gh, const int64_t* gh_bstride,
+                       const int32_t* const* csc_colptr, const int32_t* const* csc_eid,
+                       const int64_t* n_send, float* const* slab, const int64_t* slab_stride,
+                       const int64_t* B, const int64_t* rows, void* stream);
 int nlam_lin_bwd_data_multi(int n, int d, const float* const* gy, const int64_t* gy_bstride,
                             const int64_t* gy_ld, const float* const* W, const int64_t* ldW,
                             float* const* gx, const int64_t* gx_bstride, const int64_t* gx_ld,

@@ -44,6 +44,8 @@ SIGNATURES = {
     "nlam_outer_bwd_slab_stride": [_i32, _i32],
     "nlam_outer_bwd": [_p, _i64, _i64, _i32, _p, _i64, _i64, _i32, _p, _i64, _i64, _i32, _p, _p,
                        _i64, _i64, _i64, _p],
+    "nlam_lin_multi_supported": [],
+    "nlam_lin_bwd_multi": [_i32, _i32] + [_p] * 28 + [_p],
     "nlam_node_chain_supported": [],
     "nlam_node_fwd": [_p, _i64, _i64, _p, _i64, _i64, _p, _i64, _p, _p, _i64, _p, _p, _p,
                       _p, _i64, _i64, _p, _i64, _p, _p, _i64, _p, _p, _i64, _i64, _i64, _i64, _p],

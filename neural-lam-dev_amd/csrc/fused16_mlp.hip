@@ -342,11 +342,12 @@ int nlam_k16_mlp_bwd(const MlpBwdParams& q, hipStream_t s) {
 
 // ====================================================== projection backward
 // y = x [WA; WB]^T (+ b): gx = gy [WA; WB] (+ gx_add), dW = gy^T x, db = colsum(gy); k_in = 64,
-// n_out = 32 NOB in {64, 128}, 16-byte aligned views.  SUMGY: x is batch-invariant and gy is
-// summed over its gy_nsum batch slices while it is loaded (fixed order).
-template <int NOB, bool SUMGY, int TERMS>
-__global__ __launch_bounds__(K16_THREADS, 2) void lin_bwd16_kernel(LinBwdParams q) {
-  extern __shared__ __attribute__((aligned(16))) char smem16[];
+// n_out = 32 NOB in {64, 128}, 16-byte aligned views.  gy_nsum > 1: x is batch-invariant and gy
+// is summed over its gy_nsum batch slices while it is loaded (fixed order).  gh != NULL: columns
+// [0, 64) of gy are the sums of the edge-gradient rows over the row's sender list (fused16.h,
+// gather_sender_sum16) instead of a stored tensor.  One workgroup `wg` of `nwg` of a problem.
+template <int NOB, int TERMS, bool GATHER>
+__device__ __forceinline__ void lin_bwd16_body(const LinBwdParams& q, int wg, int nwg, char* smem16) {
   constexpr int K = 64, KF = 4, NO = 32 * NOB, NFO = 2 * NOB, NV = NOB / 2;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
@@ -375,8 +376,7 @@ __global__ __launch_bounds__(K16_THREADS, 2) void lin_bwd16_kernel(LinBwdParams 
 
   const int64_t tiles_per_b = (q.rows + NLAM_T16 - 1) / NLAM_T16;
   const int64_t ntiles = tiles_per_b * q.B;
-  for (int64_t tt = (int64_t)blockIdx.x * K16_NW + wave; tt < ntiles;
-       tt += (int64_t)gridDim.x * K16_NW) {
+  for (int64_t tt = (int64_t)wg * K16_NW + wave; tt < ntiles; tt += (int64_t)nwg * K16_NW) {
     const int64_t b = tt / tiles_per_b;
     const int64_t r0 = (tt - b * tiles_per_b) * NLAM_T16;
     const int nrows = (int)((q.rows - r0) < NLAM_T16 ? (q.rows - r0) : NLAM_T16);
@@ -385,8 +385,28 @@ __global__ __launch_bounds__(K16_THREADS, 2) void lin_bwd16_kernel(LinBwdParams 
     f32x4 x[KF], g[NFO];
     load_row16<KF>(x, q.x.ptr + b * q.x.bstride + row * q.x.ld, lane);
     const float* rg = q.gy.ptr + b * q.gy.bstride + row * q.gy.ld;
-    load_row16<NFO>(g, rg, lane);
-    if constexpr (SUMGY) {
+    constexpr int F0 = 4;   // quads of the gathered sender block
+    if (GATHER && q.gh != nullptr) {
+      gather_sender_sum16(g, q.gh + b * q.gh_bstride, q.csc_colptr, q.csc_eid, row, q.n_send, valid,
+                          lane);
+      for (int sl = 1; sl < q.gy_nsum; ++sl) {
+        f32x4 tv[F0];
+        gather_sender_sum16(tv, q.gh + (b + sl) * q.gh_bstride, q.csc_colptr, q.csc_eid, row, q.n_send,
+                            valid, lane);
+#pragma unroll
+        for (int fb = 0; fb < F0; ++fb) g[fb] += tv[fb];
+      }
+      if constexpr (NFO > F0) {
+        load_row16<NFO - F0>(g + F0, rg + 16 * F0, lane);
+        for (int sl = 1; sl < q.gy_nsum; ++sl) {
+          f32x4 tv[NFO - F0];
+          load_row16<NFO - F0>(tv, rg + 16 * F0 + (int64_t)sl * q.gy_sum_stride, lane);
+#pragma unroll
+          for (int fb = 0; fb < NFO - F0; ++fb) g[F0 + fb] += tv[fb];
+        }
+      }
+    } else {
+      load_row16<NFO>(g, rg, lane);
       for (int sl = 1; sl < q.gy_nsum; ++sl) {
         f32x4 tv[NFO];
         load_row16<NFO>(tv, rg + (int64_t)sl * q.gy_sum_stride, lane);
@@ -416,7 +436,7 @@ __global__ __launch_bounds__(K16_THREADS, 2) void lin_bwd16_kernel(LinBwdParams 
   }
   __syncthreads();
   float* img = reinterpret_cast<float*>(smem16);
-  float* slab = q.slab + (int64_t)blockIdx.x * q.slab_stride;
+  float* slab = q.slab + (int64_t)wg * q.slab_stride;
   // 64 output rows at a time (8 x 64 x 64 floats = 128 KB of images)
 #pragma unroll
   for (int h2 = 0; h2 < NOB / 2; ++h2)
@@ -424,14 +444,48 @@ __global__ __launch_bounds__(K16_THREADS, 2) void lin_bwd16_kernel(LinBwdParams 
   fold_vec_to_slab16<NV, K16_NW>(db, img, slab + NO * K, NO, tid, wave, lane);
 }
 
-template <int NOB, bool SUMGY>
-static int launch_lin_bwd16(const LinBwdParams& q, hipStream_t s) {
+template <int NOB, int TERMS>
+__global__ __launch_bounds__(K16_THREADS, 2) void lin_bwd16_kernel(LinBwdParams q) {
+  extern __shared__ __attribute__((aligned(16))) char smem16[];
+  lin_bwd16_body<NOB, TERMS, false>(q, (int)blockIdx.x, (int)gridDim.x, smem16);
+}
+
+// several independent projections in one launch (the sender / receiver / edge thirds of an
+// InteractionNet's first edge-MLP Linear, interaction_net.py:121: three row sets, three weights)
+#define K16_MAXP 4
+template <int NXB, int TERMS>
+__device__ __forceinline__ void outer_bwd16_body(const OuterParams& q, int wg, int nwg, char* smem16);
+// kind 0: a projection (q); kind 1: a deferred 64 x 128 first-layer weight gradient (o)
+struct LinBwdMulti {
+  LinBwdParams q[K16_MAXP];
+  OuterParams o[K16_MAXP];
+  int kind[K16_MAXP];
+  int n;
+  int wg0[K16_MAXP + 1];   // first workgroup of problem k
+};
+template <int TERMS>
+__global__ __launch_bounds__(K16_THREADS, 2) void lin_bwd16_multi_kernel(LinBwdMulti m) {
+  extern __shared__ __attribute__((aligned(16))) char smem16[];
+  int k = 0;
+  while (k + 1 < m.n && (int)blockIdx.x >= m.wg0[k + 1]) ++k;
+  const int wg = (int)blockIdx.x - m.wg0[k], nwg = m.wg0[k + 1] - m.wg0[k];
+  if (m.kind[k] == 1) outer_bwd16_body<4, TERMS>(m.o[k], wg, nwg, smem16);
+  else lin_bwd16_body<2, TERMS, true>(m.q[k], wg, nwg, smem16);
+}
+
+template <int NOB>
+static size_t lin_bwd16_lds() {
   constexpr int K = 64, NO = 32 * NOB;
   size_t lds = w16_image_bytes(NO, K) + K16_NW * (p16_bytes(NO) + p16_bytes(K));
   const size_t fold = (size_t)K16_NW * 64 * K * sizeof(float);
-  if (fold > lds) lds = fold;
+  return fold > lds ? fold : lds;
+}
+
+template <int NOB>
+static int launch_lin_bwd16(const LinBwdParams& q, hipStream_t s) {
+  const size_t lds = lin_bwd16_lds<NOB>();
   NLAM_REQUIRE(lds <= 160 * 1024, "lin_bwd16: LDS footprint %zu B exceeds 160 KiB", lds);
-  auto kern = lin_bwd16_kernel<NOB, SUMGY, 3>;
+  auto kern = lin_bwd16_kernel<NOB, 3>;
   NLAM_BIG_LDS(kern, __func__);
   const int64_t ntiles32 = ((q.rows + 31) / 32) * q.B;
   kern<<<(unsigned)nlam_bwd_grid(ntiles32), K16_THREADS, lds, s>>>(q);
@@ -439,27 +493,67 @@ static int launch_lin_bwd16(const LinBwdParams& q, hipStream_t s) {
   return 0;
 }
 
+static bool lin_bwd16_ok(const LinBwdParams& q) {
+  if (q.x.width != 64 || !q.vec_x || !q.vec_gy) return false;
+  if (q.gx != nullptr && !q.vec_gx) return false;
+  return true;
+}
+
 int nlam_k16_lin_bwd(const LinBwdParams& q, hipStream_t s) {
   if (!nlam_k16_on(K16_LIN_BWD) || !nlam_mfma_b3()) return -1;
   const int n_out = q.nA + q.nB;
-  if (q.x.width != 64 || !q.vec_x || !q.vec_gy) return -1;
-  if (q.gx != nullptr && !q.vec_gx) return -1;
-  if (q.gy_nsum > 1) {
-    if (n_out == 64) return launch_lin_bwd16<2, true>(q, s);
-    if (n_out == 128) return launch_lin_bwd16<4, true>(q, s);
-    return -1;
-  }
-  if (n_out == 64) return launch_lin_bwd16<2, false>(q, s);
-  if (n_out == 128) return launch_lin_bwd16<4, false>(q, s);
+  if (!lin_bwd16_ok(q) || q.gh != nullptr) return -1;   // (the gather exists in the multi form)
+  if (n_out == 64) return launch_lin_bwd16<2>(q, s);
+  if (n_out == 128) return launch_lin_bwd16<4>(q, s);
   return -1;
+}
+
+int nlam_k16_lin_bwd_multi(const LinBwdParams* q, const OuterParams* o, const int* kind, int n,
+                           hipStream_t s) {
+  if (!nlam_k16_on(K16_LIN_BWD) || !nlam_k16_on(K16_OUTER_BWD) || !nlam_mfma_b3() || n < 1 ||
+      n > K16_MAXP)
+    return -1;
+  LinBwdMulti m;
+  m.n = n;
+  m.wg0[0] = 0;
+  size_t lds = lin_bwd16_lds<2>();
+  for (int k = 0; k < n; ++k) {
+    m.kind[k] = kind[k];
+    m.q[k] = q[k];
+    m.o[k] = o[k];
+    int64_t rows, B;
+    if (kind[k] == 1) {
+      if (o[k].g.width != 64 || o[k].xa.width != 64 || o[k].xb.ptr == nullptr || o[k].xb.width != 64 ||
+          o[k].x_index != nullptr)
+        return -1;
+      rows = o[k].rows; B = o[k].B;
+      const size_t need = (size_t)K16_NW * (p16_bytes(64) + p16_bytes(128));
+      const size_t fold = (size_t)K16_NW * 32 * 128 * sizeof(float);
+      if (need > lds) lds = need;
+      if (fold > lds) lds = fold;
+    } else {
+      if (!lin_bwd16_ok(q[k]) || q[k].nA + q[k].nB != 64) return -1;
+      rows = q[k].rows; B = q[k].B;
+    }
+    m.wg0[k + 1] = m.wg0[k] + (int)nlam_bwd_grid(((rows + 31) / 32) * B);
+  }
+  for (int k = n; k < K16_MAXP; ++k) {
+    m.wg0[k + 1] = m.wg0[n];
+    m.kind[k] = 0;
+  }
+  NLAM_REQUIRE(lds <= 160 * 1024, "lin_bwd16_multi: LDS footprint %zu B exceeds 160 KiB", lds);
+  auto kern = lin_bwd16_multi_kernel<3>;
+  NLAM_BIG_LDS(kern, __func__);
+  kern<<<(unsigned)m.wg0[n], K16_THREADS, lds, s>>>(m);
+  NLAM_CHECK_LAUNCH("lin_bwd16_multi_kernel");
+  return 0;
 }
 
 // ================================================ deferred weight gradients
 // dW (64 x 32 NXB) = sum_rows G[r]^T (x) [xa | xb][r], db = colsum(G); x rows optionally
 // gathered by x_index.  Slab: [dW | db] as nlam_outer_bwd.
 template <int NXB, int TERMS>
-__global__ __launch_bounds__(K16_THREADS, 2) void outer_bwd16_kernel(OuterParams q) {
-  extern __shared__ __attribute__((aligned(16))) char smem16[];
+__device__ __forceinline__ void outer_bwd16_body(const OuterParams& q, int wg, int nwg, char* smem16) {
   constexpr int NG = 64, NX = 32 * NXB, KF = 2 * NXB;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
@@ -477,8 +571,7 @@ __global__ __launch_bounds__(K16_THREADS, 2) void outer_bwd16_kernel(OuterParams
   const int wa = q.xa.width, wb = q.xb.ptr ? q.xb.width : 0;
   const int64_t tiles_per_b = (q.rows + NLAM_T16 - 1) / NLAM_T16;
   const int64_t ntiles = tiles_per_b * q.B;
-  for (int64_t tt = (int64_t)blockIdx.x * K16_NW + wave; tt < ntiles;
-       tt += (int64_t)gridDim.x * K16_NW) {
+  for (int64_t tt = (int64_t)wg * K16_NW + wave; tt < ntiles; tt += (int64_t)nwg * K16_NW) {
     const int64_t b = tt / tiles_per_b;
     const int64_t r0 = (tt - b * tiles_per_b) * NLAM_T16;
     const int nrows = (int)((q.rows - r0) < NLAM_T16 ? (q.rows - r0) : NLAM_T16);
@@ -500,12 +593,18 @@ __global__ __launch_bounds__(K16_THREADS, 2) void outer_bwd16_kernel(OuterParams
   }
   __syncthreads();
   float* img = reinterpret_cast<float*>(smem16);
-  float* slab = q.slab + (int64_t)blockIdx.x * q.slab_stride;
+  float* slab = q.slab + (int64_t)wg * q.slab_stride;
   // one 32-row block of dW at a time: 8 x 32 x NX floats of images (<= 128 KB)
 #pragma unroll
   for (int ib = 0; ib < 2; ++ib)
     fold_blocks_to_slab16<1, NXB, NXB, K16_NW>(&dW[ib][0], img, NX, slab + 32 * ib * NX, tid, wave, lane);
   fold_vec_to_slab16<1, K16_NW>(db, img, slab + NG * NX, NG, tid, wave, lane);
+}
+
+template <int NXB, int TERMS>
+__global__ __launch_bounds__(K16_THREADS, 2) void outer_bwd16_kernel(OuterParams q) {
+  extern __shared__ __attribute__((aligned(16))) char smem16[];
+  outer_bwd16_body<NXB, TERMS>(q, (int)blockIdx.x, (int)gridDim.x, smem16);
 }
 
 template <int NXB>
@@ -662,8 +761,7 @@ int nlam_k16_mlp_fwd(const MlpParams& p, hipStream_t s) {
 // ================================================================ projection
 // out[:, 0:nA] = x WA^T + bA ; out[:, nA:nA+nB] = x WB^T + bB: k_in = 64, n_out = 32 NOB in {64, 128}
 template <int NOB, int TERMS>
-__global__ __launch_bounds__(K16_THREADS, 2) void lin_fwd16_kernel(LinParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem16[];
+__device__ __forceinline__ void lin_fwd16_body(const LinParams& p, int wg, int nwg, char* smem16) {
   constexpr int K = 64, KF = 4, NO = 32 * NOB, NFO = 2 * NOB;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -682,8 +780,7 @@ __global__ __launch_bounds__(K16_THREADS, 2) void lin_fwd16_kernel(LinParams p) 
   __syncthreads();
   const int64_t tiles_per_b = (p.rows + NLAM_T16 - 1) / NLAM_T16;
   const int64_t ntiles = tiles_per_b * p.B;
-  for (int64_t tt = (int64_t)blockIdx.x * K16_NW + wave; tt < ntiles;
-       tt += (int64_t)gridDim.x * K16_NW) {
+  for (int64_t tt = (int64_t)wg * K16_NW + wave; tt < ntiles; tt += (int64_t)nwg * K16_NW) {
     const int64_t b = tt / tiles_per_b;
     const int64_t r0 = (tt - b * tiles_per_b) * NLAM_T16;
     const int nrows = (int)((p.rows - r0) < NLAM_T16 ? (p.rows - r0) : NLAM_T16);
@@ -697,25 +794,179 @@ __global__ __launch_bounds__(K16_THREADS, 2) void lin_fwd16_kernel(LinParams p) 
   }
 }
 
+template <int NOB, int TERMS>
+__global__ __launch_bounds__(K16_THREADS, 2) void lin_fwd16_kernel(LinParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem16[];
+  lin_fwd16_body<NOB, TERMS>(p, (int)blockIdx.x, (int)gridDim.x, smem16);
+}
+
+struct LinFwdMulti {
+  LinParams p[K16_MAXP];
+  int n;
+  int wg0[K16_MAXP + 1];
+};
+template <int TERMS>
+__global__ __launch_bounds__(K16_THREADS, 2) void lin_fwd16_multi_kernel(LinFwdMulti m) {
+  extern __shared__ __attribute__((aligned(16))) char smem16[];
+  int k = 0;
+  while (k + 1 < m.n && (int)blockIdx.x >= m.wg0[k + 1]) ++k;
+  lin_fwd16_body<2, TERMS>(m.p[k], (int)blockIdx.x - m.wg0[k], m.wg0[k + 1] - m.wg0[k], smem16);
+}
+
+static int64_t lin_fwd16_grid(const LinParams& p) {
+  const int64_t ntiles = ((p.rows + NLAM_T16 - 1) / NLAM_T16) * p.B;
+  int64_t g = (ntiles + K16_NW - 1) / K16_NW;
+  if (g > 512) g = 512;
+  return g < 1 ? 1 : g;
+}
+
 template <int NOB>
 static int launch_lin_fwd16(const LinParams& p, hipStream_t s) {
   constexpr int K = 64, NO = 32 * NOB;
   const size_t lds = w16_image_bytes(NO, K) + NO * sizeof(float);
   auto kern = lin_fwd16_kernel<NOB, 3>;
   NLAM_BIG_LDS(kern, __func__);
-  const int64_t ntiles = ((p.rows + NLAM_T16 - 1) / NLAM_T16) * p.B;
-  int64_t g = (ntiles + K16_NW - 1) / K16_NW;
-  if (g > 512) g = 512;
-  kern<<<(unsigned)g, K16_THREADS, lds, s>>>(p);
+  kern<<<(unsigned)lin_fwd16_grid(p), K16_THREADS, lds, s>>>(p);
   NLAM_CHECK_LAUNCH("lin_fwd16_kernel");
   return 0;
 }
 
+static bool lin_fwd16_ok(const LinParams& p) {
+  return p.x.width == 64 && (p.vec_mask & 1) && (p.vec_mask & 8);
+}
+
 int nlam_k16_lin_fwd(const LinParams& p, hipStream_t s) {
   if (!nlam_k16_on(K16_LIN_FWD) || !nlam_mfma_b3()) return -1;
-  if (p.x.width != 64 || !(p.vec_mask & 1) || !(p.vec_mask & 8)) return -1;
+  if (!lin_fwd16_ok(p)) return -1;
   const int n_out = p.nA + p.nB;
   if (n_out == 64) return launch_lin_fwd16<2>(p, s);
   if (n_out == 128) return launch_lin_fwd16<4>(p, s);
   return -1;
+}
+
+int nlam_k16_lin_fwd_multi(const LinParams* p, int n, hipStream_t s) {
+  if (!nlam_k16_on(K16_LIN_FWD) || !nlam_mfma_b3() || n < 1 || n > K16_MAXP) return -1;
+  LinFwdMulti m;
+  m.n = n;
+  m.wg0[0] = 0;
+  for (int k = 0; k < n; ++k) {
+    if (!lin_fwd16_ok(p[k]) || p[k].nA + p[k].nB != 64) return -1;
+    m.p[k] = p[k];
+    m.wg0[k + 1] = m.wg0[k] + (int)lin_fwd16_grid(p[k]);
+  }
+  for (int k = n; k < K16_MAXP; ++k) m.wg0[k + 1] = m.wg0[n];
+  const size_t lds = w16_image_bytes(64, 64) + 64 * sizeof(float);
+  auto kern = lin_fwd16_multi_kernel<3>;
+  NLAM_BIG_LDS(kern, __func__);
+  kern<<<(unsigned)m.wg0[n], K16_THREADS, lds, s>>>(m);
+  NLAM_CHECK_LAUNCH("lin_fwd16_multi_kernel");
+  return 0;
+}
+
+// ==================================================================== C entry points
+extern "C" int nlam_lin_multi_supported(void) {
+  return nlam_mfma_b3() && nlam_k16_on(K16_LIN_FWD) && nlam_k16_on(K16_LIN_BWD) &&
+                 nlam_k16_on(K16_OUTER_BWD) ? 1 : 0;
+}
+
+// the d = 64 branch of nlam_lin_fwd_multi (fused_wide.hip)
+int nlam_k16_lin_fwd_multi_c(int n, const float* const* x, const int64_t* x_bstride,
+                             const int64_t* x_ld, const float* const* W, const int64_t* ldW,
+                             const float* const* bias, float* const* out,
+                             const int64_t* out_bstride, const int64_t* out_ld, const int64_t* B,
+                             const int64_t* rows, void* stream) {
+  NLAM_REQUIRE(n >= 1 && n <= K16_MAXP, "nlam_lin_fwd_multi: n %d out of [1, %d] at width 64", n, K16_MAXP);
+  LinParams p[K16_MAXP];
+  int m = 0;
+  for (int k = 0; k < n; ++k) {
+    if (B[k] <= 0 || rows[k] <= 0) continue;
+    NLAM_REQUIRE(view_vec_ok(x[k], x_bstride[k], x_ld[k], 64) &&
+                     view_vec_ok(out[k], out_bstride[k], out_ld[k], 64),
+                 "nlam_lin_fwd_multi: operand rows must be 16-byte aligned, width 64");
+    LinParams& q = p[m++];
+    q.x = RowView{x[k], x_bstride[k], x_ld[k], 64};
+    q.k_pad = 64;
+    q.WA = W[k]; q.ldWA = ldW[k]; q.bA = bias[k]; q.nA = 64;
+    q.WB = nullptr; q.ldWB = 0; q.bB = nullptr; q.nB = 0;
+    q.out = out[k]; q.out_bstride = out_bstride[k]; q.out_ld = out_ld[k];
+    q.rows = rows[k]; q.B = (int)B[k]; q.vec_mask = 9; q.timeline = 0;
+  }
+  if (m == 0) return 0;
+  const int r = nlam_k16_lin_fwd_multi(p, m, (hipStream_t)stream);
+  NLAM_REQUIRE(r >= 0, "nlam_lin_fwd_multi: width 64 needs the split-bf16 16-row kernels "
+                       "(nlam_lin_multi_supported())");
+  return r;
+}
+
+extern "C" int nlam_lin_bwd_multi(
+    int n, int d, const float* const* x, const int64_t* x_bstride, const int64_t* x_ld,
+    const float* const* xb, const int64_t* xb_bstride, const int64_t* xb_ld,
+    const float* const* gy, const int64_t* gy_bstride, const int64_t* gy_ld, const float* const* W,
+    const int64_t* ldW, float* const* gx, const int64_t* gx_bstride, const int64_t* gx_ld,
+    const float* const* gx_add, const int64_t* ga_bstride, const int64_t* ga_ld,
+    const int64_t* gy_nsum, const int64_t* gy_sum_stride, const float* const* gh,
+    const int64_t* gh_bstride, const int32_t* const* csc_colptr, const int32_t* const* csc_eid,
+    const int64_t* n_send, float* const* slab, const int64_t* slab_stride, const int64_t* B,
+    const int64_t* rows, void* stream) {
+  NLAM_REQUIRE(d == 64, "nlam_lin_bwd_multi: width %d unsupported (64)", d);
+  NLAM_REQUIRE(n >= 1 && n <= K16_MAXP, "nlam_lin_bwd_multi: n %d out of [1, %d]", n, K16_MAXP);
+  LinBwdParams q[K16_MAXP];
+  OuterParams o[K16_MAXP];
+  int kind[K16_MAXP];
+  int m = 0;
+  for (int k = 0; k < n; ++k) {
+    if (B[k] <= 0 || rows[k] <= 0) continue;
+    LinBwdParams& r = q[m];
+    OuterParams& ou = o[m];
+    kind[m] = xb[k] != nullptr ? 1 : 0;
+    ++m;
+    NLAM_REQUIRE(x[k] && slab[k] && (gy[k] || gh[k]), "nlam_lin_bwd_multi: NULL operand %d", k);
+    if (xb[k] != nullptr) {   // deferred first-layer weight gradient: dW (64 x 128) = gy^T [x | xb]
+      NLAM_REQUIRE(W[k] == nullptr && gx[k] == nullptr && gh[k] == nullptr && gy_nsum[k] <= 1,
+                   "nlam_lin_bwd_multi: problem %d with xb forms weight gradients only", k);
+      NLAM_REQUIRE(slab_stride[k] >= 64 * 128 + 64, "nlam_lin_bwd_multi: slab %d too small", k);
+      NLAM_REQUIRE(view_vec_ok(x[k], x_bstride[k], x_ld[k], 64) &&
+                       view_vec_ok(xb[k], xb_bstride[k], xb_ld[k], 64) &&
+                       view_vec_ok(gy[k], gy_bstride[k], gy_ld[k], 64),
+                   "nlam_lin_bwd_multi: operand rows of problem %d must be 16-byte aligned, width 64", k);
+      ou.g = RowView{gy[k], gy_bstride[k], gy_ld[k], 64};
+      ou.xa = RowView{x[k], x_bstride[k], x_ld[k], 64};
+      ou.xb = RowView{xb[k], xb_bstride[k], xb_ld[k], 64};
+      ou.x_index = nullptr; ou.slab = slab[k]; ou.slab_stride = slab_stride[k];
+      ou.rows = rows[k]; ou.B = (int)B[k];
+      r = LinBwdParams{};
+      continue;
+    }
+    ou = OuterParams{};
+    NLAM_REQUIRE(W[k] != nullptr, "nlam_lin_bwd_multi: NULL weight %d", k);
+    NLAM_REQUIRE(slab_stride[k] >= 64 * 64 + 64, "nlam_lin_bwd_multi: slab %d too small", k);
+    r.x = RowView{x[k], x_bstride[k], x_ld[k], 64};
+    r.gy = RowView{gy[k], gy_bstride[k], gy_ld[k], 64};
+    r.WA = W[k]; r.ldWA = ldW[k]; r.nA = 64; r.WB = nullptr; r.ldWB = 0; r.nB = 0;
+    r.gx = gx[k]; r.gx_bstride = gx_bstride[k]; r.gx_ld = gx_ld[k];
+    r.gx_add = gx_add[k]; r.ga_bstride = ga_bstride[k]; r.ga_ld = ga_ld[k];
+    r.slab = slab[k]; r.slab_stride = slab_stride[k];
+    r.rows = rows[k]; r.B = (int)B[k];
+    r.gy_nsum = gy_nsum[k] > 1 ? (int)gy_nsum[k] : 1;
+    r.gy_sum_stride = gy_sum_stride[k];
+    r.gh = gh[k]; r.gh_bstride = gh_bstride[k];
+    r.csc_colptr = csc_colptr[k]; r.csc_eid = csc_eid[k]; r.n_send = (int)n_send[k];
+    r.vec_x = view_vec_ok(x[k], x_bstride[k], x_ld[k], 64);
+    r.vec_gy = gh[k] ? 1 : view_vec_ok(gy[k], gy_bstride[k], gy_ld[k], 64);
+    r.vec_gx = gx[k] == nullptr ||
+               (view_vec_ok(gx[k], gx_bstride[k], gx_ld[k], 64) &&
+                (gx_add[k] == nullptr || view_vec_ok(gx_add[k], ga_bstride[k], ga_ld[k], 64)));
+    NLAM_REQUIRE(r.vec_x && r.vec_gy && r.vec_gx && (r.gy_nsum == 1 || gy_sum_stride[k] % 4 == 0 || gh[k]),
+                 "nlam_lin_bwd_multi: operand rows of problem %d must be 16-byte aligned, width 64", k);
+    if (gh[k]) {
+      NLAM_REQUIRE(csc_colptr[k] && csc_eid[k] && nlam_aligned16(gh[k]) && gh_bstride[k] % 4 == 0 &&
+                       n_send[k] >= 0 && n_send[k] <= rows[k],
+                   "nlam_lin_bwd_multi: gather operands of problem %d", k);
+    }
+    NLAM_REQUIRE(gx_add[k] == nullptr || gx[k] != nullptr, "nlam_lin_bwd_multi: gx_add without gx");
+  }
+  if (m == 0) return 0;
+  const int r = nlam_k16_lin_bwd_multi(q, o, kind, m, (hipStream_t)stream);
+  NLAM_REQUIRE(r >= 0, "nlam_lin_bwd_multi: needs the split-bf16 16-row kernels (nlam_lin_multi_supported())");
+  return r;
 }

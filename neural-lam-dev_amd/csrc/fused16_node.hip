@@ -125,54 +125,6 @@ static int launch_node_fwd16(const NodeFwdParams& p, hipStream_t s) {
 }
 
 // ============================================================= backward, data pass
-// Sum of the rows gh[eid[p]] over this lane's node's out-edges, in sender-list order (fixed =>
-// deterministic).  A tile is one latency chain per wavefront (26 k rows = 1.6 tiles per SIMD), so
-// the dependent loads are batched: the four lanes of a row fetch 32 edge ids in ONE round trip
-// (lane g takes positions g, g + 4, ...), then the rows of four edges are in flight together.
-// Lanes past their own degree read edge 0's row and add nothing.
-__device__ __forceinline__ void gather_sender_sum16(f32x4* __restrict__ acc, const float* __restrict__ gh,
-                                                    const int32_t* __restrict__ colptr,
-                                                    const int32_t* __restrict__ eid, int64_t node,
-                                                    int n_send, bool valid, int lane) {
-  const int t = lane & 15, g = lane >> 4;
-  int p0 = 0, deg = 0;
-  if (valid && node < n_send) {
-    p0 = colptr[node];
-    deg = colptr[node + 1] - p0;
-  }
-  int dmax = deg;
-#pragma unroll
-  for (int o = 1; o < 16; o <<= 1) dmax = max(dmax, __shfl_xor(dmax, o, 64));
-  dmax = __builtin_amdgcn_readfirstlane(dmax);   // the four lanes of a row agree; rows: xor 1..8
-#pragma unroll
-  for (int fb = 0; fb < 4; ++fb) acc[fb] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int c0 = 0; c0 < dmax; c0 += 32) {
-    int ev[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int j = c0 + 4 * u + g;
-      ev[u] = eid[j < deg ? p0 + j : 0];
-    }
-#pragma unroll
-    for (int j4 = 0; j4 < 32; j4 += 4) {
-      if (c0 + j4 < dmax) {   // wave-uniform
-        f32x4 v[4][4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int e = __shfl(ev[j4 >> 2], t + 16 * k, 64);   // position c0 + j4 + k of row t
-          load_row16<4>(v[k], gh + (int64_t)e * 64, lane);
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-          if (c0 + j4 + k < deg) {
-#pragma unroll
-            for (int fb = 0; fb < 4; ++fb) acc[fb] += v[k][fb];
-          }
-      }
-    }
-  }
-}
-
 // Diagnostic (NLAM_TIMELINE_NODE=1): s_memrealtime (100 MHz) of workgroup phases of the last
 // nlam_node_bwd launch with a node update: start, weights in LDS, first tile's gather done, G
 // formed, tile loop done, slab written -- per workgroup (first 256).

@@ -1166,6 +1166,7 @@ extern "C" int nlam_lin_bwd(const float* x, int64_t x_bstride, int64_t x_ld, int
              (gx_add == nullptr || view_vec_ok(gx_add, ga_bstride, ga_ld, k_in));
   q.gy_nsum = gy_nsum > 1 ? (int)gy_nsum : 1;
   q.gy_sum_stride = gy_sum_stride;
+  q.gh = nullptr; q.gh_bstride = 0; q.csc_colptr = nullptr; q.csc_eid = nullptr; q.n_send = 0;
   NLAM_REQUIRE(q.gy_nsum == 1 || (q.vec_x && q.vec_gy && gy_sum_stride % 4 == 0),
                "nlam_lin_bwd: gy_nsum > 1 needs 16-byte aligned x / gy rows and slices");
   hipStream_t s = (hipStream_t)stream;

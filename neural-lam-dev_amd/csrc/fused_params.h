@@ -52,6 +52,11 @@ struct LinBwdParams {
   int64_t rows; int B;
   int gy_nsum; int64_t gy_sum_stride;   // gy[b] := sum_{s < gy_nsum} gy[b][s * gy_sum_stride + ...]
   int vec_x, vec_gy, vec_gx;
+  // 16-row kernels only: columns [0, 64) of gy are NOT read but formed as the sum of the rows
+  // gh[eid] over the row's sender list (the sender-side scatter of the edge gradient as a gather;
+  // gh: (B, M, 64) in edge order, batch pitch gh_bstride -- also the pitch of the gy_nsum slices)
+  const float* gh; int64_t gh_bstride;
+  const int32_t* csc_colptr; const int32_t* csc_eid; int n_send;
 };
 
 struct OuterParams {
@@ -137,6 +142,11 @@ struct NodeOuterParams {
 // with the 32-row kernel), 0 on success, > 0 on error.
 int nlam_k16_mlp_bwd(const MlpBwdParams& q, hipStream_t s);
 int nlam_k16_lin_bwd(const LinBwdParams& q, hipStream_t s);
+// several independent projections (n_out = 64 each) in one launch: q[k].slab holds
+// nlam_bwd_grid(ceil(rows_k / 32) * B_k) slabs; 0 ok, -1 = a shape the 16-row kernels do not take
+int nlam_k16_lin_bwd_multi(const LinBwdParams* q, const OuterParams* o, const int* kind, int n,
+                           hipStream_t s);
+int nlam_k16_lin_fwd_multi(const LinParams* p, int n, hipStream_t s);
 int nlam_k16_outer_bwd(const OuterParams& q, hipStream_t s);
 int nlam_k16_mlp_fwd(const MlpParams& p, hipStream_t s);
 int nlam_k16_lin_fwd(const LinParams& p, hipStream_t s);

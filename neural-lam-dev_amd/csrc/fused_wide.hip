@@ -1144,6 +1144,12 @@ static int launch_wide_lin_fwd(WideMulti<WideLinParams>& m, hipStream_t s) {
   return 0;
 }
 
+int nlam_k16_lin_fwd_multi_c(int n, const float* const* x, const int64_t* x_bstride,
+                             const int64_t* x_ld, const float* const* W, const int64_t* ldW,
+                             const float* const* bias, float* const* out,
+                             const int64_t* out_bstride, const int64_t* out_ld, const int64_t* B,
+                             const int64_t* rows, void* stream);
+
 extern "C" int nlam_lin_fwd_multi(int n, int d, const float* const* x, const int64_t* x_bstride,
                                   const int64_t* x_ld, const float* const* W, const int64_t* ldW,
                                   const float* const* bias, float* const* out,
@@ -1154,10 +1160,13 @@ extern "C" int nlam_lin_fwd_multi(int n, int d, const float* const* x, const int
                NLAM_WIDE_MAXP);
   NLAM_REQUIRE(out_bf16_mask == 0 || d == 256, "nlam_lin_fwd_multi: bf16 rows exist at hidden 256 only");
   NLAM_REQUIRE(nlam_mfma_terms() != 0, "nlam_lin_fwd_multi: needs NLAM_MFMA=bf16x3|bf16");
+  if (d == 64)   // the 16-row hidden-64 kernels (fused16_mlp.hip)
+    return nlam_k16_lin_fwd_multi_c(n, x, x_bstride, x_ld, W, ldW, bias, out, out_bstride, out_ld, B,
+                                    rows, stream);
   if (d == 256)
     return nlam_fs_lin_fwd_multi_256(n, x, x_bstride, x_ld, W, ldW, bias, out, out_bstride, out_ld, B,
                                      rows, out_bf16_mask, stream);
-  NLAM_REQUIRE(d == 128, "nlam_lin_fwd_multi: width %d unsupported (128, 256)", d);
+  NLAM_REQUIRE(d == 128, "nlam_lin_fwd_multi: width %d unsupported (64, 128, 256)", d);
   WideMulti<WideLinParams> m;
   m.n = 0;
   for (int k = 0; k < n; ++k) {

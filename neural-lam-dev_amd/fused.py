@@ -167,20 +167,27 @@ class FusedInteractionNetFunction(torch.autograd.Function):
             else:
                 Ps = _empty(sm.B, N_s, d, device=dev)
                 Pr = _empty(rm.B, N_r, d, device=dev)
-                ops.fused_lin_fwd(sm, W1s, None, None, None, mat(Ps))
-                ops.fused_lin_fwd(rm, W1r, b1, None, None, mat(Pr))
                 psm, prm = mat(Ps), mat(Pr)
                 saved_proj = (Ps, Pr)
+            Pe = None if update_edges else _empty(em.B, M, d, device=dev)
+            # the sender / receiver / edge thirds of edge_mlp.0 that are separate row sets: one
+            # multi-problem launch (they are independent; on the small mesh levels each would be
+            # a launch of a few workgroups)
+            projs = [] if same else [(sm, W1s, None, psm), (rm, W1r, b1, prm)]
+            if not update_edges:
+                projs.append((em, W1e, None, mat(Pe)))
+            if len(projs) > 1 and ops.lin_multi_supported():
+                ops.fused_lin_fwd_multi(projs)
+            else:
+                for (xm_, W_, b_, om_) in projs:
+                    ops.fused_lin_fwd(xm_, W_, b_, None, None, om_)
             agg = _empty(B, N_r, d, device=dev)
             if update_edges:
                 e_out = _empty(B, M, d, device=dev)
                 ops.fused_edge_fwd(g, em, True, psm, prm, W1e, W2, b2, gam, bet, mat(agg),
                                    mat(e_out), mean, d)
-                Pe = None
             else:
                 e_out = None
-                Pe = _empty(em.B, M, d, device=dev)
-                ops.fused_lin_fwd(em, W1e, None, None, None, mat(Pe))
                 ops.fused_edge_fwd(g, mat(Pe), False, psm, prm, None, W2, b2, gam, bet, mat(agg),
                                    None, mean, d)
             rec_out = _empty(B, N_r, d, device=dev)
@@ -216,8 +223,13 @@ class FusedInteractionNetFunction(torch.autograd.Function):
             g_rec = _empty(B, N_r, d, device=dev)
             g_agg = _empty(B, N_r, d, device=dev)
             nd = _mlp_grad_dst(V1, V2, True)
+            # the deferred dV1 pass rides in another launch: the projections' multi-problem
+            # launch (non-shared layers) or the node-side weight-gradient pass (shared nodes)
+            node_path = (same and sm.B == B and N_s == N_r and g.n_send <= N_r
+                         and ops.node_chain_supported())
+            outer_jobs = [] if (node_path or (not same and ops.lin_multi_supported())) else None
             ops.fused_mlp_bwd(rm, mat(agg), V1, c1, V2, c2, gam2, mat(g_rec_out),
-                              mat(g_rec), mat(g_agg), True, d, d, nd)
+                              mat(g_rec), mat(g_agg), True, d, d, nd, outer_jobs=outer_jobs)
             dV1, dc1, dV2, dc2, dg2, db2n = (nd["dW1"], nd["db1"], nd["dW2"], nd["db2"],
                                              nd["dgamma"], nd["dbeta"])
             if rm.B == 1 and B > 1:   # batch-invariant receivers: their grad sums over the batch
@@ -251,7 +263,21 @@ class FusedInteractionNetFunction(torch.autograd.Function):
                     g, mat(Pe), False, psm, prm, None, W2, b2, gam, mat(g_agg), None, mat(gh),
                     gpr_m, None, ctx.mean, d, None, dW2, db2, dgam, dbet)
             # 3. sender-side reduction of gh (rows in the original edge order, sender lists of edge ids)
-            if same:
+            if same and node_path:
+                # sender gather + projections backward in one data pass (csrc/fused16_node.hip),
+                # then every 128-wide weight gradient of the layer (dV1, dW1s | dW1r) in one pass
+                gx_p = _empty(B, N_s, d, device=dev)
+                ops.node_bwd(mat(gh), g.csc_colptr, g.csc_eid, g.n_send, mat(gP), mat(g_rec),
+                             W1s, W1r, None, mat(gx_p))
+                job = outer_jobs[0] if outer_jobs else None
+                if job is not None:
+                    ops.node_outer(job["gy"], job["x"], job["xb"], mat(gP), sm, job["dW"], job["db"],
+                                   dW1[:, d : 2 * d], dW1[:, 2 * d :], db1)
+                else:
+                    ops.node_outer(None, None, None, mat(gP), sm, None, None,
+                                   dW1[:, d : 2 * d], dW1[:, 2 * d :], db1)
+                g_send, g_rec_total = gx_p, None
+            elif same:
                 if N_s > g.n_send:
                     gP[:, g.n_send :, :d].zero_()
                 ops.segment_sum(mat(gh), g.csc_colptr, g.csc_eid, mat(gP[:, : g.n_send], 0, d))
@@ -269,29 +295,42 @@ class FusedInteractionNetFunction(torch.autograd.Function):
                                   dW1[:, 2 * d :], db1, gx_add=mat(g_rec), sum_gy_batch=fold)
                 g_send, g_rec_total = gx_p, None
             else:
-                gPs = (torch.zeros if N_s > g.n_send else torch.empty)(
-                    B, N_s, d, dtype=torch.float32, device=dev)
-                ops.segment_sum(mat(gh), g.csc_colptr, g.csc_eid, mat(gPs[:, : g.n_send]))
+                multi = ops.lin_multi_supported()
                 # batch-invariant operands: the batch sum of their gradient is folded into
                 # the load of the projection backward when the rows are 16-byte aligned
-                gps_m, gpr_in = mat(gPs), mat(gPr)
-                fold_s = sm.B == 1 and B > 1 and ops.lin_bwd_can_sum(sm, gps_m)
+                gpr_in = mat(gPr)
                 fold_r = rm.B == 1 and B > 1 and ops.lin_bwd_can_sum(rm, gpr_in)
-                if sm.B == 1 and B > 1 and not fold_s:
-                    t1 = _empty(1, N_s, d, device=dev)
-                    ops.sum_batch(gPs, t1)
-                    gps_m = mat(t1)
                 if rm.B == 1 and B > 1 and not fold_r:
                     t2 = _empty(1, N_r, d, device=dev)
                     ops.sum_batch(gPr, t2)
                     gpr_in = mat(t2)
                 g_send = _empty(sm.B, N_s, d, device=dev)
-                ops.fused_lin_bwd(sm, gps_m, W1s, None, mat(g_send), dW1[:, d : 2 * d], None,
-                                  None, None, sum_gy_batch=fold_s)
                 # receiver gradient: node-update part (+ residual) + projection part
                 g_rec_total = _empty(rm.B, N_r, d, device=dev)
-                ops.fused_lin_bwd(rm, gpr_in, W1r, None, mat(g_rec_total), dW1[:, 2 * d :], db1,
-                                  None, None, gx_add=mat(g_rec), sum_gy_batch=fold_r)
+                if multi:
+                    # sender side: the scatter of gh over edge_index[0] as a gather over the
+                    # sender lists inside the projection backward (no gPs tensor, no launch)
+                    fold_s = sm.B == 1 and B > 1
+                    probs = [
+                        {"x": sm, "W": W1s, "gather": (mat(gh), g.csc_colptr, g.csc_eid, g.n_send),
+                         "nsum": B if fold_s else 1, "gx": mat(g_send), "dW": dW1[:, d : 2 * d]},
+                        {"x": rm, "gy": gpr_in, "W": W1r, "nsum": B if fold_r else 1,
+                         "gx": mat(g_rec_total), "gx_add": mat(g_rec), "dW": dW1[:, 2 * d :],
+                         "db": db1}]
+                else:
+                    gPs = (torch.zeros if N_s > g.n_send else torch.empty)(
+                        B, N_s, d, dtype=torch.float32, device=dev)
+                    ops.segment_sum(mat(gh), g.csc_colptr, g.csc_eid, mat(gPs[:, : g.n_send]))
+                    gps_m = mat(gPs)
+                    fold_s = sm.B == 1 and B > 1 and ops.lin_bwd_can_sum(sm, gps_m)
+                    if sm.B == 1 and B > 1 and not fold_s:
+                        t1 = _empty(1, N_s, d, device=dev)
+                        ops.sum_batch(gPs, t1)
+                        gps_m = mat(t1)
+                    ops.fused_lin_bwd(sm, gps_m, W1s, None, mat(g_send), dW1[:, d : 2 * d], None,
+                                      None, None, sum_gy_batch=fold_s)
+                    ops.fused_lin_bwd(rm, gpr_in, W1r, None, mat(g_rec_total), dW1[:, 2 * d :], db1,
+                                      None, None, gx_add=mat(g_rec), sum_gy_batch=fold_r)
             # 5. edge-side first-layer weights
             if ctx.update_edges:
                 g_edge = g_e
@@ -307,8 +346,14 @@ class FusedInteractionNetFunction(torch.autograd.Function):
                     ops.sum_batch(gh, t5)
                     dPe = mat(t5)
                 g_edge = _empty(em.B, M, d, device=dev)
-                ops.fused_lin_bwd(em, dPe, W1e, None, mat(g_edge), dW1[:, :d], None,
-                                  None, None, sum_gy_batch=fold_e)
+                if not same and multi:
+                    probs.append({"x": em, "gy": dPe, "W": W1e, "nsum": B if fold_e else 1,
+                                  "gx": mat(g_edge), "dW": dW1[:, :d]})
+                else:
+                    ops.fused_lin_bwd(em, dPe, W1e, None, mat(g_edge), dW1[:, :d], None,
+                                      None, None, sum_gy_batch=fold_e)
+            if not same and multi:
+                ops.fused_lin_bwd_multi(probs + outer_jobs)
         return (g_send, g_rec_total, g_edge, None, None, None, None,
                 dW1, db1, dW2, db2, dgam, dbet, dV1, dc1, dV2, dc2, dg2, db2n)
 

@@ -514,9 +514,12 @@ def reduce_segments(slab, nslabs, stride, segs):
         _flush_segments(entries)
 
 
-def fused_mlp_bwd(xa, xb, W1, b1, W2, b2, gamma, gy, gxa, gxb, add_gy_to_gxa, hid, n_out, dst):
+def fused_mlp_bwd(xa, xb, W1, b1, W2, b2, gamma, gy, gxa, gxb, add_gy_to_gxa, hid, n_out, dst,
+                  outer_jobs=None):
     """dst: dict with the gradient tensors to fill: dW1 (hid, k_in), db1 (hid,),
-    dW2 (n_out, hid), db2 (n_out,), dgamma / dbeta (n_out,) (views allowed)."""
+    dW2 (n_out, hid), db2 (n_out,), dgamma / dbeta (n_out,) (views allowed).
+    outer_jobs: a list that receives the deferred first-layer weight gradient of the K = 128 node
+    update as a problem of fused_lin_bwd_multi (instead of its own nlam_outer_bwd launch)."""
     B, rows = gy.B, gy.rows
     k_in = xa.cols + (xb.cols if xb is not None else 0)
     stride = lib.nlam_mlp_bwd_slab_stride(k_in, hid, n_out)
@@ -552,7 +555,9 @@ def fused_mlp_bwd(xa, xb, W1, b1, W2, b2, gamma, gy, gxa, gxb, add_gy_to_gxa, hi
     if gamma is not None:
         segs += [(ov + no32, 1, n_out, n_out, dst["dgamma"]),
                  (ov + 2 * no32, 1, n_out, n_out, dst["dbeta"])]
-    if defer:
+    if defer and outer_jobs is not None:
+        outer_jobs.append({"x": xa, "xb": xb, "gy": mat(ga), "dW": dst["dW1"], "db": dst["db1"]})
+    elif defer:
         fused_outer_bwd(mat(ga), xa, xb, None, dst["dW1"], dst["db1"])
     else:
         segs += [(0, hid, k_in, kp32, dst["dW1"]), (o1, 1, hid, hid, dst["db1"])]
@@ -630,6 +635,100 @@ def fused_lin_bwd(x, gy, WA, WB, gx, dWA, dbA, dWB, dbB, gx_add=None, sum_gy_bat
     reduce_segments(slab, nslabs, stride, segs)
 
 
+def lin_multi_supported():
+    """Multi-problem projection launches exist at hidden 64 in this process's arithmetic mode."""
+    return bool(lib.nlam_lin_multi_supported())
+
+
+def fused_lin_fwd_multi(problems):
+    """[(x Mat, W (64, 64) view, bias or None, out Mat)]: out_k = x_k W_k^T + bias_k, ONE launch."""
+    n = len(problems)
+    I64, P = ctypes.c_int64 * n, ctypes.c_void_p * n
+    d = problems[0][1].shape[0]
+    _launch(
+        "nlam_lin_fwd_multi", lib.nlam_lin_fwd_multi,
+        (n, d, P(*[x.ptr for x, _, _, _ in problems]), I64(*[x.bstride for x, _, _, _ in problems]),
+         I64(*[x.ld for x, _, _, _ in problems]), P(*[W.data_ptr() for _, W, _, _ in problems]),
+         I64(*[W.stride(0) for _, W, _, _ in problems]), P(*[_p(b) for _, _, b, _ in problems]),
+         P(*[o.ptr for _, _, _, o in problems]), I64(*[o.bstride for _, _, _, o in problems]),
+         I64(*[o.ld for _, _, _, o in problems]), I64(*[o.B for _, _, _, o in problems]),
+         I64(*[o.rows for _, _, _, o in problems]), 0, stream()),
+        flops=sum(2.0 * o.B * o.rows * d * d for _, _, _, o in problems),
+        nbytes=sum(8.0 * o.B * o.rows * d for _, _, _, o in problems),
+    )
+
+
+def fused_lin_bwd_multi(problems):
+    """Several projection backward passes (hidden 64) in ONE launch.  Each problem is a dict:
+    x (Mat), W ((64, 64) view), dW (destination view), db (destination or None), gx (Mat or
+    None), gx_add (Mat or None), and EITHER gy (Mat) OR gather = (gh Mat (B, M, 64), csc_colptr,
+    csc_eid, n_send): gy rows formed as sums of gh rows over the sender lists.  nsum > 1: x is
+    batch-invariant and the gradient is summed over nsum batch slices while it is read."""
+    n = len(problems)
+    I64, P = ctypes.c_int64 * n, ctypes.c_void_p * n
+    d = 64
+    rowsB, slabs, nslabs, strides = [], [], [], []
+    for pr in problems:
+        x = pr["x"]
+        nsum = pr.get("nsum", 1)
+        if nsum > 1:
+            B = 1
+        else:
+            B = pr["gather"][0].B if pr.get("gather") is not None else pr["gy"].B
+        rowsB.append((B, x.rows))
+        ns = lib.nlam_bwd_grid(_ntiles(B, x.rows))
+        nslabs.append(ns)
+        # "xb" present: a deferred 64 x 128 first-layer weight gradient (no data gradient)
+        stride = d * 2 * d + d if pr.get("xb") is not None else d * d + d
+        strides.append(stride)
+        slabs.append(torch.empty(ns * stride, dtype=torch.float32, device=pr["dW"].device))
+
+    def opt(m, f):
+        return [f(pr[m]) if pr.get(m) is not None else None for pr in problems]
+
+    def opti(m, f):
+        return [f(pr[m]) if pr.get(m) is not None else 0 for pr in problems]
+
+    gath = [pr.get("gather") for pr in problems]
+    sum_stride = []
+    for pr, g in zip(problems, gath):
+        if pr.get("nsum", 1) > 1:
+            sum_stride.append(g[0].bstride if g is not None else pr["gy"].bstride)
+        else:
+            sum_stride.append(0)
+    flops = sum(2.0 * max(B, pr.get("nsum", 1)) * r * d * d * (2 if pr.get("gx") is not None else 1)
+                for (B, r), pr in zip(rowsB, problems))
+    nbytes = sum(4.0 * max(B, pr.get("nsum", 1)) * r * d * 2 for (B, r), pr in zip(rowsB, problems))
+    nbytes += sum(4.0 * g[0].B * g[0].rows * d for g in gath if g is not None)
+    _launch(
+        "nlam_lin_bwd_multi", lib.nlam_lin_bwd_multi,
+        (n, d, P(*[pr["x"].ptr for pr in problems]), I64(*[pr["x"].bstride for pr in problems]),
+         I64(*[pr["x"].ld for pr in problems]),
+         P(*opt("xb", lambda m: m.ptr)), I64(*opti("xb", lambda m: m.bstride)),
+         I64(*opti("xb", lambda m: m.ld)),
+         P(*opt("gy", lambda m: m.ptr)),
+         I64(*[0 if pr.get("nsum", 1) > 1 or pr.get("gy") is None else pr["gy"].bstride for pr in problems]),
+         I64(*opti("gy", lambda m: m.ld)),
+         P(*opt("W", lambda w: w.data_ptr())), I64(*opti("W", lambda w: w.stride(0))),
+         P(*opt("gx", lambda m: m.ptr)), I64(*opti("gx", lambda m: m.bstride)),
+         I64(*opti("gx", lambda m: m.ld)),
+         P(*opt("gx_add", lambda m: m.ptr)), I64(*opti("gx_add", lambda m: m.bstride)),
+         I64(*opti("gx_add", lambda m: m.ld)),
+         I64(*[pr.get("nsum", 1) for pr in problems]), I64(*sum_stride),
+         P(*[g[0].ptr if g is not None else None for g in gath]),
+         I64(*[g[0].bstride if g is not None else 0 for g in gath]),
+         P(*[g[1].data_ptr() if g is not None else None for g in gath]),
+         P(*[g[2].data_ptr() if g is not None else None for g in gath]),
+         I64(*[g[3] if g is not None else 0 for g in gath]),
+         P(*[s_.data_ptr() for s_ in slabs]), I64(*strides),
+         I64(*[B for B, _ in rowsB]), I64(*[r for _, r in rowsB]), stream()),
+        flops=flops, nbytes=nbytes,
+    )
+    for pr, slab, ns, stride in zip(problems, slabs, nslabs, strides):
+        k = 2 * d if pr.get("xb") is not None else d
+        reduce_segments(slab, ns, stride, [(0, d, k, k, pr["dW"]), (d * k, 1, d, d, pr.get("db"))])
+
+
 def node_chain_supported():
     """The fused node-side kernels of an InteractionNet chain exist in this process's arithmetic
     mode (split-bf16 products, hidden width 64)."""
@@ -702,7 +801,7 @@ def node_outer(ga, xa, xb, gP, xl, dV1, dc1, dWA, dWB, dbB):
     has_a = ga is not None
     _launch(
         "nlam_node_outer", lib.nlam_node_outer,
-        (ga.data_ptr() if has_a else None,
+        ((ga.ptr if hasattr(ga, "ptr") else ga.data_ptr()) if has_a else None,
          xa.ptr if has_a else None, xa.bstride if has_a else 0, xa.ld if has_a else 0,
          xb.ptr if has_a else None, xb.bstride if has_a else 0, xb.ld if has_a else 0,
          gP.ptr, gP.bstride, gP.ld, xl.ptr, xl.bstride, xl.ld, slab.data_ptr(), stride, B, rows,
