@@ -256,6 +256,63 @@ int nlam_node_outer(const float* ga,
                     const float* xl, int64_t xl_bstride, int64_t xl_ld,
                     float* slab, int64_t slab_stride, int64_t B, int64_t rows, void* stream);
 
+/* ---- one call per InteractionNet (hidden width 64) ---------------------------------------
+ * nlam_inet_fwd / nlam_inet_bwd run the WHOLE forward / backward of the reference's
+ * InteractionNet.forward (interaction_net.py:86-131) -- hidden_layers = 1, plain MLPs, in-degree
+ * <= 32 -- as the launch sequence documented in neural_lam_amd/fused.py, from one host call: a
+ * Python caller otherwise pays one interpreter round trip per launch.  All row buffers the caller
+ * allocates are contiguous (rows x 64 fp32, batch-major); the views describe the INPUTS, which
+ * may be batch-invariant (B = 1, bstride = 0: the reference's expand_to_batch) or strided.
+ * Supported (nlam_inet_supported() = 1): split-bf16 arithmetic mode with the 16-row kernels on;
+ * shared nodes (rec.ptr == NULL) with per-sample node rows, or separate sender / receiver rows. */
+typedef struct nlam_inet_graph {     /* device tables: nlam_graph_build_host + nlam_graph_tiles_host */
+  const int32_t* tiles; int64_t ntiles;
+  const int32_t* csr_rowptr; const int32_t* csr_eid; const int32_t* csr_send; const int32_t* csr_rec;
+  const float* inv_deg;
+  const int32_t* csc_colptr; const int32_t* csc_eid;
+  int64_t n_send, n_rec, M;
+} nlam_inet_graph;
+typedef struct nlam_inet_view {      /* (B, rows, 64) fp32 input; B = 1: batch-invariant */
+  const float* ptr; int64_t B, bstride, ld;
+} nlam_inet_view;
+typedef struct nlam_inet_weights {   /* edge_mlp.{0,2,3}, aggr_mlp.{0,2,3} (utils.py:191-214) */
+  const float* W1; int64_t ldW1; const float* b1;      /* (64, 192): [edge | sender | receiver] */
+  const float* W2; int64_t ldW2; const float* b2; const float* gam; const float* bet;
+  const float* V1; int64_t ldV1; const float* c1;      /* (64, 128): [x_r | agg] */
+  const float* V2; int64_t ldV2; const float* c2; const float* gam2; const float* bet2;
+} nlam_inet_weights;
+typedef struct nlam_inet_args {
+  nlam_inet_graph g;
+  nlam_inet_weights w;
+  nlam_inet_view send, rec, edge;    /* rec.ptr == NULL: receivers are the senders (shared nodes) */
+  int64_t n_send_rows;               /* rows of send (>= g.n_send) */
+  int64_t B;                         /* batch size of the outputs */
+  int d, update_edges, mean;         /* d = 64 */
+  /* forward outputs and saved intermediates (caller-allocated, contiguous): */
+  float* P;       /* shared: (B, N, 128) = [Ps | Pr]; else Ps (send.B, n_send_rows, 64) */
+  float* Pr;      /* separate nodes: (rec.B, n_rec, 64) */
+  float* Pe;      /* update_edges == 0: (edge.B, M, 64) */
+  float* agg;     /* (B, n_rec, 64) */
+  float* e_out;   /* update_edges: (B, M, 64) */
+  float* rec_out; /* (B, n_rec, 64) */
+} nlam_inet_args;
+typedef struct nlam_inet_grads {
+  const float* g_rec_out;            /* (B, n_rec, 64) contiguous, required */
+  const float* g_edge_out;           /* (B, M, 64) contiguous or NULL */
+  float* g_send;                     /* (send.B, n_send_rows, 64): total gradient when nodes are shared */
+  float* g_rec;                      /* (rec.B, n_rec, 64); unused when nodes are shared */
+  float* g_edge;                     /* (edge.B, M, 64) */
+  float* dW1; float* db1; float* dW2; float* db2; float* dgam; float* dbet;     /* contiguous */
+  float* dV1; float* dc1; float* dV2; float* dc2; float* dgam2; float* dbet2;
+} nlam_inet_grads;
+int nlam_inet_supported(const nlam_inet_args* a);
+int nlam_inet_fwd(const nlam_inet_args* a, void* stream);
+/* workspace (fp32 elements) of nlam_inet_bwd for this configuration; the workspace holds the
+ * intermediates and the per-workgroup weight-gradient slabs, reduced by ONE launch at the end */
+int64_t nlam_inet_bwd_workspace(const nlam_inet_args* a);
+int nlam_inet_bwd(const nlam_inet_args* a, const nlam_inet_grads* gr, float* ws, int64_t ws_floats,
+                  void* stream);
+
 /* out[i] (+)= sum_s slab[s * stride + i], i < n (deterministic order). */
 int nlam_reduce_slabs(const float* slab, int64_t nslabs, int64_t stride, int64_t n,
                       float* out, int accumulate, void* stream);

@@ -44,6 +44,10 @@ SIGNATURES = {
     "nlam_outer_bwd_slab_stride": [_i32, _i32],
     "nlam_outer_bwd": [_p, _i64, _i64, _i32, _p, _i64, _i64, _i32, _p, _i64, _i64, _i32, _p, _p,
                        _i64, _i64, _i64, _p],
+    "nlam_inet_supported": [_p],
+    "nlam_inet_fwd": [_p, _p],
+    "nlam_inet_bwd_workspace": [_p],
+    "nlam_inet_bwd": [_p, _p, _p, _i64, _p],
     "nlam_lin_multi_supported": [],
     "nlam_lin_bwd_multi": [_i32, _i32] + [_p] * 28 + [_p],
     "nlam_node_chain_supported": [],
@@ -124,6 +128,7 @@ _RESTYPES = {
     "nlam_wmse_blocks": _i64,
     "nlam_mlp_bwd_slab_stride": _i64,
     "nlam_outer_bwd_slab_stride": _i64,
+    "nlam_inet_bwd_workspace": _i64,
     "nlam_node_bwd_slab_stride": _i64,
     "nlam_node_bwd_grid": _i64,
     "nlam_node_outer_slab_stride": _i64,

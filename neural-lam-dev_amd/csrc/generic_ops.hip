@@ -56,6 +56,7 @@ static int nlam_mfma_mode_value() {
     // a typo must not silently select an arithmetic (it used to fall through to fp32 / bf16)
     fprintf(stderr, "libnlam_hip: NLAM_MFMA=\"%s\" is not one of fp32 | bf16x3 | bf16\n", e);
     abort();
+    return -1;
   }();
   return mode;
 }

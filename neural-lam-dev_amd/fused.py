@@ -15,7 +15,7 @@ import os
 
 import torch
 
-from . import ops
+from . import inet_seq, ops
 from .ops import mat
 
 FORCE_GENERIC = os.environ.get("NLAM_FORCE_GENERIC", "0") == "1"
@@ -158,6 +158,33 @@ class FusedInteractionNetFunction(torch.autograd.Function):
             N_s, N_r, M = send_rep.shape[1], rec_rep.shape[1], edge_rep.shape[1]
             sm, rm, em = mat(send_rep.detach()), mat(rec_rep.detach()), mat(edge_rep.detach())
             W1e, W1s, W1r = W1[:, :d], W1[:, d : 2 * d], W1[:, 2 * d :]
+            # ---- one host call for the whole layer (csrc/inet_host.cpp) unless a per-kernel
+            # profiler wants to bracket the launches
+            if inet_seq.ENABLED and ops.PROFILER is None and not ops._DEBUG_SYNC and d == 64:
+                bufs = {"agg": _empty(B, N_r, d, device=dev), "rec_out": _empty(B, N_r, d, device=dev)}
+                if same:
+                    bufs["P"] = _empty(sm.B, N_s, 2 * d, device=dev)
+                else:
+                    bufs["P"] = _empty(sm.B, N_s, d, device=dev)
+                    bufs["Pr"] = _empty(rm.B, N_r, d, device=dev)
+                if update_edges:
+                    bufs["e_out"] = _empty(B, M, d, device=dev)
+                else:
+                    bufs["Pe"] = _empty(em.B, M, d, device=dev)
+                weights = (W1, b1, W2, b2, gam, bet, V1, c1, V2, c2, gam2, bet2)
+                sargs = inet_seq.make_args(g, sm, rm, em, same, update_edges, mean, B, weights, bufs)
+                if inet_seq.supported(sargs):
+                    inet_seq.forward(sargs, ops.stream())
+                    ctx.save_for_backward(W1, b1, W2, b2, gam, V1, c1, V2, c2, gam2)
+                    ctx.set_materialize_grads(False)
+                    ctx.g, ctx.same, ctx.update_edges, ctx.mean = g, same, update_edges, mean
+                    ctx.mats = (sm, rm, em)
+                    ctx.seq = (sargs, bufs, weights)
+                    ctx.dims = (B, N_s, N_r, M, d)
+                    if update_edges:
+                        return bufs["rec_out"], bufs["e_out"]
+                    return bufs["rec_out"]
+            ctx.seq = None
             # node-side projections of edge_mlp.0 (Pr carries the bias)
             if same:
                 P = _empty(sm.B, N_s, 2 * d, device=dev)
@@ -205,6 +232,8 @@ class FusedInteractionNetFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_rec_out, g_edge_out=None):
+        if ctx.seq is not None:
+            return FusedInteractionNetFunction._backward_seq(ctx, g_rec_out, g_edge_out)
         # every parameter-gradient slab of the layer is reduced by one launch at exit
         with ops.tag(ctx.g.tag), ops.slab_batch():
             W1, b1, W2, b2, gam, V1, c1, V2, c2, gam2 = ctx.saved_tensors
@@ -356,6 +385,34 @@ class FusedInteractionNetFunction(torch.autograd.Function):
                 ops.fused_lin_bwd_multi(probs + outer_jobs)
         return (g_send, g_rec_total, g_edge, None, None, None, None,
                 dW1, db1, dW2, db2, dgam, dbet, dV1, dc1, dV2, dc2, dg2, db2n)
+
+
+def _backward_seq(ctx, g_rec_out, g_edge_out):
+    """Backward through csrc/inet_host.cpp: allocate the gradients, one host call."""
+    sargs, bufs, weights = ctx.seq
+    ctx.seq = None
+    W1, b1, W2, b2, gam, bet, V1, c1, V2, c2, gam2, bet2 = weights
+    sm, rm, em = ctx.mats
+    B, N_s, N_r, M, d = ctx.dims
+    dev = W1.device
+    same = ctx.same
+    if g_rec_out is None:
+        g_rec_out = torch.zeros(B, N_r, d, dtype=torch.float32, device=dev)
+    g_rec_out = g_rec_out.contiguous()
+    geo = g_edge_out.contiguous() if (g_edge_out is not None and ctx.update_edges) else None
+    g_send = _empty(sm.B, N_s, d, device=dev)
+    g_rec = None if same else _empty(rm.B, N_r, d, device=dev)
+    g_edge = _empty(em.B, M, d, device=dev)
+    pg = [torch.empty_like(t) for t in (W1, b1, W2, b2, gam, bet, V1, c1, V2, c2, gam2, bet2)]
+    grads = inet_seq.Grads(g_rec_out.data_ptr(), geo.data_ptr() if geo is not None else None,
+                           g_send.data_ptr(), g_rec.data_ptr() if g_rec is not None else None,
+                           g_edge.data_ptr(), *[t.data_ptr() for t in pg])
+    ws = inet_seq.backward(sargs, grads, dev, ops.stream())
+    del ws, bufs
+    return (g_send, g_rec, g_edge, None, None, None, None, *pg)
+
+
+FusedInteractionNetFunction._backward_seq = staticmethod(_backward_seq)
 
 
 def apply_inet(net, send_rep, rec_rep, edge_rep):
