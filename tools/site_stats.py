@@ -21,7 +21,11 @@ import glob
 import json
 import re
 
-FAMILIES = [  # (kernel-name regex, family)
+FAMILIES = [  # (kernel-name regex, family); the first match wins, template arguments included
+    (r"^fs_lin_fwd_kernel<\d+, \d+, \d+, true>", "lin_bwd_data"),   # (transposed weights = data gradient)
+    (r"^node_fwd16_kernel", "node_fwd"), (r"^node_bwd16_kernel", "node_bwd"),
+    (r"^node_outer16_kernel", "node_outer"),
+    (r"^lin_fwd16_multi_kernel", "lin_fwd"), (r"^lin_bwd16_multi_kernel", "lin_bwd"),
     (r"^edge_fwd(16)?_kernel", "edge_fwd"), (r"^edge_bwd(16c?)?_kernel", "edge_bwd"),
     (r"^mlp_fwd(16)?_kernel", "mlp_fwd"), (r"^mlp_bwd(16)?_kernel", "mlp_bwd"),
     (r"^(lin_fwd(16|_b3)?|wide_lin_fwd|fs_lin_fwd)_kernel", "lin_fwd"),
@@ -41,9 +45,10 @@ FAMILIES = [  # (kernel-name regex, family)
 
 
 def kernel_family(name):
-    n = name.replace("void ", "").split("<")[0].split("(")[0].strip()
+    full = name.replace("void ", "").strip()
+    n = full.split("<")[0].split("(")[0].strip()
     for rx, fam in FAMILIES:
-        if re.match(rx, n):
+        if re.match(rx, full if "<" in rx else n):
             return fam
     return None
 
