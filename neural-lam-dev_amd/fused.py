@@ -131,7 +131,56 @@ def inet_eligible(net, send_rep, rec_rep, edge_rep):
         return False   # (InteractionNet.forward flattens leading dims before asking)
     if edge_rep.dtype != torch.float32:
         return False
-    return net.tables.ntiles > 0
+    return net.tables.ntiles > 0 or net.tables.virtual is not None
+
+
+class _VirtGraph:
+    """The tables the fused edge kernels see when receivers with more than 32 in-edges are cut
+    into virtual receivers (graph.VirtualReceivers): virtual row pointers / receiver ids /
+    tiles, the real edge ids and senders; the 1/deg scale moves to the fold-back stage."""
+
+    def __init__(self, t):
+        v = t.virtual
+        self.tiles, self.ntiles = v.tiles, v.ntiles
+        self.csr_rowptr, self.csr_rec = v.csr_rowptr, v.csr_rec
+        self.csr_eid, self.csr_send = t.csr_eid, t.csr_send
+        self.inv_deg, self.M, self.tag = None, t.M, t.tag
+
+
+def _edge_fwd_any(g, em, has_egemm, psm, prm, W1e, W2, b2, gam, bet, agg, e_out, mean, d, dev):
+    """nlam_edge_fwd on the graph's own tiles, or on its virtual receivers + fold-back."""
+    gv = g.virtual
+    if gv is None:
+        ops.fused_edge_fwd(g, em, has_egemm, psm, prm, W1e, W2, b2, gam, bet, mat(agg),
+                           mat(e_out) if e_out is not None else None, mean, d)
+        return
+    B = agg.shape[0]
+    pr_v = _empty(prm.B, gv.n_rec, d, device=dev)
+    ops.gather_rows(prm, gv.real_of_virt, mat(pr_v))
+    agg_v = _empty(B, gv.n_rec, d, device=dev)
+    ops.fused_edge_fwd(_VirtGraph(g), em, has_egemm, psm, mat(pr_v), W1e, W2, b2, gam, bet,
+                       mat(agg_v), mat(e_out) if e_out is not None else None, False, d)
+    ops.segment_sum(mat(agg_v), gv.rowptr2, None, mat(agg), scale=g.inv_deg if mean else None)
+
+
+def _edge_bwd_any(g, em, has_egemm, psm, prm, W1e, W2, b2, gam, g_agg, geo, gh, gpr_m, g_e, mean, d,
+                  dW1e, dW2, db2, dgam, dbet, dev):
+    gv = g.virtual
+    if gv is None:
+        ops.fused_edge_bwd(g, em, has_egemm, psm, prm, W1e, W2, b2, gam, mat(g_agg), geo, mat(gh),
+                           gpr_m, mat(g_e) if g_e is not None else None, mean, d, dW1e, dW2, db2,
+                           dgam, dbet)
+        return
+    B = g_agg.shape[0]
+    pr_v = _empty(prm.B, gv.n_rec, d, device=dev)
+    ops.gather_rows(prm, gv.real_of_virt, mat(pr_v))
+    g_agg_v = _empty(B, gv.n_rec, d, device=dev)
+    ops.gather_rows(mat(g_agg), gv.real_of_virt, mat(g_agg_v), row_scale=g.inv_deg if mean else None)
+    gpr_v = _empty(B, gv.n_rec, d, device=dev)
+    ops.fused_edge_bwd(_VirtGraph(g), em, has_egemm, psm, mat(pr_v), W1e, W2, b2, gam, mat(g_agg_v),
+                       geo, mat(gh), mat(gpr_v), mat(g_e) if g_e is not None else None, False, d,
+                       dW1e, dW2, db2, dgam, dbet)
+    ops.segment_sum(mat(gpr_v), gv.rowptr2, None, gpr_m)
 
 
 def _base(t):
@@ -160,7 +209,8 @@ class FusedInteractionNetFunction(torch.autograd.Function):
             W1e, W1s, W1r = W1[:, :d], W1[:, d : 2 * d], W1[:, 2 * d :]
             # ---- one host call for the whole layer (csrc/inet_host.cpp) unless a per-kernel
             # profiler wants to bracket the launches
-            if inet_seq.ENABLED and ops.PROFILER is None and not ops._DEBUG_SYNC and d == 64:
+            if (inet_seq.ENABLED and ops.PROFILER is None and not ops._DEBUG_SYNC and d == 64
+                    and g.virtual is None):
                 bufs = {"agg": _empty(B, N_r, d, device=dev), "rec_out": _empty(B, N_r, d, device=dev)}
                 if same:
                     bufs["P"] = _empty(sm.B, N_s, 2 * d, device=dev)
@@ -211,12 +261,11 @@ class FusedInteractionNetFunction(torch.autograd.Function):
             agg = _empty(B, N_r, d, device=dev)
             if update_edges:
                 e_out = _empty(B, M, d, device=dev)
-                ops.fused_edge_fwd(g, em, True, psm, prm, W1e, W2, b2, gam, bet, mat(agg),
-                                   mat(e_out), mean, d)
+                _edge_fwd_any(g, em, True, psm, prm, W1e, W2, b2, gam, bet, agg, e_out, mean, d, dev)
             else:
                 e_out = None
-                ops.fused_edge_fwd(g, mat(Pe), False, psm, prm, None, W2, b2, gam, bet, mat(agg),
-                                   None, mean, d)
+                _edge_fwd_any(g, mat(Pe), False, psm, prm, None, W2, b2, gam, bet, agg, None, mean, d,
+                              dev)
             rec_out = _empty(B, N_r, d, device=dev)
             ops.fused_mlp_fwd(rm, mat(agg), V1, c1, V2, c2, gam2, bet2, rm, mat(rec_out), d, d)
             ctx.save_for_backward(W1, b1, W2, b2, gam, V1, c1, V2, c2, gam2)
@@ -283,14 +332,12 @@ class FusedInteractionNetFunction(torch.autograd.Function):
             if ctx.update_edges:
                 g_e = _empty(B, M, d, device=dev)
                 geo = mat(g_edge_out.contiguous()) if g_edge_out is not None else None
-                ops.fused_edge_bwd(
-                    g, em, True, psm, prm, W1e, W2, b2, gam, mat(g_agg), geo, mat(gh), gpr_m,
-                    mat(g_e), ctx.mean, d, dW1[:, :d], dW2, db2, dgam, dbet)
+                _edge_bwd_any(g, em, True, psm, prm, W1e, W2, b2, gam, g_agg, geo, gh, gpr_m, g_e,
+                              ctx.mean, d, dW1[:, :d], dW2, db2, dgam, dbet, dev)
             else:
                 g_e = None
-                ops.fused_edge_bwd(
-                    g, mat(Pe), False, psm, prm, None, W2, b2, gam, mat(g_agg), None, mat(gh),
-                    gpr_m, None, ctx.mean, d, None, dW2, db2, dgam, dbet)
+                _edge_bwd_any(g, mat(Pe), False, psm, prm, None, W2, b2, gam, g_agg, None, gh, gpr_m,
+                              None, ctx.mean, d, None, dW2, db2, dgam, dbet, dev)
             # 3. sender-side reduction of gh (rows in the original edge order, sender lists of edge ids)
             if same and node_path:
                 # sender gather + projections backward in one data pass (csrc/fused16_node.hip),
@@ -451,6 +498,8 @@ def chain_eligible(nets, mesh_rep, edge_rep):
     if not all(inet_eligible(n, mesh_rep, mesh_rep, edge_rep) for n in nets):
         return False
     t0 = nets[0].tables
+    if t0.virtual is not None:
+        return False   # (virtual receivers: per-layer path)
     same = getattr(nets[0], "_chain_same_graph", None)
     if same is None or same[0] != tuple(id(n) for n in nets):
         # (decided once per module list: the comparison synchronises with the device)

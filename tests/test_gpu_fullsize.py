@@ -190,28 +190,94 @@ def test_aggregate_linearity_m2g_size(meps):
     assert abs(float(out[0].double().sum()) - float(m1.double().sum())) < 1e-3 * M ** 0.5
 
 
-def test_high_in_degree_takes_generic_kernels_and_matches_oracle():
-    """A receiver with more than 32 in-edges is outside the fused tiles' contract."""
+@pytest.mark.parametrize("shared,upd,aggr", [(True, True, "sum"), (False, False, "mean"),
+                                              (False, True, "mean")])
+def test_high_in_degree_runs_fused_on_virtual_receivers(shared, upd, aggr):
+    """Receivers with more than 32 in-edges (60+, 33 and exactly 64 here) at hidden 64: their CSR
+    segments are cut into virtual receivers of <= 32 edges (graph.VirtualReceivers), the FUSED
+    edge kernels run on those and a node-sized second stage folds the rows back.  Forward and
+    every gradient vs the CPU oracle; the generic GEMM sequence must not run."""
     import nlam_oracle as orc
-    from neural_lam_amd import fused
+    from neural_lam_amd import fused, ops
     from neural_lam_amd.interaction_net import InteractionNet
 
     gen = torch.Generator().manual_seed(5)
-    n, M, d = 40, 400, 64
-    send = torch.randint(0, n, (M,), generator=gen)
-    rec = torch.randint(0, n, (M,), generator=gen)
+    d, B = 64, 2
+    n_s, n_r, M = (40, 40, 500) if shared else (55, 31, 460)
+    send = torch.randint(0, n_s, (M,), generator=gen)
+    rec = torch.randint(0, n_r, (M,), generator=gen)
     rec[:60] = 7                                   # 60+ in-edges on receiver 7
-    rec[60], rec[61], send[62] = 0, n - 1, 0
-    send[63] = n - 1
-    ei = torch.stack((send, rec))
+    rec[60:93] = 11                                # 33+ on receiver 11
+    rec[rec == 20] = 19
+    rec[93:157] = 20                               # exactly 64 on receiver 20
+    rec[rec == 3] = 4                              # receiver 3 has none
+    rec[157], rec[158], send[159] = 0, n_r - 1, 0
+    send[160] = n_s - 1
+    ei = torch.stack((send + (0 if shared else n_r), rec))
     torch.manual_seed(6)
-    net = InteractionNet(ei, d)
+    net = InteractionNet(ei, d, update_edges=upd, aggr=aggr)
+    sd = {f"n.{k}": v.detach().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    net = net.cuda()
+    assert net.tables.ntiles == 0 and net.tables.virtual is not None
+    assert net.tables.max_in_degree >= 64
+    s_ = torch.randn(B, n_s, d, generator=gen)
+    r_ = s_ if shared else torch.randn(B, n_r, d, generator=gen)
+    e_ = torch.randn(B, M, d, generator=gen)
+    cr, ce = torch.randn(B, n_r, d, generator=gen), torch.randn(B, M, d, generator=gen)
+    sc = s_.clone().requires_grad_(True)
+    rc = sc if shared else r_.clone().requires_grad_(True)
+    ec = e_.clone().requires_grad_(True)
+    want = orc.interaction_net(sd, "n", ei, sc, rc, ec, update_edges=upd, aggr=aggr)
+    wl = (want[0] * cr).sum() + (want[1] * ce).sum() if upd else (want * cr).sum()
+    names = [k for k, _ in net.named_parameters()]
+    wg = torch.autograd.grad(wl, [sc, ec] + [sd[f"n.{k}"] for k in names])
+    sg = s_.cuda().requires_grad_(True)
+    rg = sg if shared else r_.cuda().requires_grad_(True)
+    eg = e_.cuda().requires_grad_(True)
+    assert fused.inet_eligible(net, sg, rg, eg)
+    ops.PROFILER = ops.KernelProfiler()
+    try:
+        got = net(sg, rg, eg)
+        gl = (got[0] * cr.cuda()).sum() + (got[1] * ce.cuda()).sum() if upd else (got * cr.cuda()).sum()
+        gl.backward()
+        ran = {k.split("@")[0] for k in ops.PROFILER.collect()}
+    finally:
+        ops.PROFILER = None
+    assert {"nlam_edge_fwd", "nlam_edge_bwd"} <= ran and "nlam_gemm" not in ran
+    g0 = got[0] if upd else got
+    w0 = want[0] if upd else want
+    assert rel(g0.detach().cpu(), w0.detach()) < 1e-4
+    if upd:
+        assert rel(got[1].detach().cpu(), want[1].detach()) < 1e-4
+    assert rel(sg.grad.cpu(), wg[0]) < 1e-3 and rel(eg.grad.cpu(), wg[1]) < 1e-3
+    for (k, p), w in zip(net.named_parameters(), wg[2:]):
+        assert rel(p.grad.cpu(), w) < 1e-3, k
+
+
+def test_g2m_of_a_finer_grid_runs_fused():
+    """create_graph.py:424-456 connects every grid node within 0.67 mesh spacings to a mesh node:
+    with a grid twice as fine relative to the mesh the g2m in-degree exceeds 32 (up to ~60); the
+    encoder InteractionNet must still run on the fused kernels and match the oracle."""
+    import nlam_oracle as orc
+    from neural_lam_amd import fused, graphgen
+    from neural_lam_amd.interaction_net import InteractionNet
+    from neural_lam_amd.utils import load_graph
+
+    with tempfile.TemporaryDirectory() as tmp:
+        graphgen.create_graph(tmp, graphgen.make_xy(54, 54, 2500.0), 1, False)
+        _, g = load_graph(tmp)
+    ei = g["g2m_edge_index"]
+    torch.manual_seed(8)
+    net = InteractionNet(ei, 64, update_edges=False)
     sd = {f"n.{k}": v.clone() for k, v in net.state_dict().items()}
     net = net.cuda()
-    x = torch.randn(2, n, d, generator=gen)
-    e = torch.randn(2, M, d, generator=gen)
-    assert net.tables.ntiles == 0
-    assert not fused.inet_eligible(net, x.cuda(), x.cuda(), e.cuda())
-    want = orc.interaction_net(sd, "n", ei, x, x, e)
-    got = net(x.cuda(), x.cuda(), e.cuda())
-    assert rel(got[0].cpu(), want[0]) < 1e-4 and rel(got[1].cpu(), want[1]) < 1e-4
+    assert net.tables.max_in_degree > 32 and net.tables.virtual is not None
+    gen = torch.Generator().manual_seed(9)
+    send = torch.randn(2, net.tables.n_send, 64, generator=gen)
+    rec = torch.randn(2, net.tables.n_rec, 64, generator=gen)
+    edge = torch.randn(2, ei.shape[1], 64, generator=gen)
+    assert fused.inet_eligible(net, send.cuda(), rec.cuda(), edge.cuda())
+    with torch.no_grad():
+        want = orc.interaction_net(sd, "n", ei, send, rec, edge, update_edges=False)
+        got = net(send.cuda(), rec.cuda(), edge.cuda())
+    assert rel(got.cpu(), want) < 1e-4
