@@ -537,6 +537,28 @@ int nlam_lin_fwd_multi(int n, int d, const float* const* x, const int64_t* x_bst
                        const float* const* W, const int64_t* ldW, const float* const* bias,
                        float* const* out, const int64_t* out_bstride, const int64_t* out_ld,
                        const int64_t* B, const int64_t* rows, int out_bf16_mask, void* stream);
+/* Several independent narrow-input MLP blocks in ONE launch (n <= 8): the static-feature embedders
+ * of a model -- mesh nodes and every edge set, `utils.make_mlp([k, 64, 64])` with LayerNorm
+ * (utils.py:191-214; base_graph_model.py:55-60, graph_lam.py:37-42, base_hi_graph_model.py:51-74)
+ * applied to 2-3 wide (<= 32) feature rows.  Arguments as nlam_mlp_fwd / nlam_mlp_bwd, one array
+ * entry per problem; one source, no residual; per-problem slabs as nlam_mlp_bwd
+ * (nlam_bwd_grid(B_k * ceil(rows_k / 32)) slabs of pitch >= nlam_mlp_bwd_slab_stride(k, 64, 64)). */
+int nlam_mlp_multi_supported(void);
+int nlam_mlp_fwd_multi(int n, const float* const* x, const int64_t* x_bstride, const int64_t* x_ld,
+                       const int32_t* x_width, const float* const* W1, const int64_t* ldW1,
+                       const float* const* b1, const float* const* W2, const int64_t* ldW2,
+                       const float* const* b2, const float* const* gamma, const float* const* beta,
+                       float* const* out, const int64_t* out_bstride, const int64_t* out_ld,
+                       const int64_t* B, const int64_t* rows, int hid, int n_out, void* stream);
+int nlam_mlp_bwd_multi(int n, const float* const* x, const int64_t* x_bstride, const int64_t* x_ld,
+                       const int32_t* x_width, const float* const* W1, const int64_t* ldW1,
+                       const float* const* b1, const float* const* W2, const int64_t* ldW2,
+                       const float* const* b2, const float* const* gamma,
+                       const float* const* gy, const int64_t* gy_bstride, const int64_t* gy_ld,
+                       float* const* gx, const int64_t* gx_bstride, const int64_t* gx_ld,
+                       float* const* slab, const int64_t* slab_stride,
+                       const int64_t* B, const int64_t* rows, int hid, int n_out, void* stream);
+
 /* Hidden width 64: the sender / receiver / edge thirds of an InteractionNet's first edge-MLP Linear
  * (interaction_net.py:121) differentiated in ONE launch (n <= 4 independent problems, d = 64):
  *   gx_k = gy_k W_k (+ gx_add_k)   (gx_k may be NULL), per-workgroup slabs [dW_k 64x64 | db_k 64]

@@ -48,6 +48,9 @@ SIGNATURES = {
     "nlam_inet_fwd": [_p, _p],
     "nlam_inet_bwd_workspace": [_p],
     "nlam_inet_bwd": [_p, _p, _p, _i64, _p],
+    "nlam_mlp_multi_supported": [],
+    "nlam_mlp_fwd_multi": [_i32] + [_p] * 17 + [_i32, _i32, _p],
+    "nlam_mlp_bwd_multi": [_i32] + [_p] * 21 + [_i32, _i32, _p],
     "nlam_lin_multi_supported": [],
     "nlam_lin_bwd_multi": [_i32, _i32] + [_p] * 28 + [_p],
     "nlam_node_chain_supported": [],

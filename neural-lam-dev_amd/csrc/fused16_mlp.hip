@@ -79,8 +79,7 @@ __device__ __forceinline__ void load_narrow16(f32x4* __restrict__ a, const float
 //          KB == 4: two sources of 64 columns each, 16-byte aligned.
 // gy: NOB == 2: 64 columns, 16-byte aligned; NOB == 1: any width <= 32 (element loads).
 template <int KB, int NOB, bool HAS_LN, bool DEFER, int TERMS>
-__global__ __launch_bounds__(K16_THREADS, 2) void mlp_bwd16_kernel(MlpBwdParams q) {
-  extern __shared__ __attribute__((aligned(16))) char smem16[];
+__device__ __forceinline__ void mlp_bwd16_body(const MlpBwdParams& q, int wg, int nwg, char* smem16) {
   constexpr int HID = 64, NFH = 4, KF = 2 * KB, NFO = 2 * NOB, NO = 32 * NOB, KP32 = 32 * KB;
   constexpr int KBA = DEFER ? 1 : KB;
   const MlpParams& p = q.f;
@@ -146,8 +145,7 @@ __global__ __launch_bounds__(K16_THREADS, 2) void mlp_bwd16_kernel(MlpBwdParams 
   const int64_t tiles_per_b = (p.rows + NLAM_T16 - 1) / NLAM_T16;
   const int64_t ntiles = tiles_per_b * p.B;
   const bool want_gx = q.gxa != nullptr || q.gxb != nullptr;
-  for (int64_t tt = (int64_t)blockIdx.x * K16_NW + wave; tt < ntiles;
-       tt += (int64_t)gridDim.x * K16_NW) {
+  for (int64_t tt = (int64_t)wg * K16_NW + wave; tt < ntiles; tt += (int64_t)nwg * K16_NW) {
     const int64_t b = tt / tiles_per_b;
     const int64_t r0 = (tt - b * tiles_per_b) * NLAM_T16;
     const int nrows = (int)((p.rows - r0) < NLAM_T16 ? (p.rows - r0) : NLAM_T16);
@@ -282,7 +280,7 @@ __global__ __launch_bounds__(K16_THREADS, 2) void mlp_bwd16_kernel(MlpBwdParams 
   // ---- fold the eight waves' partials in LDS (fixed order) and write the slab
   __syncthreads();
   float* img = reinterpret_cast<float*>(smem16);   // weights and planes are dead
-  float* slab = q.slab + (int64_t)blockIdx.x * q.slab_stride;
+  float* slab = q.slab + (int64_t)wg * q.slab_stride;
   constexpr int n1 = HID * KP32, n2 = NO * HID;
   if constexpr (!DEFER) {
     fold_blocks_to_slab16<2, KBA, KBA, K16_NW>(&dW1[0][0], img, KP32, slab, tid, wave, lane);
@@ -295,6 +293,29 @@ __global__ __launch_bounds__(K16_THREADS, 2) void mlp_bwd16_kernel(MlpBwdParams 
     fold_vec_to_slab16<1, K16_NW>(dgam, img, vbase + NO, NO, tid, wave, lane);
     fold_vec_to_slab16<1, K16_NW>(dbet, img, vbase + 2 * NO, NO, tid, wave, lane);
   }
+}
+
+template <int KB, int NOB, bool HAS_LN, bool DEFER, int TERMS>
+__global__ __launch_bounds__(K16_THREADS, 2) void mlp_bwd16_kernel(MlpBwdParams q) {
+  extern __shared__ __attribute__((aligned(16))) char smem16[];
+  mlp_bwd16_body<KB, NOB, HAS_LN, DEFER, TERMS>(q, (int)blockIdx.x, (int)gridDim.x, smem16);
+}
+
+// several independent narrow-input MLPs (the static-feature embedders of a model: mesh nodes and
+// every edge set, utils.py:191-214 applied to 2-3 wide rows) in one launch: KB = 1, LayerNorm
+#define K16_MAXM 8
+struct MlpBwdMulti {
+  MlpBwdParams q[K16_MAXM];
+  int n;
+  int wg0[K16_MAXM + 1];
+};
+template <int TERMS>
+__global__ __launch_bounds__(K16_THREADS, 2) void mlp_bwd16_multi_kernel(MlpBwdMulti m) {
+  extern __shared__ __attribute__((aligned(16))) char smem16[];
+  int k = 0;
+  while (k + 1 < m.n && (int)blockIdx.x >= m.wg0[k + 1]) ++k;
+  mlp_bwd16_body<1, 2, true, false, TERMS>(m.q[k], (int)blockIdx.x - m.wg0[k], m.wg0[k + 1] - m.wg0[k],
+                                           smem16);
 }
 
 template <int KB, int NOB, bool HAS_LN, bool DEFER>
@@ -636,8 +657,7 @@ int nlam_k16_outer_bwd(const OuterParams& q, hipStream_t s) {
 // LDS besides the weight images and ~100 registers: four or more waves per SIMD.  Sources as in
 // mlp_bwd16_kernel; NOB == 2: 64 outputs, 16-byte aligned (res, out); NOB == 1: any width <= 32.
 template <int KB, int NOB, bool HAS_LN, int TERMS>
-__global__ __launch_bounds__(K16_THREADS, 2) void mlp_fwd16_kernel(MlpParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem16[];
+__device__ __forceinline__ void mlp_fwd16_body(const MlpParams& p, int wg, int nwg, char* smem16) {
   constexpr int HID = 64, NFH = 4, KF = 2 * KB, NFO = 2 * NOB, NO = 32 * NOB, KP32 = 32 * KB;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -674,8 +694,7 @@ __global__ __launch_bounds__(K16_THREADS, 2) void mlp_fwd16_kernel(MlpParams p) 
   __syncthreads();
   const int64_t tiles_per_b = (p.rows + NLAM_T16 - 1) / NLAM_T16;
   const int64_t ntiles = tiles_per_b * p.B;
-  for (int64_t tt = (int64_t)blockIdx.x * K16_NW + wave; tt < ntiles;
-       tt += (int64_t)gridDim.x * K16_NW) {
+  for (int64_t tt = (int64_t)wg * K16_NW + wave; tt < ntiles; tt += (int64_t)nwg * K16_NW) {
     const int64_t b = tt / tiles_per_b;
     const int64_t r0 = (tt - b * tiles_per_b) * NLAM_T16;
     const int nrows = (int)((p.rows - r0) < NLAM_T16 ? (p.rows - r0) : NLAM_T16);
@@ -723,6 +742,25 @@ __global__ __launch_bounds__(K16_THREADS, 2) void mlp_fwd16_kernel(MlpParams p) 
       if (valid) store_row16_s<NFO>(orow, y, p.n_out, lane);
     }
   }
+}
+
+template <int KB, int NOB, bool HAS_LN, int TERMS>
+__global__ __launch_bounds__(K16_THREADS, 2) void mlp_fwd16_kernel(MlpParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem16[];
+  mlp_fwd16_body<KB, NOB, HAS_LN, TERMS>(p, (int)blockIdx.x, (int)gridDim.x, smem16);
+}
+
+struct MlpFwdMulti {
+  MlpParams p[K16_MAXM];
+  int n;
+  int wg0[K16_MAXM + 1];
+};
+template <int TERMS>
+__global__ __launch_bounds__(K16_THREADS, 2) void mlp_fwd16_multi_kernel(MlpFwdMulti m) {
+  extern __shared__ __attribute__((aligned(16))) char smem16[];
+  int k = 0;
+  while (k + 1 < m.n && (int)blockIdx.x >= m.wg0[k + 1]) ++k;
+  mlp_fwd16_body<1, 2, true, TERMS>(m.p[k], (int)blockIdx.x - m.wg0[k], m.wg0[k + 1] - m.wg0[k], smem16);
 }
 
 template <int KB, int NOB, bool HAS_LN>
@@ -863,6 +901,60 @@ int nlam_k16_lin_fwd_multi(const LinParams* p, int n, hipStream_t s) {
   return 0;
 }
 
+// ---- multi-problem embedder MLPs (KB = 1: one source of <= 32 columns, hidden = n_out = 64, LayerNorm)
+static bool mlp16_embedder_shape(const MlpParams& p) {
+  return p.nsrc == 1 && p.k_in >= 1 && p.k_in <= 32 && p.n_out == 64 && p.gamma != nullptr &&
+         p.res == nullptr && (p.vec_mask & 8) != 0;
+}
+
+int nlam_k16_mlp_fwd_multi(const MlpParams* p, int n, hipStream_t s) {
+  if (!nlam_k16_on(K16_MLP_FWD) || !nlam_mfma_b3() || n < 1 || n > K16_MAXM) return -1;
+  MlpFwdMulti m;
+  m.n = n;
+  m.wg0[0] = 0;
+  for (int k = 0; k < n; ++k) {
+    if (!mlp16_embedder_shape(p[k])) return -1;
+    m.p[k] = p[k];
+    const int64_t ntiles = ((p[k].rows + NLAM_T16 - 1) / NLAM_T16) * p[k].B;
+    int64_t g = (ntiles + K16_NW - 1) / K16_NW;
+    if (g > 512) g = 512;
+    m.wg0[k + 1] = m.wg0[k] + (int)(g < 1 ? 1 : g);
+  }
+  for (int k = n; k < K16_MAXM; ++k) m.wg0[k + 1] = m.wg0[n];
+  const size_t lds = w16_image_bytes(64, 32) + w16_image_bytes(64, 64) + (64 + 3 * 64) * sizeof(float);
+  auto kern = mlp_fwd16_multi_kernel<3>;
+  NLAM_BIG_LDS(kern, __func__);
+  kern<<<(unsigned)m.wg0[n], K16_THREADS, lds, s>>>(m);
+  NLAM_CHECK_LAUNCH("mlp_fwd16_multi_kernel");
+  return 0;
+}
+
+int nlam_k16_mlp_bwd_multi(const MlpBwdParams* q, int n, hipStream_t s) {
+  if (!nlam_k16_on(K16_MLP_BWD) || !nlam_mfma_b3() || n < 1 || n > K16_MAXM) return -1;
+  MlpBwdMulti m;
+  m.n = n;
+  m.wg0[0] = 0;
+  for (int k = 0; k < n; ++k) {
+    if (!mlp16_embedder_shape(q[k].f) || !q[k].vec_gy || q[k].gxb != nullptr || q[k].ga_out != nullptr ||
+        q[k].add_gy_to_gxa || q[k].stamp)
+      return -1;
+    m.q[k] = q[k];
+    m.wg0[k + 1] = m.wg0[k] + (int)nlam_bwd_grid(((q[k].f.rows + 31) / 32) * q[k].f.B);
+  }
+  for (int k = n; k < K16_MAXM; ++k) m.wg0[k + 1] = m.wg0[n];
+  constexpr int HID = 64, NO = 64, KP32 = 32;
+  size_t lds = w16_image_bytes(HID, KP32) + w16_image_bytes(NO, HID) + (HID + 2 * NO) * sizeof(float) +
+               K16_NW * (p16_bytes(HID) + p16_bytes(HID) + (size_t)NLAM_T16 * (HID + 4) * sizeof(float));
+  const size_t fold = (size_t)K16_NW * HID * HID * sizeof(float);
+  if (fold > lds) lds = fold;
+  NLAM_REQUIRE(lds <= 160 * 1024, "mlp_bwd16_multi: LDS footprint %zu B exceeds 160 KiB", lds);
+  auto kern = mlp_bwd16_multi_kernel<3>;
+  NLAM_BIG_LDS(kern, __func__);
+  kern<<<(unsigned)m.wg0[n], K16_THREADS, lds, s>>>(m);
+  NLAM_CHECK_LAUNCH("mlp_bwd16_multi_kernel");
+  return 0;
+}
+
 // ==================================================================== C entry points
 extern "C" int nlam_lin_multi_supported(void) {
   return nlam_mfma_b3() && nlam_k16_on(K16_LIN_FWD) && nlam_k16_on(K16_LIN_BWD) &&
@@ -968,5 +1060,87 @@ extern "C" int nlam_lin_bwd_multi(
   if (m == 0) return 0;
   const int r = nlam_k16_lin_bwd_multi(q, o, kind, m, (hipStream_t)stream);
   NLAM_REQUIRE(r >= 0, "nlam_lin_bwd_multi: needs the split-bf16 16-row kernels (nlam_lin_multi_supported())");
+  return r;
+}
+
+extern "C" int nlam_mlp_multi_supported(void) {
+  return nlam_mfma_b3() && nlam_k16_on(K16_MLP_FWD) && nlam_k16_on(K16_MLP_BWD) ? 1 : 0;
+}
+
+extern "C" int nlam_mlp_fwd_multi(int n, const float* const* x, const int64_t* x_bstride,
+                                  const int64_t* x_ld, const int32_t* x_width, const float* const* W1,
+                                  const int64_t* ldW1, const float* const* b1, const float* const* W2,
+                                  const int64_t* ldW2, const float* const* b2,
+                                  const float* const* gamma, const float* const* beta,
+                                  float* const* out, const int64_t* out_bstride, const int64_t* out_ld,
+                                  const int64_t* B, const int64_t* rows, int hid, int n_out,
+                                  void* stream) {
+  NLAM_REQUIRE(hid == 64 && n_out == 64, "nlam_mlp_fwd_multi: hidden / output width 64 only");
+  NLAM_REQUIRE(n >= 1 && n <= K16_MAXM, "nlam_mlp_fwd_multi: n %d out of [1, %d]", n, K16_MAXM);
+  MlpParams p[K16_MAXM];
+  int m = 0;
+  for (int k = 0; k < n; ++k) {
+    if (B[k] <= 0 || rows[k] <= 0) continue;
+    NLAM_REQUIRE(x[k] && W1[k] && W2[k] && gamma[k] && beta[k] && out[k], "nlam_mlp_fwd_multi: NULL operand %d", k);
+    NLAM_REQUIRE(x_width[k] >= 1 && x_width[k] <= 32, "nlam_mlp_fwd_multi: input width %d out of [1, 32]",
+                 x_width[k]);
+    MlpParams& q = p[m++];
+    q.src[0] = RowView{x[k], x_bstride[k], x_ld[k], x_width[k]};
+    q.src[1] = RowView{nullptr, 0, 0, 0};
+    q.nsrc = 1; q.k_in = x_width[k]; q.k_pad = (x_width[k] + 7) & ~7; q.n_out = 64;
+    q.W1 = W1[k]; q.ldW1 = ldW1[k]; q.b1 = b1[k]; q.W2 = W2[k]; q.ldW2 = ldW2[k]; q.b2 = b2[k];
+    q.gamma = gamma[k]; q.beta = beta[k];
+    q.res = nullptr; q.res_bstride = 0; q.res_ld = 0;
+    q.out = out[k]; q.out_bstride = out_bstride[k]; q.out_ld = out_ld[k];
+    q.rows = rows[k]; q.B = (int)B[k];
+    q.vec_mask = view_vec_ok(out[k], out_bstride[k], out_ld[k], 64) ? 8 : 0;
+    NLAM_REQUIRE(q.vec_mask & 8, "nlam_mlp_fwd_multi: output rows of problem %d must be 16-byte aligned", k);
+  }
+  if (m == 0) return 0;
+  const int r = nlam_k16_mlp_fwd_multi(p, m, (hipStream_t)stream);
+  NLAM_REQUIRE(r >= 0, "nlam_mlp_fwd_multi: needs the split-bf16 16-row kernels (nlam_mlp_multi_supported())");
+  return r;
+}
+
+extern "C" int nlam_mlp_bwd_multi(int n, const float* const* x, const int64_t* x_bstride,
+                                  const int64_t* x_ld, const int32_t* x_width, const float* const* W1,
+                                  const int64_t* ldW1, const float* const* b1, const float* const* W2,
+                                  const int64_t* ldW2, const float* const* b2,
+                                  const float* const* gamma, const float* const* gy,
+                                  const int64_t* gy_bstride, const int64_t* gy_ld, float* const* gx,
+                                  const int64_t* gx_bstride, const int64_t* gx_ld, float* const* slab,
+                                  const int64_t* slab_stride, const int64_t* B, const int64_t* rows,
+                                  int hid, int n_out, void* stream) {
+  NLAM_REQUIRE(hid == 64 && n_out == 64, "nlam_mlp_bwd_multi: hidden / output width 64 only");
+  NLAM_REQUIRE(n >= 1 && n <= K16_MAXM, "nlam_mlp_bwd_multi: n %d out of [1, %d]", n, K16_MAXM);
+  MlpBwdParams q[K16_MAXM];
+  int m = 0;
+  for (int k = 0; k < n; ++k) {
+    if (B[k] <= 0 || rows[k] <= 0) continue;
+    NLAM_REQUIRE(x[k] && W1[k] && W2[k] && gamma[k] && gy[k] && slab[k], "nlam_mlp_bwd_multi: NULL operand %d", k);
+    NLAM_REQUIRE(x_width[k] >= 1 && x_width[k] <= 32, "nlam_mlp_bwd_multi: input width %d out of [1, 32]",
+                 x_width[k]);
+    NLAM_REQUIRE(slab_stride[k] >= nlam_mlp_bwd_slab_stride(x_width[k], 64, 64),
+                 "nlam_mlp_bwd_multi: slab %d too small", k);
+    MlpBwdParams& r = q[m++];
+    MlpParams& p = r.f;
+    p.src[0] = RowView{x[k], x_bstride[k], x_ld[k], x_width[k]};
+    p.src[1] = RowView{nullptr, 0, 0, 0};
+    p.nsrc = 1; p.k_in = x_width[k]; p.k_pad = (x_width[k] + 7) & ~7; p.n_out = 64;
+    p.W1 = W1[k]; p.ldW1 = ldW1[k]; p.b1 = b1[k]; p.W2 = W2[k]; p.ldW2 = ldW2[k]; p.b2 = b2[k];
+    p.gamma = gamma[k]; p.beta = nullptr;
+    p.res = nullptr; p.res_bstride = 0; p.res_ld = 0; p.out = nullptr; p.out_bstride = 0; p.out_ld = 0;
+    p.rows = rows[k]; p.B = (int)B[k]; p.vec_mask = 8;
+    r.gy = RowView{gy[k], gy_bstride[k], gy_ld[k], 64};
+    r.gxa = gx[k]; r.gxa_bstride = gx_bstride[k]; r.gxa_ld = gx_ld[k];
+    r.gxb = nullptr; r.gxb_bstride = 0; r.gxb_ld = 0; r.add_gy_to_gxa = 0;
+    r.slab = slab[k]; r.slab_stride = slab_stride[k]; r.ga_out = nullptr;
+    r.vec_gy = view_vec_ok(gy[k], gy_bstride[k], gy_ld[k], 64);
+    r.vec_gxa = 0; r.vec_gxb = 0; r.stamp = 0;
+    NLAM_REQUIRE(r.vec_gy, "nlam_mlp_bwd_multi: gy rows of problem %d must be 16-byte aligned", k);
+  }
+  if (m == 0) return 0;
+  const int r = nlam_k16_mlp_bwd_multi(q, m, (hipStream_t)stream);
+  NLAM_REQUIRE(r >= 0, "nlam_mlp_bwd_multi: needs the split-bf16 16-row kernels (nlam_mlp_multi_supported())");
   return r;
 }

@@ -147,6 +147,9 @@ int nlam_k16_lin_bwd(const LinBwdParams& q, hipStream_t s);
 int nlam_k16_lin_bwd_multi(const LinBwdParams* q, const OuterParams* o, const int* kind, int n,
                            hipStream_t s);
 int nlam_k16_lin_fwd_multi(const LinParams* p, int n, hipStream_t s);
+int nlam_k16_mlp_fwd_multi(const MlpParams* p, int n, hipStream_t s);
+int nlam_k16_mlp_bwd_multi(const MlpBwdParams* q, int n, hipStream_t s);
+extern "C" int64_t nlam_mlp_bwd_slab_stride(int k_in, int hid, int n_out);
 int nlam_k16_outer_bwd(const OuterParams& q, hipStream_t s);
 int nlam_k16_mlp_fwd(const MlpParams& p, hipStream_t s);
 int nlam_k16_lin_fwd(const LinParams& p, hipStream_t s);

@@ -115,6 +115,85 @@ def apply_mlp(seq, x, res=None):
         ln.weight if ln is not None else None, ln.bias if ln is not None else None)
 
 
+# ------------------------------------------- several embedder MLPs in one launch
+# The static-feature embedders of a model (mesh nodes, every edge set: base_graph_model.py:55-60,
+# graph_lam.py:37-42, base_hi_graph_model.py:51-74) are independent make_mlp([k, 64, 64]) blocks on
+# 2-3 wide rows; most are a few workgroups.  They run as ONE launch per direction.
+MAX_MULTI = 8
+
+
+def _embedder_ok(seq, x):
+    if not mlp_eligible(seq, x) or x.dim() != 2:
+        return False
+    lin, ln = _mlp_parts(seq)
+    return ln is not None and lin[0].weight.shape[1] <= 32 and lin[1].weight.shape[0] == 64
+
+
+class FusedMultiMLPFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, n, *args):
+        xs, params = args[:n], args[n:]
+        P = [params[6 * k : 6 * k + 6] for k in range(n)]
+        xms = [mat(x.detach()) for x in xs]
+        outs = [_empty(x.shape[0], 64, device=x.device) for x in xs]
+        with ops.tag("static_embedders"):
+            ops.fused_mlp_fwd_multi([(xm, *P[k], mat(outs[k])) for k, xm in enumerate(xms)])
+        ctx.save_for_backward(*params)
+        ctx.set_materialize_grads(False)
+        ctx.n, ctx.xms = n, xms
+        ctx.need_gx = [x.requires_grad for x in xs]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gys):
+        n = ctx.n
+        params = ctx.saved_tensors
+        P = [params[6 * k : 6 * k + 6] for k in range(n)]
+        probs, gxs, grads = [], [], []
+        for k in range(n):
+            W1, b1, W2, b2, gam, bet = P[k]
+            xm = ctx.xms[k]
+            gy = gys[k]
+            if gy is None:
+                gy = torch.zeros(xm.rows, 64, dtype=torch.float32, device=W1.device)
+            gy = gy.contiguous()
+            gx = _empty(xm.rows, xm.cols, device=W1.device) if ctx.need_gx[k] else None
+            dst = _mlp_grad_dst(W1, W2, True)
+            probs.append({"x": xm, "W1": W1, "b1": b1, "W2": W2, "b2": b2, "gamma": gam,
+                          "gy": mat(gy), "gx": mat(gx) if gx is not None else None, "dst": dst})
+            gxs.append(gx)
+            grads += [dst["dW1"], dst["db1"], dst["dW2"], dst["db2"], dst["dgamma"], dst["dbeta"]]
+        with ops.tag("static_embedders"), ops.slab_batch():
+            ops.fused_mlp_bwd_multi(probs)
+        return (None, *gxs, *grads)
+
+
+def embed_many(items):
+    """items: [(key, HipMLP, x (rows, k))].  Returns {key: embedding}: eligible blocks in
+    multi-problem launches of up to MAX_MULTI, the rest through their own forward."""
+    out = {}
+    if not ops.mlp_multi_supported() or FORCE_GENERIC:
+        return {k: m(x) for k, m, x in items}
+    batch = [(k, m, x) for k, m, x in items if _embedder_ok(m, x)]
+    for k, m, x in items:
+        if not _embedder_ok(m, x):
+            out[k] = m(x)
+    for i in range(0, len(batch), MAX_MULTI):
+        part = batch[i : i + MAX_MULTI]
+        if len(part) == 1:
+            k, m, x = part[0]
+            out[k] = m(x)
+            continue
+        params = []
+        for _, m, _x in part:
+            lin, ln = _mlp_parts(m)
+            params += [lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias, ln.weight, ln.bias]
+        res = FusedMultiMLPFunction.apply(len(part), *[x for _, _, x in part], *params)
+        for (k, _, _), r in zip(part, res):
+            out[k] = r
+    return out
+
+
 # ---------------------------------------------------------- InteractionNet
 def inet_eligible(net, send_rep, rec_rep, edge_rep):
     if FORCE_GENERIC or not edge_rep.is_cuda:

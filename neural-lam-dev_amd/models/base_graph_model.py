@@ -3,7 +3,7 @@ same sub-module names, construction order (=> same default-init RNG stream)
 and predict_step contract; the GNN / MLP blocks are the HIP modules."""
 import torch
 
-from .. import glue, utils
+from .. import fused, glue, utils
 from ..interaction_net import InteractionNet
 from .ar_model import ARModel
 
@@ -52,8 +52,31 @@ class BaseGraphModel(ARModel):
     def process_step(self, mesh_rep):
         raise NotImplementedError("process_step not implemented")
 
+    # ---- static-feature embedders ---------------------------------------------------------
+    # The reference applies each embedder where its output is first needed (base_graph_model.py:
+    # 127-130, graph_lam.py:84-88, base_hi_graph_model.py:137-166).  They are independent small
+    # MLPs on batch-invariant static features, so one predict_step evaluates all of them in
+    # multi-problem launches up front (fused.embed_many) and the call sites read the results.
+    def static_embedders(self):
+        """[(key, module, features)] of every static-feature embedder of the model."""
+        return [("g2m", self.g2m_embedder, self.g2m_features),
+                ("m2g", self.m2g_embedder, self.m2g_features)]
+
+    def static_emb(self, key, module, features):
+        cache = getattr(self, "_static_emb", None)
+        if cache is not None and key in cache:
+            return cache[key]
+        return module(features)
+
     def predict_step(self, prev_state, prev_prev_state, forcing):
         """X_{t-1}, X_t, forcing -> X_{t+1}  (base_graph_model.py:106-177)."""
+        self._static_emb = fused.embed_many(self.static_embedders()) if prev_state.is_cuda else None
+        try:
+            return self._predict_step(prev_state, prev_prev_state, forcing)
+        finally:
+            self._static_emb = None
+
+    def _predict_step(self, prev_state, prev_prev_state, forcing):
         batch_size = prev_state.shape[0]
         srcs = (prev_state, prev_prev_state, forcing,
                 self.expand_to_batch(self.grid_static_features, batch_size))
@@ -62,8 +85,8 @@ class BaseGraphModel(ARModel):
         else:
             grid_features = torch.cat(srcs, dim=-1)
         grid_emb = self.grid_embedder(grid_features)
-        g2m_emb = self.g2m_embedder(self.g2m_features)
-        m2g_emb = self.m2g_embedder(self.m2g_features)
+        g2m_emb = self.static_emb("g2m", self.g2m_embedder, self.g2m_features)
+        m2g_emb = self.static_emb("m2g", self.m2g_embedder, self.m2g_features)
         mesh_emb = self.embedd_mesh_nodes()
 
         mesh_rep = self.g2m_gnn(

@@ -46,27 +46,40 @@ class BaseHiGraphModel(BaseGraphModel):
         num_mesh_nodes = sum(f.shape[0] for f in self.mesh_static_features)
         return num_mesh_nodes, num_mesh_nodes - self.mesh_static_features[0].shape[0]
 
+    def static_embedders(self):
+        items = super().static_embedders()
+        for l, (emb, f) in enumerate(zip(self.mesh_embedders, self.mesh_static_features)):
+            items.append((f"mesh{l}", emb, f))
+        for l, (emb, f) in enumerate(zip(self.mesh_same_embedders, self.m2m_features)):
+            items.append((f"same{l}", emb, f))
+        for l, (emb, f) in enumerate(zip(self.mesh_up_embedders, self.mesh_up_features)):
+            items.append((f"up{l}", emb, f))
+        for l, (emb, f) in enumerate(zip(self.mesh_down_embedders, self.mesh_down_features)):
+            items.append((f"down{l}", emb, f))
+        return items
+
     def embedd_mesh_nodes(self):
-        return self.mesh_embedders[0](self.mesh_static_features[0])
+        return self.static_emb("mesh0", self.mesh_embedders[0], self.mesh_static_features[0])
 
     def process_step(self, mesh_rep):
         B = mesh_rep.shape[0]
         L = self.num_levels
         mesh_rep_levels = [mesh_rep] + [
-            self.expand_to_batch(self.mesh_embedders[l](self.mesh_static_features[l]), B)
+            self.expand_to_batch(
+                self.static_emb(f"mesh{l}", self.mesh_embedders[l], self.mesh_static_features[l]), B)
             for l in range(1, L)
         ]
         mesh_same_rep = [
-            self.expand_to_batch(emb(f), B)
-            for emb, f in zip(self.mesh_same_embedders, self.m2m_features)
+            self.expand_to_batch(self.static_emb(f"same{l}", emb, f), B)
+            for l, (emb, f) in enumerate(zip(self.mesh_same_embedders, self.m2m_features))
         ]
         mesh_up_rep = [
-            self.expand_to_batch(emb(f), B)
-            for emb, f in zip(self.mesh_up_embedders, self.mesh_up_features)
+            self.expand_to_batch(self.static_emb(f"up{l}", emb, f), B)
+            for l, (emb, f) in enumerate(zip(self.mesh_up_embedders, self.mesh_up_features))
         ]
         mesh_down_rep = [
-            self.expand_to_batch(emb(f), B)
-            for emb, f in zip(self.mesh_down_embedders, self.mesh_down_features)
+            self.expand_to_batch(self.static_emb(f"down{l}", emb, f), B)
+            for l, (emb, f) in enumerate(zip(self.mesh_down_embedders, self.mesh_down_features))
         ]
         # mesh init: level l-1 -> l for l = 1..L-1
         for level_l, gnn in enumerate(self.mesh_init_gnns, start=1):

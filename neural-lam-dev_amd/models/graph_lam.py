@@ -56,11 +56,16 @@ class GraphLAM(BaseGraphModel):
     def get_num_mesh(self):
         return self.mesh_static_features.shape[0], 0
 
+    def static_embedders(self):
+        return super().static_embedders() + [
+            ("mesh0", self.mesh_embedder, self.mesh_static_features),
+            ("m2m", self.m2m_embedder, self.m2m_features)]
+
     def embedd_mesh_nodes(self):
-        return self.mesh_embedder(self.mesh_static_features)
+        return self.static_emb("mesh0", self.mesh_embedder, self.mesh_static_features)
 
     def process_step(self, mesh_rep):
         batch_size = mesh_rep.shape[0]
-        m2m_emb = self.m2m_embedder(self.m2m_features)
+        m2m_emb = self.static_emb("m2m", self.m2m_embedder, self.m2m_features)
         mesh_rep, _ = self.processor(mesh_rep, self.expand_to_batch(m2m_emb, batch_size))
         return mesh_rep

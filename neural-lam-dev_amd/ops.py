@@ -635,6 +635,79 @@ def fused_lin_bwd(x, gy, WA, WB, gx, dWA, dbA, dWB, dbB, gx_add=None, sum_gy_bat
     reduce_segments(slab, nslabs, stride, segs)
 
 
+def mlp_multi_supported():
+    """Multi-problem embedder MLP launches exist in this process's arithmetic mode."""
+    return bool(lib.nlam_mlp_multi_supported())
+
+
+def fused_mlp_fwd_multi(problems):
+    """[(x Mat (k <= 32 wide), W1, b1, W2, b2, gamma, beta, out Mat)] -> ONE launch
+    (make_mlp([k, 64, 64]) + LayerNorm each)."""
+    n = len(problems)
+    I64, I32, P = ctypes.c_int64 * n, ctypes.c_int32 * n, ctypes.c_void_p * n
+    xs = [pr[0] for pr in problems]
+    outs = [pr[7] for pr in problems]
+    _launch(
+        "nlam_mlp_fwd_multi", lib.nlam_mlp_fwd_multi,
+        (n, P(*[x.ptr for x in xs]), I64(*[x.bstride for x in xs]), I64(*[x.ld for x in xs]),
+         I32(*[x.cols for x in xs]), P(*[pr[1].data_ptr() for pr in problems]),
+         I64(*[pr[1].stride(0) for pr in problems]), P(*[_p(pr[2]) for pr in problems]),
+         P(*[pr[3].data_ptr() for pr in problems]), I64(*[pr[3].stride(0) for pr in problems]),
+         P(*[_p(pr[4]) for pr in problems]), P(*[pr[5].data_ptr() for pr in problems]),
+         P(*[pr[6].data_ptr() for pr in problems]), P(*[o.ptr for o in outs]),
+         I64(*[o.bstride for o in outs]), I64(*[o.ld for o in outs]), I64(*[o.B for o in outs]),
+         I64(*[o.rows for o in outs]), 64, 64, stream()),
+        flops=sum(2.0 * o.B * o.rows * 64 * (x.cols + 64) for x, o in zip(xs, outs)),
+        nbytes=sum(4.0 * o.B * o.rows * (x.cols + 64) for x, o in zip(xs, outs)),
+    )
+
+
+def fused_mlp_bwd_multi(problems):
+    """[dict(x, W1, b1, W2, b2, gamma, gy (Mat), gx (Mat or None), dst=dict(dW1, db1, dW2, db2,
+    dgamma, dbeta))] -> ONE launch + the slab reductions (batched by the caller's slab_batch)."""
+    n = len(problems)
+    I64, I32, P = ctypes.c_int64 * n, ctypes.c_int32 * n, ctypes.c_void_p * n
+    slabs, nsl, strides = [], [], []
+    for pr in problems:
+        x, gy = pr["x"], pr["gy"]
+        st = lib.nlam_mlp_bwd_slab_stride(x.cols, 64, 64)
+        ns = lib.nlam_bwd_grid(_ntiles(gy.B, gy.rows))
+        strides.append(st)
+        nsl.append(ns)
+        slabs.append(torch.empty(ns * st, dtype=torch.float32, device=pr["W1"].device))
+    gxs = [pr.get("gx") for pr in problems]
+    _launch(
+        "nlam_mlp_bwd_multi", lib.nlam_mlp_bwd_multi,
+        (n, P(*[pr["x"].ptr for pr in problems]), I64(*[pr["x"].bstride for pr in problems]),
+         I64(*[pr["x"].ld for pr in problems]), I32(*[pr["x"].cols for pr in problems]),
+         P(*[pr["W1"].data_ptr() for pr in problems]), I64(*[pr["W1"].stride(0) for pr in problems]),
+         P(*[_p(pr["b1"]) for pr in problems]), P(*[pr["W2"].data_ptr() for pr in problems]),
+         I64(*[pr["W2"].stride(0) for pr in problems]), P(*[_p(pr["b2"]) for pr in problems]),
+         P(*[pr["gamma"].data_ptr() for pr in problems]),
+         P(*[pr["gy"].ptr for pr in problems]), I64(*[pr["gy"].bstride for pr in problems]),
+         I64(*[pr["gy"].ld for pr in problems]),
+         P(*[g.ptr if g is not None else None for g in gxs]),
+         I64(*[g.bstride if g is not None else 0 for g in gxs]),
+         I64(*[g.ld if g is not None else 0 for g in gxs]),
+         P(*[s_.data_ptr() for s_ in slabs]), I64(*strides),
+         I64(*[pr["gy"].B for pr in problems]), I64(*[pr["gy"].rows for pr in problems]), 64, 64,
+         stream()),
+        flops=sum(4.0 * pr["gy"].B * pr["gy"].rows * 64 * (pr["x"].cols + 2 * 64) for pr in problems),
+        nbytes=sum(4.0 * pr["gy"].B * pr["gy"].rows * (2 * pr["x"].cols + 64) for pr in problems),
+    )
+    for pr, slab, ns, st in zip(problems, slabs, nsl, strides):
+        k_in = pr["x"].cols
+        kp32 = (k_in + 31) // 32 * 32
+        o1 = 64 * kp32
+        o2 = o1 + 64
+        ov = o2 + 64 * 64
+        dst = pr["dst"]
+        reduce_segments(slab, ns, st, [
+            (0, 64, k_in, kp32, dst["dW1"]), (o1, 1, 64, 64, dst["db1"]),
+            (o2, 64, 64, 64, dst["dW2"]), (ov, 1, 64, 64, dst["db2"]),
+            (ov + 64, 1, 64, 64, dst["dgamma"]), (ov + 128, 1, 64, 64, dst["dbeta"])])
+
+
 def lin_multi_supported():
     """Multi-problem projection launches exist at hidden 64 in this process's arithmetic mode."""
     return bool(lib.nlam_lin_multi_supported())

@@ -14,6 +14,24 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 
 
+def _get(q):
+    """A rank's result; a rank that died reports its traceback instead of letting the test wait."""
+    item = q.get(timeout=180)
+    if isinstance(item[1], str) and item[1] == "error":
+        raise RuntimeError(f"rank {item[0]} failed:\n{item[2]}")
+    return item
+
+
+def _guarded(name, rank, world, port, tmp, q, backend):
+    try:
+        globals()[name](rank, world, port, tmp, q, backend)
+    except BaseException:   # noqa: BLE001 - reported to the parent, then re-raised
+        import traceback
+
+        q.put((rank, "error", traceback.format_exc()))
+        raise
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -22,13 +40,20 @@ def _free_port():
     return p
 
 
+def _make_graph(tmp):
+    """Written ONCE by the parent before the ranks start (two ranks writing the same files at the
+    same time can read each other's half-written tensors)."""
+    from neural_lam_amd import graphgen
+
+    return graphgen.create_graph(tmp + "/graph/g", graphgen.make_xy(30, 28, 5000.0), None, False)
+
+
 def _build(tmp):
     import numpy as np
-    from neural_lam_amd import graphgen, synthetic
+    from neural_lam_amd import synthetic
     from neural_lam_amd.models import GraphLAM
 
-    info = graphgen.create_graph(tmp + "/graph/g", graphgen.make_xy(30, 28, 5000.0), None, False)
-    n = info["num_grid"]
+    n = 30 * 28
     gen = torch.Generator().manual_seed(0)
     ds = synthetic.SyntheticDatastore(
         tmp, torch.randn(n, 1, generator=gen).numpy(), np.zeros(5), np.ones(5), np.zeros(5),
@@ -73,13 +98,14 @@ def test_two_rank_gradients_match_single_process(backend):
     if backend == "nccl" and torch.cuda.device_count() < 2:
         pytest.skip("RCCL needs one GPU per rank (it refuses two ranks on one device)")
     with tempfile.TemporaryDirectory() as tmp:
+        _make_graph(tmp)
         ctx = mp.get_context("spawn")
         q = ctx.Queue()
         port = _free_port()
-        procs = [ctx.Process(target=_worker, args=(r, 2, port, tmp, q, backend)) for r in range(2)]
+        procs = [ctx.Process(target=_guarded, args=("_worker", r, 2, port, tmp, q, backend)) for r in range(2)]
         for p in procs:
             p.start()
-        res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+        res = sorted([_get(q) for _ in range(2)], key=lambda t: t[0])
         for p in procs:
             p.join(timeout=60)
             assert p.exitcode == 0
@@ -144,14 +170,15 @@ def test_overlapped_buckets_on_device_tensors_bit_identical(backend):
     if backend == "nccl" and torch.cuda.device_count() < 2:
         pytest.skip("RCCL needs one GPU per rank (it refuses two ranks on one device)")
     with tempfile.TemporaryDirectory() as tmp:
+        _make_graph(tmp)
         ctx = mp.get_context("spawn")
         q = ctx.Queue()
         port = _free_port()
-        procs = [ctx.Process(target=_overlap_worker, args=(r, 2, port, tmp, q, backend))
+        procs = [ctx.Process(target=_guarded, args=("_overlap_worker", r, 2, port, tmp, q, backend))
                  for r in range(2)]
         for p in procs:
             p.start()
-        res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+        res = sorted([_get(q) for _ in range(2)], key=lambda t: t[0])
         for p in procs:
             p.join(timeout=60)
             assert p.exitcode == 0
