@@ -142,13 +142,29 @@ class ARModel(_Base):
         """init_states (B,2,N,d_f), forcing (B,T,N,d_forcing), true_states (B,T,N,d_f)."""
         prev_prev_state = init_states[:, 0]
         prev_state = init_states[:, 1]
-        prediction_list, pred_std_list = [], []
         # args.ar_checkpoint (not a reference option; SURVEY 8f-2): keep only the states
         # between AR steps and recompute each predict_step in backward
         # (_RecomputedPredictStep), which lifts the ar_steps memory ceiling of BPTT at
         # about one extra forward per step
         ckpt = (getattr(self, "ar_checkpoint", False) and torch.is_grad_enabled()
                 and forcing_features.shape[1] > 1 and not self.output_std)
+        # the static-feature embeddings do not depend on the state: one evaluation serves every
+        # AR step of this rollout (the reference recomputes them per step, base_graph_model.py:
+        # 127-130; same values, and their gradient is the sum over the steps either way).  Not
+        # with ar_checkpoint, whose recomputed segments must be self-contained.
+        share = (not ckpt and forcing_features.shape[1] > 1 and prev_state.is_cuda
+                 and hasattr(self, "static_embedders"))
+        if share:
+            from .. import fused
+
+            self._static_emb_rollout = fused.embed_many(self.static_embedders())
+        try:
+            return self._unroll(prev_state, prev_prev_state, forcing_features, true_states, ckpt)
+        finally:
+            self._static_emb_rollout = None
+
+    def _unroll(self, prev_state, prev_prev_state, forcing_features, true_states, ckpt):
+        prediction_list, pred_std_list = [], []
         for i in range(forcing_features.shape[1]):
             if ckpt:
                 if not hasattr(self, "_ckpt_anchor") or self._ckpt_anchor.device != prev_state.device:

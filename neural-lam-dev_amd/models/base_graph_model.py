@@ -70,7 +70,11 @@ class BaseGraphModel(ARModel):
 
     def predict_step(self, prev_state, prev_prev_state, forcing):
         """X_{t-1}, X_t, forcing -> X_{t+1}  (base_graph_model.py:106-177)."""
-        self._static_emb = fused.embed_many(self.static_embedders()) if prev_state.is_cuda else None
+        shared = getattr(self, "_static_emb_rollout", None)   # set by a multi-step rollout
+        if shared is not None:
+            self._static_emb = shared
+        else:
+            self._static_emb = fused.embed_many(self.static_embedders()) if prev_state.is_cuda else None
         try:
             return self._predict_step(prev_state, prev_prev_state, forcing)
         finally:
