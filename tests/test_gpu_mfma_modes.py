@@ -63,3 +63,18 @@ def test_wide_cases_in_mode(mode, width):
     assert "all wide cases passed" in out.stdout
     assert f"ok autocast golden op d{width}" in out.stdout
     assert "levels=3 layers=2" in out.stdout
+
+
+@pytest.mark.parametrize("env", [{"NLAM_K16": "0"}, {"NLAM_INET_SEQ": "0"}, {"NLAM_K16": "63"}],
+                         ids=["32-row-kernels", "launch-by-launch", "no-node-chain"])
+def test_alternate_kernel_selections_hold_the_goldens(env):
+    """The kernel families are selectable per process (NLAM_K16: 16-row vs 32-row forms, node
+    chain; NLAM_INET_SEQ: C++ sequencer vs one ctypes call per launch): every selection must hold
+    the operator and model goldens, not only the default one."""
+    out = subprocess.run(
+        [sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu",
+         os.path.join(ROOT, "tests", "test_gpu_interaction_net.py"),
+         os.path.join(ROOT, "tests", "test_gpu_models.py")],
+        env=dict(os.environ, **env), capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, (out.stdout[-2500:], out.stderr[-1500:])
+    assert " passed" in out.stdout and "failed" not in out.stdout
