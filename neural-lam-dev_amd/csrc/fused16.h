@@ -266,8 +266,8 @@ __device__ __forceinline__ void vec_to_acc16(f32x4 (&v)[NF], const float* __rest
 
 // row sums over the 4 lanes (t, 0..3) that share a row
 __device__ __forceinline__ float row_sum16(float s) {
-  s += __shfl_xor(s, 16, 64);
-  s += __shfl_xor(s, 32, 64);
+  s = lane_xor16_sum(s);
+  s = lane_xor32_sum(s);
   return s;
 }
 template <int NF>

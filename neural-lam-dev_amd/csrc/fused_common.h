@@ -565,7 +565,7 @@ __device__ __forceinline__ void ln_stats(const f32x16 (&z)[NB], float& mean, flo
   for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
     for (int r = 0; r < 16; ++r) s += z[nb][r];
-  s += __shfl_xor(s, 32, 64);
+  s = lane_xor32_sum(s);
   mean = s * inv_d;
   float v = 0.f;
 #pragma unroll
@@ -575,7 +575,7 @@ __device__ __forceinline__ void ln_stats(const f32x16 (&z)[NB], float& mean, flo
       const float d = z[nb][r] - mean;
       v += d * d;
     }
-  v += __shfl_xor(v, 32, 64);
+  v = lane_xor32_sum(v);
   rstd = rsqrtf(v * inv_d + 1e-5f);
 }
 

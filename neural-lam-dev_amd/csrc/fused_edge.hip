@@ -522,8 +522,8 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
       if constexpr (MCS0) acc_to_tile_b3<NB>(prod, T1p, 0, lane);
       else acc_to_tile<NB>(prod, T1, LDT, lane);
     }
-    s1 += __shfl_xor(s1, 32, 64);
-    s2 += __shfl_xor(s2, 32, 64);
+    s1 = lane_xor32_sum(s1);
+    s2 = lane_xor32_sum(s2);
     const float m1 = s1 * inv_d, m2 = s2 * inv_d;
     wave_sync();
     if constexpr (MCS0) tile_colsum_b3<NV>(dgam, T1p, 0, lane);

@@ -893,7 +893,7 @@ __global__ __launch_bounds__(2 * D) void fs_tail_fwd_kernel(FsTailFwdParams p) {
         float sm = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) sm += z[rb][r];
-        sm += __shfl_xor(sm, 32, 64);
+        sm = lane_xor32_sum(sm);
         if (h == 0) red[(32 * rb + t) * NW + wave] = sm;
       }
       __syncthreads();
@@ -910,7 +910,7 @@ __global__ __launch_bounds__(2 * D) void fs_tail_fwd_kernel(FsTailFwdParams p) {
           const float dlt = z[rb][r] - mean[rb];
           vs += dlt * dlt;
         }
-        vs += __shfl_xor(vs, 32, 64);
+        vs = lane_xor32_sum(vs);
         if (h == 0) red[FS_R * NW + (32 * rb + t) * NW + wave] = vs;
       }
       __syncthreads();
@@ -1272,7 +1272,7 @@ __global__ __launch_bounds__(2 * D) void fs_tail_bwd_kernel(FsTailBwdParams q) {
         float sm = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) sm += z[rb][r];
-        sm += __shfl_xor(sm, 32, 64);
+        sm = lane_xor32_sum(sm);
         if (h == 0) red[(32 * rb + t) * NW + wave] = sm;
       }
       __syncthreads();
@@ -1288,7 +1288,7 @@ __global__ __launch_bounds__(2 * D) void fs_tail_bwd_kernel(FsTailBwdParams q) {
           const float dlt = z[rb][r] - mean[rb];
           vs += dlt * dlt;
         }
-        vs += __shfl_xor(vs, 32, 64);
+        vs = lane_xor32_sum(vs);
         if (h == 0) red[FS_R * NW + (32 * rb + t) * NW + wave] = vs;
       }
       __syncthreads();
@@ -1319,8 +1319,8 @@ __global__ __launch_bounds__(2 * D) void fs_tail_bwd_kernel(FsTailBwdParams q) {
             s2 += gv * xh;
           }
           fs_acc_to_tile1<LDO>(g, gtile, rb, wave, lane);
-          s1 += __shfl_xor(s1, 32, 64);
-          s2 += __shfl_xor(s2, 32, 64);
+          s1 = lane_xor32_sum(s1);
+          s2 = lane_xor32_sum(s2);
           if (h == 0) {
             red[(32 * rb + t) * NW + wave] = s1;
             red[FS_R * NW + (32 * rb + t) * NW + wave] = s2;

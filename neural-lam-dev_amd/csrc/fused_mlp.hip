@@ -623,8 +623,8 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpBwdParams q) {
         }
         acc_to_tile<1>(prod, T1 + 32 * nb, ldt1, lane);
       }
-      s1 += __shfl_xor(s1, 32, 64);
-      s2 += __shfl_xor(s2, 32, 64);
+      s1 = lane_xor32_sum(s1);
+      s2 = lane_xor32_sum(s2);
       const float m1 = s1 * inv_d, m2 = s2 * inv_d;
       wave_sync();
       tile_colsum_all<NV_O>(dgam, T1, ldt1, 0, lane);

@@ -534,8 +534,8 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(TailBwdParams q) {
       }
       wave_sync();
       tile_colsum_b3<NV_O, TERMS>(dgam, Tp, 0, lane);
-      s1 += __shfl_xor(s1, 32, 64);
-      s2 += __shfl_xor(s2, 32, 64);
+      s1 = lane_xor32_sum(s1);
+      s2 = lane_xor32_sum(s2);
       const float m1 = s1 * inv_d, m2 = s2 * inv_d;
 #pragma unroll
       for (int nb = 0; nb < NOUTB; ++nb)

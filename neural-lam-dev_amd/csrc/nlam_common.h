@@ -64,6 +64,24 @@ __device__ __forceinline__ float nlam_silu_grad(float x) {
   return s * (1.0f + x * (1.0f - s));
 }
 
+// x[l] + x[l ^ 16] / x[l] + x[l ^ 32] in every lane through gfx950's v_permlane16_swap /
+// v_permlane32_swap (a VALU half-exchange: odd 16-lane rows of the first operand <-> even rows of
+// the second; upper 32 lanes of the first <-> lower 32 of the second) instead of __shfl_xor, which
+// compiles to ds_bpermute_b32 -- a round trip through the LDS crossbar on the critical path of
+// every LayerNorm (tools/permlane_probe.hip: same sums, bit for bit).  Inline asm: with both
+// operands holding the same value hipcc 7.2 folds the builtin's two results into one register;
+// `s_nop 1` covers the "VALU write -> v_permlane read" hazard the assembler cannot see.
+__device__ __forceinline__ float lane_xor16_sum(float x) {
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+__device__ __forceinline__ float lane_xor32_sum(float x) {
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
