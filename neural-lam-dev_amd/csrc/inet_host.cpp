@@ -302,13 +302,17 @@ static int64_t inet_bwd_plan(const nlam_inet_args* a, const nlam_inet_grads* gr,
     if (!same)   // deferred dV1 = ga^T [x_r | agg], dc1 = colsum ga
       push(a->rec.ptr, a->rec.bstride, a->rec.ld, a->agg, N_r * D, ga, N_r * D, nullptr, nullptr, 0, nullptr, 0,
            1, 0, nullptr, B, N_r, run ? gr->dV1 : (float*)1, 2 * D, run ? gr->dc1 : (float*)1, 2 * D);
+    // (separate nodes: the batch sum of an edge-updating layer's g_e is issued before the
+    // projections, the order of neural_lam_amd/fused.py -- tools/site_stats.py walks rocprof
+    // traces against that order)
+    if (!same && upd && Be == 1 && B > 1) RUN(nlam_sum_batch(g_e, M * D, gr->g_edge, B, M * D, stream));
     if (n > 0)
       RUN(nlam_lin_bwd_multi(n, D, x, xbs, xld, xb, xbbs, xbld, gy, gybs, gyld, Wk, ldw, gx, gxbs, gxld, gxa,
                              gabs, gald, nsum, sstr, ghp, ghbs, colp, eidp, nsend, slab, sst, Bk, rows,
                              stream));
   }
   // 4. batch-invariant edge input of an edge-updating layer: its gradient sums over the batch
-  if (upd && Be == 1 && B > 1) RUN(nlam_sum_batch(g_e, M * D, gr->g_edge, B, M * D, stream));
+  if (same && upd && Be == 1 && B > 1) RUN(nlam_sum_batch(g_e, M * D, gr->g_edge, B, M * D, stream));
   // 5. every parameter gradient of the layer: one reduction launch
   if (run && segs.n > 0)
     RUN(nlam_reduce_slabs_batch(segs.n, segs.slab, segs.nslabs, segs.stride, segs.src_off, segs.rows,
