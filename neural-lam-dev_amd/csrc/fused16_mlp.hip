@@ -36,15 +36,22 @@ template <int KF>
 __device__ __forceinline__ void load_cat16(f32x4* __restrict__ x, const float* __restrict__ ra,
                                            int wa, const float* __restrict__ rb, int wb, int lane) {
   const int g = lane >> 4;
+  // all KF loads first, the zeroing of the columns past the end afterwards: with the select
+  // next to each load the compiler re-used one register quad and waited for every load in turn
+  // (four serial global round trips per tile in the .s)
+  bool live[KF];
 #pragma unroll
   for (int fb = 0; fb < KF; ++fb) {
     const int c0 = 16 * fb + 4 * g;
     const bool in_a = c0 < wa, in_b = !in_a && (c0 - wa) < wb;
     const float* p = in_a ? ra + c0 : (in_b ? rb + (c0 - wa) : ra);
-    f32x4 v = *reinterpret_cast<const f32x4*>(p);
-    if (!(in_a || in_b)) v = f32x4{0.f, 0.f, 0.f, 0.f};
-    x[fb] = v;
+    live[fb] = in_a || in_b;
+    x[fb] = *reinterpret_cast<const f32x4*>(p);
   }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int fb = 0; fb < KF; ++fb)
+    if (!live[fb]) x[fb] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 template <int KF>
 __device__ __forceinline__ void store_cols16(float* __restrict__ row, const f32x4* __restrict__ a,
@@ -56,7 +63,8 @@ __device__ __forceinline__ void store_cols16(float* __restrict__ row, const f32x
     if (c0 < width) *reinterpret_cast<f32x4*>(row + c0) = a[fb0 + fb];
   }
 }
-// narrow / unaligned rows: element loads from clamped addresses
+// narrow / unaligned rows: element loads from clamped addresses -- all loads first, the zeroing
+// of the columns past the end afterwards (a select next to each load serialises the loads)
 template <int NF>
 __device__ __forceinline__ void load_narrow16(f32x4* __restrict__ a, const float* __restrict__ row,
                                               int width, int lane) {
@@ -66,8 +74,15 @@ __device__ __forceinline__ void load_narrow16(f32x4* __restrict__ a, const float
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int f = 16 * fb + 4 * g + r;
-      const float v = row[f < width ? f : 0];
-      a[fb][r] = f < width ? v : 0.f;
+      a[fb][r] = row[f < width ? f : 0];
+    }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int fb = 0; fb < NF; ++fb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int f = 16 * fb + 4 * g + r;
+      if (f >= width) a[fb][r] = 0.f;
     }
 }
 
