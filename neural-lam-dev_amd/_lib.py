@@ -11,7 +11,8 @@ import torch  # noqa: F401  (loads torch's libamdhip64.so.7 first, so that the
 # library binds to the same HIP runtime as the streams/tensors it is handed)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnlam_hip.so")
+# (NLAM_LIB_PATH: another build of the same library, for same-box A/B timing of kernel variants)
+LIB_PATH = os.environ.get("NLAM_LIB_PATH") or os.path.join(_HERE, "libnlam_hip.so")
 
 _i64, _i32, _p, _f = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_float
 

@@ -360,7 +360,8 @@ template <int D, int K, int TERMS, bool TRANS>
 __device__ __forceinline__ void fs_lin_fwd_body(const FsLinParams& p, const int bid, const int gdim,
                                                 float* smem) {
   constexpr int LDO = D + 4;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: tile / batch address math goes to the scalar unit
   FsPlanes<K, TERMS> X;
   X.init(smem);
   float* otile = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + FsPlanes<K, TERMS>::bytes);
@@ -732,7 +733,8 @@ template <int D, bool HAS_LN, int TERMS, bool IO16 = false>
 __global__ __launch_bounds__(2 * D) void fs_tail_fwd_kernel(FsTailFwdParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NT = 2 * D, NW = D / 32, LDO = D + 4, CPR = D / 4;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: tile / batch address math goes to the scalar unit
   const int t = lane & 31, h = lane >> 5;
   FsPlanes<D, TERMS> S;
   S.init(smem);
@@ -1115,7 +1117,8 @@ template <int D, bool HAS_LN, int TERMS, bool IO16 = false>
 __global__ __launch_bounds__(2 * D) void fs_tail_bwd_kernel(FsTailBwdParams q) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NT = 2 * D, NW = D / 32, LDO = D + 4, CPR = D / 4;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: tile / batch address math goes to the scalar unit
   const int t = lane & 31, h = lane >> 5;
   FsPlanes<D, TERMS> S;      // kept z rows (bf16), later gz
   S.init(smem);
@@ -1514,7 +1517,8 @@ __device__ __forceinline__ void fs_outer_body(const FsOuterParams& q, const int 
                                               float* smem) {
   constexpr int NX = 32 * NXB, NT = 512;
   constexpr int NJ = GW == 256 ? NXB : 1;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: tile / batch address math goes to the scalar unit
   FsPlanes<GW, TERMS, 16> G;
   G.init(smem);
   FsPlanes<NX, TERMS, 16> X;
