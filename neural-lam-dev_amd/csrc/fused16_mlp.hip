@@ -188,17 +188,24 @@ __device__ __forceinline__ void mlp_bwd16_body(const MlpBwdParams& q, int wg, in
         gemm_acc16<NFH, KB, TERMS>(hpre, W1im, 0, 0, x, lane);
       }
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (DEFER) {
-#pragma unroll
-        for (int fb = 0; fb < NFH; ++fb) hkeep[fb] = hpre[fb];
-      } else {
-        acc16_to_tile<NFH>(hpre, HS, HID + 4, lane);          // h: back from LDS for silu'
-      }
+      // silu and silu' from ONE sigmoid (v_exp + v_rcp are quarter-rate); silu'(h) is what is
+      // kept (registers / LDS stash) for the ga product, not h
       f32x4 sact[NFH];
 #pragma unroll
       for (int fb = 0; fb < NFH; ++fb)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sact[fb][r] = nlam_silu(hpre[fb][r]);
+        for (int r = 0; r < 4; ++r) {
+          float sv, dv;
+          silu_both(hpre[fb][r], sv, dv);
+          sact[fb][r] = sv;
+          hpre[fb][r] = dv;
+        }
+      if constexpr (DEFER) {
+#pragma unroll
+        for (int fb = 0; fb < NFH; ++fb) hkeep[fb] = hpre[fb];
+      } else {
+        acc16_to_tile<NFH>(hpre, HS, HID + 4, lane);          // silu'(h): back from LDS later
+      }
       acc16_to_planes<NFH, TERMS>(sact, Ts, 0, lane);         // S stays in R0 until dW2 is formed
       const float* rg = q.gy.ptr + b * q.gy.bstride + opaque(row) * q.gy.ld;
       if constexpr (HAS_LN) {
@@ -243,7 +250,7 @@ __device__ __forceinline__ void mlp_bwd16_body(const MlpBwdParams& q, int wg, in
         if constexpr (DEFER) h4 = hkeep[fb];
         else h4 = *reinterpret_cast<const f32x4*>(HS + t * (HID + 4) + 16 * fb + 4 * gq4);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ga[fb][r] *= nlam_silu_grad(h4[r]);
+        for (int r = 0; r < 4; ++r) ga[fb][r] *= h4[r];   // (h4 holds silu'(h))
       }
     }
     __builtin_amdgcn_sched_barrier(0);

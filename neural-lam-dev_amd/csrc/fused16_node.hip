@@ -240,11 +240,14 @@ __global__ __launch_bounds__(K16_THREADS, 2) void node_bwd16_kernel(NodeBwdParam
         __builtin_amdgcn_sched_barrier(0);
         f32x4 sact[4];
 #pragma unroll
-        for (int fb = 0; fb < 4; ++fb) {
-          hkeep[fb] = hpre[fb];
+        for (int fb = 0; fb < 4; ++fb)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) sact[fb][r] = nlam_silu(hpre[fb][r]);
-        }
+          for (int r = 0; r < 4; ++r) {   // silu and silu' from one sigmoid; hkeep = silu'(h)
+            float sv, dv;
+            silu_both(hpre[fb][r], sv, dv);
+            sact[fb][r] = sv;
+            hkeep[fb][r] = dv;
+          }
         acc16_to_planes<4, TERMS>(sact, Ts, 0, lane);
         f32x4 z[4];
         vec_to_acc16<4>(z, c2s, lane);
@@ -274,7 +277,7 @@ __global__ __launch_bounds__(K16_THREADS, 2) void node_bwd16_kernel(NodeBwdParam
 #pragma unroll
       for (int fb = 0; fb < 4; ++fb)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ga[fb][r] *= nlam_silu_grad(hkeep[fb][r]);
+        for (int r = 0; r < 4; ++r) ga[fb][r] *= hkeep[fb][r];
       if (valid) store_row16<4>(q.ga_out + (b * q.rows + r0 + t) * D, ga, lane);
       f32x4 gx[8];
       zero16<8>(gx);
