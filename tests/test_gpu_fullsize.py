@@ -281,3 +281,90 @@ def test_g2m_of_a_finer_grid_runs_fused():
         want = orc.interaction_net(sd, "n", ei, send, rec, edge, update_edges=False)
         got = net(send.cuda(), rec.cuda(), edge.cuda())
     assert rel(got.cpu(), want) < 1e-4
+
+
+def test_m2m_processor_chain_vs_cpu_oracle_full_size(meps):
+    """BASELINE configs[1]'s processor as it runs in the bench: FOUR chained m2m InteractionNets
+    at full MEPS size (6,561 nodes, 57,616 edges, hidden 64, B = 1) through the fused node-side
+    chain (csrc/fused16_node.hip) against the CPU oracle: outputs, input gradients and every
+    parameter gradient.  fp32 bars: forward 1e-4, gradients 1e-3 (parameters 2e-3)."""
+    import nlam_oracle as orc
+    from neural_lam_amd import fused
+    from neural_lam_amd.interaction_net import InteractionNet
+    from neural_lam_amd.models.graph_lam import ProcessorSequential
+
+    ei = meps["m2m_edge_index"]
+    torch.manual_seed(20)
+    proc = ProcessorSequential([InteractionNet(ei, 64) for _ in range(4)])
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in proc.state_dict().items()}
+    N, M, d = 6561, ei.shape[1], 64
+    gen = torch.Generator().manual_seed(21)
+    x, e = torch.randn(1, N, d, generator=gen), torch.randn(1, M, d, generator=gen)
+    cx, ce = torch.randn(1, N, d, generator=gen), torch.randn(1, M, d, generator=gen)
+    xc, ec = x.clone().requires_grad_(True), e.clone().requires_grad_(True)
+    hx, he = xc, ec
+    for i in range(4):
+        hx, he = orc.interaction_net(sd, f"module_{i}", ei, hx, hx, he)
+    names = [k for k, _ in proc.named_parameters()]
+    want = torch.autograd.grad((hx * cx).sum() + (he * ce).sum(), [xc, ec] + [sd[k] for k in names])
+    proc = proc.cuda()
+    xg, eg = x.cuda().requires_grad_(True), e.cuda().requires_grad_(True)
+    assert fused.chain_eligible(list(proc), xg, eg) or not __import__("neural_lam_amd").ops.node_chain_supported()
+    ox, oe = proc(xg, eg)
+    ((ox * cx.cuda()).sum() + (oe * ce.cuda()).sum()).backward()
+    assert rel(ox.detach().cpu(), hx.detach()) < 1e-4 and rel(oe.detach().cpu(), he.detach()) < 1e-4
+    assert rel(xg.grad.cpu(), want[0]) < 1e-3 and rel(eg.grad.cpu(), want[1]) < 1e-3
+    for (k, p), w in zip(proc.named_parameters(), want[2:]):
+        assert rel(p.grad.cpu(), w) < 2e-3, k
+
+
+def test_graphlam64_training_step_vs_cpu_oracle_full_size():
+    """The bench workload itself (BASELINE configs[1]: GraphLAM, hidden 64, 4 processor layers,
+    MEPS 238 x 268 grid = 63,784 grid nodes, multiscale mesh) for one sample: training loss and
+    EVERY parameter gradient of the HIP path against the CPU oracle's training step
+    (oracle/nlam_oracle.training_loss, the restatement of ar_model.py:287-309 pinned by the
+    reference goldens).  Bars: loss 1e-4, gradients 2e-3 of max|ref| per tensor."""
+    import nlam_oracle as orc
+    from neural_lam_amd import synthetic
+    from neural_lam_amd.models import GraphLAM
+
+    with tempfile.TemporaryDirectory() as tmp:
+        ds, gname, info = synthetic.meps_setup(tmp)
+        torch.manual_seed(42)
+        model = GraphLAM(synthetic.model_args(graph=gname, hidden_dim=64, processor_layers=4),
+                         config=None, datastore=ds)
+        _, graph = orc.load_graph(tmp + "/graph/" + gname)
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()
+          if v.dtype.is_floating_point}
+    data = {k: getattr(model, k).detach().clone() for k in
+            ("grid_static_features", "diff_mean", "diff_std", "boundary_mask", "per_var_std")}
+    batch = synthetic.random_batch(1, 1, info["num_grid"], seed=7)
+    cfg = {"model": "graph_lam", "hidden_layers": 1, "processor_layers": 4, "mesh_aggr": "sum",
+           "loss": "wmse"}
+    want, _ = orc.training_loss(sd, graph, cfg, data, batch[0], batch[1], batch[2])
+    names = [k for k, _ in model.named_parameters()]
+    grads = torch.autograd.grad(want, [sd[k] for k in names])
+    model = model.cuda()
+    loss = model.training_step(tuple(t.cuda() if t is not None else None for t in batch))
+    loss.backward()
+    assert abs(float(loss) - float(want)) < 1e-4 * abs(float(want))
+    for (k, p), g in zip(model.named_parameters(), grads):
+        assert rel(p.grad.cpu(), g) < 2e-3, k
+
+
+@pytest.mark.parametrize("mode,kind,hidden", [("bf16x3", "hi_lam", 128), ("bf16", "hi_lam", 256)])
+def test_hilam_training_step_vs_cpu_oracle_full_size(mode, kind, hidden):
+    """BASELINE configs[2] (Hi-LAM, 3 mesh levels, hidden 128) and configs[4] (hidden 256,
+    bf16-mixed arithmetic) at full MEPS size, one sample: loss and every parameter gradient against
+    the CPU oracle's training step, in a process of that arithmetic mode (tools/parity_fullmodel.py).
+    Bars: 1e-4 / 2e-3 (fp32-grade), 1e-2 / 5e-2 (bf16)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "parity_fullmodel.py"), kind,
+                          str(hidden)], env=dict(os.environ, NLAM_MFMA=mode), capture_output=True,
+                         text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-2500:])
+    assert f"mfma mode: {mode}" in out.stdout and "full-size model case passed" in out.stdout
