@@ -64,13 +64,13 @@ class InteractionNet(nn.Module):
         # offset behind the receivers (interaction_net.py:59-62)
         self.register_buffer("edge_index", torch.stack((send + num_rec, rec)), persistent=False)
         self.tables = EdgeTables(send, rec, num_send, num_rec)
-        if self.tables.virtual is not None and (hidden_dim or input_dim) != 64:
+        if self.tables.virtual is not None and (hidden_dim or input_dim) not in (64, 128, 256):
             import warnings
 
             warnings.warn(
                 f"neural_lam_amd: a receiver has {self.tables.max_in_degree} in-edges (> 32): at "
-                "hidden widths other than 64 this InteractionNet runs on the generic HIP kernel "
-                "sequence (several times slower) instead of the fused receiver-aligned tiles",
+                "hidden widths other than 64 / 128 / 256 this InteractionNet runs on the generic HIP "
+                "kernel sequence (several times slower) instead of the fused receiver-aligned tiles",
                 RuntimeWarning, stacklevel=2)
 
         edge_mlp_recipe = [3 * input_dim] + [hidden_dim] * (hidden_layers + 1)

@@ -89,9 +89,23 @@ class Tiling:
             self.args = (None, (self.rows + 31) // 32, self.rows, None, None)
             self.ntiles = (self.rows + 31) // 32
         else:
-            self.args = (tables.tiles.data_ptr(), tables.ntiles, self.rows,
-                         tables.csr_rec.data_ptr(), tables.csr_rowptr.data_ptr())
-            self.ntiles = tables.ntiles
+            # graphs with in-degree > 32: the tiles, segment ids and row pointers of the VIRTUAL
+            # receivers (graph.VirtualReceivers); per-receiver outputs then have one row per virtual
+            # receiver and are folded back by the caller (fold_virtual)
+            t = tables.virtual if tables.virtual is not None else tables
+            self.args = (t.tiles.data_ptr(), t.ntiles, self.rows,
+                         t.csr_rec.data_ptr(), t.csr_rowptr.data_ptr())
+            self.ntiles = t.ntiles
+
+
+def recv_rows(tables):
+    """Rows of a per-receiver output of an edge-mode kernel (virtual receivers if the graph has any)."""
+    return tables.virtual.n_rec if tables.virtual is not None else tables.n_rec
+
+
+def fold_virtual(tables, per_virtual, out, scale=None):
+    """Per-virtual-receiver rows -> per-receiver rows (fixed order; scale = the 1/deg of "mean")."""
+    ops.segment_sum(mat(per_virtual), tables.virtual.rowptr2, None, out, scale=scale)
 
 
 def _src(m, idx=None):
@@ -419,7 +433,7 @@ def inet_eligible(net, send_rep, rec_rep, edge_rep):
     for t in (send_rep, rec_rep, edge_rep):
         if not _aligned(mat(t.detach())):
             return False
-    return net.tables.ntiles > 0
+    return net.tables.ntiles > 0 or net.tables.virtual is not None
 
 
 class WideInteractionNetFunction(torch.autograd.Function):
@@ -445,10 +459,14 @@ class WideInteractionNetFunction(torch.autograd.Function):
             e_out = _empty(B, M, d, device=dev) if update_edges else None
             tl = Tiling(M, g)
             z_e = keep_z(B, M, d, gam, dev)
+            virt = g.virtual is not None
+            agg_k = _empty(B, recv_rows(g), d, device=dev) if virt else agg
             tail_fwd(tl, _m(Pe), g.csr_eid, _m(Ps), g.csr_send, _m(Pr), g.csr_rec, W2, b2, gam,
                      bet, h_e, mat(e_out) if update_edges else None,
                      g.csr_eid if update_edges else None, em if update_edges else None,
-                     mat(agg), g.inv_deg if mean else None, B, d, z_e)
+                     mat(agg_k), (g.inv_deg if mean else None) if not virt else None, B, d, z_e)
+            if virt:
+                fold_virtual(g, agg_k, mat(agg), g.inv_deg if mean else None)
             del Pe, Ps, Pr
             # node update x_r + LN(V2 silu(V1 [x_r | agg] + c1) + c2)
             hn2 = _inter(d, B, N_r, d, device=dev)
@@ -515,9 +533,13 @@ class WideInteractionNetFunction(torch.autograd.Function):
             geo = None
             if ctx.update_edges and g_edge_out is not None:
                 geo = mat(g_edge_out.contiguous())
+            virt = g.virtual is not None
+            gPr_k = _empty(B, recv_rows(g), d, device=dev) if virt else gPr
             tail_bwd(Tiling(M, g), h_e, mat(g_agg), g.csr_rec, g.inv_deg if ctx.mean else None,
                      geo, g.csr_eid if geo is not None else None, W2, b2, gam, gz_e, mat(gh),
-                     g.csr_eid, mat(gPr), B, d, dgam, dbet, z_e)
+                     g.csr_eid, mat(gPr_k), B, d, dgam, dbet, z_e)
+            if virt:
+                fold_virtual(g, gPr_k, mat(gPr))
             outers.append((_m(gz_e), _m(h_e), dW2, db2, True))
             # 3. sender-side reduction of gh (edge order; sender lists of edge ids)
             gPs = (torch.zeros if N_s > g.n_send else torch.empty)(

@@ -53,7 +53,14 @@ def test_wide_tiles_of_empty_receivers(shared):
     _inet_case(shared, True, "mean", 2, empty_span=70)
 
 
-def _inet_case(shared, upd, aggr, B, empty_span=0):
+@pytest.mark.parametrize("shared,upd,aggr", [(True, True, "sum"), (False, False, "mean")])
+def test_wide_high_in_degree_runs_on_virtual_receivers(shared, upd, aggr):
+    """Receivers with 60+ / 33 / exactly 64 in-edges: the wide kernels run on virtual receivers of
+    <= 32 edges (graph.VirtualReceivers) with a fold-back stage, not on the generic GEMM sequence."""
+    _inet_case(shared, upd, aggr, 2, high_degree=True)
+
+
+def _inet_case(shared, upd, aggr, B, empty_span=0, high_degree=False):
     import nlam_oracle as orc
     from neural_lam_amd import wide
     from neural_lam_amd.interaction_net import InteractionNet
@@ -64,6 +71,14 @@ def _inet_case(shared, upd, aggr, B, empty_span=0):
     if empty_span:
         n_s, n_r, M = (120, 120, 700) if shared else (90, 110, 600)
     ei = _edges(gen, n_s, n_r, M, shared, empty_receivers=(aggr == "mean"), empty_span=empty_span)
+    if high_degree:
+        snd, rcv = ei[0] - (0 if shared else n_r), ei[1].clone()
+        rcv[10:72] = 9          # 60+ in-edges
+        rcv[72:105] = 12        # 33+
+        rcv[rcv == 15] = 14
+        rcv[105:169] = 15       # exactly 64
+        rcv[0], rcv[1] = 0, n_r - 1
+        ei = torch.stack((snd + (0 if shared else n_r), rcv))
     torch.manual_seed(5)
     net = InteractionNet(ei, d, update_edges=upd, aggr=aggr)
     with torch.no_grad():
@@ -94,6 +109,8 @@ def _inet_case(shared, upd, aggr, B, empty_span=0):
     rg = sg if shared else rec.cuda().requires_grad_(True)
     eg = edge.cuda().requires_grad_(True)
     assert wide.inet_eligible(net, sg, rg, eg)
+    if high_degree:
+        assert net.tables.virtual is not None and net.tables.max_in_degree >= 64
     g_r, g_e = run(net, sg, rg, eg, cr.cuda(), ce.cuda())
     assert rel(g_r, w_r) < FWD_BAR, ("rec", rel(g_r, w_r))
     if upd:

@@ -18,6 +18,9 @@ for shared, upd, aggr, B in T.INET_CASES + [(True, True, "mean", 5)]:
 for shared in (False, True):
     T.test_wide_tiles_of_empty_receivers(shared)
     print(f"ok inet tiles of empty receivers shared={shared}", flush=True)
+for shared, upd, aggr in ((True, True, "sum"), (False, False, "mean")):
+    T.test_wide_high_in_degree_runs_on_virtual_receivers(shared, upd, aggr)
+    print(f"ok inet in-degree > 32 on virtual receivers shared={shared}", flush=True)
 T.test_wide_stride0_batch_inputs_match_oracle()
 print("ok inet stride-0 inputs", flush=True)
 for blueprint, ln, res, rows, B in T.MLP_CASES:
