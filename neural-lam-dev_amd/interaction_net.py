@@ -133,6 +133,8 @@ class InteractionNet(nn.Module):
             return restore(wide.apply_inet(self, s3, r3, e3))
         if fused.inet_split_eligible(self, s3, r3, e3):
             return restore(fused.apply_inet_split(self, s3, r3, e3))
+        if wide.inet_split_eligible(self, s3, r3, e3):
+            return restore(wide.apply_inet_split(self, s3, r3, e3))
         eb, ep = _blocks(self.edge_mlp, self.tables.M)
         ab, ap = _blocks(self.aggr_mlp, self.num_rec)
         ab = [(r0, r1, n, ln, off + len(ep)) for (r0, r1, n, ln, off) in ab]

@@ -606,3 +606,239 @@ def apply_inet(net, send_rep, rec_rep, edge_rep):
         s, r, e, same, net.tables, net.update_edges, net.aggr == "mean",
         el[0][0].weight, el[0][0].bias, el[0][1].weight, el[0][1].bias, el[1].weight, el[1].bias,
         al[0][0].weight, al[0][0].bias, al[0][1].weight, al[0][1].bias, al[1].weight, al[1].bias)
+
+
+# ------------------------------------------- InteractionNet with SplitMLPs (hidden 128 / 256)
+# HiLAMParallel (reference hi_lam_parallel.py:26-53) runs ONE InteractionNet over the union of
+# every level's edges with a separate edge MLP per edge set and a separate node MLP per mesh level
+# (SplitMLPs, interaction_net.py:134-163).  As at hidden 64 (fused.apply_inet_split) the layer is
+# composed of an edge pass per edge chunk on that chunk's sub-graph (its own receiver-aligned
+# tiles over ALL receivers; aggregates of the chunks are summed) and a node update per row range.
+def inet_split_eligible(net, send_rep, rec_rep, edge_rep):
+    from .fused import FORCE_GENERIC
+    from .interaction_net import SplitMLPs
+
+    if FORCE_GENERIC or not edge_rep.is_cuda or edge_rep.dtype != torch.float32:
+        return False
+    e_split = isinstance(net.edge_mlp, SplitMLPs)
+    a_split = isinstance(net.aggr_mlp, SplitMLPs)
+    if not (e_split or a_split):
+        return False
+    if net.hidden_layers != 1 or net.input_dim != net.hidden_dim:
+        return False
+    if net.hidden_dim not in WIDE_HIDDEN or not enabled(net.hidden_dim):
+        return False
+    if send_rep.dim() != 3 or rec_rep.dim() != 3 or edge_rep.dim() != 3:
+        return False
+    for t in (send_rep, rec_rep, edge_rep):
+        if not _aligned(mat(t.detach())):
+            return False
+    tabs = list(net.chunk_tables) if e_split else [net.tables]
+    return all(t.ntiles > 0 or t.virtual is not None for t in tabs)
+
+
+class WideEdgePassFunction(torch.autograd.Function):
+    """(send_rep, rec_rep, the edge rows of one chunk) -> (UNSCALED sum-aggregate of the chunk's
+    messages for every receiver[, e + m for the chunk's edges]): nlam_lin_fwd_multi + nlam_tail_fwd;
+    backward nlam_tail_bwd + nlam_segment_sum + nlam_lin_bwd_data_multi + one weight-gradient launch."""
+
+    @staticmethod
+    def forward(ctx, send_rep, rec_rep, edge_rep, same, g, update_edges, W1, b1, W2, b2, gam, bet):
+        with ops.tag(g.tag):
+            dev = edge_rep.device
+            d = W2.shape[0]
+            B = max(send_rep.shape[0], rec_rep.shape[0], edge_rep.shape[0])
+            N_s, N_r, M = send_rep.shape[1], rec_rep.shape[1], edge_rep.shape[1]
+            sm, rm, em = mat(send_rep.detach()), mat(rec_rep.detach()), mat(edge_rep.detach())
+            W1e, W1s, W1r = W1[:, :d], W1[:, d : 2 * d], W1[:, 2 * d :]
+            Ps = _inter(d, sm.B, N_s, d, device=dev)
+            Pr = _inter(d, rm.B, N_r, d, device=dev)
+            Pe = _inter(d, em.B, M, d, device=dev)
+            lin_fwd_multi([(sm, W1s, None, _m(Ps)), (rm, W1r, b1, _m(Pr)), (em, W1e, None, _m(Pe))])
+            h_e = _inter(d, B, M, d, device=dev)
+            agg = _empty(B, N_r, d, device=dev)
+            e_out = _empty(B, M, d, device=dev) if update_edges else None
+            z_e = keep_z(B, M, d, gam, dev)
+            virt = g.virtual is not None
+            agg_k = _empty(B, recv_rows(g), d, device=dev) if virt else agg
+            tail_fwd(Tiling(M, g), _m(Pe), g.csr_eid, _m(Ps), g.csr_send, _m(Pr), g.csr_rec, W2, b2,
+                     gam, bet, h_e, mat(e_out) if update_edges else None,
+                     g.csr_eid if update_edges else None, em if update_edges else None,
+                     mat(agg_k), None, B, d, z_e)
+            if virt:
+                fold_virtual(g, agg_k, mat(agg))
+            ctx.save_for_backward(W1, b1, W2, b2, gam, h_e, z_e)
+            ctx.set_materialize_grads(False)
+            ctx.g, ctx.same, ctx.update_edges = g, same, update_edges
+            ctx.mats = (sm, rm, em)
+            ctx.dims = (B, N_s, N_r, M, d)
+        if update_edges:
+            return agg, e_out
+        return agg
+
+    @staticmethod
+    def backward(ctx, g_agg, g_edge_out=None):
+        with ops.tag(ctx.g.tag), ops.slab_batch():
+            W1, b1, W2, b2, gam, h_e, z_e = ctx.saved_tensors
+            g = ctx.g
+            sm, rm, em = ctx.mats
+            B, N_s, N_r, M, d = ctx.dims
+            dev = W1.device
+            W1e, W1s, W1r = W1[:, :d], W1[:, d : 2 * d], W1[:, 2 * d :]
+            same = ctx.same
+            if g_agg is None:
+                g_agg = torch.zeros(B, N_r, d, dtype=torch.float32, device=dev)
+            g_agg = g_agg.contiguous()
+            dW1, db1 = _empty(d, 3 * d, device=dev), _empty(d, device=dev)
+            dW2, db2 = torch.empty_like(W2), _empty(d, device=dev)
+            dgam, dbet = _empty(d, device=dev), _empty(d, device=dev)
+            gz_e = _inter(d, B, M, d, device=dev)
+            gh = _empty(B, M, d, device=dev)
+            gPr = _empty(B, N_r, d, device=dev)
+            geo = None
+            if ctx.update_edges and g_edge_out is not None:
+                geo = mat(g_edge_out.contiguous())
+            virt = g.virtual is not None
+            gPr_k = _empty(B, recv_rows(g), d, device=dev) if virt else gPr
+            tail_bwd(Tiling(M, g), h_e, mat(g_agg), g.csr_rec, None, geo,
+                     g.csr_eid if geo is not None else None, W2, b2, gam, gz_e, mat(gh), g.csr_eid,
+                     mat(gPr_k), B, d, dgam, dbet, z_e)
+            if virt:
+                fold_virtual(g, gPr_k, mat(gPr))
+            gPs = (torch.zeros if N_s > g.n_send else torch.empty)(
+                B, N_s, d, dtype=torch.float32, device=dev)
+            ops.segment_sum(mat(gh), g.csc_colptr, g.csc_eid, mat(gPs[:, : g.n_send]))
+            gps_m, gpr_m = mat(gPs), mat(gPr)
+            if sm.B == 1 and B > 1:
+                t1 = _empty(1, N_s, d, device=dev)
+                ops.sum_batch(gPs, t1)
+                gps_m = mat(t1)
+            if rm.B == 1 and B > 1:
+                t2 = _empty(1, N_r, d, device=dev)
+                ops.sum_batch(gPr, t2)
+                gpr_m = mat(t2)
+            dummy = [_empty(d, device=dev) for _ in range(2)]
+            outers = [(_m(gz_e), _m(h_e), dW2, db2, True),
+                      (gps_m, sm, dW1[:, d : 2 * d], dummy[0], False),
+                      (gpr_m, rm, dW1[:, 2 * d :], db1, False),
+                      (mat(gh), em, dW1[:, :d], dummy[1], False)]
+            dPe = mat(gh)
+            if not ctx.update_edges and em.B == 1 and B > 1:
+                t6 = _empty(1, M, d, device=dev)
+                ops.sum_batch(gh, t6)
+                dPe = mat(t6)
+            g_e = _empty(dPe.B, M, d, device=dev)
+            g_send = _empty(sm.B, N_s, d, device=dev)
+            if same:
+                t4 = _empty(sm.B, N_s, d, device=dev)
+                lin_bwd_data_multi([(gps_m, W1s, mat(t4), None), (dPe, W1e, mat(g_e), geo)])
+                lin_bwd_data(gpr_m, W1r, mat(g_send), mat(t4))
+                g_rec_total = None
+            else:
+                g_rec_total = _empty(rm.B, N_r, d, device=dev)
+                lin_bwd_data_multi([(gps_m, W1s, mat(g_send), None),
+                                    (gpr_m, W1r, mat(g_rec_total), None),
+                                    (dPe, W1e, mat(g_e), geo)])
+            g_edge = g_e
+            if ctx.update_edges and em.B == 1 and B > 1:
+                t5 = _empty(1, M, d, device=dev)
+                ops.sum_batch(g_e, t5)
+                g_edge = t5
+            outer_multi(outers)
+        return (g_send, g_rec_total, g_edge, None, None, None, dW1, db1, dW2, db2, dgam, dbet)
+
+
+class WideNodeUpdateFunction(torch.autograd.Function):
+    """x_r + LN(V2 silu(V1 [x_r | agg] + c1) + c2) on a range of receiver rows."""
+
+    @staticmethod
+    def forward(ctx, x_r, agg, tag, V1, c1, V2, c2, gam2, bet2):
+        with ops.tag(tag):
+            dev = x_r.device
+            d = V2.shape[0]
+            B, N = x_r.shape[0], x_r.shape[1]
+            xm, am = mat(x_r.detach()), mat(agg.detach())
+            hn1 = _inter(d, B, N, d, device=dev)
+            hn2 = _inter(d, B, N, d, device=dev)
+            lin_fwd_multi([(xm, V1[:, :d], c1, _m(hn1)), (am, V1[:, d:], None, _m(hn2))])
+            h_n = _inter(d, B, N, d, device=dev)
+            out = _empty(B, N, d, device=dev)
+            z_n = keep_z(B, N, d, gam2, dev)
+            tail_fwd(Tiling(N), _m(hn1), None, _m(hn2), None, None, None, V2, c2, gam2, bet2, h_n,
+                     mat(out), None, xm, None, None, B, d, z_n)
+            ctx.save_for_backward(V1, c1, V2, c2, gam2, h_n, z_n)
+            ctx.tag, ctx.mats, ctx.dims = tag, (xm, am), (B, N, d)
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        with ops.tag(ctx.tag), ops.slab_batch():
+            V1, c1, V2, c2, gam2, h_n, z_n = ctx.saved_tensors
+            xm, am = ctx.mats
+            B, N, d = ctx.dims
+            dev = V1.device
+            gy = gy.contiguous()
+            dV1, dc1 = torch.empty_like(V1), _empty(d, device=dev)
+            dV2, dc2 = torch.empty_like(V2), _empty(d, device=dev)
+            dg2, db2n = _empty(d, device=dev), _empty(d, device=dev)
+            gz_n = _inter(d, B, N, d, device=dev)
+            ga_n = _empty(B, N, d, device=dev)
+            tail_bwd(Tiling(N), h_n, mat(gy), None, None, None, None, V2, c2, gam2, gz_n, mat(ga_n),
+                     None, None, B, d, dg2, db2n, z_n)
+            g_x = _empty(B, N, d, device=dev)
+            g_agg = _empty(B, N, d, device=dev)
+            lin_bwd_data_multi([(mat(ga_n), V1[:, :d], mat(g_x), mat(gy)),
+                                (mat(ga_n), V1[:, d:], mat(g_agg), None)])
+            dummy = _empty(d, device=dev)
+            outer_multi([(_m(gz_n), _m(h_n), dV2, dc2, True), (mat(ga_n), xm, dV1[:, :d], dc1, False),
+                         (mat(ga_n), am, dV1[:, d:], dummy, False)])
+        return (g_x, g_agg, None, dV1, dc1, dV2, dc2, dg2, db2n)
+
+
+def apply_inet_split(net, send_rep, rec_rep, edge_rep):
+    from .fused import _base, _mlp_parts
+    from .interaction_net import SplitMLPs
+
+    same = send_rep is rec_rep
+    s = _base(send_rep)
+    r = s if same else _base(rec_rep)
+    e = _base(edge_rep)
+    B = max(s.shape[0], r.shape[0], e.shape[0])
+    if isinstance(net.edge_mlp, SplitMLPs):
+        e_mlps, e_sizes, tabs = (list(net.edge_mlp.mlps), list(net.edge_mlp.chunk_sizes),
+                                 list(net.chunk_tables))
+    else:
+        e_mlps, e_sizes, tabs = [net.edge_mlp], [net.tables.M], [net.tables]
+    agg, e_outs, o = None, [], 0
+    for mlp, m, tab in zip(e_mlps, e_sizes, tabs):
+        tab.tag = net.tables.tag
+        lin, ln = _mlp_parts(mlp)
+        out = WideEdgePassFunction.apply(
+            s, r, e[:, o : o + m], same, tab, net.update_edges,
+            lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias, ln.weight, ln.bias)
+        if net.update_edges:
+            a_c, eo_c = out
+            e_outs.append(eo_c)
+        else:
+            a_c = out
+        agg = a_c if agg is None else agg + a_c
+        o += m
+    if net.aggr == "mean":
+        agg = agg * net.tables.inv_deg.view(1, -1, 1)
+    if isinstance(net.aggr_mlp, SplitMLPs):
+        a_mlps, a_sizes = list(net.aggr_mlp.mlps), list(net.aggr_mlp.chunk_sizes)
+    else:
+        a_mlps, a_sizes = [net.aggr_mlp], [net.num_rec]
+    if r.shape[0] == 1 and B > 1:
+        r = r.expand(B, -1, -1)
+    outs, r0 = [], 0
+    for mlp, n in zip(a_mlps, a_sizes):
+        lin, ln = _mlp_parts(mlp)
+        outs.append(WideNodeUpdateFunction.apply(
+            r[:, r0 : r0 + n], agg[:, r0 : r0 + n], net.tables.tag,
+            lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias, ln.weight, ln.bias))
+        r0 += n
+    rec_out = outs[0] if len(outs) == 1 else torch.cat(outs, dim=1)
+    if net.update_edges:
+        return rec_out, (e_outs[0] if len(e_outs) == 1 else torch.cat(e_outs, dim=1))
+    return rec_out

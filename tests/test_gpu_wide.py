@@ -123,6 +123,53 @@ def _inet_case(shared, upd, aggr, B, empty_span=0, high_degree=False):
         assert rel(p.grad, osd[f"n.{k}"].grad) < GRAD_BAR, (k, rel(p.grad, osd[f"n.{k}"].grad))
 
 
+@pytest.mark.parametrize("upd,aggr", [(True, "sum"), (False, "mean")])
+def test_wide_split_mlps_vs_oracle(upd, aggr):
+    """SplitMLPs at this width (HiLAMParallel's operator, hi_lam_parallel.py:26-53,
+    interaction_net.py:134-163): one edge MLP per edge chunk, one node MLP per node range -- the
+    wide kernels run chunk by chunk (wide.apply_inet_split); forward and every gradient vs the CPU
+    oracle, and no generic GEMM may run."""
+    import nlam_oracle as orc
+    from neural_lam_amd import ops, wide
+    from neural_lam_amd.interaction_net import InteractionNet
+
+    d, B = D, 2
+    gen = torch.Generator().manual_seed(31)
+    n, M = 50, 400
+    ei = _edges(gen, n, n, M, shared=True, empty_receivers=(aggr == "mean"))
+    kw = dict(update_edges=upd, aggr=aggr, edge_chunk_sizes=[150, 130, 120], aggr_chunk_sizes=[20, 30])
+    torch.manual_seed(6)
+    net = InteractionNet(ei, d, **kw)
+    sd = {f"n.{k}": v.detach().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    net = net.cuda()
+    x = torch.randn(B, n, d, generator=gen)
+    e = torch.randn(B, M, d, generator=gen)
+    cr, ce = torch.randn(B, n, d, generator=gen), torch.randn(B, M, d, generator=gen)
+    xc, ec = x.clone().requires_grad_(True), e.clone().requires_grad_(True)
+    want = orc.interaction_net(sd, "n", ei, xc, xc, ec, **kw)
+    wl = (want[0] * cr).sum() + (want[1] * ce).sum() if upd else (want * cr).sum()
+    names = [k for k, _ in net.named_parameters()]
+    wg = torch.autograd.grad(wl, [xc, ec] + [sd[f"n.{k}"] for k in names])
+    xg, eg = x.cuda().requires_grad_(True), e.cuda().requires_grad_(True)
+    assert wide.inet_split_eligible(net, xg, xg, eg)
+    ops.PROFILER = ops.KernelProfiler()
+    try:
+        got = net(xg, xg, eg)
+        gl = (got[0] * cr.cuda()).sum() + (got[1] * ce.cuda()).sum() if upd else (got * cr.cuda()).sum()
+        gl.backward()
+        ran = {k.split("@")[0] for k in ops.PROFILER.collect()}
+    finally:
+        ops.PROFILER = None
+    assert "nlam_tail_fwd" in ran and "nlam_gemm" not in ran, ran
+    g0, w0 = (got[0], want[0]) if upd else (got, want)
+    assert rel(g0, w0) < FWD_BAR, rel(g0, w0)
+    if upd:
+        assert rel(got[1], want[1]) < FWD_BAR
+    assert rel(xg.grad, wg[0]) < GRAD_BAR and rel(eg.grad, wg[1]) < GRAD_BAR
+    for (k, p), w in zip(net.named_parameters(), wg[2:]):
+        assert rel(p.grad, w) < GRAD_BAR, (k, rel(p.grad, w))
+
+
 def test_wide_stride0_batch_inputs_match_oracle():
     """g2m-style call at d = 128: receiver and edge reps are stride-0 expands (expand_to_batch)."""
     import nlam_oracle as orc

@@ -21,6 +21,9 @@ for shared in (False, True):
 for shared, upd, aggr in ((True, True, "sum"), (False, False, "mean")):
     T.test_wide_high_in_degree_runs_on_virtual_receivers(shared, upd, aggr)
     print(f"ok inet in-degree > 32 on virtual receivers shared={shared}", flush=True)
+for upd, aggr in ((True, "sum"), (False, "mean")):
+    T.test_wide_split_mlps_vs_oracle(upd, aggr)
+    print(f"ok inet SplitMLPs upd={upd} aggr={aggr}", flush=True)
 T.test_wide_stride0_batch_inputs_match_oracle()
 print("ok inet stride-0 inputs", flush=True)
 for blueprint, ln, res, rows, B in T.MLP_CASES:
@@ -47,7 +50,8 @@ def model_case(kind, hierarchical, levels, grid=(30, 28), layers=1):
             tmp, torch.randn(ng, 1, generator=gen).numpy(), np.zeros(5), np.ones(5), np.zeros(5),
             np.ones(5), (torch.rand(ng, generator=gen) < 0.2).float().numpy(), n_forcing=2)
         torch.manual_seed(2)
-        cls = {"graph_lam": models.GraphLAM, "hi_lam": models.HiLAM}[kind]
+        cls = {"graph_lam": models.GraphLAM, "hi_lam": models.HiLAM,
+               "hi_lam_parallel": models.HiLAMParallel}[kind]
         model = cls(synthetic.model_args(graph="g", hidden_dim=T.D, processor_layers=layers),
                     config=None, datastore=ds)
         _, graph = orc.load_graph(tmp + "/graph/g")
@@ -124,6 +128,7 @@ model_case("graph_lam", False, None)
 model_case("hi_lam", True, None)
 # BASELINE configs[2] / [4] structure: 3 mesh levels (needs the 81 x 83 grid), two processor layers
 model_case("hi_lam", True, 3, grid=(81, 83), layers=2)
+model_case("hi_lam_parallel", True, None)   # SplitMLPs on the wide kernels (wide.apply_inet_split)
 if T._BF16:
     autocast_goldens()
 print("all wide cases passed")
