@@ -461,11 +461,12 @@ int nlam_wmse_bwd(const float* pred, const float* target, const float* keep,
  *   y[idx_y[p]] = m[p] (+ res[idx_y[p]])  (optional)
  *   agg[i] = inv_deg[i] * sum_{p: csr_rec[p] = i} m[p]          (optional, edge mode)
  * i.e. edge_mlp / aggr_mlp / embedder blocks after their first Linear (nlam_lin_fwd).
- * d = 256 (NLAM_MFMA=bf16 only; csrc/fused_fs.hip): W2 silu(h) + b2 is rounded to bf16 before the
+ * d = 256 (csrc/fused_fs.hip), NLAM_MFMA=bf16: W2 silu(h) + b2 is rounded to bf16 before the
  * LayerNorm -- the Linear output dtype under the reference's `--precision bf16-mixed` autocast
  * (train_model.py:73-76) -- and z_keep (optional; (B, rows, d) bf16 rows, position order, batch
  * pitch z_bstride elements) receives those rows for nlam_tail_bwd, which then needs no second
- * GEMM.  d = 128 ignores z_keep (its backward repeats the GEMM from h).
+ * GEMM.  d = 256 in the default split-bf16 mode: no rounding, z_keep holds fp32 rows (16-byte
+ * aligned, pitch in fp32 elements).  d = 128 ignores z_keep (its backward repeats the GEMM from h).
  *
  * bf16 STORAGE of intermediates (hidden 256 only; the dtype the reference's autocast gives the
  * outputs of nn.Linear and their gradients): `out_bf16` / `io_bf16` say which row operands are

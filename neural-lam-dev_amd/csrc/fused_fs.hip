@@ -13,8 +13,10 @@
 //     wave); outputs go through an fp32 LDS tile so that global stores, row scatters and the
 //     receiver-aligned segment sums stay whole-row and coalesced.
 // Same entry points and semantics as fused_wide.hip (the host sequence in wide.py is shared);
-// arithmetic: plain bf16 products, fp32 accumulate, fp32 LayerNorm / residuals / aggregates
-// (NLAM_MFMA=bf16).  TERMS = 3 (split-bf16) is templated in for hidden 128 but not dispatched.
+// arithmetic: TERMS = 1 (NLAM_MFMA=bf16): plain bf16 products, fp32 accumulate, fp32 LayerNorm /
+// residuals / aggregates, bf16 storage of the Linear outputs; TERMS = 3 (the default mode):
+// split-bf16 operands (hi + lo planes, three products), every stored row fp32 -- fp32-grade
+// results from the same kernels at about a third of the MFMA rate and twice the plane bytes.
 #include <stdlib.h>
 
 #include "fused_bf16x3.h"
@@ -22,6 +24,13 @@
 #include "fused_fs.h"
 
 #define FS_R 64   // rows per workgroup tile
+
+// The arithmetic of a call: 1 (NLAM_MFMA=bf16) or 3 (split bf16, the default mode); bf16-stored
+// rows exist in the bf16 mode only.
+#define FS_TERMS(what, any_bf16_rows)                                                          \
+  const int terms_ = nlam_mfma_terms();                                                        \
+  NLAM_REQUIRE(terms_ == 1 || terms_ == 3, what ": hidden 256 runs on the MFMA modes (bf16x3, bf16)"); \
+  NLAM_REQUIRE(terms_ == 1 || !(any_bf16_rows), what ": bf16 rows exist under NLAM_MFMA=bf16 only")
 
 template <int K, int TERMS>
 struct FsW {   // register-resident slice of a weight matrix: A fragments of all K / 16 steps
@@ -366,7 +375,8 @@ __device__ __forceinline__ void fs_lin_fwd_body(const FsLinParams& p, const int 
   X.init(smem);
   float* otile = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + FsPlanes<K, TERMS>::bytes);
   FsW<K, TERMS> A;
-  if constexpr (TRANS) fs_load_w_cols_lds<K, TERMS>(A, p.W, p.ldW, 32 * wave, p.x.width, otile, tid);
+  if constexpr (TRANS && TERMS == 1) fs_load_w_cols_lds<K, TERMS>(A, p.W, p.ldW, 32 * wave, p.x.width, otile, tid);
+  else if constexpr (TRANS) fs_load_w_cols<K, TERMS>(A, p.W, p.ldW, 32 * wave, p.x.width, lane);
   else fs_load_w_rows<K, TERMS>(A, p.W, p.ldW, 32 * wave, p.n_out, p.x.width, lane);
   const f32x16 bias = fs_vec_block(p.bias, p.n_out, wave, lane);
   constexpr int CPR = D / 4;
@@ -530,7 +540,7 @@ int nlam_fs_lin_fwd_256(const float* x, int64_t x_bstride, int64_t x_ld, int k_i
   NLAM_REQUIRE(!out_bf16 || (n_out == 256 && out_ld % 8 == 0 && out_bstride % 8 == 0),
                "fs_lin_fwd: bf16 output rows are 256 wide with pitches %% 8 == 0");
   if (B <= 0 || rows <= 0) return 0;
-  NLAM_REQUIRE(nlam_mfma_terms() == 1, "hidden 256 needs NLAM_MFMA=bf16");
+  FS_TERMS("nlam_lin_fwd", out_bf16);
   NLAM_REQUIRE(n_out >= 4 && n_out <= 256 && n_out % 4 == 0, "fs_lin_fwd: n_out %d unsupported", n_out);
   NLAM_REQUIRE(k_in >= 1 && k_in <= 256, "fs_lin_fwd: k_in %d out of range", k_in);
   NLAM_REQUIRE(view_vec_ok(out, out_bstride, out_ld, n_out),
@@ -542,11 +552,11 @@ int nlam_fs_lin_fwd_256(const float* x, int64_t x_bstride, int64_t x_ld, int k_i
   p.add = nullptr; p.add_bstride = 0; p.add_ld = 0;
   p.rows = rows; p.B = (int)B; p.out_bf16 = out_bf16;
   hipStream_t s = (hipStream_t)stream;
-  if (k_in <= 32) { p.x_vec = (k_in == 32 && view_vec_ok(x, x_bstride, x_ld, 32)); return launch_fs_lin_fwd<256, 32, 1>(p, s); }
-  if (k_in <= 64) { p.x_vec = (k_in == 64 && view_vec_ok(x, x_bstride, x_ld, 64)); return launch_fs_lin_fwd<256, 64, 1>(p, s); }
+  if (k_in <= 32) { p.x_vec = (k_in == 32 && view_vec_ok(x, x_bstride, x_ld, 32)); return terms_ == 3 ? launch_fs_lin_fwd<256, 32, 3>(p, s) : launch_fs_lin_fwd<256, 32, 1>(p, s); }
+  if (k_in <= 64) { p.x_vec = (k_in == 64 && view_vec_ok(x, x_bstride, x_ld, 64)); return terms_ == 3 ? launch_fs_lin_fwd<256, 64, 3>(p, s) : launch_fs_lin_fwd<256, 64, 1>(p, s); }
   NLAM_REQUIRE(k_in == 256 || k_in <= 256, "fs_lin_fwd: k_in %d", k_in);
   p.x_vec = (k_in == 256 && view_vec_ok(x, x_bstride, x_ld, 256));
-  return launch_fs_lin_fwd<256, 256, 1>(p, s);
+  return terms_ == 3 ? launch_fs_lin_fwd<256, 256, 3>(p, s) : launch_fs_lin_fwd<256, 256, 1>(p, s);
 }
 
 // gx = gy W (+ gx_add), W: 256 x 256 (data gradient of a Linear); NLAM_MFMA=bf16.
@@ -555,7 +565,7 @@ int nlam_fs_lin_bwd_data_256(const float* gy, int64_t gy_bstride, int64_t gy_ld,
                              const float* gx_add, int64_t ga_bstride, int64_t ga_ld, int64_t B,
                              int64_t rows, void* stream) {
   if (B <= 0 || rows <= 0) return 0;
-  NLAM_REQUIRE(nlam_mfma_terms() == 1, "hidden 256 needs NLAM_MFMA=bf16");
+  FS_TERMS("nlam_lin_bwd_data", 0);
   NLAM_REQUIRE(view_vec_ok(gy, gy_bstride, gy_ld, 256) && view_vec_ok(gx, gx_bstride, gx_ld, 256) &&
                    (gx_add == nullptr || view_vec_ok(gx_add, ga_bstride, ga_ld, 256)),
                "fs_lin_bwd_data: operand rows must be 16-byte aligned with pitch %% 4 == 0");
@@ -565,7 +575,8 @@ int nlam_fs_lin_bwd_data_256(const float* gy, int64_t gy_bstride, int64_t gy_ld,
   p.out = gx; p.out_bstride = gx_bstride; p.out_ld = gx_ld;
   p.add = gx_add; p.add_bstride = ga_bstride; p.add_ld = ga_ld;
   p.rows = rows; p.B = (int)B; p.x_vec = 1; p.out_bf16 = 0;
-  return launch_fs_lin_fwd<256, 256, 1, true>(p, (hipStream_t)stream);
+  return terms_ == 3 ? launch_fs_lin_fwd<256, 256, 3, true>(p, (hipStream_t)stream)
+                     : launch_fs_lin_fwd<256, 256, 1, true>(p, (hipStream_t)stream);
 }
 
 // accumulator blocks -> bf16 planes (hi only / hi + lo)
@@ -592,7 +603,7 @@ int nlam_fs_lin_fwd_multi_256(int n, const float* const* x, const int64_t* x_bst
                               const float* const* bias, float* const* out,
                               const int64_t* out_bstride, const int64_t* out_ld, const int64_t* B,
                               const int64_t* rows, int out_bf16_mask, void* stream) {
-  NLAM_REQUIRE(nlam_mfma_terms() == 1, "hidden 256 needs NLAM_MFMA=bf16");
+  FS_TERMS("nlam_lin_fwd_multi", out_bf16_mask);
   WideMulti<FsLinParams> m;
   m.n = 0;
   for (int k = 0; k < n; ++k) {
@@ -610,7 +621,8 @@ int nlam_fs_lin_fwd_multi_256(int n, const float* const* x, const int64_t* x_bst
                  "nlam_lin_fwd_multi: bf16 output pitches must be multiples of 8");
   }
   if (m.n == 0) return 0;
-  return launch_fs_lin_fwd<256, 256, 1>(m, (hipStream_t)stream);
+  return terms_ == 3 ? launch_fs_lin_fwd<256, 256, 3>(m, (hipStream_t)stream)
+                     : launch_fs_lin_fwd<256, 256, 1>(m, (hipStream_t)stream);
 }
 
 int nlam_fs_lin_bwd_data_multi_256(int n, const float* const* gy, const int64_t* gy_bstride,
@@ -619,7 +631,7 @@ int nlam_fs_lin_bwd_data_multi_256(int n, const float* const* gy, const int64_t*
                                    const float* const* gx_add, const int64_t* ga_bstride,
                                    const int64_t* ga_ld, const int64_t* B, const int64_t* rows,
                                    void* stream) {
-  NLAM_REQUIRE(nlam_mfma_terms() == 1, "hidden 256 needs NLAM_MFMA=bf16");
+  FS_TERMS("nlam_lin_bwd_data_multi", 0);
   WideMulti<FsLinParams> m;
   m.n = 0;
   for (int k = 0; k < n; ++k) {
@@ -636,7 +648,8 @@ int nlam_fs_lin_bwd_data_multi_256(int n, const float* const* gy, const int64_t*
     p.rows = rows[k]; p.B = (int)B[k]; p.x_vec = 1; p.out_bf16 = 0;
   }
   if (m.n == 0) return 0;
-  return launch_fs_lin_fwd<256, 256, 1, true>(m, (hipStream_t)stream);
+  return terms_ == 3 ? launch_fs_lin_fwd<256, 256, 3, true>(m, (hipStream_t)stream)
+                     : launch_fs_lin_fwd<256, 256, 1, true>(m, (hipStream_t)stream);
 }
 
 // Diagnostic (NLAM_STAMP=1): wave 0 of every workgroup of fs_tail_fwd adds the s_memtime cycles
@@ -674,7 +687,7 @@ struct FsTailFwdParams {
   const float* W2; int64_t ldW2; const float* b2; const float* gamma; const float* beta;
   int n_out;
   float* h_out; int64_t h_bstride;
-  __bf16* z_keep; int64_t z_bstride;     // optional (HAS_LN): the pre-LayerNorm rows, bf16, position order
+  void* z_keep; int64_t z_bstride;       // optional (HAS_LN): the pre-LayerNorm rows, position order: bf16 (TERMS 1) / fp32 (TERMS 3)
   float* y; int64_t y_bstride; int64_t y_ld; const int32_t* idx_y;
   RowView res;
   float* agg; int64_t agg_bstride; int64_t agg_ld; const float* inv_deg;
@@ -883,10 +896,13 @@ __global__ __launch_bounds__(2 * D) void fs_tail_fwd_kernel(FsTailFwdParams p) {
       // The Linear output is a bf16 tensor, as under the reference's autocast (LayerNorm then
       // works in fp32 on those bf16 values): the backward reads the kept bf16 rows instead of
       // repeating this GEMM, and sees exactly the values normalised here.
+      // (split-bf16 mode: z stays fp32 and is kept as fp32 rows, hi + lo of the planes)
+      if constexpr (TERMS == 1) {
 #pragma unroll
-      for (int rb = 0; rb < 2; ++rb)
+        for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) z[rb][r] = (float)(__bf16)z[rb][r];
+          for (int r = 0; r < 16; ++r) z[rb][r] = (float)(__bf16)z[rb][r];
+      }
       // LayerNorm over the D features of a row = over the NW waves: exchange through LDS
       const float inv_n = 1.0f / (float)p.n_out;
       float mean[2], rstd[2];
@@ -928,10 +944,19 @@ __global__ __launch_bounds__(2 * D) void fs_tail_fwd_kernel(FsTailFwdParams p) {
         for (int k = 0; k < 8; ++k) {
           const int r = rg + 8 * k;
           const int rb = r >> 5;
-          if ((r & 31) < sub.ne(rb))
-            reinterpret_cast<bf16x4*>(p.z_keep + sub.b(rb) * p.z_bstride +
-                                      (int64_t)(sub.p0(rb) + (r & 31)) * D)[c4] =
-                *reinterpret_cast<const bf16x4*>(S.hi + r * S.P + 4 * c4);
+          if ((r & 31) < sub.ne(rb)) {
+            const int64_t zoff = sub.b(rb) * p.z_bstride + (int64_t)(sub.p0(rb) + (r & 31)) * D;
+            const bf16x4 zh = *reinterpret_cast<const bf16x4*>(S.hi + r * S.P + 4 * c4);
+            if constexpr (TERMS == 3) {
+              const bf16x4 zl = *reinterpret_cast<const bf16x4*>(S.lo + r * S.P + 4 * c4);
+              f32x4 zf;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) zf[j] = (float)zh[j] + (float)zl[j];
+              reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.z_keep) + zoff)[c4] = zf;
+            } else {
+              reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(p.z_keep) + zoff)[c4] = zh;
+            }
+          }
         }
       }
       const f32x16 gav = fs_vec_block(p.gamma, p.n_out, wave, lane);
@@ -1027,7 +1052,9 @@ int nlam_fs_tail_fwd_256(
   NLAM_REQUIRE(z_keep == nullptr || (gamma != nullptr && (reinterpret_cast<uintptr_t>(z_keep) & 7u) == 0 &&
                                      z_bstride % 4 == 0),
                "nlam_tail_fwd: z_keep needs the LayerNorm form and 8-byte aligned rows");
-  NLAM_REQUIRE(nlam_mfma_terms() == 1, "hidden 256 needs NLAM_MFMA=bf16");
+  FS_TERMS("nlam_tail_fwd", io_bf16);
+  NLAM_REQUIRE(terms_ == 1 || z_keep == nullptr || (nlam_aligned16(z_keep) && z_bstride % 4 == 0),
+               "nlam_tail_fwd: fp32 z_keep rows must be 16-byte aligned");
   NLAM_REQUIRE(n_out >= 1 && n_out <= d, "nlam_tail_fwd: n_out %d out of range", n_out);
   NLAM_REQUIRE(gamma == nullptr || n_out == d, "nlam_tail_fwd: LayerNorm needs n_out == d");
   NLAM_REQUIRE(view_vec_ok(a, a_bstride, a_ld, d) && (!b || view_vec_ok(b, b_bstride, b_ld, d)) &&
@@ -1045,7 +1072,7 @@ int nlam_fs_tail_fwd_256(
   p.c = RowView{c, c_bstride, c_ld, d}; p.idx_c = idx_c;
   p.W2 = W2; p.ldW2 = ldW2; p.b2 = b2; p.gamma = gamma; p.beta = beta; p.n_out = n_out;
   p.h_out = h_out; p.h_bstride = h_bstride;
-  p.z_keep = reinterpret_cast<__bf16*>(z_keep); p.z_bstride = z_bstride;
+  p.z_keep = z_keep; p.z_bstride = z_bstride;
   p.y = y; p.y_bstride = y_bstride; p.y_ld = y_ld; p.idx_y = idx_y;
   p.res = RowView{res, res_bstride, res_ld, n_out};
   p.agg = agg; p.agg_bstride = agg_bstride; p.agg_ld = agg_ld; p.inv_deg = inv_deg;
@@ -1056,6 +1083,9 @@ int nlam_fs_tail_fwd_256(
   if (io_bf16)
     return gamma != nullptr ? launch_fs_tail_fwd<256, true, 1, true>(p, s)
                             : launch_fs_tail_fwd<256, false, 1, true>(p, s);
+  if (terms_ == 3)
+    return gamma != nullptr ? launch_fs_tail_fwd<256, true, 3>(p, s)
+                            : launch_fs_tail_fwd<256, false, 3>(p, s);
   return gamma != nullptr ? launch_fs_tail_fwd<256, true, 1>(p, s)
                           : launch_fs_tail_fwd<256, false, 1>(p, s);
 }
@@ -1101,7 +1131,7 @@ __device__ __forceinline__ void fs_acc_to_planes1(const f32x16& acc, const FsPla
 struct FsTailBwdParams {
   FsTiling tl;
   const float* h; int64_t h_bstride;
-  const __bf16* z_keep; int64_t z_bstride;   // HAS_LN: the bf16 pre-LayerNorm rows kept by the forward
+  const void* z_keep; int64_t z_bstride;     // HAS_LN: the pre-LayerNorm rows kept by the forward: bf16 (TERMS 1) / fp32 (TERMS 3)
   RowView g1; const int32_t* idx_g1; const float* scale1;
   RowView g2; const int32_t* idx_g2;
   const float* W2; int64_t ldW2; const float* b2; const float* gamma; int n_out;
@@ -1124,11 +1154,14 @@ __global__ __launch_bounds__(2 * D) void fs_tail_bwd_kernel(FsTailBwdParams q) {
   S.init(smem);
   __bf16* DS = reinterpret_cast<__bf16*>(reinterpret_cast<char*>(smem) + FsPlanes<D, TERMS>::bytes);
   constexpr int PD = D + 4;  // silu'(h) as one bf16 plane (2^-9 relative: inside the bf16-mixed budget)
-  float* gtile = reinterpret_cast<float*>(reinterpret_cast<char*>(DS) + (size_t)FS_R * PD * sizeof(__bf16));
+  static_assert(!(IO16 && TERMS == 3), "bf16 rows exist in the bf16 mode only");
+  float* gtile = reinterpret_cast<float*>(reinterpret_cast<char*>(DS) +
+                                          (TERMS == 1 ? (size_t)FS_R * PD * sizeof(__bf16) : 0));
   float* red = gtile + FS_R * LDO;                            // [2][FS_R][NW]
   int* itab0 = reinterpret_cast<int*>(red + 2 * FS_R * NW);   // [2][4][FS_R]: g1, g2, gh, scale
   FsW<D, TERMS> A2;
-  fs_load_w_cols_lds<D, TERMS>(A2, q.W2, q.ldW2, 32 * wave, q.n_out, gtile, tid);
+  if constexpr (TERMS == 1) fs_load_w_cols_lds<D, TERMS>(A2, q.W2, q.ldW2, 32 * wave, q.n_out, gtile, tid);
+  else fs_load_w_cols<D, TERMS>(A2, q.W2, q.ldW2, 32 * wave, q.n_out, lane);
   f32x16 dgam, dbet;
 #pragma unroll
   for (int r = 0; r < 16; ++r) dgam[r] = dbet[r] = 0.f;
@@ -1175,7 +1208,8 @@ __global__ __launch_bounds__(2 * D) void fs_tail_bwd_kernel(FsTailBwdParams q) {
           const int pos = fs_slot_pos(sub, r);
           vh[k] = fs_ld8(q.h, sub.b(r >> 5) * q.h_bstride + (int64_t)pos * D, c8);
           if (HAS_LN)
-            vz[k] = reinterpret_cast<const fs_bf16x8*>(q.z_keep + sub.b(r >> 5) * q.z_bstride + (int64_t)pos * D)[c8];
+            vz[k] = reinterpret_cast<const fs_bf16x8*>(reinterpret_cast<const __bf16*>(q.z_keep) +
+                                                       sub.b(r >> 5) * q.z_bstride + (int64_t)pos * D)[c8];
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -1189,6 +1223,28 @@ __global__ __launch_bounds__(2 * D) void fs_tail_bwd_kernel(FsTailBwdParams q) {
           if (HAS_LN) fs_plane_put8(S.hi, r * S.P + 8 * c8, vz[k]);
         }
       } else {
+      if constexpr (TERMS == 3) {
+        // split-bf16 mode: silu'(h) is taken from the fp32 h rows where it is applied (no bf16
+        // plane); the kept z rows are fp32 and go to the hi + lo planes
+        if (HAS_LN) {
+          f32x4 vz[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const int r = rg + 8 * k;
+            const int pos = fs_slot_pos(sub, r);
+            vz[k] = reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(q.z_keep) +
+                                                   sub.b(r >> 5) * q.z_bstride + (int64_t)pos * D)[c4];
+          }
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const int r = rg + 8 * k;
+            bf16x4 hi, lo;
+            b3_split4(vz[k], hi, lo);
+            *reinterpret_cast<bf16x4*>(S.hi + r * S.P + 4 * c4) = hi;
+            *reinterpret_cast<bf16x4*>(S.lo + r * S.P + 4 * c4) = lo;
+          }
+        }
+      } else {
       f32x4 vh[8];
       bf16x4 vz[8];
 #pragma unroll
@@ -1197,7 +1253,8 @@ __global__ __launch_bounds__(2 * D) void fs_tail_bwd_kernel(FsTailBwdParams q) {
         const int pos = fs_slot_pos(sub, r);
         vh[k] = reinterpret_cast<const f32x4*>(q.h + sub.b(r >> 5) * q.h_bstride + (int64_t)pos * D)[c4];
         if (HAS_LN)
-          vz[k] = reinterpret_cast<const bf16x4*>(q.z_keep + sub.b(r >> 5) * q.z_bstride + (int64_t)pos * D)[c4];
+          vz[k] = reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(q.z_keep) +
+                                                  sub.b(r >> 5) * q.z_bstride + (int64_t)pos * D)[c4];
       }
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
@@ -1208,6 +1265,7 @@ __global__ __launch_bounds__(2 * D) void fs_tail_bwd_kernel(FsTailBwdParams q) {
         for (int j = 0; j < 4; ++j) dh[j] = (__bf16)(valid ? nlam_silu_grad(vh[k][j]) : 0.f);
         *reinterpret_cast<bf16x4*>(DS + r * PD + 4 * c4) = dh;
         if (HAS_LN) *reinterpret_cast<bf16x4*>(S.hi + r * S.P + 4 * c4) = vz[k];
+      }
       }
       }
       if (q.vec_g) {
@@ -1264,9 +1322,15 @@ __global__ __launch_bounds__(2 * D) void fs_tail_bwd_kernel(FsTailBwdParams q) {
       for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) {
-          const bf16x4 zv = *reinterpret_cast<const bf16x4*>(S.hi + (32 * rb + t) * S.P + 32 * wave + 8 * qq + 4 * h);
+          const int zo = (32 * rb + t) * S.P + 32 * wave + 8 * qq + 4 * h;
+          const bf16x4 zv = *reinterpret_cast<const bf16x4*>(S.hi + zo);
 #pragma unroll
           for (int j = 0; j < 4; ++j) z[rb][4 * qq + j] = (float)zv[j];
+          if constexpr (TERMS == 3) {
+            const bf16x4 zl = *reinterpret_cast<const bf16x4*>(S.lo + zo);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) z[rb][4 * qq + j] += (float)zl[j];
+          }
         }
       const float inv_n = 1.0f / (float)q.n_out;
       float mean[2], rstd[2];
@@ -1389,6 +1453,24 @@ __global__ __launch_bounds__(2 * D) void fs_tail_bwd_kernel(FsTailBwdParams q) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) gh[rb][r] = 0.f;
     fs_gemm<D, TERMS>(gh, A2, S, lane);
+    if constexpr (TERMS == 3) {
+      f32x4 hv[2][4];
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        const int pos = fs_slot_pos(sub, 32 * rb + t);
+        const float* hb = q.h + sub.b(rb) * q.h_bstride + (int64_t)pos * D + 32 * wave + 4 * h;
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) hv[rb][qq] = *reinterpret_cast<const f32x4*>(hb + 8 * qq);
+      }
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        const bool valid = t < sub.ne(rb);
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) gh[rb][4 * qq + j] *= valid ? nlam_silu_grad(hv[rb][qq][j]) : 0.f;
+      }
+    } else {
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
@@ -1397,6 +1479,7 @@ __global__ __launch_bounds__(2 * D) void fs_tail_bwd_kernel(FsTailBwdParams q) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) gh[rb][4 * qq + j] *= (float)dv[j];
       }
+    }
     if (tid < FS_R && more) put_idx(itab0 + (par ^ 1) * 4 * FS_R);
     __syncthreads();   // the gz rows have been read from the tile
     fs_acc_to_tile<LDO>(gh, gtile, wave, lane);
@@ -1441,7 +1524,7 @@ __global__ __launch_bounds__(2 * D) void fs_tail_bwd_kernel(FsTailBwdParams q) {
 
 template <int D, bool HAS_LN, int TERMS, bool IO16 = false>
 static int launch_fs_tail_bwd(const FsTailBwdParams& q, hipStream_t s, unsigned grid) {
-  const size_t lds = FsPlanes<D, TERMS>::bytes + (size_t)FS_R * (D + 4) * sizeof(__bf16) +
+  const size_t lds = FsPlanes<D, TERMS>::bytes + (TERMS == 1 ? (size_t)FS_R * (D + 4) * sizeof(__bf16) : 0) +
                      (size_t)FS_R * (D + 4) * sizeof(float) +
                      (size_t)2 * FS_R * (D / 32) * sizeof(float) + (size_t)8 * FS_R * sizeof(int);
   NLAM_REQUIRE(lds <= 160 * 1024, "fs_tail_bwd: LDS footprint %zu B exceeds 160 KiB", lds);
@@ -1470,7 +1553,9 @@ int nlam_fs_tail_bwd_256(
   NLAM_REQUIRE(gamma == nullptr || (z_keep != nullptr && (reinterpret_cast<uintptr_t>(z_keep) & 7u) == 0 &&
                                     z_bstride % 4 == 0),
                "nlam_tail_bwd: hidden 256 with LayerNorm needs the z_keep rows of nlam_tail_fwd");
-  NLAM_REQUIRE(nlam_mfma_terms() == 1, "hidden 256 needs NLAM_MFMA=bf16");
+  FS_TERMS("nlam_tail_bwd", io_bf16);
+  NLAM_REQUIRE(terms_ == 1 || z_keep == nullptr || (nlam_aligned16(z_keep) && z_bstride % 4 == 0),
+               "nlam_tail_bwd: fp32 z_keep rows must be 16-byte aligned");
   NLAM_REQUIRE(gamma == nullptr || n_out == d, "nlam_tail_bwd: LayerNorm needs n_out == d");
   NLAM_REQUIRE(h != nullptr && nlam_aligned16(h) && h_bstride % 4 == 0, "nlam_tail_bwd: bad h");
   NLAM_REQUIRE(g1 != nullptr && gz_out != nullptr && nlam_aligned16(gz_out) && gz_bstride % 4 == 0,
@@ -1480,7 +1565,7 @@ int nlam_fs_tail_bwd_256(
   FsTailBwdParams q;
   q.tl = FsTiling{tiles, ntiles, rows, csr_rec, csr_rowptr, (int)B};
   q.h = h; q.h_bstride = h_bstride;
-  q.z_keep = reinterpret_cast<const __bf16*>(z_keep); q.z_bstride = z_bstride;
+  q.z_keep = z_keep; q.z_bstride = z_bstride;
   q.g1 = RowView{g1, g1_bstride, g1_ld, n_out}; q.idx_g1 = idx_g1; q.scale1 = scale1;
   q.g2 = RowView{g2, g2_bstride, g2_ld, n_out}; q.idx_g2 = idx_g2;
   q.W2 = W2; q.ldW2 = ldW2; q.b2 = b2; q.gamma = gamma; q.n_out = n_out;
@@ -1492,6 +1577,9 @@ int nlam_fs_tail_bwd_256(
              (g2 == nullptr || view_vec_ok(g2, g2_bstride, g2_ld, n_out))) ? 1 : 0;
   hipStream_t s = (hipStream_t)stream;
   if (io_bf16) return launch_fs_tail_bwd<256, true, 1, true>(q, s, grid);
+  if (terms_ == 3)
+    return gamma != nullptr ? launch_fs_tail_bwd<256, true, 3>(q, s, grid)
+                            : launch_fs_tail_bwd<256, false, 3>(q, s, grid);
   return gamma != nullptr ? launch_fs_tail_bwd<256, true, 1>(q, s, grid)
                           : launch_fs_tail_bwd<256, false, 1>(q, s, grid);
 }
@@ -1766,12 +1854,18 @@ int nlam_fs_outer_256(const float* g, int64_t g_bstride, int64_t g_ld, int ng,
                       const float* x, int64_t x_bstride, int64_t x_ld, int nx, int silu_x,
                       float* slab, int64_t slab_stride, int64_t B, int64_t rows, unsigned grid,
                       int io_bf16, void* stream) {
-  NLAM_REQUIRE(nlam_mfma_terms() == 1, "hidden 256 needs NLAM_MFMA=bf16");
+  FS_TERMS("nlam_wide_outer", io_bf16);
   FsOuterParams q;
   if (fs_outer_fill(q, g, g_bstride, g_ld, ng, x, x_bstride, x_ld, nx, silu_x, slab, slab_stride, B, rows,
                     io_bf16))
     return 1;
   hipStream_t s = (hipStream_t)stream;
+  if (terms_ == 3) {
+    if (ng == 32) return launch_fs_outer<32, 8, 3>(q, s, grid);
+    if (nx <= 32) return launch_fs_outer<256, 1, 3>(q, s, grid);
+    if (nx <= 64) return launch_fs_outer<256, 2, 3>(q, s, grid);
+    return launch_fs_outer<256, 8, 3>(q, s, grid);
+  }
   if (ng == 32) return launch_fs_outer<32, 8, 1>(q, s, grid);
   if (nx <= 32) return launch_fs_outer<256, 1, 1>(q, s, grid);
   if (nx <= 64) return launch_fs_outer<256, 2, 1>(q, s, grid);
@@ -1784,7 +1878,9 @@ int nlam_fs_outer_multi_256(int n, const float* const* g, const int64_t* g_bstri
                             const int64_t* x_ld, const int32_t* silu_x, float* const* slab,
                             const int64_t* slab_stride, const int64_t* B, const int64_t* rows,
                             const unsigned* grid, const int32_t* io_bf16, void* stream) {
-  NLAM_REQUIRE(nlam_mfma_terms() == 1, "hidden 256 needs NLAM_MFMA=bf16");
+  int any16 = 0;
+  for (int k = 0; k < n && io_bf16; ++k) any16 |= io_bf16[k];
+  FS_TERMS("nlam_wide_outer_multi", any16);
   WideMulti<FsOuterParams> m;
   m.n = 0;
   m.first[0] = 0;
@@ -1798,5 +1894,6 @@ int nlam_fs_outer_multi_256(int n, const float* const* g, const int64_t* g_bstri
   }
   if (m.n == 0) return 0;
   for (int k = m.n; k < NLAM_WIDE_MAXP; ++k) m.first[k + 1] = m.first[m.n];
-  return launch_fs_outer<256, 8, 1>(m, (hipStream_t)stream);
+  return terms_ == 3 ? launch_fs_outer<256, 8, 3>(m, (hipStream_t)stream)
+                     : launch_fs_outer<256, 8, 1>(m, (hipStream_t)stream);
 }

@@ -365,8 +365,8 @@ extern "C" int nlam_lin_fwd(const float* x, int64_t x_bstride, int64_t x_ld, int
   if (view_vec_ok(x, x_bstride, x_ld, k_in)) p.vec_mask |= 1;
   if (view_vec_ok(out, out_bstride, out_ld, p.nA + p.nB)) p.vec_mask |= 8;
   hipStream_t s = (hipStream_t)stream;
-  // hidden 256, bf16-mixed (fused_fs.hip): register-stationary weight slices
-  if (nlam_mfma_terms() == 1 && nA == 256 && p.nB == 0 && (p.vec_mask & 8))
+  // hidden 256 (fused_fs.hip): register-stationary weight slices, bf16 or split-bf16 operands
+  if (nlam_mfma_terms() != 0 && nA == 256 && p.nB == 0 && (p.vec_mask & 8))
     return nlam_fs_lin_fwd_256(x, x_bstride, x_ld, k_in, WA, ldWA, bA, nA, out, out_bstride, out_ld,
                                B, rows, out_bf16, stream);
   NLAM_REQUIRE(!out_bf16, "nlam_lin_fwd: bf16 output rows need 16-byte aligned rows, pitch %% 8 == 0");

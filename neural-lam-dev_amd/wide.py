@@ -32,9 +32,14 @@ WIDE_HIDDEN = (128, 256)
 
 
 def enabled(hid=128):
-    """hidden 128: split-bf16 or bf16 arithmetic; hidden 256: bf16 only."""
-    mode = int(lib.nlam_mfma_mode())
-    return mode == 2 if hid == 256 else mode != 0
+    """Both widths run in both MFMA modes: split-bf16 (the default, fp32-grade) and bf16."""
+    return int(lib.nlam_mfma_mode()) != 0
+
+
+def bf16_rows(d):
+    """Hidden 256 under NLAM_MFMA=bf16 stores its Linear outputs (and their gradients) as bf16
+    rows; every other combination stores fp32 rows."""
+    return d == 256 and int(lib.nlam_mfma_mode()) == 2
 
 
 import os
@@ -53,10 +58,10 @@ def _empty(*shape, device):
 
 def _inter(d, *shape, device):
     """An edge- / node-sized intermediate that is the output of a Linear (projection, pre-activation)
-    or the gradient of one (gz): bf16 at hidden 256 -- the dtype the reference's autocast gives
-    them, and half the vector-memory instructions of kernels that are bound by those -- fp32
-    otherwise."""
-    dt = torch.bfloat16 if d == 256 else torch.float32
+    or the gradient of one (gz): bf16 at hidden 256 in the bf16 mode -- the dtype the reference's
+    autocast gives them, and half the vector-memory instructions of kernels that are bound by
+    those -- fp32 otherwise."""
+    dt = torch.bfloat16 if bf16_rows(d) else torch.float32
     return torch.empty(*shape, dtype=dt, device=device)
 
 
@@ -115,10 +120,12 @@ def _src(m, idx=None):
 
 
 def keep_z(B, rows, d, gamma, device):
-    """bf16 (B, rows, d) buffer for the pre-LayerNorm rows the hidden-256 backward reads back."""
+    """(B, rows, d) buffer for the pre-LayerNorm rows the hidden-256 backward reads back: bf16
+    in the bf16 mode, fp32 in the split-bf16 mode."""
     if d != 256 or gamma is None:
         return None
-    return torch.empty(B, rows, d, dtype=torch.bfloat16, device=device)
+    return torch.empty(B, rows, d, dtype=torch.bfloat16 if bf16_rows(d) else torch.float32,
+                       device=device)
 
 
 def tail_fwd(tl, a, idx_a, b, idx_b, c, idx_c, W2, b2, gamma, beta, h_out, y, idx_y, res, agg,

@@ -99,7 +99,8 @@ def test_m2m_layer_vs_cpu_oracle_full_size_other_modes(mode, width):
     the feature-split kernels of csrc/fused_fs.hip) and at 128 in bf16 against the CPU oracle,
     parameter gradients included -- 57,616-row reductions, the sizes at which bf16 weight
     gradients are most exposed; bf16 bars 1e-2 / 5e-2.  Hidden 256 in the default mode runs the
-    generic exact-fp32 kernels (fp32 bars).  Arithmetic mode is per process: tools/parity_fullsize.py."""
+    same feature-split kernels with split-bf16 operands and fp32 rows (fp32 bars 1e-4 / 1e-3).
+    Arithmetic mode is per process: tools/parity_fullsize.py."""
     import os
     import subprocess
     import sys
@@ -352,10 +353,11 @@ def test_graphlam64_training_step_vs_cpu_oracle_full_size():
         assert rel(p.grad.cpu(), g) < 2e-3, k
 
 
-@pytest.mark.parametrize("mode,kind,hidden", [("bf16x3", "hi_lam", 128), ("bf16", "hi_lam", 256)])
+@pytest.mark.parametrize("mode,kind,hidden", [("bf16x3", "hi_lam", 128), ("bf16", "hi_lam", 256),
+                                               ("bf16x3", "hi_lam", 256)])
 def test_hilam_training_step_vs_cpu_oracle_full_size(mode, kind, hidden):
     """BASELINE configs[2] (Hi-LAM, 3 mesh levels, hidden 128) and configs[4] (hidden 256,
-    bf16-mixed arithmetic) at full MEPS size, one sample: loss and every parameter gradient against
+    bf16-mixed arithmetic; and the same width in the default split-bf16 mode) at full MEPS size, one sample: loss and every parameter gradient against
     the CPU oracle's training step, in a process of that arithmetic mode (tools/parity_fullmodel.py).
     Bars: 1e-4 / 2e-3 (fp32-grade), 1e-2 / 5e-2 (bf16)."""
     import os
