@@ -418,6 +418,14 @@ int nlam_adamw_step(float* p, const float* g, float* m, float* v, int64_t n,
                     float weight_decay, int64_t step, float grad_scale,
                     void* stream);
 
+/* Gradient packing for the flat-buffer all-reduce (the reference leaves this to DDP's bucket
+ * copies, train_model.py:265-274 `strategy="ddp"`): n gradient tensors -> their slices of one
+ * fp32 buffer in ONE launch.  table (device memory, int64): n triples [source address | element
+ * offset in dst | numel], then first[n + 1] = prefix sums of ceil(numel / nlam_pack_chunk());
+ * nchunks = first[n].  A null source address writes zeros.  Slices must not overlap. */
+int64_t nlam_pack_chunk(void);
+int nlam_pack_segments(const int64_t* table, int n, int64_t nchunks, float* dst, void* stream);
+
 /* ------------------------------------------------------------ rollout glue --
  * y = a + x * scale[f] + shift[f] over (rows, F): the state residual
  * prev_state + net_out * diff_std + diff_mean (base_graph_model.py:174-177). */

@@ -108,6 +108,8 @@ SIGNATURES = {
     "nlam_lin_bwd_data_multi": [_i32, _i32] + [_p] * 13 + [_p],
     "nlam_wide_outer_multi": [_i32, _i32] + [_p] * 13 + [_p],
     "nlam_concat_rows": [_i32, _p, _p, _p, _p, _p, _i64, _i64, _p],
+    "nlam_pack_chunk": [],
+    "nlam_pack_segments": [_p, _i32, _i64, _p, _p],
     "nlam_std_head_fwd": [_p, _p, _p, _p, _p, _p, _i64, _i32, _p],
     "nlam_std_head_bwd": [_p, _p, _p, _p, _p, _i64, _i32, _p],
     "nlam_nll_fwd": [_p, _p, _p, _p, _p, _p, _i64, _i64, _i32, _f, _p],
@@ -130,6 +132,7 @@ _RESTYPES = {
     "nlam_lin_bwd_slab_stride": _i64,
     "nlam_edge_bwd_slab_stride": _i64,
     "nlam_wmse_blocks": _i64,
+    "nlam_pack_chunk": _i64,
     "nlam_mlp_bwd_slab_stride": _i64,
     "nlam_outer_bwd_slab_stride": _i64,
     "nlam_inet_bwd_workspace": _i64,

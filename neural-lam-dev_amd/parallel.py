@@ -41,6 +41,9 @@ class FlatParams:
             p.data = self.flat[o : o + n].view(p.shape)
         self.grad = torch.zeros_like(self.flat)
         self._pad = {}   # pad length -> zeros
+        self._tables = {}     # (lo, hi) -> last pack table of that range (_pack_native)
+        self._captured = []   # tables a HIP-graph capture refers to
+        self._spare = {}      # (lo, hi) -> page-locked buffer put aside for a later capture
 
     def span(self, lo, hi):
         """[a, b) element range of params[lo:hi] in the flat buffers (padding included)."""
@@ -64,6 +67,8 @@ class FlatParams:
         if hi <= lo:
             return
         a, b = self.span(lo, hi)
+        if self.grad.is_cuda:
+            return self._pack_native(lo, hi)
         parts = []
         for i in range(lo, hi):
             p = self.params[i]
@@ -74,6 +79,55 @@ class FlatParams:
             if pad:
                 parts.append(self._zeros(pad))
         torch.cat(parts, out=self.grad[a:b])
+
+    def _pack_native(self, lo, hi):
+        """One launch (nlam_pack_segments) for the whole range.  The table of source addresses is
+        uploaded only when it differs from the one last used for this range: under HIP-graph
+        replay it never does, and in eager steps the caching allocator hands backward the same
+        blocks step after step.  Tables made during a graph capture are kept for the life of
+        this object (replays read the captured host copy again)."""
+        from . import ops
+        from ._lib import lib
+
+        srcs = []
+        for i in range(lo, hi):
+            g = self.params[i].grad
+            if g is not None and not (g.is_contiguous() and g.dtype == torch.float32):
+                g = g.contiguous().float()
+                self.params[i].grad = g
+            srcs.append(g.data_ptr() if g is not None else 0)
+        key = (lo, hi, tuple(srcs))
+        hit = self._tables.get((lo, hi))
+        if hit is None or hit[0] != key:
+            chunk = int(lib.nlam_pack_chunk())
+            first, rows = [0], []
+            for i, ptr in zip(range(lo, hi), srcs):
+                n = self.params[i].numel()
+                rows += [ptr, self.offsets[i], n]
+                first.append(first[-1] + -(-n // chunk))
+            table = torch.tensor(rows + first, dtype=torch.int64)
+            if torch.cuda.is_current_stream_capturing():
+                # page-locked memory cannot be allocated inside a capture: take the buffer an
+                # earlier eager call of this range put aside; the capture owns it from here on
+                host = self._spare.pop((lo, hi), None)
+                if host is None:
+                    raise RuntimeError("FlatParams.pack_grads: run one eager step before capturing "
+                                       "it into a HIP graph (the address table needs a page-locked "
+                                       "buffer allocated outside the capture)")
+                host.copy_(table)
+            else:
+                host = table.pin_memory()
+                if (lo, hi) not in self._spare:
+                    self._spare[(lo, hi)] = torch.empty_like(table).pin_memory()
+            dev = torch.empty(host.numel(), dtype=torch.int64, device=self.grad.device)
+            dev.copy_(host, non_blocking=True)
+            hit = (key, dev, first[-1], host)
+            if torch.cuda.is_current_stream_capturing():
+                self._captured.append(hit)
+            self._tables[(lo, hi)] = hit
+        _, dev, nchunks, _ = hit
+        ops._launch("nlam_pack_segments", lib.nlam_pack_segments,
+                    (dev.data_ptr(), hi - lo, nchunks, self.grad.data_ptr(), ops.stream()))
 
     def zero_grad(self):
         for p in self.params:

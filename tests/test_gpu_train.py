@@ -33,6 +33,44 @@ def test_flat_adamw_matches_torch():
         assert torch.allclose(a, b.cpu(), rtol=1e-5, atol=1e-6), k
 
 
+def test_pack_grads_one_launch_matches_concatenation():
+    """FlatParams.pack_grads on device tensors (nlam_pack_segments, one launch): every gradient
+    lands bit-exactly in its slice -- odd sizes, a slice larger than one chunk, a gradient that
+    is an unaligned view, a missing gradient (zeros), sub-ranges, and a second step whose
+    gradients live elsewhere (the address table is rebuilt) -- and the padding stays zero."""
+    from neural_lam_amd import parallel
+
+    torch.manual_seed(3)
+    shapes = [(7,), (13, 5), (64, 192), (1,), (129, 131), (3, 3)]
+    params = torch.nn.ParameterList([torch.nn.Parameter(torch.randn(*s)) for s in shapes]).cuda()
+    flat = parallel.FlatParams(params)
+    for step in range(2):
+        big = torch.randn(10_000, device="cuda")
+        for i, p in enumerate(flat.params):
+            p.grad = torch.randn_like(p) if i != 3 else None
+        flat.params[1].grad = big[3 : 3 + 65].view(13, 5)          # 4-byte aligned view
+        flat.grad.fill_(-7.0) if step == 0 else None               # stale content is overwritten
+        if step == 0:   # (the pads are never written: they must start as zeros)
+            for i, p in enumerate(flat.params):
+                end = flat.offsets[i + 1] if i + 1 < len(flat.params) else flat.numel
+                flat.grad[flat.offsets[i] + p.numel() : end] = 0
+        flat.pack_grads()
+        for i, p in enumerate(flat.params):
+            got = flat.grad[flat.offsets[i] : flat.offsets[i] + p.numel()]
+            want = p.grad.reshape(-1) if p.grad is not None else torch.zeros(p.numel(), device="cuda")
+            assert torch.equal(got, want), (step, i)
+            end = flat.offsets[i + 1] if i + 1 < len(flat.params) else flat.numel
+            assert not flat.grad[flat.offsets[i] + p.numel() : end].any()
+    # a sub-range leaves the other slices alone
+    before = flat.grad.clone()
+    flat.params[2].grad = torch.ones_like(flat.params[2])
+    flat.params[0].grad = torch.ones_like(flat.params[0])
+    flat.pack_grads(2, 3)
+    a, b = flat.span(2, 3)
+    assert torch.equal(flat.grad[:a], before[:a]) and torch.equal(flat.grad[b:], before[b:])
+    assert bool((flat.grad[a : a + 64 * 192] == 1).all())
+
+
 def test_graphlam_training_loss_decreases():
     from neural_lam_amd import graphgen, parallel, synthetic
     from neural_lam_amd.models import GraphLAM
