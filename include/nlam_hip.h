@@ -432,6 +432,19 @@ int nlam_pack_segments(const int64_t* table, int n, int64_t nchunks, float* dst,
 int nlam_affine_residual(const float* a, const float* x, const float* scale,
                          const float* shift, float* y, int64_t rows, int F,
                          void* stream);
+
+/* One rollout step's state update in one pass -- the residual above followed by the boundary
+ * overwrite (ar_model.py:244-247: boundary_mask * true_state + interior_mask * pred_state):
+ *   out[b][n][f] = mask[n] ? truth[b][n][f] : prev[b][n][f] + net_out[b][n][f] * scale[f] + shift[f]
+ * prev / truth are (B, N, F) views with their own batch pitch (slices of the batch tensors),
+ * net_out / out are contiguous; mask (N) in {0, 1}.  Backward: gx = (1 - mask) g scale[f],
+ * gprev = (1 - mask) g (optional, null to skip). */
+int nlam_state_step(const float* prev, int64_t prev_bstride, const float* net_out,
+                    const float* truth, int64_t truth_bstride, const float* mask,
+                    const float* scale, const float* shift, float* out, int64_t B, int64_t N,
+                    int F, void* stream);
+int nlam_state_step_bwd(const float* g, const float* mask, const float* scale, float* gx,
+                        float* gprev, int64_t B, int64_t N, int F, void* stream);
 /* gx = g * scale[f] (its backward w.r.t. x). */
 int nlam_scale_cols(const float* g, const float* scale, float* gx, int64_t rows,
                     int F, void* stream);

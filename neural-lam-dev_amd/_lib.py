@@ -108,6 +108,8 @@ SIGNATURES = {
     "nlam_lin_bwd_data_multi": [_i32, _i32] + [_p] * 13 + [_p],
     "nlam_wide_outer_multi": [_i32, _i32] + [_p] * 13 + [_p],
     "nlam_concat_rows": [_i32, _p, _p, _p, _p, _p, _i64, _i64, _p],
+    "nlam_state_step": [_p, _i64, _p, _p, _i64, _p, _p, _p, _p, _i64, _i64, _i32, _p],
+    "nlam_state_step_bwd": [_p, _p, _p, _p, _p, _i64, _i64, _i32, _p],
     "nlam_pack_chunk": [],
     "nlam_pack_segments": [_p, _i32, _i64, _p, _p],
     "nlam_std_head_fwd": [_p, _p, _p, _p, _p, _p, _i64, _i32, _p],

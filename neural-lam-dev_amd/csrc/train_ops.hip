@@ -105,6 +105,68 @@ extern "C" int nlam_boundary_mix(const float* pred, const float* truth, const fl
   return 0;
 }
 
+// The two steps above in one pass, on batch-strided inputs (the rollout's states are slices
+// init_states[:, 1] / target_states[:, t] of larger tensors):
+//   new[b][n][f] = mask[n] ? truth[b][n][f] : prev[b][n][f] + x[b][n][f] * scale[f] + shift[f]
+// backward: gx = (1 - mask) * g * scale[f], gprev = (1 - mask) * g (optional).
+__global__ __launch_bounds__(256) void state_step_kernel(
+    const float* __restrict__ prev, int64_t prev_bstride, const float* __restrict__ x,
+    const float* __restrict__ truth, int64_t truth_bstride, const float* __restrict__ mask,
+    const float* __restrict__ scale, const float* __restrict__ shift, float* __restrict__ out,
+    int64_t B, int64_t N, int F) {
+  const int64_t per = N * F, total = B * per;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t b = i / per, j = i - b * per;
+    const int64_t node = j / F;
+    const int f = (int)(j - node * F);
+    const float m = mask[node];
+    const float pr = prev[b * prev_bstride + j] + x[i] * scale[f] + shift[f];
+    out[i] = m * truth[b * truth_bstride + j] + (1.0f - m) * pr;
+  }
+}
+__global__ __launch_bounds__(256) void state_step_bwd_kernel(
+    const float* __restrict__ g, const float* __restrict__ mask, const float* __restrict__ scale,
+    float* __restrict__ gx, float* __restrict__ gprev, int64_t B, int64_t N, int F) {
+  const int64_t per = N * F, total = B * per;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t j = i % per;
+    const int64_t node = j / F;
+    const int f = (int)(j - node * F);
+    const float gp = (1.0f - mask[node]) * g[i];
+    gx[i] = gp * scale[f];
+    if (gprev) gprev[i] = gp;
+  }
+}
+extern "C" int nlam_state_step(const float* prev, int64_t prev_bstride, const float* net_out,
+                               const float* truth, int64_t truth_bstride, const float* mask,
+                               const float* scale, const float* shift, float* out, int64_t B,
+                               int64_t N, int F, void* stream) {
+  const int64_t n = B * N * F;
+  if (n <= 0) return 0;
+  NLAM_REQUIRE(prev && net_out && truth && mask && scale && shift && out, "nlam_state_step: null operand");
+  NLAM_REQUIRE(prev_bstride >= N * F && truth_bstride >= N * F, "nlam_state_step: batch pitch below N * F");
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  state_step_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(
+      prev, prev_bstride, net_out, truth, truth_bstride, mask, scale, shift, out, B, N, F);
+  NLAM_CHECK_LAUNCH("state_step");
+  return 0;
+}
+extern "C" int nlam_state_step_bwd(const float* g, const float* mask, const float* scale, float* gx,
+                                   float* gprev, int64_t B, int64_t N, int F, void* stream) {
+  const int64_t n = B * N * F;
+  if (n <= 0) return 0;
+  NLAM_REQUIRE(g && mask && scale && gx, "nlam_state_step_bwd: null operand");
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  state_step_bwd_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(g, mask, scale, gx, gprev,
+                                                                          B, N, F);
+  NLAM_CHECK_LAUNCH("state_step_bwd");
+  return 0;
+}
+
 // ------------------------------------------------------------------------ loss
 // loss = scale * sum_{r < rows, f} w[f] * keep[r % N] * (pred - target)^2
 //   = torch.mean over (B, T) of  sum_f mean_{interior n} (pred - target)^2 / std_f^2

@@ -66,6 +66,49 @@ class BoundaryMix(torch.autograd.Function):
         return gp, None, None
 
 
+def _batch_view(t):
+    """(pointer, batch pitch) of a (B, N, F) tensor whose (N, F) items are contiguous -- e.g. a
+    slice init_states[:, 1] of the batch tensor -- or of a contiguous copy otherwise."""
+    B, N, F = t.shape
+    if not (t.stride(2) == 1 and t.stride(1) == F and (B == 1 or t.stride(0) >= N * F)):
+        t = t.contiguous()
+    return t, (t.stride(0) if B > 1 else N * F)
+
+
+class StateStep(torch.autograd.Function):
+    """StateResidual followed by BoundaryMix in one pass (one launch each way instead of two, and
+    no contiguous copies of the sliced batch tensors):
+    boundary_mask * truth + interior_mask * (prev_state + net_out * diff_std + diff_mean)."""
+
+    @staticmethod
+    def forward(ctx, prev_state, net_out, truth, mask, diff_std, diff_mean):
+        net_out = net_out.contiguous()
+        ops._require_dev(net_out, "net_out")
+        B, N, F = net_out.shape
+        prev_state, pb = _batch_view(prev_state)
+        truth, tb = _batch_view(truth)
+        out = torch.empty_like(net_out)
+        ops._launch("nlam_state_step", lib.nlam_state_step,
+                    (prev_state.data_ptr(), pb, net_out.data_ptr(), truth.data_ptr(), tb,
+                     mask.data_ptr(), diff_std.data_ptr(), diff_mean.data_ptr(), out.data_ptr(),
+                     B, N, F, ops.stream()), nbytes=16.0 * net_out.numel())
+        ctx.save_for_backward(mask, diff_std)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        mask, diff_std = ctx.saved_tensors
+        g = g.contiguous()
+        B, N, F = g.shape
+        gx = torch.empty_like(g)
+        gprev = torch.empty_like(g) if ctx.needs_input_grad[0] else None
+        ops._launch("nlam_state_step_bwd", lib.nlam_state_step_bwd,
+                    (g.data_ptr(), mask.data_ptr(), diff_std.data_ptr(), gx.data_ptr(),
+                     gprev.data_ptr() if gprev is not None else None, B, N, F, ops.stream()),
+                    nbytes=(8.0 if gprev is None else 12.0) * g.numel())
+        return gprev, gx, None, None, None, None
+
+
 class MaskedWMSE(torch.autograd.Function):
     """mean over the leading dims of sum_f mean_{kept n} (pred - target)^2 * w_f."""
 

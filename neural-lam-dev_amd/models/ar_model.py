@@ -165,6 +165,10 @@ class ARModel(_Base):
 
     def _unroll(self, prev_state, prev_prev_state, forcing_features, true_states, ckpt):
         prediction_list, pred_std_list = [], []
+        # residual + boundary overwrite in one kernel (glue.StateStep) where predict_step offers it
+        import inspect
+        fuse_mix = (prev_state.is_cuda and not self.output_std and not ckpt
+                    and "boundary_truth" in inspect.signature(self.predict_step).parameters)
         for i in range(forcing_features.shape[1]):
             if ckpt:
                 if not hasattr(self, "_ckpt_anchor") or self._ckpt_anchor.device != prev_state.device:
@@ -172,17 +176,23 @@ class ARModel(_Base):
                 pred_state = _RecomputedPredictStep.apply(
                     self._ckpt_anchor, self, prev_state, prev_prev_state, forcing_features[:, i])
                 pred_std = None
+            elif fuse_mix:
+                new_state, pred_std = self.predict_step(
+                    prev_state, prev_prev_state, forcing_features[:, i],
+                    boundary_truth=true_states[:, i])
             else:
                 pred_state, pred_std = self.predict_step(
                     prev_state, prev_prev_state, forcing_features[:, i]
                 )
-            new_state = glue.BoundaryMix.apply(pred_state, true_states[:, i], self.boundary_mask)
+            if not fuse_mix:
+                new_state = glue.BoundaryMix.apply(pred_state, true_states[:, i], self.boundary_mask)
             prediction_list.append(new_state)
             if self.output_std:
                 pred_std_list.append(pred_std)
             prev_prev_state = prev_state
             prev_state = new_state
-        prediction = torch.stack(prediction_list, dim=1)
+        prediction = (prediction_list[0].unsqueeze(1) if len(prediction_list) == 1
+                      else torch.stack(prediction_list, dim=1))
         if self.output_std:
             pred_std = torch.stack(pred_std_list, dim=1)
         else:

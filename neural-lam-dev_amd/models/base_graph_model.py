@@ -68,19 +68,22 @@ class BaseGraphModel(ARModel):
             return cache[key]
         return module(features)
 
-    def predict_step(self, prev_state, prev_prev_state, forcing):
-        """X_{t-1}, X_t, forcing -> X_{t+1}  (base_graph_model.py:106-177)."""
+    def predict_step(self, prev_state, prev_prev_state, forcing, boundary_truth=None):
+        """X_{t-1}, X_t, forcing -> X_{t+1}  (base_graph_model.py:106-177).  With boundary_truth
+        (device path without output_std only: the rollout's use), the boundary overwrite of
+        ar_model.py:244-247 is applied in the same kernel as the state residual and the returned
+        state is the rollout's new state."""
         shared = getattr(self, "_static_emb_rollout", None)   # set by a multi-step rollout
         if shared is not None:
             self._static_emb = shared
         else:
             self._static_emb = fused.embed_many(self.static_embedders()) if prev_state.is_cuda else None
         try:
-            return self._predict_step(prev_state, prev_prev_state, forcing)
+            return self._predict_step(prev_state, prev_prev_state, forcing, boundary_truth)
         finally:
             self._static_emb = None
 
-    def _predict_step(self, prev_state, prev_prev_state, forcing):
+    def _predict_step(self, prev_state, prev_prev_state, forcing, boundary_truth=None):
         batch_size = prev_state.shape[0]
         srcs = (prev_state, prev_prev_state, forcing,
                 self.expand_to_batch(self.grid_static_features, batch_size))
@@ -103,9 +106,13 @@ class BaseGraphModel(ARModel):
         grid_rep = self.m2g_gnn(mesh_rep, grid_rep, self.expand_to_batch(m2g_emb, batch_size))
         net_output = self.output_map(grid_rep)
 
+        assert boundary_truth is None or (prev_state.is_cuda and not self.output_std)
         if self.output_std:
             # chunk + softplus + rescale + residual in one kernel (glue.StdHead)
             return glue.StdHead.apply(prev_state, net_output, self.diff_std, self.diff_mean)
+        if boundary_truth is not None:
+            return glue.StateStep.apply(prev_state, net_output, boundary_truth, self.boundary_mask,
+                                        self.diff_std, self.diff_mean), None
         new_state = glue.StateResidual.apply(
             prev_state, net_output, self.diff_std, self.diff_mean
         )

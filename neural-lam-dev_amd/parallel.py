@@ -317,6 +317,8 @@ class GraphedTrainStep:
         self.model, self.flat, self.batch = model, flat, batch
         self.graph = None
         self.loss = None
+        # d loss / d loss, made once (loss.backward() would fill a fresh ones tensor every step)
+        self._one = torch.ones((), dtype=torch.float32, device=flat.flat.device)
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -329,7 +331,7 @@ class GraphedTrainStep:
             flat.zero_grad()
             with torch.cuda.graph(g):
                 loss = model.training_step(batch)
-                loss.backward()
+                loss.backward(self._one)
                 flat.pack_grads()
             self.graph, self.loss = g, loss
         except Exception as e:  # pragma: no cover - depends on the runtime
@@ -342,7 +344,7 @@ class GraphedTrainStep:
     def _eager(self):
         self.flat.zero_grad()
         loss = self.model.training_step(self.batch)
-        loss.backward()
+        loss.backward(self._one)
         self.flat.pack_grads()
         return loss
 
