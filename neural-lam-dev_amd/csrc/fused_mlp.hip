@@ -1372,7 +1372,19 @@ __global__ __launch_bounds__(64 * G) void reduce_slabs_multi_kernel(ReduceSegs q
   const int e = threadIdx.x & 63, gsub = threadIdx.x >> 6;
   const int64_t i = (int64_t)blockIdx.x * 64 + e;
   const int64_t n = q.first[q.nseg];
+  // segment of this workgroup's first output by a wave-uniform binary search (scalar loads of the
+  // kernel argument block; a lane-by-lane linear walk was up to 64 dependent loads), then the
+  // few steps a lane needs when the workgroup's 64 outputs straddle segment boundaries
   int k = 0;
+  {
+    const int64_t i0 = (int64_t)blockIdx.x * 64;
+    int lo = 0, hi = q.nseg;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if ((int64_t)q.first[mid] <= i0) lo = mid; else hi = mid;
+    }
+    k = lo;
+  }
   while (k + 1 < q.nseg && i >= q.first[k + 1]) ++k;
   const int64_t local = i - q.first[k];
   const int cols = q.cols[k] > 0 ? q.cols[k] : 1;

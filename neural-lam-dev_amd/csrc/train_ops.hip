@@ -402,10 +402,23 @@ __global__ void concat_rows_kernel(ConcatParams p) {
   const float* src = p.src[k];
   const int64_t bs = p.bstride[k], ld = p.ld[k];
   const int64_t stride = (int64_t)gridDim.x * (blockDim.x >> 6);
-  for (int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); row < rows;
-       row += stride) {
-    const int64_t b = row / p.N, n = row - b * p.N;
-    if (col < p.W) p.out[row * p.W + col] = src[b * bs + n * ld + c];
+  if (col >= p.W) return;
+  // four rows in flight per lane (a row is one 4-byte element per lane: latency, not bytes)
+  for (int64_t row0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); row0 < rows;
+       row0 += 4 * stride) {
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t row = row0 + j * stride;
+      const int64_t rr = row < rows ? row : row0;
+      const int64_t b = rr / p.N, n = rr - b * p.N;
+      v[j] = src[b * bs + n * ld + c];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t row = row0 + j * stride;
+      if (row < rows) p.out[row * p.W + col] = v[j];
+    }
   }
 }
 // generic width
