@@ -35,6 +35,8 @@ FAMILIES = [  # (kernel-name regex, family); the first match wins, template argu
     (r"^reduce_slabs_multi_kernel", "reduce_slabs_multi"), (r"^reduce_slabs_kernel", "reduce_slabs"),
     (r"^segment_sum_", "segment_sum"), (r"^sum_batch", "sum_batch"), (r"^concat_rows", "concat_rows"),
     (r"^boundary_mix", "boundary_mix"), (r"^affine_residual", "affine_residual"),
+    (r"^state_step_bwd", "state_step_bwd"), (r"^state_step", "state_step"),
+    (r"^pack_segments", "pack_segments"),
     (r"^scale_cols", "scale_cols"), (r"^wmse_(partial|final)", "wmse_fwd"), (r"^wmse_bwd", "wmse_bwd"),
     (r"^gemm", "gemm"), (r"^silu_fwd", "silu_fwd"), (r"^silu_bwd", "silu_bwd"),
     (r"^layernorm_fwd", "layernorm_fwd"), (r"^layernorm_bwd", "layernorm_bwd"),
