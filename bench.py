@@ -433,41 +433,41 @@ def main():
                             "launch; `value` / ms_per_step from the timed windows (HIP-graph replay "
                             "at N = 1), so the kernel times sum to slightly more than a step")
         layer = layer_roofline(stats, nprof, args, info, B, model)
-        # the scatter-add the north star names: m2m aggregate (segment-sum) launches
-        agg = stats.get("nlam_segment_sum@m2m")
-        if agg and agg["ms"] > 0:
-            g = agg["bytes"] / (agg["ms"] / 1e3) / 1e9
-            scatter = {"kernel": "nlam_segment_sum@m2m", "bound": "hbm", "achieved": g,
-                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": g / HBM_PEAK_GBS,
-                       "avg_launch_us": agg["ms"] * 1e3 / agg["calls"],
-                       "note": "backward's sender-side scatter-add (stand-alone kernel); the "
-                               "forward scatter-add is fused into nlam_edge_fwd@m2m, see "
-                               "fused_forward"}
+        # the scatter-add the north star names: the m2m aggregate.  In the step it has no launch of
+        # its own any more (forward: receiver sums inside nlam_edge_fwd@m2m; backward: the
+        # sender-side sums are a CSC gather inside nlam_node_bwd / nlam_lin_bwd_multi), so the bare
+        # kernel is timed here on the same m2m tables: 50 launches between ONE event pair (a
+        # 12-16 us kernel carries a few us of per-launch event overhead otherwise).  Algorithmic
+        # bytes: SURVEY.md 8(d) "aggregate only" = 4 d (M + N_r) + indices per sample.
+        net0 = getattr(model, "processor", None)
+        net0 = getattr(net0, "module_0", None) if net0 is not None else None
+        if net0 is not None and getattr(net0, "tables", None) is not None:
+            tb = net0.tables
+            Mm, Nr, dd = int(tb.M), int(tb.n_rec), args.hidden_dim
+            msg = torch.randn(B, Mm, dd, device=dev)
+            out_ = torch.empty(B, Nr, dd, device=dev)
+            for _ in range(3):
+                ops.segment_sum(ops.mat(msg), tb.csr_rowptr, tb.csr_eid, ops.mat(out_))
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(50):
+                ops.segment_sum(ops.mat(msg), tb.csr_rowptr, tb.csr_eid, ops.mat(out_))
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / 50
+            nbytes = B * (4.0 * dd * (Mm + Nr) + 4.0 * Mm + 4.0 * (Nr + 1))
+            g = nbytes / us / 1e3
+            scatter = {"kernel": "nlam_segment_sum on the m2m tables (stand-alone aggregate)",
+                       "bound": "hbm", "achieved": g, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": g / HBM_PEAK_GBS, "avg_launch_us": us, "launches": 50,
+                       "algorithmic_bytes": nbytes,
+                       "note": "bare kernel, back to back; inside the step the forward scatter-add "
+                               "is fused into nlam_edge_fwd@m2m (fused_forward) and the backward's "
+                               "sender-side sums into nlam_node_bwd@m2m"}
             fw = stats.get("nlam_edge_fwd@m2m")
             if fw and fw["ms"] > 0:
                 scatter["fused_forward"] = roofline_entry("nlam_edge_fwd@m2m", fw, mfma_mode)
-            # the same kernel on the same m2m tables, 50 launches between ONE event pair:
-            # a 12-16 us kernel carries a few us of per-launch event overhead above
-            net0 = getattr(model, "processor", None)
-            net0 = getattr(net0, "module_0", None) if net0 is not None else None
-            if net0 is not None:
-                tb = net0.tables
-                Mm, Nr, dd = int(tb.M), int(tb.n_rec), args.hidden_dim
-                msg = torch.randn(B, Mm, dd, device=dev)
-                out_ = torch.empty(B, Nr, dd, device=dev)
-                for _ in range(3):
-                    ops.segment_sum(ops.mat(msg), tb.csr_rowptr, tb.csr_eid, ops.mat(out_))
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(50):
-                    ops.segment_sum(ops.mat(msg), tb.csr_rowptr, tb.csr_eid, ops.mat(out_))
-                e1.record()
-                torch.cuda.synchronize()
-                us = e0.elapsed_time(e1) * 1e3 / 50
-                nbytes = B * (4.0 * dd * (Mm + Nr) + 4.0 * Mm + 4.0 * (Nr + 1))
-                scatter["back_to_back"] = {"launches": 50, "avg_launch_us": us,
-                                           "achieved": nbytes / us / 1e3,
-                                           "frac": nbytes / us / 1e3 / HBM_PEAK_GBS}
+            del msg, out_
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
