@@ -59,20 +59,25 @@ __device__ __forceinline__ void load_weight_lds_b3(const B3Image& im, int row0,
     // and most launches of the hierarchical models are small)
     constexpr int NB = 16;
     for (int base = 0; base < total; base += NB * nthreads) {
+      // every load is unconditional on a clamped address and masked afterwards: a load inside
+      // `ok ? load : 0` sits in its own basic block, and the register allocator then parked one
+      // loaded value with `s_waitcnt vmcnt(0); v_mov` in the middle of the batch -- a full global
+      // round trip of stall in every prologue (seen in the ISA of tail_fwd_kernel<128, ...>)
       f32x4 v[NB];
 #pragma unroll
       for (int u = 0; u < NB; ++u) {
         const int idx = base + u * nthreads + tid;
         const int i = idx / cpr, c = idx - i * cpr;
         const bool ok = idx < total && i < n_out && 4 * c < k_in;
-        v[u] = ok ? *reinterpret_cast<const f32x4*>(W + (int64_t)i * ldW + 4 * c)
-                  : f32x4{0.f, 0.f, 0.f, 0.f};
+        v[u] = *reinterpret_cast<const f32x4*>(W + (ok ? (int64_t)i * ldW + 4 * c : 0));
       }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int u = 0; u < NB; ++u) {
         const int idx = base + u * nthreads + tid;
         if (idx < total) {
           const int i = idx / cpr, c = idx - i * cpr;
+          if (!(i < n_out && 4 * c < k_in)) v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
           bf16x4 hi, lo;
           b3_split4(v[u], hi, lo);
           *reinterpret_cast<bf16x4*>(im.hi + (row0 + i) * im.pitch + 4 * c) = hi;
@@ -131,12 +136,11 @@ __device__ __forceinline__ void w16_issue(WLoad16<NU>& w, const float* __restric
     const int cpr = k_pad32 >> 2;
     const int total = n_pad * cpr;
 #pragma unroll
-    for (int u = 0; u < NU; ++u) {
+    for (int u = 0; u < NU; ++u) {   // unconditional, clamped; masked in w16_commit (see load_weight_lds_b3)
       const int idx = u * nthreads + tid;
       const int i = idx / cpr, c = idx - i * cpr;
       const bool ok = idx < total && i < n_out && 4 * c < k_in;
-      w.v[u] = ok ? *reinterpret_cast<const f32x4*>(W + (int64_t)i * ldW + 4 * c)
-                  : f32x4{0.f, 0.f, 0.f, 0.f};
+      w.v[u] = *reinterpret_cast<const f32x4*>(W + (ok ? (int64_t)i * ldW + 4 * c : 0));
     }
   }
 }
@@ -152,8 +156,9 @@ __device__ __forceinline__ void w16_commit(const WLoad16<NU>& w, const B3Image& 
       const int idx = u * nthreads + tid;
       if (idx < total) {
         const int i = idx / cpr, c = idx - i * cpr;
+        const f32x4 x = (i < n_out && 4 * c < k_in) ? w.v[u] : f32x4{0.f, 0.f, 0.f, 0.f};
         bf16x4 hi, lo;
-        b3_split4(w.v[u], hi, lo);
+        b3_split4(x, hi, lo);
         *reinterpret_cast<bf16x4*>(im.hi + (row0 + i) * im.pitch + 4 * c) = hi;
         *reinterpret_cast<bf16x4*>(im.lo + (row0 + i) * im.pitch + 4 * c) = lo;
       }

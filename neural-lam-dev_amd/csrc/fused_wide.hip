@@ -37,6 +37,23 @@ struct WideTiling {
 struct WTile {
   int p0, ne, r0, nr;        // wave-uniform
 };
+// the header load alone / its decoding: a prologue issues the load, then its weight loads, and
+// decodes (= waits for the header) only after those are in flight
+__device__ __forceinline__ int4 wide_tile_raw(const WideTiling& tl, int64_t k) {
+  return tl.tiles != nullptr ? reinterpret_cast<const int4*>(tl.tiles)[k] : int4{0, 0, 0, 0};
+}
+__device__ __forceinline__ WTile wide_tile_decode(const WideTiling& tl, int64_t k, const int4& hdr) {
+  WTile w;
+  if (tl.tiles != nullptr) {
+    w.p0 = hdr.x; w.ne = hdr.y - hdr.x; w.r0 = hdr.z; w.nr = hdr.w - hdr.z;
+  } else {
+    w.p0 = (int)(k * NLAM_TILE);
+    const int64_t left = tl.rows - (int64_t)w.p0;
+    w.ne = (int)(left < NLAM_TILE ? left : NLAM_TILE);
+    w.r0 = 0; w.nr = 0;
+  }
+  return w;
+}
 __device__ __forceinline__ WTile wide_tile(const WideTiling& tl, int64_t k) {
   WTile w;
   if (tl.tiles != nullptr) {
@@ -128,37 +145,53 @@ __global__ __launch_bounds__(256) void tail_fwd_kernel(TailFwdParams p) {
   // per-wave slot-index tables [a | b | c | y] (see lane_row_index)
   int* itab = reinterpret_cast<int*>(bs + NO + 4 * (NLAM_TILE * LDT)) + wave * (4 * NLAM_TILE);
   const B3Image W2im = b3_image(W2s, NO, D);
-  {
-    static_assert(NO <= 256, "one vector entry per thread");
-    VecLoads<3> lv;
-    const float* const vsrc[3] = {p.b2, p.gamma, p.beta};
-    float* const vdst[3] = {b2s, gs, bs};
-    vecs_issue(lv, vsrc, p.n_out, tid);
-    load_weight_lds_b3(W2im, 0, p.W2, p.ldW2, p.n_out, D, NO, D, tid, 256);
-    vecs_commit(lv, vdst, NO, tid);
-  }
-  __syncthreads();
-
   // slot indices of a tile (lanes 0..31), fetched ONE TILE AHEAD so that the row gathers do
   // not wait for an index load
   struct Ctx { WTile w; int ia, ib, ic, iy, rcv; };
-  auto load_ctx = [&](int64_t task, int64_t total) {
-    Ctx c;
+  auto load_hdr = [&](int64_t task, int64_t total) {
     const int64_t tq = task < total ? task : total - 1;
     const int64_t bq = tq / p.tl.ntiles;
-    c.w = wide_tile(p.tl, tq - bq * p.tl.ntiles);
+    return wide_tile(p.tl, tq - bq * p.tl.ntiles);
+  };
+  auto load_idx = [&](const WTile& w) {
+    Ctx c;
+    c.w = w;
+    c.rcv = p.tl.csr_rec ? wide_index(p.tl.csr_rec, c.w, lane) : 0;
     c.ia = wide_index(p.idx_a, c.w, lane);
     c.ib = p.b.ptr ? wide_index(p.idx_b, c.w, lane) : 0;
     c.ic = p.c.ptr ? wide_index(p.idx_c, c.w, lane) : 0;
     c.iy = wide_index(p.idx_y, c.w, lane);
-    c.rcv = p.tl.csr_rec ? wide_index(p.tl.csr_rec, c.w, lane) : 0;
     return c;
   };
+  auto load_ctx = [&](int64_t task, int64_t total) { return load_idx(load_hdr(task, total)); };
   const int64_t total = p.tl.ntiles * p.B;
   const int64_t tstride = (int64_t)gridDim.x * 4;
   int64_t tt = (int64_t)blockIdx.x * 4 + wave;
+  // Prologue as ONE chain of overlapping round trips (most launches of the hierarchical models
+  // are one tile per wave, i.e. all prologue): first tile's header, then the weights and vectors
+  // (in flight), then the slot indices as soon as the header is there, then the LDS images.
+  Ctx cur;
+  {
+    static_assert(NO <= 256, "one vector entry per thread");
+    const int64_t tq0 = tt < total ? tt : total - 1;
+    // (wave-uniform by construction; readfirstlane lets the header come through the scalar
+    // cache, on its own counter, so waiting for it does not wait for the weight loads)
+    const int64_t k0 = __builtin_amdgcn_readfirstlane((int)(tq0 - (tq0 / p.tl.ntiles) * p.tl.ntiles));
+    const int4 hdr0 = wide_tile_raw(p.tl, k0);
+    __builtin_amdgcn_sched_barrier(0);
+    VecLoads<3> lv;
+    const float* const vsrc[3] = {p.b2, p.gamma, p.beta};
+    float* const vdst[3] = {b2s, gs, bs};
+    vecs_issue(lv, vsrc, p.n_out, tid);
+    WLoad16<16> lw;
+    w16_issue(lw, p.W2, p.ldW2, p.n_out, D, NO, D, tid, 256);
+    __builtin_amdgcn_sched_barrier(0);
+    cur = load_idx(wide_tile_decode(p.tl, k0, hdr0));
+    w16_commit(lw, W2im, 0, p.W2, p.ldW2, p.n_out, D, NO, D, tid, 256);
+    vecs_commit(lv, vdst, NO, tid);
+  }
+  __syncthreads();
   if (tt >= total) return;
-  Ctx cur = load_ctx(tt, total);
   for (; tt < total; tt += tstride) {
     const int64_t b = tt / p.tl.ntiles;
     const WTile w = cur.w;
@@ -379,13 +412,45 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(TailBwdParams q) {
   float* tile = gs + NO + wave * (NLAM_TILE * LDT);
   int* itab = reinterpret_cast<int*>(gs + NO + 4 * (NLAM_TILE * LDT)) + wave * (4 * NLAM_TILE);
   const B3Image W2im = b3_image(W2s, NO, D);
+  // slot indices / row scales of a tile (lanes 0..31), fetched one tile ahead
+  struct Ctx { WTile w; int i1, i2, igh, rcv; float sc1; };
+  auto load_idx = [&](const WTile& w) {
+    Ctx c;
+    c.w = w;
+    c.rcv = q.tl.csr_rec ? wide_index(q.tl.csr_rec, c.w, lane) : 0;
+    c.i1 = wide_index(q.idx_g1, c.w, lane);
+    c.i2 = q.g2.ptr ? wide_index(q.idx_g2, c.w, lane) : 0;
+    c.igh = wide_index(q.idx_gh, c.w, lane);
+    c.sc1 = q.scale1 ? q.scale1[c.i1] : 1.0f;   // (dependent load, hidden by the prefetch)
+    return c;
+  };
+  auto load_ctx = [&](int64_t task, int64_t total) {
+    const int64_t tq = task < total ? task : total - 1;
+    const int64_t bq = tq / q.tl.ntiles;
+    return load_idx(wide_tile(q.tl, tq - bq * q.tl.ntiles));
+  };
+  const int64_t total = q.tl.ntiles * q.B;
+  const int64_t tstride = (int64_t)gridDim.x * 4;
+  int64_t tt = (int64_t)blockIdx.x * 4 + wave;
+  // prologue: first tile's header (scalar load), weights + vectors in flight, then the slot
+  // indices, then the LDS images (see tail_fwd_kernel)
+  Ctx cur;
   {
     static_assert(NO <= 256, "one vector entry per thread");
+    const int64_t tot1 = total > 0 ? total : 1;
+    const int64_t tq0 = tt < tot1 ? tt : tot1 - 1;
+    const int64_t k0 = __builtin_amdgcn_readfirstlane((int)(tq0 - (tq0 / q.tl.ntiles) * q.tl.ntiles));
+    const int4 hdr0 = wide_tile_raw(q.tl, k0);
+    __builtin_amdgcn_sched_barrier(0);
     VecLoads<2> lv;
     const float* const vsrc[2] = {q.b2, q.gamma};
     float* const vdst[2] = {b2s, gs};
     vecs_issue(lv, vsrc, q.n_out, tid);
-    load_weight_lds_b3(W2im, 0, q.W2, q.ldW2, q.n_out, D, NO, D, tid, 256);
+    WLoad16<16> lw;
+    w16_issue(lw, q.W2, q.ldW2, q.n_out, D, NO, D, tid, 256);
+    __builtin_amdgcn_sched_barrier(0);
+    cur = load_idx(wide_tile_decode(q.tl, k0, hdr0));
+    w16_commit(lw, W2im, 0, q.W2, q.ldW2, q.n_out, D, NO, D, tid, 256);
     vecs_commit(lv, vdst, NO, tid);
   }
   __syncthreads();
@@ -395,25 +460,6 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(TailBwdParams q) {
 #pragma unroll
   for (int j = 0; j < NV_O; ++j) dgam[j] = dbet[j] = 0.f;
   const B3Tile Tp = b3_tile(tile, NO);   // bf16-plane view of the tile (column sums)
-
-  // slot indices / row scales of a tile (lanes 0..31), fetched one tile ahead
-  struct Ctx { WTile w; int i1, i2, igh, rcv; float sc1; };
-  auto load_ctx = [&](int64_t task, int64_t total) {
-    Ctx c;
-    const int64_t tq = task < total ? task : total - 1;
-    const int64_t bq = tq / q.tl.ntiles;
-    c.w = wide_tile(q.tl, tq - bq * q.tl.ntiles);
-    c.i1 = wide_index(q.idx_g1, c.w, lane);
-    c.i2 = q.g2.ptr ? wide_index(q.idx_g2, c.w, lane) : 0;
-    c.igh = wide_index(q.idx_gh, c.w, lane);
-    c.rcv = q.tl.csr_rec ? wide_index(q.tl.csr_rec, c.w, lane) : 0;
-    c.sc1 = q.scale1 ? q.scale1[c.i1] : 1.0f;   // (dependent load, hidden by the prefetch)
-    return c;
-  };
-  const int64_t total = q.tl.ntiles * q.B;
-  const int64_t tstride = (int64_t)gridDim.x * 4;
-  int64_t tt = (int64_t)blockIdx.x * 4 + wave;
-  Ctx cur = load_ctx(tt, total > 0 ? total : 1);
   for (; tt < total; tt += tstride) {
     const int64_t b = tt / q.tl.ntiles;
     const WTile w = cur.w;
@@ -723,16 +769,29 @@ __device__ __forceinline__ void lin_bwd_data_body(const LinBwdDataParams& q, int
   float* tile = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) +
                                          (size_t)2 * NO * WP * sizeof(__bf16)) +
                 wave * (NLAM_TILE * LDT);
-  load_weight_lds_b3(Wim, 0, q.W, q.ldW, q.n_out, q.k_in, NO, K, tid, 256);
-  __syncthreads();
   const int64_t tiles_per_b = (q.rows + NLAM_TILE - 1) / NLAM_TILE;
   const int64_t ntiles = tiles_per_b * q.B;
-  for (int64_t tt = (int64_t)bid * 4 + wave; tt < ntiles; tt += (int64_t)gdim * 4) {
+  const int64_t tt0 = (int64_t)bid * 4 + wave;
+  // prologue: the weight loads and the FIRST tile's rows are in flight together (most launches
+  // of the hierarchical models are one tile per wave), then the LDS image
+  f32x4 vg[4 * NOUTB];
+  {
+    WLoad16<(NO * K / 4 + 255) / 256> lw;
+    w16_issue(lw, q.W, q.ldW, q.n_out, q.k_in, NO, K, tid, 256);
+    const int64_t tq = tt0 < ntiles ? tt0 : ntiles - 1;
+    const int64_t b = tq / tiles_per_b;
+    const int64_t r0 = (tq - b * tiles_per_b) * NLAM_TILE;
+    const int nrows = (int)((q.rows - r0) < NLAM_TILE ? (q.rows - r0) : NLAM_TILE);
+    view_load_v<4 * NOUTB>(vg, q.gy, b, r0, nrows, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    w16_commit(lw, Wim, 0, q.W, q.ldW, q.n_out, q.k_in, NO, K, tid, 256);
+  }
+  __syncthreads();
+  for (int64_t tt = tt0; tt < ntiles; tt += (int64_t)gdim * 4) {
     const int64_t b = tt / tiles_per_b;
     const int64_t r0 = (tt - b * tiles_per_b) * NLAM_TILE;
     const int nrows = (int)((q.rows - r0) < NLAM_TILE ? (q.rows - r0) : NLAM_TILE);
-    f32x4 vg[4 * NOUTB];
-    view_load_v<4 * NOUTB>(vg, q.gy, b, r0, nrows, lane);
+    if (tt != tt0) view_load_v<4 * NOUTB>(vg, q.gy, b, r0, nrows, lane);
     const B3Tile Gp = b3_tile(tile, NO);
     put_rows_v_b3<4 * NOUTB>(Gp, 0, NO, nrows, lane, vg);
     wave_sync();
@@ -1089,24 +1148,33 @@ __device__ __forceinline__ void wide_lin_fwd_body(const WideLinParams& p, int bi
   const B3Image W = b3_image(smem, NO, K);
   float* bs = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + b3_image_bytes(NO, K));
   float* tile = bs + NO + wave * (NLAM_TILE * ldt);
-  {
+  const int64_t tiles_per_b = (p.rows + NLAM_TILE - 1) / NLAM_TILE;
+  const int64_t ntiles = tiles_per_b * p.B;
+  const int64_t tt0 = (int64_t)bid * 4 + wave;
+  f32x4 vx[8 * KB];
+  {   // weights, bias and the first tile's rows in flight together, then the LDS image
     static_assert(NO <= 256, "one vector entry per thread");
     VecLoads<1> lv;
     const float* const vsrc[1] = {p.bias};
     float* const vdst[1] = {bs};
     vecs_issue(lv, vsrc, NO, tid);
-    load_weight_lds_b3(W, 0, p.W, p.ldW, NO, K, NO, K, tid, 256);
+    WLoad16<(NO * K / 4 + 255) / 256> lw;
+    w16_issue(lw, p.W, p.ldW, NO, K, NO, K, tid, 256);
+    const int64_t tq = tt0 < ntiles ? tt0 : ntiles - 1;
+    const int64_t b = tq / tiles_per_b;
+    const int64_t r0 = (tq - b * tiles_per_b) * NLAM_TILE;
+    const int nrows = (int)((p.rows - r0) < NLAM_TILE ? (p.rows - r0) : NLAM_TILE);
+    view_load_v<8 * KB>(vx, p.x, b, r0, nrows, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    w16_commit(lw, W, 0, p.W, p.ldW, NO, K, NO, K, tid, 256);
     vecs_commit(lv, vdst, NO, tid);
   }
   __syncthreads();
-  const int64_t tiles_per_b = (p.rows + NLAM_TILE - 1) / NLAM_TILE;
-  const int64_t ntiles = tiles_per_b * p.B;
-  for (int64_t tt = (int64_t)bid * 4 + wave; tt < ntiles; tt += (int64_t)gdim * 4) {
+  for (int64_t tt = tt0; tt < ntiles; tt += (int64_t)gdim * 4) {
     const int64_t b = tt / tiles_per_b;
     const int64_t r0 = (tt - b * tiles_per_b) * NLAM_TILE;
     const int nrows = (int)((p.rows - r0) < NLAM_TILE ? (p.rows - r0) : NLAM_TILE);
-    f32x4 vx[8 * KB];
-    view_load_v<8 * KB>(vx, p.x, b, r0, nrows, lane);
+    if (tt != tt0) view_load_v<8 * KB>(vx, p.x, b, r0, nrows, lane);
     const B3Tile Xp = b3_tile(tile, K);
     put_rows_v_b3<8 * KB>(Xp, 0, K, nrows, lane, vx);
     wave_sync();
