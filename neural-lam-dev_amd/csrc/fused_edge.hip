@@ -70,8 +70,17 @@ __global__ __launch_bounds__(256, 2) void edge_fwd_kernel(EdgeFwdParams p) {
   // per-wave slot-index tables [eid | send | rec] (see lane_row_index)
   int* itab = reinterpret_cast<int*>(bs + D + 4 * (NLAM_TILE * LDT)) + wave * (3 * NLAM_TILE);
   const B3Image W1im = b3_image(W1s, D, D), W2im = b3_image(W2s, D, D);
+  const unsigned total = (unsigned)(p.ntiles * p.B);
+  const unsigned stride = gridDim.x * 4;
+  unsigned tt = blockIdx.x * 4 + wave;
+  TileCtx cur;
+  int4 hdr_n;
   if (B3 && D == 64) {
-    // every global load of the prologue in flight together (fused_bf16x3.h, batched prologue loads)
+    // every global load of the prologue in flight together (fused_bf16x3.h, batched prologue
+    // loads) -- including the FIRST tile's header (scalar load: tt is wave-uniform) and slot
+    // indices, which used to be two more dependent round trips after the barrier
+    const int4 hdr0 = load_tile_hdr(p, (unsigned)__builtin_amdgcn_readfirstlane((int)tt), total);
+    __builtin_amdgcn_sched_barrier(0);
     VLoad16 lv;
     const float* const vecs[8] = {p.b2, p.gamma, p.beta, nullptr, nullptr, nullptr, nullptr, nullptr};
     const int lens[8] = {D, D, D, 0, 0, 0, 0, 0};
@@ -79,6 +88,9 @@ __global__ __launch_bounds__(256, 2) void edge_fwd_kernel(EdgeFwdParams p) {
     WLoad16<D * D / 4 / 256> l1, l2;
     if (HAS_EGEMM) w16_issue(l1, p.W1e, p.ldW1e, D, D, D, D, tid, 256);
     w16_issue(l2, p.W2, p.ldW2, D, D, D, D, tid, 256);
+    __builtin_amdgcn_sched_barrier(0);
+    cur = load_tile_ctx(p, hdr0, lane);
+    hdr_n = load_tile_hdr(p, tt + stride, total);
     v16_commit(lv, b2s, 3, tid);
     if (HAS_EGEMM) w16_commit(l1, W1im, 0, p.W1e, p.ldW1e, D, D, D, D, tid, 256);
     w16_commit(l2, W2im, 0, p.W2, p.ldW2, D, D, D, D, tid, 256);
@@ -97,12 +109,11 @@ __global__ __launch_bounds__(256, 2) void edge_fwd_kernel(EdgeFwdParams p) {
   __syncthreads();
 
   constexpr int NV = D / 8;
-  const unsigned total = (unsigned)(p.ntiles * p.B);
-  const unsigned stride = gridDim.x * 4;
-  unsigned tt = blockIdx.x * 4 + wave;
   if (tt >= total) return;
-  TileCtx cur = load_tile_ctx(p, load_tile_hdr(p, tt, total), lane);
-  int4 hdr_n = load_tile_hdr(p, tt + stride, total);
+  if (!(B3 && D == 64)) {
+    cur = load_tile_ctx(p, load_tile_hdr(p, tt, total), lane);
+    hdr_n = load_tile_hdr(p, tt + stride, total);
+  }
   for (; tt < total; tt += stride) {
     const unsigned b = tt / (unsigned)p.ntiles;
     const int p0 = cur.p0, ne = cur.ne, r0 = cur.r0, nr = cur.nr;
@@ -313,14 +324,26 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
   // per-wave slot-index tables, double-buffered over tiles: [2][eid | send | rec][32]
   int* itab = reinterpret_cast<int*>(T0base + 4 * WSTRIDE) + wave * (6 * NLAM_TILE);
   const B3Image W1im = b3_image(W1s, D, D), W2im = b3_image(W2s, D, D);
+  const unsigned total = (unsigned)(p.ntiles * p.B);
+  const unsigned stride = gridDim.x * 4;
+  unsigned tt = blockIdx.x * 4 + wave;
+  TileCtx cur;
+  int4 hdr_n;
   if (B3 && D == 64) {
-    VLoad16 lv;   // (batched prologue loads: one global round trip)
+    // (batched prologue loads: one global round trip, the first tile's header -- a scalar
+    // load, tt is wave-uniform -- and slot indices included; see edge_fwd_kernel)
+    const int4 hdr0 = load_tile_hdr(p, (unsigned)__builtin_amdgcn_readfirstlane((int)tt), total);
+    __builtin_amdgcn_sched_barrier(0);
+    VLoad16 lv;
     const float* const vecs[8] = {p.b2, p.gamma, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     const int lens[8] = {D, D, 0, 0, 0, 0, 0, 0};
     v16_issue(lv, vecs, lens, tid);
     WLoad16<D * D / 4 / 256> l1, l2;
     if (HAS_EGEMM) w16_issue(l1, p.W1e, p.ldW1e, D, D, D, D, tid, 256);
     w16_issue(l2, p.W2, p.ldW2, D, D, D, D, tid, 256);
+    __builtin_amdgcn_sched_barrier(0);
+    cur = load_tile_ctx(p, hdr0, lane);
+    hdr_n = load_tile_hdr(p, tt + stride, total);
     v16_commit(lv, b2s, 2, tid);
     if (HAS_EGEMM) w16_commit(l1, W1im, 0, p.W1e, p.ldW1e, D, D, D, D, tid, 256);
     w16_commit(l2, W2im, 0, p.W2, p.ldW2, D, D, D, D, tid, 256);
@@ -349,13 +372,12 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(EdgeBwdParams q) {
 #pragma unroll
   for (int j = 0; j < NV; ++j) db2[j] = dgam[j] = dbet[j] = 0.f;
 
-  const unsigned total = (unsigned)(p.ntiles * p.B);
-  const unsigned stride = gridDim.x * 4;
   const int t = lane & 31, hh = lane >> 5;
   const bool has_geo = HAS_EGEMM && q.g_eout != nullptr;
-  unsigned tt = blockIdx.x * 4 + wave;
-  TileCtx cur = load_tile_ctx(p, load_tile_hdr(p, tt, total), lane);
-  int4 hdr_n = load_tile_hdr(p, tt + stride, total);
+  if (!(B3 && D == 64)) {
+    cur = load_tile_ctx(p, load_tile_hdr(p, tt, total), lane);
+    hdr_n = load_tile_hdr(p, tt + stride, total);
+  }
   unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   // The five row gathers of a tile (e, ps, pr, g_agg, g_eout) are issued ONE TILE AHEAD,
   // at the start of the previous tile's last phase, and land while its MFMAs run: with
