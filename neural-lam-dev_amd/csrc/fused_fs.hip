@@ -232,7 +232,14 @@ __device__ __forceinline__ FsSub fs_sub(const FsTiling& tl, int64_t id) {
   s.b = id / tl.ntiles;
   const int64_t k = id - s.b * tl.ntiles;
   if (tl.tiles != nullptr) {
-    const int4 hdr = reinterpret_cast<const int4*>(tl.tiles)[k];
+    // The tile table is graph data no kernel writes, and the tile id of a workgroup is uniform:
+    // read it through the constant address space, i.e. as a SCALAR load (own counter, scalar
+    // cache).  As plain global loads the two headers of a 64-row tile were two serialized vector
+    // round trips at the top of EVERY tile (the kernels' stores may alias, so the compiler
+    // could not make them scalar itself).
+    typedef int fs_i32x4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(4))) fs_i32x4* const_i32x4_ptr;
+    const fs_i32x4 hdr = ((const_i32x4_ptr)(uintptr_t)tl.tiles)[k];
     s.p0 = hdr.x; s.ne = hdr.y - hdr.x; s.r0 = hdr.z; s.nr = hdr.w - hdr.z;
   } else {
     s.p0 = (int)(k * NLAM_TILE);
