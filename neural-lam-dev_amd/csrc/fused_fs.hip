@@ -103,14 +103,16 @@ __device__ __forceinline__ void fs_load_w_cols(FsW<K, TERMS>& A, const float* __
 // with coalesced float4 loads, written TRANSPOSED as bf16 (T[col][k], pitch 68) and picked up as
 // fragments.  (The per-lane column walk above issues 128 strided dword loads per lane: ~50 us of
 // prologue, which is the whole run time on the small mesh levels of Hi-LAM.)  scratch: >= 256 *
-// 68 bf16; every thread of the 512-thread workgroup must call; ends with a barrier.
+// 68 bf16 (twice that for the hi + lo images of TERMS = 3); every thread of the 512-thread
+// workgroup must call; ends with a barrier.
 template <int K, int TERMS>
 __device__ __forceinline__ void fs_load_w_cols_lds(FsW<K, TERMS>& A, const float* __restrict__ W,
                                                    int64_t ldW, int col0, int n_rows,
                                                    void* scratch, int tid) {
-  static_assert(K == 256 && TERMS == 1, "fs_load_w_cols_lds: 256-wide bf16 slices only");
+  static_assert(K == 256, "fs_load_w_cols_lds: 256-wide slices only");
   constexpr int TP = 68;
   __bf16* T = reinterpret_cast<__bf16*>(scratch);
+  __bf16* TL = T + 256 * TP;   // (TERMS == 3: the lo parts)
   const int lane = tid & 63;
   const int i = lane & 31, h = lane >> 5;
   const int c4 = tid & 63, rg = tid >> 6;   // 64 float4 chunk columns x 8 row groups
@@ -137,22 +139,34 @@ __device__ __forceinline__ void fs_load_w_cols_lds(FsW<K, TERMS>& A, const float
   for (int c = 0; c < K / 64; ++c) {   // (unrolled: A.hi must stay in registers)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      bf16x4 lo, hi;
+      bf16x4 r03, r47;   // rows 8 rg + 0..3 / + 4..7 of column 4 c4 + j
+      bf16x4 l03, l47;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        lo[k] = (__bf16)v[c][k][j];
-        hi[k] = (__bf16)v[c][4 + k][j];
+        r03[k] = (__bf16)v[c][k][j];
+        r47[k] = (__bf16)v[c][4 + k][j];
+        if constexpr (TERMS == 3) {
+          l03[k] = (__bf16)(v[c][k][j] - (float)r03[k]);
+          l47[k] = (__bf16)(v[c][4 + k][j] - (float)r47[k]);
+        }
       }
-      __bf16* dst = T + (4 * c4 + j) * TP + 8 * rg;
-      *reinterpret_cast<bf16x4*>(dst) = lo;
-      *reinterpret_cast<bf16x4*>(dst + 4) = hi;
+      const int off = (4 * c4 + j) * TP + 8 * rg;
+      *reinterpret_cast<bf16x4*>(T + off) = r03;
+      *reinterpret_cast<bf16x4*>(T + off + 4) = r47;
+      if constexpr (TERMS == 3) {
+        *reinterpret_cast<bf16x4*>(TL + off) = l03;
+        *reinterpret_cast<bf16x4*>(TL + off + 4) = l47;
+      }
     }
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const __bf16* tr = T + (col0 + i) * TP + 16 * u + 4 * h;
-      A.hi[4 * c + u] = b3_join(*reinterpret_cast<const bf16x4*>(tr),
-                                *reinterpret_cast<const bf16x4*>(tr + 8));
+      const int off = (col0 + i) * TP + 16 * u + 4 * h;
+      A.hi[4 * c + u] = b3_join(*reinterpret_cast<const bf16x4*>(T + off),
+                                *reinterpret_cast<const bf16x4*>(T + off + 8));
+      if constexpr (TERMS == 3)
+        A.lo[4 * c + u] = b3_join(*reinterpret_cast<const bf16x4*>(TL + off),
+                                  *reinterpret_cast<const bf16x4*>(TL + off + 8));
     }
     __syncthreads();
   }
@@ -382,7 +396,9 @@ __device__ __forceinline__ void fs_lin_fwd_body(const FsLinParams& p, const int 
   X.init(smem);
   float* otile = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + FsPlanes<K, TERMS>::bytes);
   FsW<K, TERMS> A;
-  if constexpr (TRANS && TERMS == 1) fs_load_w_cols_lds<K, TERMS>(A, p.W, p.ldW, 32 * wave, p.x.width, otile, tid);
+  // (TERMS == 3: hi + lo transposed images = 69.6 KB, over the planes and the output tile, which
+  //  are contiguous from smem and unused until the first tile)
+  if constexpr (TRANS && K == 256) fs_load_w_cols_lds<K, TERMS>(A, p.W, p.ldW, 32 * wave, p.x.width, TERMS == 1 ? (void*)otile : (void*)smem, tid);
   else if constexpr (TRANS) fs_load_w_cols<K, TERMS>(A, p.W, p.ldW, 32 * wave, p.x.width, lane);
   else fs_load_w_rows<K, TERMS>(A, p.W, p.ldW, 32 * wave, p.n_out, p.x.width, lane);
   const f32x16 bias = fs_vec_block(p.bias, p.n_out, wave, lane);
@@ -1167,8 +1183,8 @@ __global__ __launch_bounds__(2 * D) void fs_tail_bwd_kernel(FsTailBwdParams q) {
   float* red = gtile + FS_R * LDO;                            // [2][FS_R][NW]
   int* itab0 = reinterpret_cast<int*>(red + 2 * FS_R * NW);   // [2][4][FS_R]: g1, g2, gh, scale
   FsW<D, TERMS> A2;
-  if constexpr (TERMS == 1) fs_load_w_cols_lds<D, TERMS>(A2, q.W2, q.ldW2, 32 * wave, q.n_out, gtile, tid);
-  else fs_load_w_cols<D, TERMS>(A2, q.W2, q.ldW2, 32 * wave, q.n_out, lane);
+  // (TERMS == 3: hi + lo transposed images over the S planes and the g tile, contiguous from smem)
+  fs_load_w_cols_lds<D, TERMS>(A2, q.W2, q.ldW2, 32 * wave, q.n_out, TERMS == 1 ? (void*)gtile : (void*)smem, tid);
   f32x16 dgam, dbet;
 #pragma unroll
   for (int r = 0; r < 16; ++r) dgam[r] = dbet[r] = 0.f;
