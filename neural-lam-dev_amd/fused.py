@@ -946,12 +946,16 @@ def apply_inet_split(net, send_rep, rec_rep, edge_rep):
         e_mlps, e_sizes, tabs = list(net.edge_mlp.mlps), list(net.edge_mlp.chunk_sizes), list(net.chunk_tables)
     else:
         e_mlps, e_sizes, tabs = [net.edge_mlp], [net.tables.M], [net.tables]
-    agg, e_outs, o = None, [], 0
-    for mlp, m, tab in zip(e_mlps, e_sizes, tabs):
+    # torch.split, as the reference's SplitMLPs.forward does (interaction_net.py:159-163): its
+    # backward is ONE concatenation of the chunk gradients; indexing e[:, o : o + m] per chunk gave
+    # a zero-filled full-size gradient + a copy per chunk and a chain of full-size adds
+    agg, e_outs = None, []
+    e_chunks = torch.split(e, e_sizes, dim=1) if len(e_sizes) > 1 else (e,)
+    for mlp, e_c, tab in zip(e_mlps, e_chunks, tabs):
         tab.tag = net.tables.tag
         lin, ln = _mlp_parts(mlp)
         out = FusedEdgePassFunction.apply(
-            s, r, e[:, o : o + m], same, tab, net.update_edges,
+            s, r, e_c, same, tab, net.update_edges,
             lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias, ln.weight, ln.bias)
         if net.update_edges:
             a_c, eo_c = out
@@ -959,7 +963,6 @@ def apply_inet_split(net, send_rep, rec_rep, edge_rep):
         else:
             a_c = out
         agg = a_c if agg is None else agg + a_c
-        o += m
     if net.aggr == "mean":
         agg = agg * net.tables.inv_deg.view(1, -1, 1)
     if isinstance(net.aggr_mlp, SplitMLPs):
@@ -968,13 +971,14 @@ def apply_inet_split(net, send_rep, rec_rep, edge_rep):
         a_mlps, a_sizes = [net.aggr_mlp], [net.num_rec]
     if r.shape[0] == 1 and B > 1:
         r = r.expand(B, -1, -1)
-    outs, r0 = [], 0
-    for mlp, n in zip(a_mlps, a_sizes):
+    outs = []
+    r_chunks = torch.split(r, a_sizes, dim=1) if len(a_sizes) > 1 else (r,)
+    g_chunks = torch.split(agg, a_sizes, dim=1) if len(a_sizes) > 1 else (agg,)
+    for mlp, r_c, g_c in zip(a_mlps, r_chunks, g_chunks):
         lin, ln = _mlp_parts(mlp)
         outs.append(FusedNodeUpdateFunction.apply(
-            r[:, r0 : r0 + n], agg[:, r0 : r0 + n], net.tables.tag,
+            r_c, g_c, net.tables.tag,
             lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias, ln.weight, ln.bias))
-        r0 += n
     rec_out = outs[0] if len(outs) == 1 else torch.cat(outs, dim=1)
     if net.update_edges:
         return rec_out, (e_outs[0] if len(e_outs) == 1 else torch.cat(e_outs, dim=1))
