@@ -418,6 +418,11 @@ int nlam_adamw_step(float* p, const float* g, float* m, float* v, int64_t n,
                     float weight_decay, int64_t step, float grad_scale,
                     void* stream);
 
+/* out = src[0] + ... + src[n - 1] over numel fp32 elements (n <= 8, fixed order, 16-byte aligned
+ * contiguous operands): the per-chunk aggregates of a SplitMLPs InteractionNet
+ * (interaction_net.py:134-163; hi_lam_parallel.py:26-53) in one pass. */
+int nlam_sum_many(int n, const float* const* src, float* out, int64_t numel, void* stream);
+
 /* Gradient packing for the flat-buffer all-reduce (the reference leaves this to DDP's bucket
  * copies, train_model.py:265-274 `strategy="ddp"`): n gradient tensors -> their slices of one
  * fp32 buffer in ONE launch.  table (device memory, int64): n triples [source address | element

@@ -514,3 +514,52 @@ extern "C" int nlam_pack_segments(const int64_t* table, int n, int64_t nchunks, 
   NLAM_CHECK_LAUNCH("pack_segments");
   return 0;
 }
+
+// out = src[0] + src[1] + ... + src[n - 1] (n <= 8 equally shaped fp32 tensors, fixed order): the
+// per-chunk aggregates of a SplitMLPs InteractionNet (interaction_net.py:134-163) in ONE pass
+// instead of a chain of n - 1 full-size additions.
+struct SumManyParams {
+  const float* src[8];
+  int n;
+};
+__global__ __launch_bounds__(256) void sum_many_kernel(SumManyParams p, float* __restrict__ out,
+                                                       int64_t n4, int64_t numel) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    f32x4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (k < p.n) v[k] = reinterpret_cast<const f32x4*>(p.src[k])[i];
+    f32x4 s = v[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k)
+      if (k < p.n) s += v[k];
+    reinterpret_cast<f32x4*>(out)[i] = s;
+  }
+  if (blockIdx.x == 0) {   // (numel % 4 tail)
+    for (int64_t i = 4 * n4 + threadIdx.x; i < numel; i += blockDim.x) {
+      float s = p.src[0][i];
+      for (int k = 1; k < p.n; ++k) s += p.src[k][i];
+      out[i] = s;
+    }
+  }
+}
+extern "C" int nlam_sum_many(int n, const float* const* src, float* out, int64_t numel, void* stream) {
+  NLAM_REQUIRE(n >= 1 && n <= 8, "nlam_sum_many: %d sources (1..8)", n);
+  NLAM_REQUIRE(out != nullptr && nlam_aligned16(out), "nlam_sum_many: output must be 16-byte aligned");
+  if (numel <= 0) return 0;
+  SumManyParams p;
+  p.n = n;
+  for (int k = 0; k < 8; ++k) {
+    p.src[k] = k < n ? src[k] : nullptr;
+    NLAM_REQUIRE(k >= n || (src[k] != nullptr && nlam_aligned16(src[k])),
+                 "nlam_sum_many: source %d missing or not 16-byte aligned", k);
+  }
+  const int64_t n4 = numel / 4;
+  int64_t blocks = (n4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  sum_many_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(p, out, n4, numel);
+  NLAM_CHECK_LAUNCH("sum_many");
+  return 0;
+}

@@ -247,3 +247,37 @@ class ConcatRows(torch.autograd.Function):
                 outs.append(None)
             o += w
         return tuple(outs)
+
+
+class SumMany(torch.autograd.Function):
+    """a_0 + a_1 + ... (up to 8 equally shaped tensors per launch, fixed order) in one pass; the
+    gradient of every term is the incoming gradient itself."""
+
+    @staticmethod
+    def forward(ctx, *terms):
+        import ctypes
+
+        ops._require_dev(terms[0], "term")
+        terms = [t.contiguous() for t in terms]
+        out = torch.empty_like(terms[0])
+        acc = None
+        for i in range(0, len(terms), 7 if len(terms) > 8 else 8):
+            part = ([acc] if acc is not None else []) + terms[i : i + (7 if len(terms) > 8 else 8)]
+            arr = (ctypes.c_void_p * len(part))(*[t.data_ptr() for t in part])
+            ops._launch("nlam_sum_many", lib.nlam_sum_many,
+                        (len(part), arr, out.data_ptr(), out.numel(), ops.stream()),
+                        nbytes=4.0 * out.numel() * (len(part) + 1))
+            acc = out
+        ctx.n = len(terms)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g,) * ctx.n
+
+
+def sum_many(terms):
+    terms = list(terms)
+    if len(terms) == 1:
+        return terms[0]
+    return SumMany.apply(*terms)

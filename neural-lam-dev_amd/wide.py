@@ -819,7 +819,7 @@ def apply_inet_split(net, send_rep, rec_rep, edge_rep):
     # torch.split, as the reference's SplitMLPs.forward does (interaction_net.py:159-163): its
     # backward is ONE concatenation of the chunk gradients; indexing e[:, o : o + m] per chunk gave
     # a zero-filled full-size gradient + a copy per chunk and a chain of full-size adds
-    agg, e_outs = None, []
+    aggs, e_outs = [], []
     e_chunks = torch.split(e, e_sizes, dim=1) if len(e_sizes) > 1 else (e,)
     for mlp, e_c, tab in zip(e_mlps, e_chunks, tabs):
         tab.tag = net.tables.tag
@@ -832,7 +832,10 @@ def apply_inet_split(net, send_rep, rec_rep, edge_rep):
             e_outs.append(eo_c)
         else:
             a_c = out
-        agg = a_c if agg is None else agg + a_c
+        aggs.append(a_c)
+    from . import glue
+
+    agg = glue.sum_many(aggs)   # (one pass over the chunk aggregates, not a chain of adds)
     if net.aggr == "mean":
         agg = agg * net.tables.inv_deg.view(1, -1, 1)
     if isinstance(net.aggr_mlp, SplitMLPs):

@@ -267,3 +267,23 @@ def test_state_step_matches_residual_then_boundary_mix(prev_grad):
     assert torch.allclose(g_net, net.grad, rtol=1e-6, atol=1e-7)
     if prev_grad:
         assert torch.allclose(g_prev, prev.grad, rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("n,shape", [(2, (3, 50, 64)), (7, (4, 737, 64)), (11, (2, 33, 5))])
+def test_sum_many_matches_chain_of_adds(n, shape):
+    """glue.sum_many (nlam_sum_many: one pass over up to 8 terms, chained beyond) against the
+    chain of additions it replaces in the SplitMLPs operator: same fixed order, so bit-identical
+    for up to 8 terms; every term's gradient is the incoming gradient."""
+    from neural_lam_amd import glue
+
+    gen = torch.Generator().manual_seed(n)
+    terms = [torch.randn(*shape, generator=gen).cuda().requires_grad_(True) for _ in range(n)]
+    got = glue.sum_many(terms)
+    want = terms[0]
+    for t in terms[1:]:
+        want = want + t
+    assert torch.equal(got, want) if n <= 8 else torch.allclose(got, want, rtol=1e-6, atol=1e-6)
+    w = torch.randn(*shape, generator=gen).cuda()
+    (got * w).sum().backward()
+    for t in terms:
+        assert torch.equal(t.grad, w)
