@@ -16,6 +16,15 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.cpp")))
 
 
+def _file_flags(src):
+    """Extra hipcc flags a source asks for in a `// NLAM_HIPCC_FLAGS: ...` line of its header."""
+    with open(src) as f:
+        for line in f.readlines()[:60]:
+            if line.startswith("// NLAM_HIPCC_FLAGS:"):
+                return line.split(":", 1)[1].split()
+    return []
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
@@ -35,7 +44,7 @@ def build(force=False, verbose=True):
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
-            cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+            cmd = [hipcc] + FLAGS + _file_flags(src) + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd)))

@@ -274,7 +274,9 @@ extern "C" int nlam_edge_fwd(
 // Diagnostic build only (NLAM_STAMP=1): per-phase cycle sums of the backward tile loop,
 // summed over all waves (s_memtime stamps; they perturb the schedule, read the SHARES).
 __device__ unsigned long long g_edge_bwd_stamps[8];
+int nlam_edge_bwd2_stamps(unsigned long long* out, int reset);   // fused_edge2.hip (NLAM_STAMP2=1)
 extern "C" int nlam_debug_edge_bwd_stamps(unsigned long long* out, int reset) {
+  if (getenv("NLAM_STAMP2") != nullptr) return nlam_edge_bwd2_stamps(out, reset);
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_edge_bwd_stamps), sizeof(unsigned long long) * 8) !=
       hipSuccess)
     return 1;
@@ -739,6 +741,8 @@ extern "C" int nlam_edge_bwd(
   q.slab = slab; q.slab_stride = slab_stride;
   hipStream_t s = (hipStream_t)stream;
   {
+    const int r2 = nlam_edge_bwd2(q, has_egemm, s);
+    if (r2 >= 0) return r2;
     const int r16 = nlam_k16_edge_bwd(q, has_egemm, s);
     if (r16 >= 0) return r16;
   }

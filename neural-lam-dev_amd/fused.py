@@ -290,25 +290,32 @@ class FusedInteractionNetFunction(torch.autograd.Function):
             # profiler wants to bracket the launches
             if (inet_seq.ENABLED and ops.PROFILER is None and not ops._DEBUG_SYNC and d == 64
                     and g.virtual is None):
-                bufs = {"agg": _empty(B, N_r, d, device=dev), "rec_out": _empty(B, N_r, d, device=dev)}
-                if same:
-                    bufs["P"] = _empty(sm.B, N_s, 2 * d, device=dev)
-                else:
-                    bufs["P"] = _empty(sm.B, N_s, d, device=dev)
-                    bufs["Pr"] = _empty(rm.B, N_r, d, device=dev)
-                if update_edges:
-                    bufs["e_out"] = _empty(B, M, d, device=dev)
-                else:
-                    bufs["Pe"] = _empty(em.B, M, d, device=dev)
                 weights = (W1, b1, W2, b2, gam, bet, V1, c1, V2, c2, gam2, bet2)
-                sargs = inet_seq.make_args(g, sm, rm, em, same, update_edges, mean, B, weights, bufs)
-                if inet_seq.supported(sargs):
+                # shape-only query first (null output pointers): nothing is allocated twice when
+                # the sequencer declines (NLAM_MFMA=fp32 / bf16, an NLAM_K16 mask, ...)
+                if inet_seq.supported(inet_seq.make_args(g, sm, rm, em, same, update_edges, mean, B,
+                                                         weights, {})):
+                    bufs = {"agg": _empty(B, N_r, d, device=dev),
+                            "rec_out": _empty(B, N_r, d, device=dev)}
+                    if same:
+                        bufs["P"] = _empty(sm.B, N_s, 2 * d, device=dev)
+                    else:
+                        bufs["P"] = _empty(sm.B, N_s, d, device=dev)
+                        bufs["Pr"] = _empty(rm.B, N_r, d, device=dev)
+                    if update_edges:
+                        bufs["e_out"] = _empty(B, M, d, device=dev)
+                    else:
+                        bufs["Pe"] = _empty(em.B, M, d, device=dev)
+                    sargs = inet_seq.make_args(g, sm, rm, em, same, update_edges, mean, B, weights, bufs)
                     inet_seq.forward(sargs, ops.stream())
-                    ctx.save_for_backward(W1, b1, W2, b2, gam, V1, c1, V2, c2, gam2)
+                    # bet / bet2 are saved too: the backward rebuilds the weight block from
+                    # saved_tensors, so an in-place change of a weight between forward and
+                    # backward raises (as on the launch-by-launch path) instead of being used
+                    ctx.save_for_backward(W1, b1, W2, b2, gam, bet, V1, c1, V2, c2, gam2, bet2)
                     ctx.set_materialize_grads(False)
                     ctx.g, ctx.same, ctx.update_edges, ctx.mean = g, same, update_edges, mean
                     ctx.mats = (sm, rm, em)
-                    ctx.seq = (sargs, bufs, weights)
+                    ctx.seq = (sargs, bufs)
                     ctx.dims = (B, N_s, N_r, M, d)
                     if update_edges:
                         return bufs["rec_out"], bufs["e_out"]
@@ -515,9 +522,12 @@ class FusedInteractionNetFunction(torch.autograd.Function):
 
 def _backward_seq(ctx, g_rec_out, g_edge_out):
     """Backward through csrc/inet_host.cpp: allocate the gradients, one host call."""
-    sargs, bufs, weights = ctx.seq
+    sargs, bufs = ctx.seq
     ctx.seq = None
+    # saved_tensors checks the version counters: a weight modified in place since forward raises
+    weights = ctx.saved_tensors
     W1, b1, W2, b2, gam, bet, V1, c1, V2, c2, gam2, bet2 = weights
+    sargs.w = inet_seq.weights_struct(weights)
     sm, rm, em = ctx.mats
     B, N_s, N_r, M, d = ctx.dims
     dev = W1.device

@@ -59,8 +59,8 @@ class EdgeTables(torch.nn.Module):
             self.register_buffer(k, torch.from_numpy(out[k]), persistent=False)
         deg = np.diff(out["csr_rowptr"])
         self.max_in_degree = int(deg.max())
-        # receiver-aligned 32-edge tiles for the fused edge kernels (None if a
-        # receiver has more than 32 in-edges: such graphs take the generic path)
+        # receiver-aligned 32-edge tiles for the fused edge kernels (None if a receiver has more
+        # than 32 in-edges: such graphs run the same kernels on virtual receivers, below)
         self.ntiles = 0
         self.virtual = None
         if self.max_in_degree <= 32:
@@ -77,7 +77,9 @@ class EdgeTables(torch.nn.Module):
             # a receiver with more than 32 in-edges does not fit one receiver-aligned tile: its
             # segment is cut into VIRTUAL receivers of <= 32 consecutive CSR positions; the fused
             # edge kernels run on the virtual graph and a (node-sized) second stage folds the
-            # virtual rows back (VirtualReceivers).  Hidden 128 / 256 still take the generic path.
+            # virtual rows back (VirtualReceivers) -- at hidden 64, 128 and 256 alike (wide.Tiling takes
+            # the virtual tiling).  Only the hidden-64 SplitMLPs path (fused.inet_split_eligible)
+            # still falls back to the generic kernels for such graphs, with a RuntimeWarning.
             self.tiles = None
             self.virtual = VirtualReceivers(out, n_rec, M)
 

@@ -64,16 +64,22 @@ def _ptr(t):
     return t.data_ptr() if t is not None else None
 
 
+def weights_struct(weights):
+    W1, b1, W2, b2, gam, bet, V1, c1, V2, c2, gam2, bet2 = weights
+    return Weights(W1.data_ptr(), W1.stride(0), b1.data_ptr(), W2.data_ptr(), W2.stride(0),
+                   b2.data_ptr(), gam.data_ptr(), bet.data_ptr(), V1.data_ptr(), V1.stride(0),
+                   c1.data_ptr(), V2.data_ptr(), V2.stride(0), c2.data_ptr(), gam2.data_ptr(),
+                   bet2.data_ptr())
+
+
 def make_args(tables, sm, rm, em, same, update_edges, mean, B, weights, bufs):
     """weights: (W1, b1, W2, b2, gam, bet, V1, c1, V2, c2, gam2, bet2); bufs: dict of the
-    caller-allocated tensors P, Pr, Pe, agg, e_out, rec_out (None where unused)."""
-    W1, b1, W2, b2, gam, bet, V1, c1, V2, c2, gam2, bet2 = weights
+    caller-allocated tensors P, Pr, Pe, agg, e_out, rec_out (None where unused; an empty dict
+    gives the shape-only block nlam_inet_supported() is asked with)."""
+    W1, W2, V1, V2 = weights[0], weights[2], weights[6], weights[8]
     if any(w.stride(-1) != 1 for w in (W1, W2, V1, V2)):
         return None
-    w = Weights(W1.data_ptr(), W1.stride(0), b1.data_ptr(), W2.data_ptr(), W2.stride(0),
-                b2.data_ptr(), gam.data_ptr(), bet.data_ptr(), V1.data_ptr(), V1.stride(0),
-                c1.data_ptr(), V2.data_ptr(), V2.stride(0), c2.data_ptr(), gam2.data_ptr(),
-                bet2.data_ptr())
+    w = weights_struct(weights)
     rec = View(None, 0, 0, 0) if same else _view(rm)
     return Args(graph_struct(tables), w, _view(sm), rec, _view(em), sm.rows, B, 64,
                 int(update_edges), int(mean), _ptr(bufs.get("P")), _ptr(bufs.get("Pr")),

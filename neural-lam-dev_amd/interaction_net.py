@@ -99,6 +99,14 @@ class InteractionNet(nn.Module):
                 tabs.append(EdgeTables(send[o : o + m], rec[o : o + m], num_send, num_rec))
                 o += m
             self.chunk_tables = nn.ModuleList(tabs)
+            if hidden_dim == 64 and any(t.virtual is not None for t in tabs):
+                import warnings
+
+                warnings.warn(
+                    "neural_lam_amd: an edge chunk of this SplitMLPs InteractionNet has a receiver "
+                    "with more than 32 in-edges: at hidden 64 the SplitMLPs path then runs on the "
+                    "generic HIP kernel sequence (several times slower) instead of the fused tiles",
+                    RuntimeWarning, stacklevel=2)
 
     def forward(self, send_rep, rec_rep, edge_rep):
         if rec_rep.shape[-2] != self.num_rec:

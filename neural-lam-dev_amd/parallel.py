@@ -117,15 +117,26 @@ class FlatParams:
                 host.copy_(table)
             else:
                 host = table.pin_memory()
-                if (lo, hi) not in self._spare:
-                    self._spare[(lo, hi)] = torch.empty_like(table).pin_memory()
             dev = torch.empty(host.numel(), dtype=torch.int64, device=self.grad.device)
             dev.copy_(host, non_blocking=True)
-            hit = (key, dev, first[-1], host)
-            if torch.cuda.is_current_stream_capturing():
+            capturing = torch.cuda.is_current_stream_capturing()
+            ev = None
+            if not capturing:
+                # a later cache hit may launch on another stream (e.g. warm-up on a side stream,
+                # then eager steps on the main one): that launch waits for this upload
+                ev = torch.cuda.Event()
+                ev.record()
+            hit = (key, dev, first[-1], host, ev, torch.cuda.current_stream().cuda_stream)
+            if capturing:
                 self._captured.append(hit)
             self._tables[(lo, hi)] = hit
-        _, dev, nchunks, _ = hit
+        if not torch.cuda.is_current_stream_capturing() and (lo, hi) not in self._spare:
+            # (every eager call, hit or miss: a capture takes the spare of its range)
+            self._spare[(lo, hi)] = torch.empty(3 * (hi - lo) + (hi - lo + 1),
+                                                dtype=torch.int64).pin_memory()
+        _, dev, nchunks, _, ev, up_stream = hit
+        if ev is not None and up_stream != torch.cuda.current_stream().cuda_stream:
+            torch.cuda.current_stream().wait_event(ev)
         ops._launch("nlam_pack_segments", lib.nlam_pack_segments,
                     (dev.data_ptr(), hi - lo, nchunks, self.grad.data_ptr(), ops.stream()))
 

@@ -38,3 +38,57 @@ def test_bench_line_contract():
     sc = line["scatter_add_roofline"]
     assert sc["bound"] == "hbm" and sc["frac"] > 0.4, sc
     assert line["launch"]["mode"] == "hip_graph"
+    # the other BASELINE configs, run as child processes of the same bench invocation
+    other = line["other_configs"]
+    assert set(other) == {n for n, _a, _e in _bench_module().OTHER_CONFIGS}
+    for name, ent in other.items():
+        assert "error" not in ent, (name, ent)
+        assert ent["ms_per_step"] > 0 and ent["value"] > 0 and ent["roofline"]["kernel"], (name, ent)
+        assert 0 < ent["roofline"]["frac"] <= 1
+    assert other["hi_lam-256 bf16 (configs[4], per GPU)"]["dtype"] == "bf16"
+    assert other["graph_lam-64 ar_steps=4 (configs[3], per GPU)"]["ar_steps"] == 4
+
+
+def _bench_module():
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("_bench_mod", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_two_rank_bench_control_flow_over_gloo():
+    """`bench.py --gpus 2` on ONE card with the gloo rehearsal backend: the spawn / rendezvous /
+    barrier / MAX-over-ranks control flow of the multi-GPU bench (the RCCL run itself needs two
+    cards; reference DDP: train_model.py:279)."""
+    env = dict(os.environ, NLAM_BENCH_BACKEND="gloo")
+    out = subprocess.run(
+        [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+         "--windows", "1", "--no-cpu-baseline"],
+        capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["backend"] == "gloo"
+    assert line["config"]["global_batch"] == 8 and line["config"]["parallelism"] == "dp2"
+    assert line["launch"]["mode"] in ("eager", "eager+overlapped_allreduce")
+    assert line["scaling"] == "weak" and line["other_configs"] is None
+    # value = world * B * ar_steps * P * N_mesh / t_step
+    assert abs(line["value"] - 2 * 4 * 1 * 4 * 6561 / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-6
+
+
+def test_gpus_1_is_the_default_path():
+    """`--gpus 1` is bit-for-bit the default invocation (same workload, same launch mode, no
+    process group): SCALE's N = 1 point is the BENCH line."""
+    outs = []
+    for extra in ([], ["--gpus", "1"]):
+        out = subprocess.run(
+            [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--windows",
+             "1", "--no-cpu-baseline", "--no-kernel-timing", "--no-other-configs"] + extra,
+            capture_output=True, text=True, timeout=900, cwd=ROOT)
+        assert out.returncode == 0, out.stderr[-3000:]
+        outs.append(json.loads(out.stdout.strip().splitlines()[-1]))
+    a, b = outs
+    for key in ("metric", "unit", "n_gpus", "config", "launch", "hip_graph", "rccl_ranks", "backend",
+                "dtype", "loss"):
+        assert a[key] == b[key], key

@@ -22,6 +22,22 @@ def _get(q):
     return item
 
 
+def _collect(procs, q, n):
+    """Results of all ranks; whatever happens, no rank is left alive on the card (a rank blocked
+    in a collective after its peer died would disturb the timing-sensitive tests that follow)."""
+    try:
+        res = sorted([_get(q) for _ in range(n)], key=lambda t: t[0])
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        return res
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+                p.join(timeout=30)
+
+
 def _guarded(name, rank, world, port, tmp, q, backend):
     try:
         globals()[name](rank, world, port, tmp, q, backend)
@@ -105,10 +121,7 @@ def test_two_rank_gradients_match_single_process(backend):
         procs = [ctx.Process(target=_guarded, args=("_worker", r, 2, port, tmp, q, backend)) for r in range(2)]
         for p in procs:
             p.start()
-        res = sorted([_get(q) for _ in range(2)], key=lambda t: t[0])
-        for p in procs:
-            p.join(timeout=60)
-            assert p.exitcode == 0
+        res = _collect(procs, q, 2)
         model, n = _build(tmp)
     model = model.cuda()
     flat = parallel.FlatParams(model)
@@ -178,10 +191,7 @@ def test_overlapped_buckets_on_device_tensors_bit_identical(backend):
                  for r in range(2)]
         for p in procs:
             p.start()
-        res = sorted([_get(q) for _ in range(2)], key=lambda t: t[0])
-        for p in procs:
-            p.join(timeout=60)
-            assert p.exitcode == 0
+        res = _collect(procs, q, 2)
     for rank, same_g, same_w, stats, nbuckets, stats_off in res:
         assert same_g and same_w, f"rank {rank}: overlap changed the result"
         assert nbuckets >= 3
