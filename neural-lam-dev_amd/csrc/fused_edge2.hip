@@ -502,7 +502,9 @@ __global__ __launch_bounds__(256) void edge_bwd2_kernel(EdgeBwdParams q) {
       put_rows<NVC>(T2 + 16 * LDT, xr, sub, c4);
     }
     wave_sync();
-    const int roff = rcv - r0;                    // this slot's receiver row in the compact tile
+    // this slot's receiver row in the compact tile (a tile without edges: row 0 -- its slots point
+    // at CSR position 0, whose receiver is not one of the tile's)
+    const int roff = ne > 0 ? rcv - r0 : 0;
     f32x16 hpre[NB];
     row_to_acc<false>(hpre, T1, t, hh);
     row_to_acc<true>(hpre, T2, roff, hh);
