@@ -304,6 +304,9 @@ typedef struct nlam_inet_grads {
   float* g_edge;                     /* (edge.B, M, 64) */
   float* dW1; float* db1; float* dW2; float* db2; float* dgam; float* dbet;     /* contiguous */
   float* dV1; float* dc1; float* dV2; float* dc2; float* dgam2; float* dbet2;
+  /* optional addend of g_send (same shape; separate sender / receiver nodes only): a gradient
+   * that reached send_rep through another consumer, added inside the projection backward */
+  const float* g_send_add;
 } nlam_inet_grads;
 int nlam_inet_supported(const nlam_inet_args* a);
 int nlam_inet_fwd(const nlam_inet_args* a, void* stream);

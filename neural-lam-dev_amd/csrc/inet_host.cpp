@@ -287,8 +287,8 @@ static int64_t inet_bwd_plan(const nlam_inet_args* a, const nlam_inet_grads* gr,
     if (!same) {
       const bool fs = Bs == 1 && B > 1, fr = Br == 1 && B > 1;
       push(a->send.ptr, a->send.bstride, a->send.ld, nullptr, 0, nullptr, 0, W1s, run ? gr->g_send : nullptr,
-           Bs > 1 ? N_s * D : 0, nullptr, 0, fs ? B : 1, 0, gh, fs ? 1 : B, N_s, run ? dW1 + D : (float*)1,
-           3 * D, nullptr, D);
+           Bs > 1 ? N_s * D : 0, run ? gr->g_send_add : nullptr, Bs > 1 ? N_s * D : 0, fs ? B : 1, 0, gh,
+           fs ? 1 : B, N_s, run ? dW1 + D : (float*)1, 3 * D, nullptr, D);
       push(a->rec.ptr, a->rec.bstride, a->rec.ld, nullptr, 0, gpr, fr ? 0 : N_r * D, W1r,
            run ? gr->g_rec : nullptr, Br > 1 ? N_r * D : 0, g_res, g_res_bs, fr ? B : 1, fr ? N_r * D : 0,
            nullptr, fr ? 1 : B, N_r, run ? dW1 + 2 * D : (float*)1, 3 * D, run ? gr->db1 : (float*)1, D);

@@ -61,8 +61,9 @@ class FusedMLPFunction(torch.autograd.Function):
     """y = [res +] [LN](W2 silu(W1 x + b1) + b2), x: (..., rows, k_in)."""
 
     @staticmethod
-    def forward(ctx, x, res, W1, b1, W2, b2, gamma, beta):
+    def forward(ctx, x, res, W1, b1, W2, b2, gamma, beta, give=None):
         ctx.tag = ops._TAG[-1] if ops._TAG else "mlp"
+        ctx.give = give   # glue.GradSlot: leave the input gradient there as well (glue.Tee)
         hid, n_out = W1.shape[0], W2.shape[0]
         xm = mat(x.detach())
         res_is_x = res is x
@@ -95,7 +96,10 @@ class FusedMLPFunction(torch.autograd.Function):
         gres = gy if ctx.res_mode == 2 else None
         if ctx.res_mode == 1 and not need_gx:
             gres = None
-        return (gx.reshape(ctx.x_shape) if need_gx else None, gres, dW1, db1, dW2, db2, dg, dbt)
+        gx_out = gx.reshape(ctx.x_shape) if need_gx else None
+        if ctx.give is not None and gx_out is not None:
+            ctx.give.value = gx_out
+        return (gx_out, gres, dW1, db1, dW2, db2, dg, dbt, None)
 
 
 def _mlp_grad_dst(W1, W2, has_ln):
@@ -108,11 +112,17 @@ def _mlp_grad_dst(W1, W2, has_ln):
     return dst
 
 
+def _sink(t, role):
+    s = getattr(t, "_nlam_grad_sink", None)
+    return s[1] if (s is not None and s[0] == role) else None
+
+
 def apply_mlp(seq, x, res=None):
     lin, ln = _mlp_parts(seq)
     return FusedMLPFunction.apply(
         x, res, lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias,
-        ln.weight if ln is not None else None, ln.bias if ln is not None else None)
+        ln.weight if ln is not None else None, ln.bias if ln is not None else None,
+        _sink(x, "give") if (res is None or res is x) else None)
 
 
 # ------------------------------------------- several embedder MLPs in one launch
@@ -278,7 +288,8 @@ def _base(t):
 class FusedInteractionNetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, send_rep, rec_rep, edge_rep, same, g, update_edges, mean,
-                W1, b1, W2, b2, gam, bet, V1, c1, V2, c2, gam2, bet2):
+                W1, b1, W2, b2, gam, bet, V1, c1, V2, c2, gam2, bet2, take=None):
+        ctx.take = take   # glue.GradSlot: another consumer's gradient on send_rep, folded into g_send
         with ops.tag(g.tag):
             dev = edge_rep.device
             d = W2.shape[0]
@@ -473,9 +484,11 @@ class FusedInteractionNetFunction(torch.autograd.Function):
                     # sender side: the scatter of gh over edge_index[0] as a gather over the
                     # sender lists inside the projection backward (no gPs tensor, no launch)
                     fold_s = sm.B == 1 and B > 1
+                    add_s = _take_addend(ctx, g_send)
                     probs = [
                         {"x": sm, "W": W1s, "gather": (mat(gh), g.csc_colptr, g.csc_eid, g.n_send),
-                         "nsum": B if fold_s else 1, "gx": mat(g_send), "dW": dW1[:, d : 2 * d]},
+                         "nsum": B if fold_s else 1, "gx": mat(g_send), "dW": dW1[:, d : 2 * d],
+                         "gx_add": mat(add_s) if add_s is not None else None},
                         {"x": rm, "gy": gpr_in, "W": W1r, "nsum": B if fold_r else 1,
                          "gx": mat(g_rec_total), "gx_add": mat(g_rec), "dW": dW1[:, 2 * d :],
                          "db": db1}]
@@ -517,7 +530,20 @@ class FusedInteractionNetFunction(torch.autograd.Function):
             if not same and multi:
                 ops.fused_lin_bwd_multi(probs + outer_jobs)
         return (g_send, g_rec_total, g_edge, None, None, None, None,
-                dW1, db1, dW2, db2, dgam, dbet, dV1, dc1, dV2, dc2, dg2, db2n)
+                dW1, db1, dW2, db2, dgam, dbet, dV1, dc1, dV2, dc2, dg2, db2n, None)
+
+
+def _take_addend(ctx, g_send):
+    """The gradient another consumer of send_rep left in the Tee's slot (glue.Tee), if it can be
+    folded into this layer's g_send store; marks the slot consumed."""
+    slot = ctx.take
+    if slot is None or slot.value is None or ctx.same:
+        return None
+    v = slot.value
+    if v.shape != g_send.shape or not v.is_contiguous() or v.dtype != torch.float32:
+        return None
+    slot.consumed = True
+    return v
 
 
 def _backward_seq(ctx, g_rec_out, g_edge_out):
@@ -540,12 +566,14 @@ def _backward_seq(ctx, g_rec_out, g_edge_out):
     g_rec = None if same else _empty(rm.B, N_r, d, device=dev)
     g_edge = _empty(em.B, M, d, device=dev)
     pg = [torch.empty_like(t) for t in (W1, b1, W2, b2, gam, bet, V1, c1, V2, c2, gam2, bet2)]
+    add_s = _take_addend(ctx, g_send)
     grads = inet_seq.Grads(g_rec_out.data_ptr(), geo.data_ptr() if geo is not None else None,
                            g_send.data_ptr(), g_rec.data_ptr() if g_rec is not None else None,
-                           g_edge.data_ptr(), *[t.data_ptr() for t in pg])
+                           g_edge.data_ptr(), *[t.data_ptr() for t in pg],
+                           add_s.data_ptr() if add_s is not None else None)
     ws = inet_seq.backward(sargs, grads, dev, ops.stream())
     del ws, bufs
-    return (g_send, g_rec, g_edge, None, None, None, None, *pg)
+    return (g_send, g_rec, g_edge, None, None, None, None, *pg, None)
 
 
 FusedInteractionNetFunction._backward_seq = staticmethod(_backward_seq)
@@ -561,7 +589,8 @@ def apply_inet(net, send_rep, rec_rep, edge_rep):
     out = FusedInteractionNetFunction.apply(
         s, r, e, same, net.tables, net.update_edges, net.aggr == "mean",
         el[0][0].weight, el[0][0].bias, el[0][1].weight, el[0][1].bias, el[1].weight, el[1].bias,
-        al[0][0].weight, al[0][0].bias, al[0][1].weight, al[0][1].bias, al[1].weight, al[1].bias)
+        al[0][0].weight, al[0][0].bias, al[0][1].weight, al[0][1].bias, al[1].weight, al[1].bias,
+        None if same else _sink(send_rep, "take"))
     return out
 
 

@@ -40,7 +40,8 @@ class Args(ctypes.Structure):
 class Grads(ctypes.Structure):
     _fields_ = [("g_rec_out", _P), ("g_edge_out", _P), ("g_send", _P), ("g_rec", _P), ("g_edge", _P),
                 ("dW1", _P), ("db1", _P), ("dW2", _P), ("db2", _P), ("dgam", _P), ("dbet", _P),
-                ("dV1", _P), ("dc1", _P), ("dV2", _P), ("dc2", _P), ("dgam2", _P), ("dbet2", _P)]
+                ("dV1", _P), ("dc1", _P), ("dV2", _P), ("dc2", _P), ("dgam2", _P), ("dbet2", _P),
+                ("g_send_add", _P)]
 
 
 def graph_struct(t):

@@ -92,12 +92,15 @@ class BaseGraphModel(ARModel):
         else:
             grid_features = torch.cat(srcs, dim=-1)
         grid_emb = self.grid_embedder(grid_features)
+        # two consumers (the g2m senders and the grid's own encoding MLP): their gradients meet in
+        # the g2m projection backward instead of a full-size elementwise add (glue.Tee)
+        grid_emb_s, grid_emb = glue.tee(grid_emb) if prev_state.is_cuda else (grid_emb, grid_emb)
         g2m_emb = self.static_emb("g2m", self.g2m_embedder, self.g2m_features)
         m2g_emb = self.static_emb("m2g", self.m2g_embedder, self.m2g_features)
         mesh_emb = self.embedd_mesh_nodes()
 
         mesh_rep = self.g2m_gnn(
-            grid_emb, self.expand_to_batch(mesh_emb, batch_size),
+            grid_emb_s, self.expand_to_batch(mesh_emb, batch_size),
             self.expand_to_batch(g2m_emb, batch_size),
         )
         # grid_rep = grid_emb + MLP(grid_emb): residual fused into the MLP kernel

@@ -353,6 +353,52 @@ def test_graphlam64_training_step_vs_cpu_oracle_full_size():
         assert rel(p.grad.cpu(), g) < 2e-3, k
 
 
+def test_graphlam64_ar4_rollout_vs_cpu_oracle_full_size():
+    """BASELINE configs[3]'s per-GPU workload: GraphLAM-64 at full MEPS size, ar_steps = 4, one
+    sample -- the unrolled training loss and EVERY parameter gradient against the CPU oracle's
+    rollout (ar_model.py:204-309), once with plain back-propagation through time and once with
+    the per-step recompute (args.ar_checkpoint); the two HIP runs must also agree with each other
+    to rounding (the recompute replays the same deterministic kernels; only the order in which the
+    four steps' contributions to a parameter gradient are added differs)."""
+    import nlam_oracle as orc
+    from neural_lam_amd import synthetic
+    from neural_lam_amd.models import GraphLAM
+
+    T = 4
+    with tempfile.TemporaryDirectory() as tmp:
+        ds, gname, info = synthetic.meps_setup(tmp)
+        models = []
+        for ckpt in (False, True):
+            torch.manual_seed(42)
+            args = synthetic.model_args(graph=gname, hidden_dim=64, processor_layers=4)
+            args.ar_checkpoint = ckpt
+            models.append(GraphLAM(args, config=None, datastore=ds))
+        _, graph = orc.load_graph(tmp + "/graph/" + gname)
+    model = models[0]
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()
+          if v.dtype.is_floating_point}
+    data = {k: getattr(model, k).detach().clone() for k in
+            ("grid_static_features", "diff_mean", "diff_std", "boundary_mask", "per_var_std")}
+    batch = synthetic.random_batch(1, T, info["num_grid"], seed=9)
+    cfg = {"model": "graph_lam", "hidden_layers": 1, "processor_layers": 4, "mesh_aggr": "sum",
+           "loss": "wmse"}
+    want, _ = orc.training_loss(sd, graph, cfg, data, batch[0], batch[1], batch[2])
+    names = [k for k, _ in model.named_parameters()]
+    grads = torch.autograd.grad(want, [sd[k] for k in names])
+    got = []
+    for m in models:
+        m = m.cuda()
+        loss = m.training_step(tuple(t.cuda() if t is not None else None for t in batch))
+        loss.backward()
+        assert abs(float(loss) - float(want)) < 1e-4 * abs(float(want)), (m.ar_checkpoint, float(loss))
+        for (k, p), g in zip(m.named_parameters(), grads):
+            assert rel(p.grad.cpu(), g) < 2e-3, (m.ar_checkpoint, k)
+        got.append((float(loss), [p.grad.clone() for p in m.parameters()]))
+    assert abs(got[0][0] - got[1][0]) <= 1e-6 * abs(got[0][0])
+    for k, a, b in zip(names, got[0][1], got[1][1]):
+        assert rel(a.cpu(), b.cpu()) < 1e-5, k
+
+
 @pytest.mark.parametrize("mode,kind,hidden", [("bf16x3", "hi_lam", 128), ("bf16", "hi_lam", 256),
                                                ("bf16x3", "hi_lam", 256)])
 def test_hilam_training_step_vs_cpu_oracle_full_size(mode, kind, hidden):
