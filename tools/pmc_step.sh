@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 case $OUT in /*) ;; *) OUT=$R/$OUT;; esac
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
-ARGS="--steps 3 --warmup 1 --windows 1 --no-cpu-baseline --no-fp32-compare --no-kernel-timing $*"
+ARGS="--steps 3 --warmup 1 --windows 1 --no-cpu-baseline --no-fp32-compare --no-kernel-timing --no-other-configs $*"
 P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAVES"
 P2="SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
 timeout -k 10 300 rocprofv3 --pmc $P1 --output-format csv -d $OUT/p1 -o p -- python3 $R/bench.py $ARGS > $OUT/p1.log 2>&1

@@ -9,7 +9,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 case $OUT in /*) ;; *) OUT=$R/$OUT;; esac
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
-ARGS="--steps 6 --warmup 2 --windows 1 --no-cpu-baseline --no-fp32-compare $*"
+ARGS="--steps 6 --warmup 2 --windows 1 --no-cpu-baseline --no-fp32-compare --no-other-configs $*"
 NLAM_BENCH_DUMP_ORDER=$OUT/order.json timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python3 $R/bench.py $ARGS > $OUT/trace.log 2>&1
 echo "trace pass done"
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o f -- python3 $R/bench.py $ARGS > $OUT/fetch.log 2>&1
