@@ -664,10 +664,6 @@ int nlam_debug_edge_bwd_stamps(unsigned long long* out, int reset);
 int nlam_debug_mlp_bwd_stamps(unsigned long long* out, int reset);
 /* The same for the hidden-256 tail kernels (16 values: forward phases 0..7, backward 8..15). */
 int nlam_debug_fs_stamps(unsigned long long* out, int reset);
-/* The same for the 16-row per-wave nlam_edge_bwd (NLAM_STAMP16=1): out[0..10] = prefetched rows
- * landed + transposed, next prefetch + first GEMM, Ps / Pr landed, silu + second GEMM, LayerNorm
- * backward + column sums, dW2, W2^T gz, gh tile / stores / receiver sums, g_e, loop overhead, tail. */
-int nlam_debug_k16_stamps(unsigned long long* out, int reset);
 /* Diagnostic (NLAM_TIMELINE=1 in the environment of the process): nlam_lin_fwd records
  * s_memrealtime (100 MHz) per workgroup at start / after the weight prologue / at exit;
  * out: host array of 3 * 1024 values (first 1024 workgroups of the last launch). */
@@ -683,13 +679,14 @@ int nlam_debug_node_timeline(unsigned long long* out);
  * for the integer test pattern documented in csrc/mfma_probe.hip. */
 int nlam_mfma_probe(float* out, void* stream);
 
-/* Tuning hook: which hidden-64 kernel families run in their 16-row, two-waves-per-SIMD form
- * (csrc/fused16_*.hip) instead of the 32-row, one-wave-per-SIMD form.  Bit mask: 1 nlam_mlp_bwd,
- * 2 nlam_lin_bwd, 4 nlam_outer_bwd, 8 nlam_edge_bwd (no edge update), 16 nlam_mlp_fwd,
- * 32 nlam_lin_fwd, 64 nlam_edge_fwd, 128 nlam_edge_bwd (update_edges), 256 the nlam_node_*
- * chain kernels (off: nlam_node_chain_supported() returns 0).  Default: the families
- * whose 16-row form measured faster (or NLAM_K16 in the environment).  Same entry points, slab
- * layouts and results (to rounding) either way; used to time both forms in one process. */
+/* Tuning hook: which hidden-64 kernel families run in their newer form.  Bit mask: 1 nlam_mlp_bwd,
+ * 2 nlam_lin_bwd, 4 nlam_outer_bwd, 16 nlam_mlp_fwd, 32 nlam_lin_fwd (16-row, two-waves-per-SIMD
+ * kernels, csrc/fused16_*.hip, instead of the 32-row ones), 256 the nlam_node_* chain kernels
+ * (off: nlam_node_chain_supported() returns 0), 512 / 1024 nlam_edge_bwd without / with an edge
+ * update in its round-4 pipelined form (csrc/fused_edge2.hip) instead of the round-2 kernel.
+ * Bits 8, 64 and 128 (16-row edge kernels) are retired.  Default: all of the above (or NLAM_K16 in
+ * the environment).  Same entry points, slab layouts and results (to rounding) either way; used
+ * to time both forms in one process. */
 int nlam_set_k16(int mask);
 
 #ifdef __cplusplus

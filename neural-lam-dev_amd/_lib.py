@@ -120,7 +120,6 @@ SIGNATURES = {
     "nlam_debug_edge_bwd_stamps": [_p, _i32],
     "nlam_debug_mlp_bwd_stamps": [_p, _i32],
     "nlam_debug_fs_stamps": [_p, _i32],
-    "nlam_debug_k16_stamps": [_p, _i32],
     "nlam_debug_lin_fwd_timeline": [_p],
     "nlam_debug_node_timeline": [_p],
     "nlam_mfma_probe": [_p, _p],

@@ -261,10 +261,6 @@ extern "C" int nlam_edge_fwd(
   p.e_out = e_out; p.eo_bstride = eo_bstride; p.eo_ld = eo_ld;
   p.B = (int)B;
   hipStream_t s = (hipStream_t)stream;
-  if (d == 64) {   // 16-row, two-waves-per-SIMD form (fused16_edge.hip)
-    const int r16 = nlam_k16_edge_fwd(p, has_egemm, s);
-    if (r16 >= 0) return r16;
-  }
   if (d == 64 && nlam_mfma_b3())   // (unaligned weights take the scalar image loader)
     return has_egemm ? launch_edge_fwd<64, true, true>(p, s) : launch_edge_fwd<64, false, true>(p, s);
   if (d == 64) return has_egemm ? launch_edge_fwd<64, true>(p, s) : launch_edge_fwd<64, false>(p, s);
@@ -741,10 +737,8 @@ extern "C" int nlam_edge_bwd(
   q.slab = slab; q.slab_stride = slab_stride;
   hipStream_t s = (hipStream_t)stream;
   {
-    const int r2 = nlam_edge_bwd2(q, has_egemm, s);
+    const int r2 = nlam_edge_bwd2(q, has_egemm, s);   // split-bf16 arithmetic: fused_edge2.hip
     if (r2 >= 0) return r2;
-    const int r16 = nlam_k16_edge_bwd(q, has_egemm, s);
-    if (r16 >= 0) return r16;
   }
   static const bool stamp = getenv("NLAM_STAMP") != nullptr;
   if (stamp && has_egemm && nlam_mfma_b3()) return launch_edge_bwd<64, true, true, true>(q, s);

@@ -153,17 +153,17 @@ extern "C" int64_t nlam_mlp_bwd_slab_stride(int k_in, int hid, int n_out);
 int nlam_k16_outer_bwd(const OuterParams& q, hipStream_t s);
 int nlam_k16_mlp_fwd(const MlpParams& p, hipStream_t s);
 int nlam_k16_lin_fwd(const LinParams& p, hipStream_t s);
-int nlam_k16_edge_fwd(const EdgeFwdParams& p, int has_egemm, hipStream_t s);
-int nlam_k16_edge_bwd(const EdgeBwdParams& q, int has_egemm, hipStream_t s);
 int nlam_edge_bwd2(const EdgeBwdParams& q, int has_egemm, hipStream_t s);   // fused_edge2.hip
 // bit mask of the kernel families that take the 16-row form (NLAM_K16 in the environment,
 // default all; nlam_set_k16 changes it at run time for A/B timing in one process)
-enum { K16_MLP_BWD = 1, K16_LIN_BWD = 2, K16_OUTER_BWD = 4, K16_EDGE_BWD = 8, K16_MLP_FWD = 16,
-       K16_LIN_FWD = 32, K16_EDGE_FWD = 64, K16_EDGE_BWD_UPD = 128, K16_NODE_CHAIN = 256,
+// (bits 8, 64 and 128 selected the 16-row forms of the edge kernels: measured slower than the
+// 32-row edge forward and than the round-4 edge backward, and removed in round 4)
+enum { K16_MLP_BWD = 1, K16_LIN_BWD = 2, K16_OUTER_BWD = 4, K16_MLP_FWD = 16,
+       K16_LIN_FWD = 32, K16_NODE_CHAIN = 256,
        // round 4: the pipelined, mask-free 32-row edge backward (fused_edge2.hip) for layers
        // without / with an edge update; it takes precedence over the 16-row forms above
        K16_EDGE_BWD2 = 512, K16_EDGE_BWD2_UPD = 1024 };
 // default: the families whose 16-row form is the faster one on MI355X (profiles/r03_*)
-#define K16_DEFAULT (K16_MLP_BWD | K16_LIN_BWD | K16_OUTER_BWD | K16_EDGE_BWD | K16_MLP_FWD | \
+#define K16_DEFAULT (K16_MLP_BWD | K16_LIN_BWD | K16_OUTER_BWD | K16_MLP_FWD | \
                      K16_LIN_FWD | K16_NODE_CHAIN | K16_EDGE_BWD2 | K16_EDGE_BWD2_UPD)
 bool nlam_k16_on(int family);
