@@ -32,12 +32,15 @@ extern "C" {
 const char* nlam_last_error(void);
 /* ABI version of this header; bumped on any signature change. */
 int nlam_abi_version(void);
-/* GEMM arithmetic of the fused kernels, fixed per process by NLAM_MFMA in the environment
- * (fp32 | bf16x3, default bf16x3):
+/* GEMM arithmetic of the fused kernels: a property of a run, as the reference's `--precision`
+ * (train_model.py:72-77,285).  Initial value: NLAM_MFMA in the environment (fp32 | bf16x3 | bf16,
+ * default bf16x3); nlam_set_mfma_mode() changes it between runs of one process (every launch
+ * reads it; a forward and its backward must run in the same mode).
  * 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = split-bf16 ("bf16x3": every fp32 operand
  * as bf16 hi + lo, three v_mfma_f32_32x32x16_bf16 products, fp32 accumulate; ~2^-16
  * relative error per product, tighter than the TF32 of train_model.py:246-248). */
 int nlam_mfma_mode(void);   /* 0 = fp32, 1 = bf16x3 (default), 2 = bf16 (NLAM_MFMA) */
+int nlam_set_mfma_mode(int mode);   /* 0 / 1 / 2 as above; 2 = the arithmetic of `--precision bf16-mixed` */
 
 /* ---------------------------------------------------------------- graph --
  * Host-side preprocessing, run once per InteractionNet at construction.

@@ -21,6 +21,7 @@ SIGNATURES = {
     "nlam_last_error": [],
     "nlam_abi_version": [],
     "nlam_mfma_mode": [],
+    "nlam_set_mfma_mode": [_i32],
     "nlam_graph_build_host": [_p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p],
     "nlam_gemm": [_i64, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _p, _p, _i64, _i32, _i32, _p, _p],
     "nlam_silu_fwd": [_p, _p, _i64, _p],

@@ -18,6 +18,7 @@ void nlam_set_error(const char* fmt, ...) {
 extern "C" const char* nlam_last_error(void) { return g_err; }
 
 #include <cctype>
+#include <atomic>
 #include <string>
 #include <mutex>
 #include <utility>
@@ -44,21 +45,31 @@ extern "C" int nlam_abi_version(void) { return 1; }
 
 // GEMM arithmetic of the fused kernels (see fused_bf16x3.h): NLAM_MFMA=fp32 | bf16x3
 #define NLAM_MFMA_DEFAULT_MODE 1
-static int nlam_mfma_mode_value() {
-  static const int mode = [] {
-    const char* e = getenv("NLAM_MFMA");
-    if (e == nullptr || e[0] == 0) return NLAM_MFMA_DEFAULT_MODE;
-    std::string v(e);
-    for (char& c : v) c = (char)tolower((unsigned char)c);
-    if (v == "fp32") return 0;
-    if (v == "bf16x3" || v == "b3") return 1;
-    if (v == "bf16") return 2;
-    // a typo must not silently select an arithmetic (it used to fall through to fp32 / bf16)
-    fprintf(stderr, "libnlam_hip: NLAM_MFMA=\"%s\" is not one of fp32 | bf16x3 | bf16\n", e);
-    abort();
-    return -1;
-  }();
+static int mfma_mode_from_env() {
+  const char* e = getenv("NLAM_MFMA");
+  if (e == nullptr || e[0] == 0) return NLAM_MFMA_DEFAULT_MODE;
+  std::string v(e);
+  for (char& c : v) c = (char)tolower((unsigned char)c);
+  if (v == "fp32") return 0;
+  if (v == "bf16x3" || v == "b3") return 1;
+  if (v == "bf16") return 2;
+  // a typo must not silently select an arithmetic (it used to fall through to fp32 / bf16)
+  fprintf(stderr, "libnlam_hip: NLAM_MFMA=\"%s\" is not one of fp32 | bf16x3 | bf16\n", e);
+  abort();
+  return -1;
+}
+// The arithmetic is a property of a RUN (the reference takes `--precision` per run,
+// train_model.py:72-77,285): the environment gives the initial value, nlam_set_mfma_mode()
+// changes it between runs of one process.  Every launcher reads it at launch time.
+static std::atomic<int>& mfma_mode_cell() {
+  static std::atomic<int> mode{mfma_mode_from_env()};
   return mode;
+}
+static int nlam_mfma_mode_value() { return mfma_mode_cell().load(std::memory_order_relaxed); }
+extern "C" int nlam_set_mfma_mode(int mode) {
+  NLAM_REQUIRE(mode >= 0 && mode <= 2, "nlam_set_mfma_mode: mode %d not in {0 fp32, 1 bf16x3, 2 bf16}", mode);
+  mfma_mode_cell().store(mode, std::memory_order_relaxed);
+  return 0;
 }
 bool nlam_mfma_b3() { return nlam_mfma_mode_value() != 0; }
 int nlam_mfma_terms() {

@@ -79,3 +79,54 @@ def test_alternate_kernel_selections_hold_the_goldens(env):
         env=dict(os.environ, **env), capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, (out.stdout[-2500:], out.stderr[-1500:])
     assert " passed" in out.stdout and "failed" not in out.stdout
+
+
+def test_precision_is_selectable_per_run_in_one_process():
+    """The reference takes `--precision` per run (train_model.py:72-77,285); here
+    neural_lam_amd.set_precision() switches the GEMM arithmetic between runs of ONE process:
+    the hidden-128 operator golden is held at the fp32 bars in both fp32-grade modes and at the
+    bf16 bars in bf16-mixed, the three forwards differ from one another (the switch is real), and
+    the hidden-64 operator golden (split-bf16 in every bf16 mode, exact MFMA in fp32-exact) holds
+    the fp32 bars throughout."""
+    import torch
+
+    import neural_lam_amd
+    from conftest import GOLDEN, load_fixture
+    from neural_lam_amd.interaction_net import InteractionNet
+
+    def rel(a, b):
+        return float((a.detach().cpu() - b).abs().max() / (b.abs().max() + 1e-30))
+
+    def run(fx):
+        net = InteractionNet(fx["edge_index"], fx["d"], **fx["kwargs"])
+        net.load_state_dict(fx["state_dict"], strict=True)
+        net = net.cuda()
+        s = fx["send"].cuda().requires_grad_(True)
+        r = s if fx["shared"] else fx["rec"].cuda().requires_grad_(True)
+        e = fx["edge"].cuda().requires_grad_(True)
+        o_rec, o_edge = net(s, r, e)
+        ((o_rec * fx["cot_rec"].cuda()).sum() + (o_edge * fx["cot_edge"].cuda()).sum()).backward()
+        fwd = max(rel(o_rec, fx["out_rec"]), rel(o_edge, fx["out_edge"]))
+        grad = max([rel(s.grad, fx["grad_send"]), rel(e.grad, fx["grad_edge"])] +
+                   [rel(p.grad, fx["grad_params"][k]) for k, p in net.named_parameters()])
+        return fwd, grad, o_rec.detach().clone()
+
+    fx128 = load_fixture(os.path.join(GOLDEN, "op_d128_sum_upd.pt"))
+    fx64 = load_fixture(os.path.join(GOLDEN, "op_d64_sum_upd.pt"))
+    start = neural_lam_amd.get_precision()
+    outs = {}
+    try:
+        for prec, fbar, gbar in (("fp32-exact", 1e-4, 1e-3), ("bf16-mixed", 1e-2, 5e-2), ("32-true", 1e-4, 1e-3)):
+            neural_lam_amd.set_precision(prec)
+            assert neural_lam_amd.get_precision() == prec
+            f, g, o = run(fx128)
+            assert f < fbar and g < gbar, (prec, f, g)
+            outs[prec] = o
+            f64, g64, _ = run(fx64)
+            assert f64 < 1e-4 and g64 < 1e-3, (prec, f64, g64)
+    finally:
+        neural_lam_amd.set_precision(start)
+    assert not torch.equal(outs["fp32-exact"], outs["32-true"])
+    assert not torch.equal(outs["bf16-mixed"], outs["32-true"])
+    # the bf16 run is the coarse one: visibly further from the exact run than split-bf16 is
+    assert rel(outs["bf16-mixed"], outs["fp32-exact"].cpu()) > 10 * rel(outs["32-true"], outs["fp32-exact"].cpu())
