@@ -26,7 +26,7 @@ FAMILIES = [  # (kernel-name regex, family); the first match wins, template argu
     (r"^node_fwd16_kernel", "node_fwd"), (r"^node_bwd16_kernel", "node_bwd"),
     (r"^node_outer16_kernel", "node_outer"),
     (r"^lin_fwd16_multi_kernel", "lin_fwd"), (r"^lin_bwd16_multi_kernel", "lin_bwd"),
-    (r"^edge_fwd(16)?_kernel", "edge_fwd"), (r"^edge_bwd(16c?)?_kernel", "edge_bwd"),
+    (r"^edge_fwd_kernel", "edge_fwd"), (r"^edge_bwd2?_kernel", "edge_bwd"),
     (r"^mlp_fwd(16)?(_multi)?_kernel", "mlp_fwd"), (r"^mlp_bwd(16)?(_multi)?_kernel", "mlp_bwd"),
     (r"^(lin_fwd(16|_b3)?|wide_lin_fwd|fs_lin_fwd)_kernel", "lin_fwd"),
     (r"^lin_bwd_data_kernel", "lin_bwd_data"), (r"^lin_bwd(16)?_kernel", "lin_bwd"),
