@@ -33,7 +33,11 @@ __device__ __forceinline__ TileCtx load_tile_ctx(const EdgeFwdParams& p, int4 hd
   TileCtx c;
   c.p0 = hdr.x; c.ne = hdr.y - hdr.x; c.r0 = hdr.z; c.nr = hdr.w - hdr.z;
   const int t = lane & 31;
-  const int pos = (t < c.ne) ? c.p0 + t : 0;
+  // padded slots replicate the tile's last edge (a tile without edges: CSR position 0): their rows
+  // exist and are finite, so the forward kernel stages them unmasked -- they are left out of the
+  // receiver sums and of the row stores; the exact-fp32 backward zero-fills them when it stages
+  const int last = c.ne > 0 ? c.ne - 1 : 0;
+  const int pos = (c.ne > 0 ? c.p0 : 0) + (t < last ? t : last);
   c.eid = p.csr_eid[pos];
   c.snd = p.csr_send[pos];
   c.rcv = p.csr_rec[pos];
@@ -54,7 +58,10 @@ __device__ __forceinline__ int4 load_tile_hdr(const EdgeFwdParams& p, unsigned t
 
 // B3: the two d x d GEMMs run as split-bf16 MFMAs (fused_bf16x3.h); the weight images have
 // the byte size of the fp32 ones, so the LDS layout is shared.
-template <int D, bool HAS_EGEMM, bool B3 = false>
+// LEAN (split-bf16, hidden 64, every edge- / receiver-indexed operand below 4 GiB per batch item):
+// padded slots staged unmasked, 32-bit row offsets on scalar bases (one v_mad_u32_u24 per row
+// access instead of a 64-bit multiply-add chain).
+template <int D, bool HAS_EGEMM, bool B3 = false, bool LEAN = false>
 __global__ __launch_bounds__(256, 2) void edge_fwd_kernel(EdgeFwdParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NB = D / 32;
@@ -124,6 +131,7 @@ __global__ __launch_bounds__(256, 2) void edge_fwd_kernel(EdgeFwdParams p) {
     // all row gathers of this tile in flight together (per-lane row indices: no shuffles),
     // then the next tile's indices
     f32x4 vE[NV], vS[NV], vR[NV];
+    static_assert(!LEAN || (B3 && D == 64), "LEAN is a form of the split-bf16 hidden-64 kernel");
     {
       stash_slot_index(itab, eid, lane);
       stash_slot_index(itab + NLAM_TILE, snd, lane);
@@ -133,9 +141,24 @@ __global__ __launch_bounds__(256, 2) void edge_fwd_kernel(EdgeFwdParams p) {
       lane_row_index<NV>(ie, itab, D, lane);
       lane_row_index<NV>(is, itab + NLAM_TILE, D, lane);
       lane_row_index<NV>(ir, itab + 2 * NLAM_TILE, D, lane);
-      load_rows_i<NV>(vE, eb, p.e.ld, ie, D, lane);
-      load_rows_i<NV>(vS, psb, p.ps.ld, is, D, lane);
-      load_rows_i<NV>(vR, prb, p.pr.ld, ir, D, lane);
+      if constexpr (LEAN) {
+        // (row ids below 2^24 and operands below 4 GiB per batch item: checked by the launcher)
+        const unsigned bu = (unsigned)__builtin_amdgcn_readfirstlane((int)b);
+        const char* ebc = reinterpret_cast<const char*>(p.e.ptr + (int64_t)bu * p.e.bstride);
+        const char* prc = reinterpret_cast<const char*>(p.pr.ptr + (int64_t)bu * p.pr.bstride);
+        const unsigned c16 = 16u * (unsigned)(lane & 15);
+        const unsigned ldE = 4u * (unsigned)p.e.ld, ldR = 4u * (unsigned)p.pr.ld;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+          vE[k] = *reinterpret_cast<const f32x4*>(ebc + (__umul24((unsigned)ie[k], ldE) + c16));
+          vR[k] = *reinterpret_cast<const f32x4*>(prc + (__umul24((unsigned)ir[k], ldR) + c16));
+        }
+        load_rows_i<NV>(vS, psb, p.ps.ld, is, D, lane);   // (sender ids are not bounded by the tile count)
+      } else {
+        load_rows_i<NV>(vE, eb, p.e.ld, ie, D, lane);
+        load_rows_i<NV>(vS, psb, p.ps.ld, is, D, lane);
+        load_rows_i<NV>(vR, prb, p.pr.ld, ir, D, lane);
+      }
     }
     const TileCtx nxt = load_tile_ctx(p, hdr_n, lane);
     const int4 hdr_nn = load_tile_hdr(p, tt + 2 * stride, total);
@@ -143,8 +166,10 @@ __global__ __launch_bounds__(256, 2) void edge_fwd_kernel(EdgeFwdParams p) {
     for (int k = 0; k < NV; ++k) vS[k] += vR[k];
 
     f32x16 a1[NB], ebuf[NB];
+    // (LEAN: the padded slots hold copies of the tile's last edge -- staged as they are)
+    const int nstage = LEAN ? NLAM_TILE : ne;
     if (HAS_EGEMM) {
-      put_rows_v<NV, false>(tile, LDT, 0, D, ne, lane, vE);
+      put_rows_v<NV, false>(tile, LDT, 0, D, nstage, lane, vE);
       wave_sync();
       tile_to_acc<NB>(ebuf, tile, LDT, lane);
       wave_sync();
@@ -152,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void edge_fwd_kernel(EdgeFwdParams p) {
 #pragma unroll
       for (int k = 0; k < NV; ++k) vS[k] += vE[k];     // Pe + Ps + Pr
     }
-    put_rows_v<NV, false>(tile, LDT, 0, D, ne, lane, vS);
+    put_rows_v<NV, false>(tile, LDT, 0, D, nstage, lane, vS);
     wave_sync();
     tile_to_acc<NB>(a1, tile, LDT, lane);
     if (HAS_EGEMM) {
@@ -212,12 +237,12 @@ __global__ __launch_bounds__(256, 2) void edge_fwd_kernel(EdgeFwdParams p) {
   }
 }
 
-template <int D, bool HAS_EGEMM, bool B3 = false>
+template <int D, bool HAS_EGEMM, bool B3 = false, bool LEAN = false>
 static int launch_edge_fwd(const EdgeFwdParams& p, hipStream_t s) {
   const size_t lds = ((size_t)(HAS_EGEMM ? 2 : 1) * D * (D + 4) + 3 * D +
                       (size_t)4 * NLAM_TILE * (D + 4) + 4 * 3 * NLAM_TILE) * sizeof(float);
   NLAM_REQUIRE(lds <= 160 * 1024, "edge_fwd: LDS footprint %zu B exceeds 160 KiB", lds);
-  auto kern = edge_fwd_kernel<D, HAS_EGEMM, B3>;
+  auto kern = edge_fwd_kernel<D, HAS_EGEMM, B3, LEAN>;
   NLAM_BIG_LDS(kern, __func__);
   kern<<<persistent_grid(p.ntiles * p.B, lds), 256, lds, s>>>(p);
   NLAM_CHECK_LAUNCH("edge_fwd_kernel");
@@ -261,8 +286,15 @@ extern "C" int nlam_edge_fwd(
   p.e_out = e_out; p.eo_bstride = eo_bstride; p.eo_ld = eo_ld;
   p.B = (int)B;
   hipStream_t s = (hipStream_t)stream;
-  if (d == 64 && nlam_mfma_b3())   // (unaligned weights take the scalar image loader)
+  if (d == 64 && nlam_mfma_b3()) {   // (unaligned weights take the scalar image loader)
+    // 32-bit row offsets: edge / receiver ids are below 32 * ntiles; ids < 2^24, pitches < 2^22
+    // floats and a batch item of each such operand below 4 GiB
+    const int64_t Mb = ntiles * 32;
+    auto ok = [](int64_t rows, int64_t ld) { return rows < (1 << 24) && ld < (1 << 22) && rows * ld * 4 < (1ll << 32); };
+    if (ok(Mb, e_ld) && ok(Mb, pr_ld))
+      return has_egemm ? launch_edge_fwd<64, true, true, true>(p, s) : launch_edge_fwd<64, false, true, true>(p, s);
     return has_egemm ? launch_edge_fwd<64, true, true>(p, s) : launch_edge_fwd<64, false, true>(p, s);
+  }
   if (d == 64) return has_egemm ? launch_edge_fwd<64, true>(p, s) : launch_edge_fwd<64, false>(p, s);
   return has_egemm ? launch_edge_fwd<128, true>(p, s) : launch_edge_fwd<128, false>(p, s);
 }
