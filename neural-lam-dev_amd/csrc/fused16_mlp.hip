@@ -179,11 +179,16 @@ __device__ __forceinline__ void mlp_bwd16_body(const MlpBwdParams& q, int wg, in
     const B3Tile Ts = p16_tile(R0, HID), Tz = p16_tile(R1, NO);
     f32x4 hkeep[DEFER ? NFH : 1];   // DEFER: h stays in registers (no weight-gradient blocks of W1)
     f32x4 g[NFO];
+    const float* rg = q.gy.ptr + b * q.gy.bstride + opaque(row) * q.gy.ld;
     {
       f32x4 hpre[NFH];
       {
         f32x4 x[KF];
         load_x(x);
+        // the upstream gradient rows are requested with the x rows: their latency rides under
+        // the forward recompute (they used to be requested where they are first needed, after the
+        // second GEMM, behind a scheduling fence: one exposed HBM round trip per tile)
+        if constexpr (NOB == 2) load_row16<NFO>(g, rg, lane);
         vec_to_acc16<NFH>(hpre, b1s, lane);
         gemm_acc16<NFH, KB, TERMS>(hpre, W1im, 0, 0, x, lane);
       }
@@ -207,13 +212,11 @@ __device__ __forceinline__ void mlp_bwd16_body(const MlpBwdParams& q, int wg, in
         acc16_to_tile<NFH>(hpre, HS, HID + 4, lane);          // silu'(h): back from LDS later
       }
       acc16_to_planes<NFH, TERMS>(sact, Ts, 0, lane);         // S stays in R0 until dW2 is formed
-      const float* rg = q.gy.ptr + b * q.gy.bstride + opaque(row) * q.gy.ld;
       if constexpr (HAS_LN) {
         f32x4 z[NFO];
         vec_to_acc16<NFO>(z, b2s, lane);
         gemm_acc16<NFO, 2, TERMS>(z, W2im, 0, 0, sact, lane);
         __builtin_amdgcn_sched_barrier(0);
-        load_row16<NFO>(g, rg, lane);
         mask16<NFO>(g, valid);   // padded rows carry a zero gradient: every sum below ignores them
         acc16_to_planes<NFO, TERMS>(g, Tz, 0, lane);          // dbeta summand: gy
         wave_sync();
@@ -225,7 +228,6 @@ __device__ __forceinline__ void mlp_bwd16_body(const MlpBwdParams& q, int wg, in
         wave_sync();
       } else {
         if constexpr (NOB == 1) load_narrow16<NFO>(g, rg, p.n_out, lane);
-        else load_row16<NFO>(g, rg, lane);
         mask16<NFO>(g, valid);
       }
     }
@@ -238,6 +240,19 @@ __device__ __forceinline__ void mlp_bwd16_body(const MlpBwdParams& q, int wg, in
     outer_accum16<NOB, 2, TERMS>(dW2, Tz, 0, Ts, 0, lane);
     __builtin_amdgcn_sched_barrier(0);
     // ---- ga = (W2^T gz) * silu'(h)
+    // (the x rows of the first layer's weight gradient and the residual's gy rows are requested
+    // here: L2-hot re-reads whose round trip rides under the next two GEMMs instead of being
+    // exposed where the values are first used)
+    constexpr bool X2_EARLY = !DEFER && KB == 1;   // (KB = 2: 16 more live registers spill)
+    f32x4 x2[DEFER ? 1 : KF];
+    if constexpr (X2_EARLY) load_x(x2);
+    // (the residual's rows early only where the registers allow it: the K = 128 node update, which
+    // keeps no x rows here; the K = 64 blocks spilled with both sets live)
+    constexpr bool GY2_EARLY = DEFER;
+    f32x4 gy2[4];
+    const bool add_gy = want_gx && q.gxa != nullptr && q.add_gy_to_gxa;
+    if (GY2_EARLY && add_gy)
+      load_row16<4>(gy2, q.gy.ptr + b * q.gy.bstride + opaque(row) * q.gy.ld, lane);
     f32x4 ga[NFH];
     zero16<NFH>(ga);
     gemm_acc16_wt<NFH, NOB, TERMS>(ga, W2im, 0, 0, g, lane);
@@ -261,11 +276,8 @@ __device__ __forceinline__ void mlp_bwd16_body(const MlpBwdParams& q, int wg, in
       wave_sync();
       const B3Tile Ta = p16_tile(R1, HID), Tx = p16_tile(R0, KP32);
       acc16_to_planes<NFH, TERMS>(ga, Ta, 0, lane);
-      {
-        f32x4 x[KF];
-        load_x(x);
-        acc16_to_planes<KF, TERMS>(x, Tx, 0, lane);
-      }
+      if constexpr (!X2_EARLY) load_x(x2);
+      acc16_to_planes<KF, TERMS>(x2, Tx, 0, lane);
       wave_sync();
       colsum16<1, TERMS>(db1, Ta, 0, lane);
       outer_accum16<2, KB, TERMS>(dW1, Ta, 0, Tx, 0, lane);
@@ -279,8 +291,7 @@ __device__ __forceinline__ void mlp_bwd16_body(const MlpBwdParams& q, int wg, in
       const int wa = p.src[0].width;
       if (q.gxa != nullptr) {
         if (q.add_gy_to_gxa) {   // n_out == wa == 64 (checked by the host side)
-          f32x4 gy2[4];
-          load_row16<4>(gy2, q.gy.ptr + b * q.gy.bstride + opaque(row) * q.gy.ld, lane);
+          if (!GY2_EARLY) load_row16<4>(gy2, q.gy.ptr + b * q.gy.bstride + opaque(row) * q.gy.ld, lane);
 #pragma unroll
           for (int fb = 0; fb < 4 && fb < KF; ++fb) gx[fb] += gy2[fb];
         }
