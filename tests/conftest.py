@@ -24,6 +24,24 @@ def load_fixture(path):
     return fx
 
 
+def elementwise_excess(a, b, tol):
+    """Worst |a - b| / (tol * (|b| + rms(b))) over the elements: < 1 means every element is
+    inside a tolerance scaled by ITS OWN magnitude plus the tensor's rms -- the max-norm bars
+    (error / max|ref|) say nothing about the small-magnitude entries of a tensor; this one does.
+    rms(b) (not max|b|) is the floor: typically 3-10 x smaller."""
+    import torch
+
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    rms = float(b.pow(2).mean().sqrt())
+    return float(((a - b).abs() / (tol * (b.abs() + rms) + 1e-300)).max())
+
+
+def l2_rel(a, b):
+    """||a - b||_2 / ||b||_2."""
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).norm() / (b.norm() + 1e-300))
+
+
 def fixture_files(pattern, autocast=False):
     """Golden files matching `pattern`: the fp32 ones, or the bf16-autocast ones."""
     import glob

@@ -8,7 +8,7 @@ import os
 import pytest
 import torch
 
-from conftest import GOLDEN, fixture_files
+from conftest import GOLDEN, elementwise_excess, fixture_files, l2_rel
 
 pytestmark = pytest.mark.gpu
 OP_FILES = fixture_files("op_*.pt")   # the bf16-autocast ones: tests/test_gpu_mfma_modes.py
@@ -49,6 +49,14 @@ def run_case(fx, force_generic):
             assert rel(r.grad, fx["grad_rec"]) < 1e-3
         for k, p in net.named_parameters():
             assert rel(p.grad, fx["grad_params"][k]) < 1e-3, k
+        # the same bars in the 2-norm and element by element (|err| <= tol (|ref| + rms(ref))):
+        # small-magnitude entries of a tensor are held too, not only its largest ones
+        pairs = [("out_rec", o_rec, fx["out_rec"], 1e-4), ("grad_send", s.grad, fx["grad_send"], 1e-3),
+                 ("grad_edge", e.grad, fx["grad_edge"], 1e-3)]
+        pairs += [(k, p.grad, fx["grad_params"][k], 1e-3) for k, p in net.named_parameters()]
+        for name, got, want, tol in pairs:
+            assert l2_rel(got, want) < tol, name
+            assert elementwise_excess(got, want, tol) < 1.0, name
     finally:
         fused.FORCE_GENERIC = old
 

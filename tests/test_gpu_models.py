@@ -58,6 +58,13 @@ def test_training_step_vs_reference_golden(path):
     loss = model.training_step(batch)
     assert abs(float(loss) - fx["loss"]) < 1e-4 * abs(fx["loss"])
     loss.backward()
+    from conftest import elementwise_excess, l2_rel
+
+    assert l2_rel(pred, fx["prediction"]) < 1e-4
+    assert elementwise_excess(pred, fx["prediction"], 1e-4) < 1.0
     for k, p in model.named_parameters():
         assert p.grad is not None, k
         assert rel(p.grad, fx["grad_params"][k]) < 2e-3, k
+        # (2-norm and element-by-element forms of the same bar: conftest.elementwise_excess)
+        assert l2_rel(p.grad, fx["grad_params"][k]) < 2e-3, k
+        assert elementwise_excess(p.grad, fx["grad_params"][k], 2e-3) < 1.0, k
