@@ -79,7 +79,12 @@ __global__ __launch_bounds__(256, 2) void edge_fwd_kernel(EdgeFwdParams p) {
   const B3Image W1im = b3_image(W1s, D, D), W2im = b3_image(W2s, D, D);
   const unsigned total = (unsigned)(p.ntiles * p.B);
   const unsigned stride = gridDim.x * 4;
-  unsigned tt = blockIdx.x * 4 + wave;
+  // XCD-aware order (LEAN form): workgroups go round-robin over the 8 XCDs, each with its own L2,
+  // and neighbouring tiles share sender / receiver rows -- XCD x takes a contiguous eighth of
+  // every round's tiles instead of every eighth tile
+  const unsigned G = gridDim.x;
+  const unsigned wg = (LEAN && (G & 7u) == 0) ? (blockIdx.x & 7u) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+  unsigned tt = wg * 4 + wave;
   TileCtx cur;
   int4 hdr_n;
   if (B3 && D == 64) {

@@ -346,7 +346,7 @@ int nlam_edge_bwd2_stamps(unsigned long long* out, int reset) {
 // ABL (diagnostic, NLAM_ABL2=1): every row access goes to row 0 / a scratch row -- the same
 // instruction stream without HBM traffic (results are meaningless).
 template <bool HAS_EGEMM, bool HAS_GEO, bool STAMP = false, bool ABL = false>
-__global__ __launch_bounds__(256) void edge_bwd2_kernel(EdgeBwdParams q) {
+__global__ __launch_bounds__(256) void edge_bwd2_kernel(EdgeBwdParams q, int xcd_remap) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int LDW = D + 4;
   constexpr int WSTRIDE = 3 * NLAM_TILE * LDT;
@@ -369,7 +369,13 @@ __global__ __launch_bounds__(256) void edge_bwd2_kernel(EdgeBwdParams q) {
   const unsigned ntiles = (unsigned)p.ntiles;
   const unsigned total = ntiles * (unsigned)p.B;
   const unsigned stride = gridDim.x * 4;
-  unsigned tt = blockIdx.x * 4 + wave;
+  // XCD-aware order: workgroups are dispatched round-robin over the 8 XCDs (each with its own
+  // L2), and neighbouring tiles share sender / receiver rows -- so XCD x takes a CONTIGUOUS eighth
+  // of every round's tiles instead of every eighth tile (node rows are then fetched by one L2,
+  // not by all eight)
+  const unsigned G = gridDim.x;
+  const unsigned wg = (xcd_remap && (G & 7u) == 0) ? (blockIdx.x & 7u) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+  unsigned tt = wg * 4 + wave;
 
   auto task_hdr = [&](unsigned task, int& b) {   // header + batch item of a (clamped) task
     const unsigned tq = task < total ? task : total - 1;
@@ -743,7 +749,8 @@ static int launch_edge_bwd2(const EdgeBwdParams& q, hipStream_t s) {
                      (size_t)4 * NLAM_TILE * IND_PITCH * sizeof(__bf16);
   auto kern = edge_bwd2_kernel<HAS_EGEMM, HAS_GEO, STAMP, ABL>;
   NLAM_BIG_LDS(kern, __func__);
-  kern<<<(unsigned)nlam_bwd_grid(q.f.ntiles * q.f.B), 256, lds, s>>>(q);
+  static const int xcd = getenv("NLAM_NO_XCD_ORDER") == nullptr;
+  kern<<<(unsigned)nlam_bwd_grid(q.f.ntiles * q.f.B), 256, lds, s>>>(q, xcd);
   NLAM_CHECK_LAUNCH("edge_bwd2_kernel");
   return 0;
 }
