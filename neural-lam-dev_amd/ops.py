@@ -460,11 +460,17 @@ class WeightGradLane:
             self.side.wait_stream(self.main)
             self.ctx = torch.cuda.stream(self.side)
             self.ctx.__enter__()
-        _SLAB_BATCH.append(self.pending)
+        # a disabled lane inside a slab_batch(): its reductions join the enclosing block's single
+        # launch (they used to be flushed by finish() as a second reduction launch per layer:
+        # 46 launches of ~8 us per Hi-LAM step at hidden 128 / 256)
+        self._own = self.enabled or not _SLAB_BATCH
+        if self._own:
+            _SLAB_BATCH.append(self.pending)
         return self
 
     def __exit__(self, et, ev, tb):
-        _SLAB_BATCH.pop()
+        if self._own:
+            _SLAB_BATCH.pop()
         if self.enabled:
             self.ctx.__exit__(et, ev, tb)
             self.ctx = None
