@@ -397,7 +397,15 @@ int nlam_lin_bwd(const float* x, int64_t x_bstride, int64_t x_ld, int k_in,
  * batch-invariant Pe, over the batch; gpr (B, N_r, d) = per-receiver sum of gh;
  * g_e (B, M, d, original order; has_egemm) = g_eout + W1e^T gh; per-workgroup
  * slabs [dW1e (d x d) | dW2 (d x d) | db2 | dgamma | dbeta], count =
- * nlam_bwd_grid(B * ntiles). */
+ * nlam_bwd_grid(B * ntiles).
+ * Without an edge update (has_egemm = 0) a non-NULL g_e, (M, d) with pitch ge_ld, receives
+ * dPe = sum_b gh_out[b]: the gradient of a batch-invariant Pe (e_bstride = 0), formed in the
+ * kernel's registers when the split-bf16 round-4 kernel runs (a wave then takes whole tiles and
+ * runs their batch items back to back), by one nlam_sum_batch launch otherwise.
+ * nlam_edge_bwd_forms_batch_sum(): 1 if the in-kernel form would run for this tile count / batch
+ * (it hands out whole tiles and is only taken when that costs at most ~6 % in rounds); callers
+ * that get 0 keep the batch sum folded into the projection backward's load (gy_nsum). */
+int nlam_edge_bwd_forms_batch_sum(int64_t ntiles, int64_t B, int d);
 int64_t nlam_edge_bwd_slab_stride(int d);
 int nlam_edge_bwd(const int32_t* tiles, int64_t ntiles,
                   const int32_t* csr_rowptr, const int32_t* csr_eid,

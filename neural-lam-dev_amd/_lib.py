@@ -22,6 +22,7 @@ SIGNATURES = {
     "nlam_abi_version": [],
     "nlam_mfma_mode": [],
     "nlam_set_mfma_mode": [_i32],
+    "nlam_edge_bwd_forms_batch_sum": [_i64, _i64, _i32],
     "nlam_graph_build_host": [_p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p],
     "nlam_gemm": [_i64, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _p, _p, _i64, _i32, _i32, _p, _p],
     "nlam_silu_fwd": [_p, _p, _i64, _p],

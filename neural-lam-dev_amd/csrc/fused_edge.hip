@@ -773,15 +773,32 @@ extern "C" int nlam_edge_bwd(
   q.g_e = g_e; q.ge_bstride = ge_bstride; q.ge_ld = ge_ld;
   q.slab = slab; q.slab_stride = slab_stride;
   hipStream_t s = (hipStream_t)stream;
+  // Without an edge update a non-NULL g_e asks for dPe = sum_b gh[b], (1, M, d): the gradient of a
+  // batch-invariant first-layer edge term.  Where the kernel that runs does not form it in its
+  // registers (fused_edge2.hip, batch-inner form), one more launch does.
+  const bool want_bsum = !has_egemm && g_e != nullptr;
+  auto finish = [&](int rc) {
+    if (rc != 0 || !want_bsum) return rc;
+    return nlam_sum_batch(gh_out, gh_bstride, g_e, B, gh_bstride, stream);
+  };
   {
-    const int r2 = nlam_edge_bwd2(q, has_egemm, s);   // split-bf16 arithmetic: fused_edge2.hip
+    int r2 = nlam_edge_bwd2(q, has_egemm, s);   // split-bf16 arithmetic: fused_edge2.hip
     if (r2 >= 0) return r2;
+    if (want_bsum) {
+      NLAM_REQUIRE(ge_ld == d && gh_bstride > 0 && gh_bstride % d == 0,
+                   "nlam_edge_bwd: the batch sum of gh needs contiguous (B, M, d) gh and (M, d) g_e");
+      q.g_e = nullptr;
+      if (r2 == -2) {
+        r2 = nlam_edge_bwd2(q, has_egemm, s);
+        if (r2 >= 0) return finish(r2);
+      }
+    }
   }
   static const bool stamp = getenv("NLAM_STAMP") != nullptr;
   if (stamp && has_egemm && nlam_mfma_b3()) return launch_edge_bwd<64, true, true, true>(q, s);
   if (stamp && has_egemm) return launch_edge_bwd<64, true, true>(q, s);
   if (nlam_mfma_b3())
     return has_egemm ? launch_edge_bwd<64, true, false, true>(q, s)
-                     : launch_edge_bwd<64, false, false, true>(q, s);
-  return has_egemm ? launch_edge_bwd<64, true>(q, s) : launch_edge_bwd<64, false>(q, s);
+                     : finish(launch_edge_bwd<64, false, false, true>(q, s));
+  return has_egemm ? launch_edge_bwd<64, true>(q, s) : finish(launch_edge_bwd<64, false>(q, s));
 }

@@ -345,8 +345,13 @@ int nlam_edge_bwd2_stamps(unsigned long long* out, int reset) {
 // HAS_GEO: an upstream gradient on e' exists (every edge-updating layer but the last of a chain).
 // ABL (diagnostic, NLAM_ABL2=1): every row access goes to row 0 / a scratch row -- the same
 // instruction stream without HBM traffic (results are meaningless).
-template <bool HAS_EGEMM, bool HAS_GEO, bool STAMP = false, bool ABL = false>
+// BSUM (no edge update, batch-invariant first-layer edge term Pe, B > 1): a wave takes whole tiles
+// and runs their B batch items back to back, sums gh over the batch in registers and writes
+// dPe = sum_b gh[b] (1, M, d) to q.g_e -- the gradient of the batch-invariant operand, which the
+// projection backward otherwise forms by reading gh B times (m2g: 261 MB of its 1,154 MB).
+template <bool HAS_EGEMM, bool HAS_GEO, bool STAMP = false, bool ABL = false, bool BSUM = false>
 __global__ __launch_bounds__(256) void edge_bwd2_kernel(EdgeBwdParams q, int xcd_remap) {
+  static_assert(!BSUM || !HAS_EGEMM, "the batch sum is the no-edge-update form's extra output");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int LDW = D + 4;
   constexpr int WSTRIDE = 3 * NLAM_TILE * LDT;
@@ -375,9 +380,28 @@ __global__ __launch_bounds__(256) void edge_bwd2_kernel(EdgeBwdParams q, int xcd
   // not by all eight)
   const unsigned G = gridDim.x;
   const unsigned wg = (xcd_remap && (G & 7u) == 0) ? (blockIdx.x & 7u) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x;
-  unsigned tt = wg * 4 + wave;
-
-  auto task_hdr = [&](unsigned task, int& b) {   // header + batch item of a (clamped) task
+  // Tasks of this wave, numbered j = 0, 1, ...: strided over the (batch item, tile) pairs, or --
+  // BSUM -- a contiguous range of tiles with the batch items innermost.
+  const unsigned wid = wg * 4 + wave;
+  const unsigned Bu = (unsigned)p.B;
+  unsigned tile0 = 0, niter;
+  if (BSUM) {
+    const unsigned per = (ntiles + stride - 1) / stride;          // tiles per wave
+    tile0 = wid * per;
+    const unsigned tile1 = tile0 + per < ntiles ? tile0 + per : ntiles;
+    niter = tile1 > tile0 ? (tile1 - tile0) * Bu : 0;
+  } else {
+    niter = total > wid ? (total - wid + stride - 1) / stride : 0;
+  }
+  auto task_hdr = [&](unsigned j, int& b) {   // header + batch item of task j (clamped to the last)
+    if (BSUM) {
+      const unsigned jc = niter == 0 ? 0 : (j < niter ? j : niter - 1);
+      const unsigned tl = jc / Bu;
+      b = (int)(jc - tl * Bu);
+      const unsigned tile = tile0 + tl;
+      return load_hdr(p, tile < ntiles ? tile : ntiles - 1);
+    }
+    const unsigned task = wid + j * stride;
     const unsigned tq = task < total ? task : total - 1;
     const unsigned bb = tq / ntiles;
     b = (int)bb;
@@ -385,9 +409,9 @@ __global__ __launch_bounds__(256) void edge_bwd2_kernel(EdgeBwdParams q, int xcd
   };
   // ---- prologue: weights, vectors and the first tiles' indices in one global round trip
   int b0, b1, b2i;
-  const Hdr h0 = task_hdr(tt, b0);
-  const Hdr h1 = task_hdr(tt + stride, b1);
-  Hdr hdr2 = task_hdr(tt + 2 * stride, b2i);
+  const Hdr h0 = task_hdr(0, b0);
+  const Hdr h1 = task_hdr(1, b1);
+  Hdr hdr2 = task_hdr(2, b2i);
   __builtin_amdgcn_sched_barrier(0);
   VLoad16 lv;
   const float* const vecs[8] = {p.b2, p.gamma, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -462,7 +486,7 @@ __global__ __launch_bounds__(256) void edge_bwd2_kernel(EdgeBwdParams q, int xcd
   auto fetch_R = [&](int k) { vR[k] = ldg_off(prN, row_off(crow(hN, k), ldR, col16)); };
 
   int par = 0;
-  if (tt < total) {
+  if (niter > 0) {
     fetch_begin(cur, 0);
 #pragma unroll
     for (int k = 0; k < NVR; ++k) { fetch_E(k); fetch_S(k); }
@@ -476,7 +500,12 @@ __global__ __launch_bounds__(256) void edge_bwd2_kernel(EdgeBwdParams q, int xcd
   __builtin_amdgcn_s_waitcnt(0x0F70);
   unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tprev = STAMP ? __builtin_amdgcn_s_memtime() : 0;
-  for (; tt < total; tt += stride) {
+  f32x16 gsum[BSUM ? NB : 1];   // BSUM: sum of gh over the batch items of the current tile
+#pragma unroll
+  for (int nb = 0; nb < (BSUM ? NB : 1); ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gsum[nb][r] = 0.f;
+  for (unsigned j = 0; j < niter; ++j) {
     const Hdr H = cur.h;
     const int ne = H.ne, nr = H.nr, r0 = H.r0;
     const int rcv = cur.rcv;
@@ -631,7 +660,7 @@ __global__ __launch_bounds__(256) void edge_bwd2_kernel(EdgeBwdParams q, int xcd
     // indices of the tile after next (consumed one tile from now: no wait in this tile)
     Ctx nn = load_ctx(p, hdr2, b2i, lane);
     nxt.sc = load_scale(p, nxt);   // (nxt.rcv landed a tile ago; the prologue's value is the same)
-    hdr2 = task_hdr(tt + 3 * stride, b2i);
+    hdr2 = task_hdr(j + 3, b2i);
     outer_cb(dW2, T1p, T2p, lane, [&](int st_) { fetch_S(2 * st_); fetch_S(2 * st_ + 1); });
     tile_colsum_b3<1>(db2, T1p, 0, lane);
     f32x16 gh[NB];
@@ -700,6 +729,25 @@ __global__ __launch_bounds__(256) void edge_bwd2_kernel(EdgeBwdParams q, int xcd
       seg_mfma(seg, ind, T1p, lane);
 #pragma unroll
       for (int k = 0; k < NVR; ++k) store_gh(k);
+      if constexpr (BSUM) {
+        // dPe = sum over the batch items of this tile (b runs innermost; first item: plain copy)
+        const float keep = b == 0 ? 0.0f : 1.0f;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) gsum[nb][r] = fmaf(gsum[nb][r], keep, gh[nb][r]);
+        if (b == (int64_t)p.B - 1 && ne > 0) {   // (wave-uniform) the tile's last batch item: emit the rows
+          acc_to_tile<NB>(gsum, T0, LDT, lane);   // (T0 is free without an edge GEMM)
+          wave_sync();
+#pragma unroll
+          for (int k = 0; k < NVR; ++k) {
+            const int tr = sub + 4 * k;
+            const int trc = tr < lastrow ? tr : lastrow;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(T0 + trc * LDT + 4 * c4);
+            stg_off(q.g_e, row_off(tabC[sub + 4 * k], ldGE, col16), v);
+          }
+        }
+      }
       wave_sync();   // (the gh rows of T2 are read)
       seg_store(seg, T2, nr, gb, (uint32_t)r0 * ldGP, ldGP, lane);
     }
@@ -742,12 +790,12 @@ __global__ __launch_bounds__(256) void edge_bwd2_kernel(EdgeBwdParams q, int xcd
   }
 }
 
-template <bool HAS_EGEMM, bool HAS_GEO, bool STAMP = false, bool ABL = false>
+template <bool HAS_EGEMM, bool HAS_GEO, bool STAMP = false, bool ABL = false, bool BSUM = false>
 static int launch_edge_bwd2(const EdgeBwdParams& q, hipStream_t s) {
   const size_t lds = ((size_t)(HAS_EGEMM ? 2 : 1) * D * (D + 4) + 2 * D +
                       (size_t)4 * 3 * NLAM_TILE * LDT + 4 * 4 * NLAM_TILE) * sizeof(float) +
                      (size_t)4 * NLAM_TILE * IND_PITCH * sizeof(__bf16);
-  auto kern = edge_bwd2_kernel<HAS_EGEMM, HAS_GEO, STAMP, ABL>;
+  auto kern = edge_bwd2_kernel<HAS_EGEMM, HAS_GEO, STAMP, ABL, BSUM>;
   NLAM_BIG_LDS(kern, __func__);
   static const int xcd = getenv("NLAM_NO_XCD_ORDER") == nullptr;
   kern<<<(unsigned)nlam_bwd_grid(q.f.ntiles * q.f.B), 256, lds, s>>>(q, xcd);
@@ -755,7 +803,21 @@ static int launch_edge_bwd2(const EdgeBwdParams& q, hipStream_t s) {
   return 0;
 }
 
-// -1: a shape this kernel does not take (the caller continues with the older kernels)
+// Whether nlam_edge_bwd (no edge update, batch-invariant Pe) forms dPe = sum_b gh[b] inside the
+// kernel: callers ask before they request it, and keep the batch sum folded into the projection
+// backward's load otherwise.
+extern "C" int nlam_edge_bwd_forms_batch_sum(int64_t ntiles, int64_t B, int d) {
+  if (d != D || B <= 1 || ntiles <= 0 || !nlam_mfma_b3() || !nlam_k16_on(K16_EDGE_BWD2)) return 0;
+  if (getenv("NLAM_STAMP") != nullptr) return 0;
+  const int64_t nw = 4 * nlam_bwd_grid(ntiles * B);
+  const int64_t rounds_tiles = ((ntiles + nw - 1) / nw) * B;
+  const double rounds_tasks = (double)ntiles * (double)B / (double)nw;
+  return (double)rounds_tiles <= 1.06 * rounds_tasks + 0.5 ? 1 : 0;
+}
+
+// -1: a shape this kernel does not take (the caller continues with the older kernels); -2: the
+// batch sum dPe was requested but the batch-inner form would be unbalanced (the caller runs this
+// kernel again without g_e and forms the sum with nlam_sum_batch)
 int nlam_edge_bwd2(const EdgeBwdParams& q, int has_egemm, hipStream_t s) {
   const EdgeFwdParams& p = q.f;
   if (p.e.width != D || !nlam_mfma_b3() || getenv("NLAM_STAMP") != nullptr) return -1;
@@ -773,6 +835,18 @@ int nlam_edge_bwd2(const EdgeBwdParams& q, int has_egemm, hipStream_t s) {
   if (abl && has_egemm && q.g_eout) return launch_edge_bwd2<true, true, false, true>(q, s);
   if (stamp && has_egemm && q.g_eout) return launch_edge_bwd2<true, true, true>(q, s);
   if (stamp && !has_egemm) return launch_edge_bwd2<false, false, true>(q, s);
-  if (!has_egemm) return launch_edge_bwd2<false, false>(q, s);
+  if (!has_egemm) {
+    // dPe = sum_b gh[b] requested (g_e != NULL): only meaningful for a batch-invariant Pe.  The
+    // batch-inner form hands out whole tiles: taken when that costs at most ~6 % in rounds
+    // (m2g: 7,973 tiles on 1,024 waves = 8 tiles each, 32 rounds against 31.1; g2m: 3,191 tiles
+    // = 4 each, 16 rounds against 12.5 -- there the strided form runs and the caller sums)
+    if (q.g_e != nullptr) {
+      if (!(p.e.bstride == 0 && p.B > 1 && ok(M, q.ge_ld))) return -1;
+      if (nlam_edge_bwd_forms_batch_sum(p.ntiles, p.B, D))
+        return launch_edge_bwd2<false, false, false, false, true>(q, s);
+      return -2;   // (this kernel WITHOUT the batch sum: see nlam_edge_bwd)
+    }
+    return launch_edge_bwd2<false, false>(q, s);
+  }
   return q.g_eout ? launch_edge_bwd2<true, true>(q, s) : launch_edge_bwd2<true, false>(q, s);
 }

@@ -210,6 +210,8 @@ static int64_t inet_bwd_plan(const nlam_inet_args* a, const nlam_inet_grads* gr,
   const int64_t gpr_bs = N_r * (same ? 2 * D : D), gpr_ld = same ? 2 * D : D;
   float* g_e = nullptr;
   if (upd) g_e = (Be == 1 && B > 1) ? c.take(B * M * D) : (run ? gr->g_edge : nullptr);
+  const bool bsum = !upd && Be == 1 && B > 1 && nlam_edge_bwd_forms_batch_sum(g.ntiles, B, D) != 0;
+  float* dPe1 = bsum ? c.take(M * D) : nullptr;
   const int64_t st2 = nlam_edge_bwd_slab_stride(D), ns2 = nlam_bwd_grid(B * g.ntiles);
   float* slab2 = c.take(ns2 * st2);
   const float *ps, *pr;
@@ -225,10 +227,11 @@ static int64_t inet_bwd_plan(const nlam_inet_args* a, const nlam_inet_grads* gr,
                       w.ldW1, w.W2, w.ldW2, w.b2, w.gam, g_agg, N_r * D, D, gr->g_edge_out, M * D, D, gh,
                       M * D, gpr, gpr_bs, gpr_ld, g_e, M * D, D, slab2, st2, B, D, stream));
   } else {
+    // batch-invariant edge term: dPe = sum_b gh[b] comes out of the edge kernel (nlam_hip.h)
     RUN(nlam_edge_bwd(g.tiles, g.ntiles, g.csr_rowptr, g.csr_eid, g.csr_send, g.csr_rec, inv_deg, a->Pe,
                       Be > 1 ? M * D : 0, D, 0, ps, ps_bs, ps_ld, pr, pr_bs, pr_ld, nullptr, 0, w.W2, w.ldW2,
-                      w.b2, w.gam, g_agg, N_r * D, D, nullptr, 0, 0, gh, M * D, gpr, gpr_bs, gpr_ld, nullptr,
-                      0, 0, slab2, st2, B, D, stream));
+                      w.b2, w.gam, g_agg, N_r * D, D, nullptr, 0, 0, gh, M * D, gpr, gpr_bs, gpr_ld, dPe1,
+                      0, D, slab2, st2, B, D, stream));
   }
   {
     // slab layout of nlam_edge_bwd: [dW1e d x d | dW2 d x d | db2 | dgamma | dbeta]
@@ -294,10 +297,10 @@ static int64_t inet_bwd_plan(const nlam_inet_args* a, const nlam_inet_grads* gr,
            nullptr, fr ? 1 : B, N_r, run ? dW1 + 2 * D : (float*)1, 3 * D, run ? gr->db1 : (float*)1, D);
     }
     if (!upd) {
-      const bool fe = Be == 1 && B > 1;
-      push(a->edge.ptr, a->edge.bstride, a->edge.ld, nullptr, 0, gh, fe ? 0 : M * D, W1e,
-           run ? gr->g_edge : nullptr, Be > 1 ? M * D : 0, nullptr, 0, fe ? B : 1, fe ? M * D : 0, nullptr,
-           fe ? 1 : B, M, dW1, 3 * D, nullptr, D);
+      const bool fe = Be == 1 && B > 1;   // (bsum: gy = dPe1, already summed over the batch)
+      push(a->edge.ptr, a->edge.bstride, a->edge.ld, nullptr, 0, bsum ? dPe1 : gh, fe ? 0 : M * D, W1e,
+           run ? gr->g_edge : nullptr, Be > 1 ? M * D : 0, nullptr, 0, (fe && !bsum) ? B : 1,
+           (fe && !bsum) ? M * D : 0, nullptr, fe ? 1 : B, M, dW1, 3 * D, nullptr, D);
     }
     if (!same)   // deferred dV1 = ga^T [x_r | agg], dc1 = colsum ga
       push(a->rec.ptr, a->rec.bstride, a->rec.ld, a->agg, N_r * D, ga, N_r * D, nullptr, nullptr, 0, nullptr, 0,

@@ -433,8 +433,13 @@ class FusedInteractionNetFunction(torch.autograd.Function):
                               ctx.mean, d, dW1[:, :d], dW2, db2, dgam, dbet, dev)
             else:
                 g_e = None
+                # batch-invariant edge term: the kernel also returns dPe = sum_b gh[b] (1, M, d)
+                dPe1 = None
+                if em.B == 1 and B > 1 and g.virtual is None and \
+                        ops.lib.nlam_edge_bwd_forms_batch_sum(g.ntiles, B, d):
+                    dPe1 = _empty(1, M, d, device=dev)
                 _edge_bwd_any(g, mat(Pe), False, psm, prm, None, W2, b2, gam, g_agg, None, gh, gpr_m,
-                              None, ctx.mean, d, None, dW2, db2, dgam, dbet, dev)
+                              dPe1, ctx.mean, d, None, dW2, db2, dgam, dbet, dev)
             # 3. sender-side reduction of gh (rows in the original edge order, sender lists of edge ids)
             if same and node_path:
                 # sender gather + projections backward in one data pass (csrc/fused16_node.hip),
@@ -514,12 +519,15 @@ class FusedInteractionNetFunction(torch.autograd.Function):
                     ops.sum_batch(g_e, t4)
                     g_edge = t4
             else:
-                dPe = mat(gh)
-                fold_e = em.B == 1 and B > 1 and ops.lin_bwd_can_sum(em, dPe)
-                if em.B == 1 and B > 1 and not fold_e:
-                    t5 = _empty(1, M, d, device=dev)
-                    ops.sum_batch(gh, t5)
-                    dPe = mat(t5)
+                if dPe1 is not None:
+                    dPe, fold_e = mat(dPe1), False
+                else:
+                    dPe = mat(gh)
+                    fold_e = em.B == 1 and B > 1 and ops.lin_bwd_can_sum(em, dPe)
+                    if em.B == 1 and B > 1 and not fold_e:
+                        t5 = _empty(1, M, d, device=dev)
+                        ops.sum_batch(gh, t5)
+                        dPe = mat(t5)
                 g_edge = _empty(em.B, M, d, device=dev)
                 if not same and multi:
                     probs.append({"x": em, "gy": dPe, "W": W1e, "nsum": B if fold_e else 1,

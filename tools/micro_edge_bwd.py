@@ -24,6 +24,8 @@ ap.add_argument("--iters", type=int, default=30)
 ap.add_argument("--masks", type=int, nargs="+", default=[511, 2047])
 ap.add_argument("--mean", action="store_true")
 ap.add_argument("--no-geo", action="store_true")
+ap.add_argument("--bsum", action="store_true",
+                help="(g2m / m2g) also ask for dPe = sum_b gh[b]; checked against gh.sum(0)")
 args = ap.parse_args()
 
 from neural_lam_amd import graph, graphgen, ops  # noqa: E402
@@ -60,16 +62,19 @@ geo = torch.randn(B, M, d, device=dev) if (upd and not args.no_geo) else None
 def run():
     gh = torch.empty(B, M, d, device=dev)
     gpr = torch.empty(B, n_rec, d, device=dev)
-    g_e = torch.empty(B, M, d, device=dev) if upd else None
+    g_e = torch.empty(B, M, d, device=dev) if upd else (
+        torch.empty(1, M, d, device=dev) if args.bsum else None)
     dW1e = torch.empty(d, d, device=dev) if upd else None
     dW2, db2 = torch.empty(d, d, device=dev), torch.empty(d, device=dev)
     dg, dbt = torch.empty(d, device=dev), torch.empty(d, device=dev)
     ops.fused_edge_bwd(t, mat(e), upd, mat(ps), mat(pr), W1e, W2, b2, gam, mat(g_agg),
                        mat(geo) if geo is not None else None, mat(gh), mat(gpr),
-                       mat(g_e) if upd else None, args.mean, d, dW1e, dW2, db2, dg, dbt)
+                       mat(g_e) if g_e is not None else None, args.mean, d, dW1e, dW2, db2, dg, dbt)
     out = {"gh": gh, "gpr": gpr, "dW2": dW2, "db2": db2, "dgamma": dg, "dbeta": dbt}
     if upd:
         out.update(g_e=g_e, dW1e=dW1e)
+    elif args.bsum:
+        out["dPe_minus_gh_sum"] = g_e - gh.sum(0, keepdim=True) + 1.0   # (== 1 where they agree)
     return out
 
 
