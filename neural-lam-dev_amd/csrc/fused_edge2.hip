@@ -668,7 +668,13 @@ __global__ __launch_bounds__(256) void edge_bwd2_kernel(EdgeBwdParams q, int xcd
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) gh[nb][r] = 0.f;
-    gemm_tile_wt_cb(gh, W2im, T1p, lane, [&](int st_) { fetch_E(2 * st_); fetch_E(2 * st_ + 1); fetch_R(st_); });
+    // (BSUM: the batch items of a tile run back to back and Pe is batch-invariant -- its rows are
+    // only fetched when the next task starts a new tile)
+    const bool new_e = !BSUM || nxt.b == 0;
+    gemm_tile_wt_cb(gh, W2im, T1p, lane, [&](int st_) {
+      if (new_e) { fetch_E(2 * st_); fetch_E(2 * st_ + 1); }
+      fetch_R(st_);
+    });
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
