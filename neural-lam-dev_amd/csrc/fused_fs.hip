@@ -678,7 +678,9 @@ int nlam_fs_lin_bwd_data_multi_256(int n, const float* const* gy, const int64_t*
 // Diagnostic (NLAM_STAMP=1): wave 0 of every workgroup of fs_tail_fwd adds the s_memtime cycles
 // of each phase of each tile to g_fs_stamps (tools/stamp_fs.py).
 __device__ unsigned long long g_fs_stamps[16];
+int nlam_wide_stamps(unsigned long long* out, int reset);   // fused_wide.hip (NLAM_STAMP_WIDE=1)
 extern "C" int nlam_debug_fs_stamps(unsigned long long* out, int reset) {
+  if (getenv("NLAM_STAMP_WIDE") != nullptr) return nlam_wide_stamps(out, reset);
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fs_stamps), sizeof(unsigned long long) * 16) != hipSuccess)
     return 1;
   if (reset) {

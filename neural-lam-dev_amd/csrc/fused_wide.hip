@@ -23,6 +23,7 @@
 #include <stdlib.h>
 
 #include "fused_bf16x3.h"
+#include <type_traits>
 #include "fused_common.h"
 #include "fused_fs.h"
 
@@ -116,6 +117,33 @@ __device__ __forceinline__ void fold_block_rows_to_slab(const f32x16 (&dW)[NI][N
 }
 
 // ============================================================== tail forward ===
+// Diagnostic (NLAM_STAMP_WIDE=1): per-phase s_memtime cycle sums of the hidden-128 tail kernels over
+// all waves (tools/stamp_wide.py): [0..7] tail_fwd, [8..15] tail_bwd.  Read through
+// nlam_debug_fs_stamps() (fused_fs.hip delegates when the variable is set).
+__device__ unsigned long long g_wide_stamps[16];
+int nlam_wide_stamps(unsigned long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wide_stamps), sizeof(unsigned long long) * 16) != hipSuccess)
+    return 1;
+  if (reset) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_wide_stamps), z, sizeof(z)) != hipSuccess) return 1;
+  }
+  return 0;
+}
+static int wide_stamp_flag() {
+  static const int f = getenv("NLAM_STAMP_WIDE") != nullptr ? 1 : 0;
+  return f;
+}
+#define WSTAMP(k)                                                   \
+  if constexpr (STAMP) {                                                      \
+    __builtin_amdgcn_sched_barrier(0);                              \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();   \
+    __builtin_amdgcn_s_waitcnt(0xC07F);                             \
+    __builtin_amdgcn_sched_barrier(0);                              \
+    wst[k] += now_ - wprev;                                         \
+    wprev = now_;                                                   \
+  }
+
 struct TailFwdParams {
   WideTiling tl;
   RowView a; const int32_t* idx_a;
@@ -129,9 +157,10 @@ struct TailFwdParams {
   float* agg; int64_t agg_bstride; int64_t agg_ld; const float* inv_deg;   // optional (edge mode)
   int B;
   int vec_y;                             // y / res rows 16-byte aligned, n_out % 4 == 0
+  int stamp;                             // NLAM_STAMP_WIDE=1
 };
 
-template <int D, int NOUTB, bool HAS_LN, int TERMS>
+template <int D, int NOUTB, bool HAS_LN, int TERMS, bool STAMP = false>
 __global__ __launch_bounds__(256) void tail_fwd_kernel(TailFwdParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NB = D / 32, NV = D / 8, NO = 32 * NOUTB;
@@ -192,6 +221,8 @@ __global__ __launch_bounds__(256) void tail_fwd_kernel(TailFwdParams p) {
   }
   __syncthreads();
   if (tt >= total) return;
+  unsigned long long wst[STAMP ? 8 : 1] = {0};
+  unsigned long long wprev = STAMP ? __builtin_amdgcn_s_memtime() : 0;
   for (; tt < total; tt += tstride) {
     const int64_t b = tt / p.tl.ntiles;
     const WTile w = cur.w;
@@ -210,6 +241,13 @@ __global__ __launch_bounds__(256) void tail_fwd_kernel(TailFwdParams p) {
       lane_row_index<NV>(ia, itab, D, lane);
       load_rows_i<NV>(vA, p.a.ptr + b * p.a.bstride, p.a.ld, ia, D, lane);
     }
+    // residual rows of the output (e' = e + m): requested with the gathers, used at the very end
+    // of the tile -- their HBM round trip rides under the whole tile.  (Inside the store loop
+    // each load was its own basic block with a full wait: 16 serialized round trips per tile,
+    // half of the kernel's time: tools/stamp_wide.py.)  Padded slots carry the clamped index
+    // of the tile's last row.
+    const bool res_rows = p.y != nullptr && p.res.ptr != nullptr && p.vec_y && NO == D;
+    f32x4 vRes[NV];
     const Ctx nxt = load_ctx(tt + tstride, total);   // (lands during this tile's work)
     if (p.b.ptr) {
       f32x4 vB[NV];
@@ -229,23 +267,31 @@ __global__ __launch_bounds__(256) void tail_fwd_kernel(TailFwdParams p) {
 #pragma unroll
       for (int k = 0; k < NV; ++k) vA[k] += vB[k];
     }
+    // (requested AFTER the gathers were waited for: memory operations retire in order, and the
+    // residual rows are not needed before the end of the tile)
+    if (res_rows) load_rows_i<NV>(vRes, p.res.ptr + b * p.res.bstride, p.res.ld, iy, D, lane);
     if (p.h_out != nullptr)
       store_rows_regs<NV>(p.h_out + b * p.h_bstride + (int64_t)w.p0 * D, D, D, ne, lane, vA);
+    WSTAMP(0)   // slot tables, row gathers a / b / c issued + landed + summed, h rows stored
     put_rows_v<NV, false>(tile, LDT, 0, D, ne, lane, vA);
     wave_sync();
     f32x16 a1[NB];
     tile_to_acc<NB>(a1, tile, LDT, lane);
+    WSTAMP(1)   // h tile staged + back in accumulator layout
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) a1[nb][r] = nlam_silu(a1[nb][r]);
     f32x16 m[NOUTB];
     vec_to_acc<NOUTB>(m, b2s, lane);
+    WSTAMP(2)   // silu
     gemm_acc_b3<NOUTB, NB, TERMS>(m, W2im, 0, a1, lane);
+    WSTAMP(3)   // GEMM (W2 silu(h) + b2)
     if (HAS_LN) ln_apply<NOUTB>(m, gs, bs, lane);
     wave_sync();
     acc_to_tile<NOUTB>(m, tile, LDT, lane);
     wave_sync();
+    WSTAMP(4)   // LayerNorm + message tile
     if (p.agg != nullptr) {
       float* aggb = p.agg + b * p.agg_bstride;
       const int t = lane & 31;
@@ -274,14 +320,28 @@ __global__ __launch_bounds__(256) void tail_fwd_kernel(TailFwdParams p) {
         }
       }
     }
+    WSTAMP(5)   // receiver sums
     if (p.y != nullptr) {
       // scattered rows (idx_y) are float4-only (checked on the host); narrow outputs are
       // contiguous rows and take the scalar path
       float* yb = p.y + b * p.y_bstride;
       const float* rb = p.res.ptr ? p.res.ptr + b * p.res.bstride : nullptr;
       if (p.vec_y && NO == D) {
-        if (rb) store_rows_i<NV, true>(tile, LDT, 0, D, ne, lane, yb, p.y_ld, iy, rb, p.res.ld);
-        else store_rows_i<NV, false>(tile, LDT, 0, D, ne, lane, yb, p.y_ld, iy);
+        if (rb) {
+          // (residual rows: requested at the top of the tile)
+          constexpr int lpr = D >> 2, rpi = 64 / lpr;
+          const int sub = lane / lpr, c4 = lane - sub * lpr;
+#pragma unroll
+          for (int k = 0; k < NV; ++k) {
+            const int tr = sub + k * rpi;
+            if (tr < ne) {
+              const f32x4 x = *(reinterpret_cast<const f32x4*>(tile + tr * LDT) + c4) + vRes[k];
+              reinterpret_cast<f32x4*>(yb + (int64_t)iy[k] * p.y_ld)[c4] = x;
+            }
+          }
+        } else {
+          store_rows_i<NV, false>(tile, LDT, 0, D, ne, lane, yb, p.y_ld, iy);
+        }
       } else {
         auto y_row = [&](int s) { return yb + (int64_t)(w.p0 + s) * p.y_ld; };
         auto r_row = [&](int s) { return rb + (int64_t)(w.p0 + s) * p.res.ld; };
@@ -295,7 +355,14 @@ __global__ __launch_bounds__(256) void tail_fwd_kernel(TailFwdParams p) {
       }
     }
     wave_sync();
+    WSTAMP(6)   // row stores (+ residual)
     cur = nxt;
+  }
+  if constexpr (STAMP) {
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) atomicAdd(&g_wide_stamps[k], wst[k]);
+    }
   }
 }
 
@@ -313,6 +380,7 @@ static int launch_tail_fwd(const TailFwdParams& p, hipStream_t s) {
                      (size_t)4 * 4 * NLAM_TILE * sizeof(int);
   NLAM_REQUIRE(lds <= 160 * 1024, "tail_fwd: LDS footprint %zu B exceeds 160 KiB", lds);
   auto kern = tail_fwd_kernel<D, NOUTB, HAS_LN, TERMS>;
+  if (HAS_LN && TERMS == 3 && p.stamp) kern = tail_fwd_kernel<D, NOUTB, HAS_LN, TERMS, HAS_LN && TERMS == 3>;
   NLAM_BIG_LDS(kern, "tail_fwd_kernel");
   kern<<<wide_grid(p.tl.ntiles * p.B), 256, lds, s>>>(p);
   NLAM_CHECK_LAUNCH("tail_fwd_kernel");
@@ -373,6 +441,7 @@ extern "C" int nlam_tail_fwd(
   p.B = (int)B;
   p.vec_y = (y != nullptr && view_vec_ok(y, y_bstride, y_ld, n_out) &&
              (res == nullptr || view_vec_ok(res, res_bstride, res_ld, n_out))) ? 1 : 0;
+  p.stamp = wide_stamp_flag();
   NLAM_REQUIRE(idx_y == nullptr || y == nullptr || (p.vec_y && n_out == d),
                "nlam_tail_fwd: scattered output rows must be 16-byte aligned and d wide");
   hipStream_t s = (hipStream_t)stream;
@@ -396,9 +465,10 @@ struct TailBwdParams {
   float* slab; int64_t slab_stride;
   int B;
   int vec_g;                                             // g1 / g2 rows float4-loadable
+  int stamp;                                             // NLAM_STAMP_WIDE=1
 };
 
-template <int D, int NOUTB, bool HAS_LN, int TERMS>
+template <int D, int NOUTB, bool HAS_LN, int TERMS, bool STAMP = false>
 __global__ __launch_bounds__(256) void tail_bwd_kernel(TailBwdParams q) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NB = D / 32, NV = D / 8, NO = 32 * NOUTB, NVG = NO / 8;
@@ -460,6 +530,8 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(TailBwdParams q) {
 #pragma unroll
   for (int j = 0; j < NV_O; ++j) dgam[j] = dbet[j] = 0.f;
   const B3Tile Tp = b3_tile(tile, NO);   // bf16-plane view of the tile (column sums)
+  unsigned long long wst[STAMP ? 8 : 1] = {0};
+  unsigned long long wprev = STAMP ? __builtin_amdgcn_s_memtime() : 0;
   for (; tt < total; tt += tstride) {
     const int64_t b = tt / q.tl.ntiles;
     const WTile w = cur.w;
@@ -490,6 +562,7 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(TailBwdParams q) {
       put_rows_v<NV, false>(tile, LDT, 0, D, ne, lane, vH);
       wave_sync();
     }
+    WSTAMP(0)   // slot tables, h rows requested + landed + staged
     // ---- incoming gradient rows -> tile (their loads fly under the GEMM below)
     f32x4 vG[NVG];
     if (q.vec_g) {
@@ -525,6 +598,7 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(TailBwdParams q) {
       vec_to_acc<NOUTB>(z, b2s, lane);
       gemm_acc_b3<NOUTB, NB, TERMS>(z, W2im, 0, sact, lane);
     }
+    WSTAMP(1)   // gradient rows issued, silu, GEMM (z recomputed)
     wave_sync();
     if (q.vec_g) {
       put_rows_v<NVG, false>(tile, LDT, 0, NO, ne, lane, vG);
@@ -588,6 +662,7 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(TailBwdParams q) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) g[nb][r] = rstd * (g[nb][r] - m1 - z[nb][r] * m2);
     }
+    WSTAMP(2)   // gradient rows staged, LayerNorm backward, dbeta / dgamma column sums
     // g = gz (zero on padded slots / columns): publish it for the weight-gradient pass
     wave_sync();
     acc_to_tile<NOUTB>(g, tile, LDT, lane);
@@ -597,6 +672,7 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(TailBwdParams q) {
       auto gz_row = [&](int s) { return gzb + (int64_t)s * NO; };
       store_rows<true>(tile, LDT, 0, NO, ne, lane, gz_row);
     }
+    WSTAMP(3)   // gz tile + row stores
     // gh = (W2^T gz) * silu'(h)
     f32x16 gh[NB];
 #pragma unroll
@@ -612,6 +688,7 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(TailBwdParams q) {
       put_rows_v<NV, false>(tile, LDT, 0, D, ne, lane, vH);
       wave_sync();
     }
+    WSTAMP(4)   // h rows again + GEMM (W2^T gz)
     {
       f32x16 hpre[NB];
       tile_to_acc<NB>(hpre, tile, LDT, lane);
@@ -629,6 +706,7 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(TailBwdParams q) {
       lane_row_index<NV>(igh, itab + 2 * NLAM_TILE, D, lane);
       store_rows_i<NV, false>(tile, LDT, 0, D, ne, lane, ghb, q.gh_ld, igh);
     }
+    WSTAMP(5)   // silu', gh tile + row stores
     if (q.gpr != nullptr) {
       float* gb = q.gpr + b * q.gpr_bstride;
       const int ri = w.r0 + (lane < w.nr ? lane : w.nr);
@@ -652,9 +730,16 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(TailBwdParams q) {
       }
     }
     wave_sync();
+    WSTAMP(6)   // receiver sums
     cur = nxt;
   }
   (void)t;
+  if constexpr (STAMP) {
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) atomicAdd(&g_wide_stamps[8 + k], wst[k]);
+    }
+  }
   if (HAS_LN) {
     __syncthreads();
     float* img = smem;
@@ -674,6 +759,7 @@ static int launch_tail_bwd(const TailBwdParams& q, hipStream_t s) {
                      (size_t)4 * 4 * NLAM_TILE * sizeof(int);
   NLAM_REQUIRE(lds <= 160 * 1024, "tail_bwd: LDS footprint %zu B exceeds 160 KiB", lds);
   auto kern = tail_bwd_kernel<D, NOUTB, HAS_LN, TERMS>;
+  if (HAS_LN && TERMS == 3 && q.stamp) kern = tail_bwd_kernel<D, NOUTB, HAS_LN, TERMS, HAS_LN && TERMS == 3>;
   NLAM_BIG_LDS(kern, "tail_bwd_kernel");
   kern<<<wide_grid(q.tl.ntiles * q.B), 256, lds, s>>>(q);
   NLAM_CHECK_LAUNCH("tail_bwd_kernel");
@@ -736,6 +822,7 @@ extern "C" int nlam_tail_bwd(
   const int no = (n_out + 31) & ~31;
   q.vec_g = (n_out == no && view_vec_ok(g1, g1_bstride, g1_ld, n_out) &&
              (g2 == nullptr || view_vec_ok(g2, g2_bstride, g2_ld, n_out))) ? 1 : 0;
+  q.stamp = wide_stamp_flag();
   hipStream_t s = (hipStream_t)stream;
   const bool t3 = nlam_mfma_terms() == 3;
   if (gamma != nullptr)
@@ -772,28 +859,53 @@ __device__ __forceinline__ void lin_bwd_data_body(const LinBwdDataParams& q, int
   const int64_t tiles_per_b = (q.rows + NLAM_TILE - 1) / NLAM_TILE;
   const int64_t ntiles = tiles_per_b * q.B;
   const int64_t tt0 = (int64_t)bid * 4 + wave;
-  // prologue: the weight loads and the FIRST tile's rows are in flight together (most launches
-  // of the hierarchical models are one tile per wave), then the LDS image
+  const int64_t tstride = (int64_t)gdim * 4;
+  static_assert(NO == 128 && K == 128, "row mappings below are the 128-wide ones");
+  constexpr int NV = K / 8;   // float4 per lane that cover a 32 x 128 tile (row t = sub + 2 k)
+  const int sub = lane >> 5, c4 = lane & 31;
+  // The gradient rows of tile n + 1 are requested as soon as tile n's registers are staged (their
+  // round trip rides under tile n's MFMAs); past the end the last tile is requested again.
   f32x4 vg[4 * NOUTB];
-  {
-    WLoad16<(NO * K / 4 + 255) / 256> lw;
-    w16_issue(lw, q.W, q.ldW, q.n_out, q.k_in, NO, K, tid, 256);
-    const int64_t tq = tt0 < ntiles ? tt0 : ntiles - 1;
+  auto request = [&](int64_t task) {
+    const int64_t tq = task < ntiles ? task : ntiles - 1;
     const int64_t b = tq / tiles_per_b;
     const int64_t r0 = (tq - b * tiles_per_b) * NLAM_TILE;
     const int nrows = (int)((q.rows - r0) < NLAM_TILE ? (q.rows - r0) : NLAM_TILE);
-    view_load_v<4 * NOUTB>(vg, q.gy, b, r0, nrows, lane);
+    RowView gv = q.gy;
+    gv.width = NO;   // (compile-time row mapping: no per-load branches)
+    view_load_v<4 * NOUTB>(vg, gv, b, r0, nrows, lane);
+  };
+  {
+    // prologue: the weight loads and the FIRST tile's rows are in flight together (most launches
+    // of the hierarchical models are one tile per wave), then the LDS image
+    WLoad16<(NO * K / 4 + 255) / 256> lw;
+    w16_issue(lw, q.W, q.ldW, q.n_out, q.k_in, NO, K, tid, 256);
+    request(tt0);
     __builtin_amdgcn_sched_barrier(0);
     w16_commit(lw, Wim, 0, q.W, q.ldW, q.n_out, q.k_in, NO, K, tid, 256);
   }
   __syncthreads();
-  for (int64_t tt = tt0; tt < ntiles; tt += (int64_t)gdim * 4) {
+  // (nothing in flight at loop entry: the loop-top wait then counts this tile's stores as younger
+  // than the rows it waits for on BOTH paths into the loop header, and does not drain them)
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  // (the loop exists twice, with and without addend: a load under a branch inside the loop would
+  // make the compiler's wait for it a full drain)
+  auto run = [&](auto has_add_t) {
+  constexpr bool has_add = decltype(has_add_t)::value;
+  for (int64_t tt = tt0; tt < ntiles; tt += tstride) {
     const int64_t b = tt / tiles_per_b;
     const int64_t r0 = (tt - b * tiles_per_b) * NLAM_TILE;
     const int nrows = (int)((q.rows - r0) < NLAM_TILE ? (q.rows - r0) : NLAM_TILE);
-    if (tt != tt0) view_load_v<4 * NOUTB>(vg, q.gy, b, r0, nrows, lane);
     const B3Tile Gp = b3_tile(tile, NO);
     put_rows_v_b3<4 * NOUTB>(Gp, 0, NO, nrows, lane, vg);
+    // addend rows of THIS tile (used at its end), then the next tile's gradient rows: memory
+    // operations retire in order, so waiting for the addend does not wait for the younger rows
+    f32x4 va[NV];
+    if constexpr (has_add) {
+      RowView av{q.gx_add, q.ga_bstride, q.ga_ld, K};
+      view_load_v<NV>(va, av, b, r0, nrows, lane);
+    }
+    request(tt + tstride);
     wave_sync();
     f32x16 gx[KB];
 #pragma unroll
@@ -804,17 +916,24 @@ __device__ __forceinline__ void lin_bwd_data_body(const LinBwdDataParams& q, int
     wave_sync();
     acc_to_tile<KB>(gx, tile, LDT, lane);
     wave_sync();
+    // UNCONDITIONAL stores (padded slots repeat the tile's last row: same value, same address):
+    // a store under a branch is not counted by the compiler's wait bookkeeping, and the next
+    // loop-top wait would then drain every store of this tile
     float* ob = q.gx + b * q.gx_bstride + r0 * q.gx_ld;
-    auto op = [&](int t) { return ob + (int64_t)t * q.gx_ld; };
-    if (q.gx_add != nullptr) {
-      const float* ab = q.gx_add + b * q.ga_bstride + r0 * q.ga_ld;
-      auto ap = [&](int t) { return ab + (int64_t)t * q.ga_ld; };
-      store_rows_res<true>(tile, LDT, 0, q.k_in, nrows, lane, op, ap);
-    } else {
-      store_rows<true>(tile, LDT, 0, q.k_in, nrows, lane, op);
+    const int last = nrows - 1;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int t = sub + 2 * k;
+      const int tc = t < last ? t : last;
+      f32x4 x = *(reinterpret_cast<const f32x4*>(tile + tc * LDT) + c4);
+      if constexpr (has_add) x += va[k];
+      reinterpret_cast<f32x4*>(ob + (int64_t)tc * q.gx_ld)[c4] = x;
     }
     wave_sync();
   }
+  };
+  if (q.gx_add != nullptr) run(std::true_type{});
+  else run(std::false_type{});
 }
 
 template <int NOUTB, int KB, int TERMS>
@@ -964,23 +1083,32 @@ __device__ __forceinline__ void wide_outer_body(const WideOuterParams& q, int bi
   TGp.pitch = ldg; TGp.hi = reinterpret_cast<__bf16*>(TG); TGp.lo = TGp.hi + NLAM_TILE * ldg;
   TXp.pitch = ldx; TXp.hi = reinterpret_cast<__bf16*>(TX); TXp.lo = TXp.hi + NLAM_TILE * ldx;
   const bool silu_x = q.silu_x != 0;
-  for (int64_t tt = (int64_t)bid * 4 + wave; tt < ntiles; tt += (int64_t)gdim * 4) {
+  constexpr int NVX = NXB >= 4 ? 4 * NXB : 8;   // float4 per lane that cover 32 rows of x
+  bool x_vec = true;   // (128-wide x: always float4 rows, checked on the host)
+  if constexpr (NXB < 4) x_vec = q.x_vec != 0;
+  RowView xv = q.x;
+  if constexpr (NXB >= 4) xv.width = NX;   // compile-time row mapping for the 128-wide form
+  // The rows of tile n + 1 are requested as soon as tile n's registers are staged, so their
+  // round trip rides under tile n's MFMAs (one wave per SIMD: nobody else hides it).  Past the
+  // end the last tile is requested again and never used.
+  f32x4 vg[4 * NGB];
+  f32x4 vx[NVX];
+  auto request = [&](int64_t task) {
+    const int64_t tq = task < ntiles ? task : ntiles - 1;
+    const int64_t b = tq / tiles_per_b;
+    const int64_t r0 = (tq - b * tiles_per_b) * NLAM_TILE;
+    const int nrows = (int)((q.rows - r0) < NLAM_TILE ? (q.rows - r0) : NLAM_TILE);
+    view_load_v<4 * NGB>(vg, q.g, b, r0, nrows, lane);
+    if (x_vec) view_load_v<NVX>(vx, xv, b, r0, nrows, lane);
+  };
+  const int64_t tstride = (int64_t)gdim * 4;
+  request((int64_t)bid * 4 + wave);
+  for (int64_t tt = (int64_t)bid * 4 + wave; tt < ntiles; tt += tstride) {
     const int64_t b = tt / tiles_per_b;
     const int64_t r0 = (tt - b * tiles_per_b) * NLAM_TILE;
     const int nrows = (int)((q.rows - r0) < NLAM_TILE ? (q.rows - r0) : NLAM_TILE);
-    constexpr int NVX = NXB >= 4 ? 4 * NXB : 8;   // float4 per lane that cover 32 rows of x
-    {
-      f32x4 vg[4 * NGB];
-      view_load_v<4 * NGB>(vg, q.g, b, r0, nrows, lane);
-      put_rows_v_b3<4 * NGB>(TGp, 0, NG, nrows, lane, vg);
-    }
-    bool x_vec = true;   // (128-wide x: always float4 rows, checked on the host)
-    if constexpr (NXB < 4) x_vec = q.x_vec != 0;
+    put_rows_v_b3<4 * NGB>(TGp, 0, NG, nrows, lane, vg);
     if (x_vec) {
-      f32x4 vx[NVX];
-      RowView xv = q.x;
-      if constexpr (NXB >= 4) xv.width = NX;   // compile-time row mapping for the 128-wide form
-      view_load_v<NVX>(vx, xv, b, r0, nrows, lane);
       if (silu_x) {
 #pragma unroll
         for (int k = 0; k < NVX; ++k)
@@ -1007,6 +1135,7 @@ __device__ __forceinline__ void wide_outer_body(const WideOuterParams& q, int bi
         TXp.lo[tr * TXp.pitch + cc] = (__bf16)(v - (float)hi);
       }
     }
+    request(tt + tstride);
     wave_sync();
     tile_colsum_b3<NV, TERMS>(db, TGp, 0, lane);
     outer_accum_b3<NGB, NXB, TERMS>(dW, TGp, 0, TXp, 0, lane);
@@ -1151,7 +1280,20 @@ __device__ __forceinline__ void wide_lin_fwd_body(const WideLinParams& p, int bi
   const int64_t tiles_per_b = (p.rows + NLAM_TILE - 1) / NLAM_TILE;
   const int64_t ntiles = tiles_per_b * p.B;
   const int64_t tt0 = (int64_t)bid * 4 + wave;
-  f32x4 vx[8 * KB];
+  const int64_t tstride = (int64_t)gdim * 4;
+  constexpr int NV = NO / 8;
+  const int sub = lane >> 5, c4 = lane & 31;
+  // rows of tile n + 1 requested as soon as tile n's registers are staged (see lin_bwd_data_body)
+  f32x4 vx[4 * KB];
+  auto request = [&](int64_t task) {
+    const int64_t tq = task < ntiles ? task : ntiles - 1;
+    const int64_t b = tq / tiles_per_b;
+    const int64_t r0 = (tq - b * tiles_per_b) * NLAM_TILE;
+    const int nrows = (int)((p.rows - r0) < NLAM_TILE ? (p.rows - r0) : NLAM_TILE);
+    RowView xv = p.x;
+    xv.width = K;   // (compile-time row mapping: no per-load branches)
+    view_load_v<4 * KB>(vx, xv, b, r0, nrows, lane);
+  };
   {   // weights, bias and the first tile's rows in flight together, then the LDS image
     static_assert(NO <= 256, "one vector entry per thread");
     VecLoads<1> lv;
@@ -1160,23 +1302,20 @@ __device__ __forceinline__ void wide_lin_fwd_body(const WideLinParams& p, int bi
     vecs_issue(lv, vsrc, NO, tid);
     WLoad16<(NO * K / 4 + 255) / 256> lw;
     w16_issue(lw, p.W, p.ldW, NO, K, NO, K, tid, 256);
-    const int64_t tq = tt0 < ntiles ? tt0 : ntiles - 1;
-    const int64_t b = tq / tiles_per_b;
-    const int64_t r0 = (tq - b * tiles_per_b) * NLAM_TILE;
-    const int nrows = (int)((p.rows - r0) < NLAM_TILE ? (p.rows - r0) : NLAM_TILE);
-    view_load_v<8 * KB>(vx, p.x, b, r0, nrows, lane);
+    request(tt0);
     __builtin_amdgcn_sched_barrier(0);
     w16_commit(lw, W, 0, p.W, p.ldW, NO, K, NO, K, tid, 256);
     vecs_commit(lv, vdst, NO, tid);
   }
   __syncthreads();
-  for (int64_t tt = tt0; tt < ntiles; tt += (int64_t)gdim * 4) {
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // (nothing in flight at loop entry: lin_bwd_data_body)
+  for (int64_t tt = tt0; tt < ntiles; tt += tstride) {
     const int64_t b = tt / tiles_per_b;
     const int64_t r0 = (tt - b * tiles_per_b) * NLAM_TILE;
     const int nrows = (int)((p.rows - r0) < NLAM_TILE ? (p.rows - r0) : NLAM_TILE);
-    if (tt != tt0) view_load_v<8 * KB>(vx, p.x, b, r0, nrows, lane);
     const B3Tile Xp = b3_tile(tile, K);
-    put_rows_v_b3<8 * KB>(Xp, 0, K, nrows, lane, vx);
+    put_rows_v_b3<4 * KB>(Xp, 0, K, nrows, lane, vx);
+    request(tt + tstride);
     wave_sync();
     f32x16 a[NOUTB];
     vec_to_acc<NOUTB>(a, bs, lane);
@@ -1184,9 +1323,16 @@ __device__ __forceinline__ void wide_lin_fwd_body(const WideLinParams& p, int bi
     wave_sync();
     acc_to_tile<NOUTB>(a, tile, ldt, lane);
     wave_sync();
+    // unconditional stores; padded slots repeat the tile's last row (lin_bwd_data_body)
     float* ob = p.out + b * p.out_bstride + r0 * p.out_ld;
-    auto op = [&](int t) { return ob + (int64_t)t * p.out_ld; };
-    store_rows<true>(tile, ldt, 0, NO, nrows, lane, op);
+    const int last = nrows - 1;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int t = sub + 2 * k;
+      const int tc = t < last ? t : last;
+      reinterpret_cast<f32x4*>(ob + (int64_t)tc * p.out_ld)[c4] =
+          *(reinterpret_cast<const f32x4*>(tile + tc * ldt) + c4);
+    }
     wave_sync();
   }
 }
