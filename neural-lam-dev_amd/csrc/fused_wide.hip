@@ -905,7 +905,10 @@ __device__ __forceinline__ void lin_bwd_data_body(const LinBwdDataParams& q, int
       RowView av{q.gx_add, q.ga_bstride, q.ga_ld, K};
       view_load_v<NV>(va, av, b, r0, nrows, lane);
     }
-    request(tt + tstride);
+    // (no-addend loop: a wave's last tile requests nothing -- loads in flight at the end hold the
+    // wave for a round trip; with an addend the request stays unconditional, or the wait for the
+    // addend rows would cover it)
+    if (has_add || tt + tstride < ntiles) request(tt + tstride);
     wave_sync();
     f32x16 gx[KB];
 #pragma unroll
@@ -1089,8 +1092,7 @@ __device__ __forceinline__ void wide_outer_body(const WideOuterParams& q, int bi
   RowView xv = q.x;
   if constexpr (NXB >= 4) xv.width = NX;   // compile-time row mapping for the 128-wide form
   // The rows of tile n + 1 are requested as soon as tile n's registers are staged, so their
-  // round trip rides under tile n's MFMAs (one wave per SIMD: nobody else hides it).  Past the
-  // end the last tile is requested again and never used.
+  // round trip rides under tile n's MFMAs (one wave per SIMD: nobody else hides it).
   f32x4 vg[4 * NGB];
   f32x4 vx[NVX];
   auto request = [&](int64_t task) {
@@ -1135,7 +1137,7 @@ __device__ __forceinline__ void wide_outer_body(const WideOuterParams& q, int bi
         TXp.lo[tr * TXp.pitch + cc] = (__bf16)(v - (float)hi);
       }
     }
-    request(tt + tstride);
+    if (tt + tstride < ntiles) request(tt + tstride);   // (nothing for a wave's last tile)
     wave_sync();
     tile_colsum_b3<NV, TERMS>(db, TGp, 0, lane);
     outer_accum_b3<NGB, NXB, TERMS>(dW, TGp, 0, TXp, 0, lane);
@@ -1315,7 +1317,7 @@ __device__ __forceinline__ void wide_lin_fwd_body(const WideLinParams& p, int bi
     const int nrows = (int)((p.rows - r0) < NLAM_TILE ? (p.rows - r0) : NLAM_TILE);
     const B3Tile Xp = b3_tile(tile, K);
     put_rows_v_b3<4 * KB>(Xp, 0, K, nrows, lane, vx);
-    request(tt + tstride);
+    if (tt + tstride < ntiles) request(tt + tstride);   // (nothing for a wave's last tile)
     wave_sync();
     f32x16 a[NOUTB];
     vec_to_acc<NOUTB>(a, bs, lane);
