@@ -113,14 +113,28 @@ def parse():
     return ap.parse_args()
 
 
+def single_rank_rccl():
+    """NLAM_BENCH_SINGLE_RANK_RCCL=1 (N = 1 only): take the multi-rank code path with a ONE-rank
+    RCCL group -- process-group init on the device, parameter broadcast, hook-issued bucket
+    all-reduces on the side stream, the eager-vs-graph probe, barriers and the MAX over ranks all
+    execute on a one-GPU box.  The reported line is still an N = 1 measurement (n_gpus 1)."""
+    return (os.environ.get("NLAM_BENCH_SINGLE_RANK_RCCL") == "1"
+            and int(os.environ.get("WORLD_SIZE", "1")) == 1)
+
+
 def setup_dist(args):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     ndev = max(1, torch.cuda.device_count())
     dev_index = local % ndev   # one rank per GPU; rehearsals may stack ranks on one card
-    if world > 1:
+    if world > 1 or single_rank_rccl():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(dev_index)
         # RCCL ("nccl") over xGMI is the product path; NLAM_BENCH_BACKEND=gloo only exists
@@ -339,7 +353,8 @@ def main():
     model, info = build(args, tmp)
     model = model.to(dev)
     flat = parallel.FlatParams(model)
-    reducer = parallel.GradAllReduce(flat)
+    multi = world > 1 or single_rank_rccl()   # (a process group exists, collectives are issued)
+    reducer = parallel.GradAllReduce(flat, single_rank_collectives=single_rank_rccl())
     reducer.broadcast_params()
     opt = parallel.FlatAdamW(flat, lr=1e-3)
     B, T = args.batch, args.ar_steps
@@ -355,7 +370,7 @@ def main():
         return loss
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
 
     graphed = None
@@ -372,7 +387,7 @@ def main():
     backend_name = os.environ.get("NLAM_BENCH_BACKEND", "nccl")
     multirank_graph = os.environ.get(
         "NLAM_BENCH_MULTIRANK_GRAPH", "probe" if backend_name == "nccl" else "off") == "probe"
-    if not args.no_graph and (world == 1 or multirank_graph):
+    if not args.no_graph and (not multi or multirank_graph):
         reducer.hooks_enabled = False      # no collectives inside the capture
         graphed = parallel.GraphedTrainStep(model, flat, batch)
         reducer.hooks_enabled = True
@@ -384,7 +399,7 @@ def main():
             return loss
 
     use_graph = graphed is not None and graphed.graph is not None
-    if use_graph and world > 1:
+    if use_graph and multi:
         # Two schedules for a multi-rank step: (a) eager launches, gradient buckets all-reduced
         # from backward hooks (overlap, but ~40 us of host time per launch: Hi-LAM at hidden 64
         # is then host-bound), (b) HIP-graph replay of forward + backward + packing, buckets
@@ -411,8 +426,8 @@ def main():
             torch.cuda.empty_cache()
     reducer.hooks_enabled = not use_graph
     if use_graph:
-        launch["mode"] = "hip_graph" if world == 1 else "hip_graph+trailing_allreduce"
-    elif world > 1 and reducer.overlap:
+        launch["mode"] = "hip_graph" if not multi else "hip_graph+trailing_allreduce"
+    elif multi and reducer.overlap:
         launch["mode"] = "eager+overlapped_allreduce"
     timed_step = gstep if use_graph else step
 
@@ -434,7 +449,7 @@ def main():
         barrier()
         torch.cuda.synchronize()
         w = time.perf_counter() - t0
-        if world > 1:
+        if multi:
             t = torch.tensor([w], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             w = float(t.item())
@@ -583,8 +598,9 @@ def main():
             "all_receiver_updates_per_s": world * B * T * all_receiver_updates(args, info)
             / (elapsed / args.steps),
             "hip_graph": bool(use_graph), "launch": launch,
-            "rccl_ranks": dist.get_world_size() if world > 1 else 1,
-            "backend": (dist.get_backend() if world > 1 else None),
+            "single_rank_rccl": single_rank_rccl(),
+            "rccl_ranks": dist.get_world_size() if multi else 1,
+            "backend": (dist.get_backend() if multi else None),
             "grad_allreduce": reducer.describe(),
             "roofline": roofline, "layer_roofline": layer, "scatter_add_roofline": scatter,
             "cpu_baseline": cpu,
@@ -596,7 +612,7 @@ def main():
         if cpu:
             out["speedup_vs_cpu_baseline"] = value / cpu["value"]
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
     tmpdir.cleanup()
 

@@ -174,15 +174,19 @@ class GradAllReduce:
     the two schedules give bit-identical results."""
 
     def __init__(self, flat, bucket_bytes=32 << 20, group=None, overlap=None,
-                 min_overlap_bytes=4 << 20):
+                 min_overlap_bytes=4 << 20, single_rank_collectives=False):
         self.flat = flat
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # single_rank_collectives: issue every collective even in a ONE-rank group -- the RCCL
+        # calls, streams and hooks of the multi-GPU path executed on a one-GPU box (a one-rank
+        # all-reduce returns its input: results are those of the plain path)
+        self.active = self.world > 1 or (bool(single_rank_collectives) and dist.is_initialized())
         sizes = [p.numel() for p in flat.params]
         self.bucket_bytes = bucket_bytes
         self.ranges = bucket_ranges(sizes, max(1, bucket_bytes // 4))
         if overlap is None:
-            overlap = self.world > 1 and flat.numel * 4 >= min_overlap_bytes
+            overlap = self.active and flat.numel * 4 >= min_overlap_bytes
         self.overlap = bool(overlap)
         self.side = None
         self._handles = []
@@ -210,7 +214,7 @@ class GradAllReduce:
                 "overlap_with_backward": self.overlap}
 
     def broadcast_params(self, src=0):
-        if self.world > 1:
+        if self.active:
             dist.broadcast(self.flat.flat, src=src, group=self.group)
 
     # ---- overlap machinery ---------------------------------------------------
@@ -228,7 +232,7 @@ class GradAllReduce:
                 return   # the same parameter again (re-entrant backward): counted once
             self._seen[i] = True
             self._left[bi] -= 1
-            if self._left[bi] == 0 and self.world > 1:
+            if self._left[bi] == 0 and self.active:
                 self._launch(bi, in_backward=True)
         return hook
 
@@ -260,7 +264,7 @@ class GradAllReduce:
         """Pack (unless the caller already did) + all-reduce every bucket that backward's
         hooks have not issued yet; returns when all are complete on the current stream."""
         f = self.flat
-        if self.world == 1:
+        if not self.active:
             if not packed:
                 f.pack_grads()
             self._reset()

@@ -92,3 +92,36 @@ def test_gpus_1_is_the_default_path():
     for key in ("metric", "unit", "n_gpus", "config", "launch", "hip_graph", "rccl_ranks", "backend",
                 "dtype", "loss"):
         assert a[key] == b[key], key
+
+
+@pytest.mark.parametrize("model_args,overlap", [
+    ((), False),                                            # GraphLAM-64: 0.86 MB, one collective
+    (("--model", "hi_lam", "--hidden-dim", "128"), True),   # 22 MB: buckets issued from hooks
+])
+def test_single_rank_rccl_rehearsal(model_args, overlap):
+    """The RCCL ("nccl") branch of bench.py EXECUTED on the one card of the test box: a one-rank
+    process group on the device, parameter broadcast, bucket all-reduces (hook-issued on the side
+    stream for the 22 MB payload), the eager-vs-graph probe, barriers and the MAX over ranks.
+    (Bit-identity of a step under one-rank collectives: tests/test_gpu_dp.py.)"""
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1",
+            "--windows", "1", "--no-fp32-compare", "--no-cpu-baseline", "--no-other-configs",
+            "--no-kernel-timing", *model_args]
+    lines = []
+    for env_extra in ({"NLAM_BENCH_SINGLE_RANK_RCCL": "1"}, {}):
+        env = {k: v for k, v in os.environ.items() if k != "NLAM_BENCH_SINGLE_RANK_RCCL"}
+        env.update(env_extra)
+        out = subprocess.run(base, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+        assert out.returncode == 0, out.stderr[-3000:]
+        lines.append(json.loads(out.stdout.strip().splitlines()[-1]))
+    rccl, plain = lines
+    assert rccl["backend"] == "nccl" and rccl["rccl_ranks"] == 1 and rccl["n_gpus"] == 1
+    assert rccl["single_rank_rccl"] is True and plain["backend"] is None
+    assert rccl["grad_allreduce"]["overlap_with_backward"] is overlap
+    # both schedules of a multi-rank step ran (and were timed) under RCCL
+    probe = rccl["launch"]["probe_ms"]
+    assert probe["eager_overlap"] > 0 and probe["hip_graph_trailing_allreduce"] > 0
+    assert rccl["launch"]["mode"] in ("hip_graph+trailing_allreduce", "eager+overlapped_allreduce",
+                                      "eager")
+    # (the probe runs extra optimiser steps before the timed ones: compare the step COUNT first)
+    assert rccl["ms_per_step"] > 0 and rccl["loss"] == rccl["loss"]
+    assert rccl["value"] > 0.5 * plain["value"], (rccl["ms_per_step"], plain["ms_per_step"])

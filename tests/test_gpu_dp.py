@@ -198,3 +198,75 @@ def test_overlapped_buckets_on_device_tensors_bit_identical(backend):
         assert stats["launched_in_backward"] > 0, stats
         assert stats["launched_in_backward"] + stats["launched_in_reduce"] == 3 * nbuckets
         assert stats_off["launched_in_backward"] == 0
+
+
+def _one_rank_rccl_worker(rank, world, port, tmp, q, backend):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from neural_lam_amd import parallel, synthetic
+
+    out = {}
+    for overlap in (False, True):
+        model, n = _build(tmp)
+        model = model.cuda()
+        flat = parallel.FlatParams(model)
+        # (small buckets: several collectives, several of them issued from backward hooks)
+        red = parallel.GradAllReduce(flat, bucket_bytes=64 << 10, overlap=overlap,
+                                     single_rank_collectives=True)
+        assert red.active and len(red.ranges) > 2
+        red.broadcast_params()
+        opt = parallel.FlatAdamW(flat, lr=1e-2)
+        full = synthetic.random_batch(4, 2, n, n_state=5, n_forcing_window=6, seed=3, device="cuda")
+        for _ in range(2):
+            flat.zero_grad()
+            model.training_step(full).backward()
+            red.reduce()
+            opt.step(grad_scale=1.0)
+        torch.cuda.synchronize()
+        out[overlap] = (flat.grad.cpu(), flat.flat.cpu(), dict(red.stats))
+    t = torch.ones(4, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.barrier()
+    q.put((0, {k: (v[0].tolist(), v[1].tolist(), v[2]) for k, v in out.items()}, None))
+    dist.destroy_process_group()
+
+
+def test_one_rank_rccl_collectives_leave_the_step_unchanged():
+    """The RCCL ("nccl") backend itself, executed on the one card of the test box: a one-rank
+    group created on the device, parameter broadcast, the flat gradient buckets all-reduced as ONE
+    trailing pass and as hook-issued collectives on the side stream during backward, then MAX
+    all-reduce + barrier (the bench's timing protocol).  A one-rank all-reduce returns its input,
+    so gradients and weights after two optimiser steps must be BIT-identical to the plain
+    single-process step's -- any mis-ordered stream wait or mis-sliced bucket view shows."""
+    from neural_lam_amd import parallel, synthetic
+
+    with tempfile.TemporaryDirectory() as tmp:
+        _make_graph(tmp)
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_guarded,
+                             args=("_one_rank_rccl_worker", 0, 1, _free_port(), tmp, q, "nccl"))]
+        procs[0].start()
+        res = _collect(procs, q, 1)[0][1]
+        model, n = _build(tmp)
+    model = model.cuda()
+    flat = parallel.FlatParams(model)
+    opt = parallel.FlatAdamW(flat, lr=1e-2)
+    full = synthetic.random_batch(4, 2, n, n_state=5, n_forcing_window=6, seed=3, device="cuda")
+    for _ in range(2):
+        flat.zero_grad()
+        model.training_step(full).backward()
+        flat.pack_grads()
+        opt.step(grad_scale=1.0)
+    want_g, want_w = flat.grad.cpu(), flat.flat.cpu()
+    for overlap in (False, True):
+        g, w, stats = res[overlap]
+        assert torch.equal(torch.tensor(g), want_g), overlap
+        assert torch.equal(torch.tensor(w), want_w), overlap
+        if overlap:
+            assert stats["launched_in_backward"] > 0, stats
+        else:
+            assert stats["launched_in_backward"] == 0 and stats["launched_in_reduce"] > 0, stats
