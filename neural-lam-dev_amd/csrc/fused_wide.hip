@@ -950,17 +950,30 @@ __global__ __launch_bounds__(256) void lin_bwd_data_kernel(WideMulti<LinBwdDataP
 // grid shares of the problems of a multi launch: wide_grid() each, scaled down to <= 512 in all
 template <typename P, typename TilesOf>
 static unsigned wide_multi_grid(WideMulti<P>& m, TilesOf tiles_of) {
-  int64_t want[NLAM_WIDE_MAXP], sum = 0;
+  // Workgroups per problem: proportional to the problems' WORK (tile rounds), at most 256 in all
+  // -- one workgroup is resident per CU (LDS), so a 257th would wait for a whole share to finish
+  // -- never more than a problem has rounds, at least one each; what rounding leaves over goes
+  // to the largest problem.  (Equal shares of the capped wants gave an edge problem and two node
+  // problems a third of the device each although the edge rows are 8 x the node rows, and more
+  // than 256 workgroups queued the node problems behind the edge problem.)
+  int64_t rounds[NLAM_WIDE_MAXP], g[NLAM_WIDE_MAXP], sum = 0, used = 0;
+  int big = 0;
   for (int k = 0; k < m.n; ++k) {
-    want[k] = wide_grid(tiles_of(m.p[k]));
-    sum += want[k];
+    rounds[k] = (tiles_of(m.p[k]) + 4 - 1) / 4;
+    if (rounds[k] < 1) rounds[k] = 1;
+    sum += rounds[k];
+    if (rounds[k] > rounds[big]) big = k;
   }
+  const int64_t cap = 256;
+  for (int k = 0; k < m.n; ++k) {
+    g[k] = sum > cap ? (rounds[k] * cap) / sum : rounds[k];
+    if (g[k] < 1) g[k] = 1;
+    used += g[k];
+  }
+  if (sum > cap && used < cap) g[big] += cap - used;
+  if (g[big] > rounds[big]) g[big] = rounds[big];
   m.first[0] = 0;
-  for (int k = 0; k < m.n; ++k) {
-    int64_t g = sum > 512 ? (want[k] * 512 + sum - 1) / sum : want[k];
-    if (g < 1) g = 1;
-    m.first[k + 1] = m.first[k] + (int)g;
-  }
+  for (int k = 0; k < m.n; ++k) m.first[k + 1] = m.first[k] + (int)g[k];
   for (int k = m.n; k < NLAM_WIDE_MAXP; ++k) m.first[k + 1] = m.first[m.n];
   return (unsigned)m.first[m.n];
 }

@@ -284,7 +284,7 @@ def outer_multi(problems):
     # is d*d floats written and read back, so 7 x 256 of them would out-weigh the operands
     tiles = [g.B * ((g.rows + 31) // 32) for g, _, _, _, _ in problems]
     total = max(1, sum(tiles))
-    budget = max(512, 64 * n)
+    budget = max(int(os.environ.get('NLAM_OUTER_BUDGET', '512')), 64 * n)
     slabs, ns = [], []
     for t in tiles:
         nsl = max(1, min(int(lib.nlam_bwd_grid(t)), -(-budget * t // total)))
