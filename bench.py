@@ -455,7 +455,7 @@ def main():
             w = float(t.item())
         window_s.append(w)
     elapsed = sorted(window_s)[len(window_s) // 2]
-    loss_val = float(loss)
+    loss_val = float(loss.detach())
 
     # per-kernel HIP-event pass (same steps, events bracket every C-ABI launch on the
     # launch stream); kept out of the timed region above so `value` is unperturbed

@@ -280,11 +280,13 @@ def outer_multi(problems):
     n = len(problems)
     dev = problems[0][2].device
     stride = d * d + d
-    # slabs (= workgroups) per problem: proportional to the row counts, ~512 in all -- every slab
-    # is d*d floats written and read back, so 7 x 256 of them would out-weigh the operands
+    # slabs (= workgroups) per problem: proportional to the row counts, one round of the device
+    # (256; one workgroup is resident per CU) or 64 per problem in all -- every slab is d*d floats
+    # written and read back.  Measured on Hi-LAM-128 / -256: 512 in all 20.22 / 32.97 ms, 256:
+    # 19.89 / 32.19; an average below 64 per problem 20.7 / 33.8
     tiles = [g.B * ((g.rows + 31) // 32) for g, _, _, _, _ in problems]
     total = max(1, sum(tiles))
-    budget = max(int(os.environ.get('NLAM_OUTER_BUDGET', '512')), 64 * n)
+    budget = max(256, 64 * n)
     slabs, ns = [], []
     for t in tiles:
         nsl = max(1, min(int(lib.nlam_bwd_grid(t)), -(-budget * t // total)))
