@@ -271,6 +271,11 @@ def lin_bwd_data_multi(problems):
     )
 
 
+# slabs of a weight-gradient launch: in all / average floor per problem (tunables; see outer_multi)
+_OUTER_BUDGET = int(os.environ.get("NLAM_OUTER_BUDGET", "256"))
+_OUTER_FLOOR = int(os.environ.get("NLAM_OUTER_FLOOR", "64"))
+
+
 def outer_multi(problems):
     """[(g Mat (.., d), x Mat (.., d), dW view, db, silu_x)] -> one launch + the layer's slab
     reduction (all d x d)."""
@@ -286,7 +291,7 @@ def outer_multi(problems):
     # 19.89 / 32.19; an average below 64 per problem 20.7 / 33.8
     tiles = [g.B * ((g.rows + 31) // 32) for g, _, _, _, _ in problems]
     total = max(1, sum(tiles))
-    budget = max(256, 64 * n)
+    budget = max(_OUTER_BUDGET, _OUTER_FLOOR * n)
     slabs, ns = [], []
     for t in tiles:
         nsl = max(1, min(int(lib.nlam_bwd_grid(t)), -(-budget * t // total)))
