@@ -7,6 +7,7 @@
 // One wavefront owns a tile of 32 rows (fused_common.h); a 256-thread workgroup
 // keeps the weights in LDS and walks tiles persistently.  Forward saves nothing;
 // backward recomputes the hidden activations from the inputs.
+#include <type_traits>
 #include <cstdlib>
 #include "fused_common.h"
 #include "fused_bf16x3.h"
@@ -1363,21 +1364,27 @@ static inline bool reduce_seg_fits(int64_t nslabs, int64_t stride, int64_t src_o
 // 1 when a small layer has a handful: a 256 x 256 gradient is 1,024 workgroups per matrix, and
 // 16-wave workgroups of which 15 waves had no slab made the reduction of an 81-node level of
 // Hi-LAM-256 take 57 us).
-template <int G>
+// V4: every segment is float4-addressable (host-checked): a lane owns FOUR consecutive outputs, a
+// wavefront reads 1 KB of every slab per load instead of 256 B (slabs are 64 KB - 256 KB apart:
+// with 4-byte lanes every wave-load opened a new DRAM page for 256 bytes, 2.0 TB/s on the 120 MB
+// of a hidden-256 layer).
+template <int G, bool V4>
 __global__ __launch_bounds__(64 * G) void reduce_slabs_multi_kernel(ReduceSegs q) {
-  // 64 consecutive outputs per workgroup (256-byte rows of every slab), G sub-groups that
-  // split the slabs; eight slab loads in flight per thread (clamped + masked, so they issue
-  // back to back); the summation order is fixed by the launch shape
-  __shared__ float red[G][65];
+  // 64 (V4: 256) consecutive outputs per workgroup, G sub-groups that split the slabs; eight slab
+  // loads in flight per thread (clamped + masked, so they issue back to back); the summation
+  // order is fixed by the launch shape
+  constexpr int W = V4 ? 4 : 1;
+  typedef typename std::conditional<V4, f32x4, float>::type vec_t;
+  __shared__ vec_t red[G][65];
   const int e = threadIdx.x & 63, gsub = threadIdx.x >> 6;
-  const int64_t i = (int64_t)blockIdx.x * 64 + e;
+  const int64_t i = ((int64_t)blockIdx.x * 64 + e) * W;
   const int64_t n = q.first[q.nseg];
   // segment of this workgroup's first output by a wave-uniform binary search (scalar loads of the
   // kernel argument block; a lane-by-lane linear walk was up to 64 dependent loads), then the
-  // few steps a lane needs when the workgroup's 64 outputs straddle segment boundaries
+  // few steps a lane needs when the workgroup's outputs straddle segment boundaries
   int k = 0;
   {
-    const int64_t i0 = (int64_t)blockIdx.x * 64;
+    const int64_t i0 = (int64_t)blockIdx.x * 64 * W;
     int lo = 0, hi = q.nseg;
     while (hi - lo > 1) {
       const int mid = (lo + hi) >> 1;
@@ -1391,32 +1398,43 @@ __global__ __launch_bounds__(64 * G) void reduce_slabs_multi_kernel(ReduceSegs q
   const int64_t r = local / cols, c = local - r * cols;
   const float* __restrict__ slab = q.slab[k] + (int64_t)q.src_off[k] + r * (int64_t)q.src_ld[k] + c;
   const int64_t nslabs = q.nslabs[k], stride = q.stride[k];
-  float s = 0.f;
+  vec_t s = vec_t{};
   if (i < n) {
     for (int64_t sl = gsub; sl < nslabs; sl += G * 8) {
-      float v[8];
+      vec_t v[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int64_t su = sl + G * u;
-        v[u] = slab[(su < nslabs ? su : sl) * stride];
+        v[u] = *reinterpret_cast<const vec_t*>(slab + (su < nslabs ? su : sl) * stride);
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u)
         if (sl + G * u < nslabs) s += v[u];
     }
   }
+  float* const out = q.dst[k] + r * (int64_t)q.dst_ld[k] + c;
   if constexpr (G == 1) {
-    if (i < n) q.dst[k][r * (int64_t)q.dst_ld[k] + c] = s;
+    if (i < n) *reinterpret_cast<vec_t*>(out) = s;
   } else {
     red[gsub][e] = s;
     __syncthreads();
     if (gsub == 0 && i < n) {
-      float v = 0.f;
+      vec_t v = vec_t{};
 #pragma unroll
       for (int g = 0; g < G; ++g) v += red[g][e];
-      q.dst[k][r * (int64_t)q.dst_ld[k] + c] = v;
+      *reinterpret_cast<vec_t*>(out) = v;
     }
   }
+}
+
+// every segment float4-addressable: boundaries, row widths, pitches, offsets and base pointers
+static bool reduce_segs_vec4(const ReduceSegs& q) {
+  for (int k = 0; k < q.nseg; ++k) {
+    if ((q.first[k] | q.first[k + 1] | q.cols[k] | q.src_off[k] | q.src_ld[k] | q.dst_ld[k] | q.stride[k]) & 3)
+      return false;
+    if (((uintptr_t)q.slab[k] | (uintptr_t)q.dst[k]) & 15) return false;
+  }
+  return true;
 }
 
 static int launch_reduce_segs(ReduceSegs& q, hipStream_t s) {
@@ -1428,10 +1446,19 @@ static int launch_reduce_segs(ReduceSegs& q, hipStream_t s) {
   if (n <= 0) return 0;
   int maxn = 1;
   for (int k = 0; k < q.nseg; ++k) maxn = q.nslabs[k] > maxn ? q.nslabs[k] : maxn;
-  const unsigned grid = (unsigned)((n + 63) / 64);
-  if (maxn <= 8) reduce_slabs_multi_kernel<1><<<grid, 64, 0, s>>>(q);
-  else if (maxn <= 32) reduce_slabs_multi_kernel<4><<<grid, 256, 0, s>>>(q);
-  else reduce_slabs_multi_kernel<16><<<grid, 1024, 0, s>>>(q);
+  // (float4 lanes need enough outputs to fill the device: at hidden 64 a layer's gradients are
+  // ~30 k elements = 120 workgroups of 256 outputs, and the 4-byte form was 0.2-0.4 % faster)
+  if (n >= 65536 && reduce_segs_vec4(q)) {
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    if (maxn <= 8) reduce_slabs_multi_kernel<1, true><<<grid, 64, 0, s>>>(q);
+    else if (maxn <= 32) reduce_slabs_multi_kernel<4, true><<<grid, 256, 0, s>>>(q);
+    else reduce_slabs_multi_kernel<16, true><<<grid, 1024, 0, s>>>(q);
+  } else {
+    const unsigned grid = (unsigned)((n + 63) / 64);
+    if (maxn <= 8) reduce_slabs_multi_kernel<1, false><<<grid, 64, 0, s>>>(q);
+    else if (maxn <= 32) reduce_slabs_multi_kernel<4, false><<<grid, 256, 0, s>>>(q);
+    else reduce_slabs_multi_kernel<16, false><<<grid, 1024, 0, s>>>(q);
+  }
   NLAM_CHECK_LAUNCH("reduce_slabs_multi");
   return 0;
 }
