@@ -793,7 +793,7 @@ __global__ __launch_bounds__(2 * D) void fs_tail_fwd_kernel(FsTailFwdParams p) {
   float* red = mtile + FS_R * LDO;                 // [2][FS_R][NW]
   int* itab0 = reinterpret_cast<int*>(red + 2 * FS_R * NW);   // [2][4][FS_R]: a, b, c, y
   FsW<D, TERMS> A;
-  fs_load_w_rows<D, TERMS>(A, p.W2, p.ldW2, 32 * wave, p.n_out, D, lane);
+  const unsigned long long fstart = p.stamp ? __builtin_amdgcn_s_memtime() : 0;
   const int c4 = tid % CPR, rg = tid / CPR;        // staging map: rows rg + 8 k
   const int64_t nsub = p.tl.ntiles * p.tl.B;
   const int64_t ntiles = (nsub + 1) / 2;
@@ -816,12 +816,17 @@ __global__ __launch_bounds__(2 * D) void fs_tail_fwd_kernel(FsTailFwdParams p) {
   int par = 0;
   const bool stamp = p.stamp != 0;
   unsigned long long fst[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  fs_load_w_rows<D, TERMS>(A, p.W2, p.ldW2, 32 * wave, p.n_out, D, lane);
   unsigned long long fprev = stamp ? __builtin_amdgcn_s_memtime() : 0;
+  fst[7] = fprev - fstart;   // weight slice
+  // (requesting the indices BEFORE the weight slice moved their 4 k cycles into the weight phase
+  // and saved nothing: tools/stamp_fs.py, N = 81)
   if (tid < FS_R && (int64_t)blockIdx.x < ntiles) {
     fetch_idx(blockIdx.x);
     put_idx(itab0);
   }
   __syncthreads();
+  FSSTAMP(6)   // first tile's header -> indices -> tables + barrier
   for (int64_t tt = blockIdx.x; tt < ntiles; tt += gridDim.x, par ^= 1) {
     const FsSub2 sub = {fs_sub(p.tl, 2 * tt), fs_sub(p.tl, 2 * tt + 1)};
     const int* itab = itab0 + par * 4 * FS_R;
@@ -1053,7 +1058,7 @@ __global__ __launch_bounds__(2 * D) void fs_tail_fwd_kernel(FsTailFwdParams p) {
   }
   if (stamp && tid == 0) {
 #pragma unroll
-    for (int k = 0; k < 6; ++k) atomicAdd(&g_fs_stamps[k], fst[k]);
+    for (int k = 0; k < 8; ++k) atomicAdd(&g_fs_stamps[k], fst[k]);
   }
 }
 

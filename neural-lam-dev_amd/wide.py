@@ -274,6 +274,7 @@ def lin_bwd_data_multi(problems):
 # slabs of a weight-gradient launch: in all / average floor per problem (tunables; see outer_multi)
 _OUTER_BUDGET = int(os.environ.get("NLAM_OUTER_BUDGET", "256"))
 _OUTER_FLOOR = int(os.environ.get("NLAM_OUTER_FLOOR", "64"))
+_OUTER_MIN_TILES = int(os.environ.get("NLAM_OUTER_MIN_TILES", "8"))   # 32-row tiles per slab, at least
 
 
 def outer_multi(problems):
@@ -294,7 +295,7 @@ def outer_multi(problems):
     budget = max(_OUTER_BUDGET, _OUTER_FLOOR * n)
     slabs, ns = [], []
     for t in tiles:
-        nsl = max(1, min(int(lib.nlam_bwd_grid(t)), -(-budget * t // total)))
+        nsl = max(1, min(int(lib.nlam_bwd_grid(t)), -(-budget * t // total), -(-t // _OUTER_MIN_TILES)))
         ns.append(nsl)
         slabs.append(torch.empty(nsl * stride, dtype=torch.float32, device=dev))
     _launch(

@@ -10,7 +10,7 @@ from neural_lam_amd._lib import lib
 from neural_lam_amd.interaction_net import InteractionNet
 
 gen = torch.Generator().manual_seed(0)
-N, d, B = 6561, 256, 4
+N, d, B = int(os.environ.get('N', '6561')), 256, 4
 deg = torch.randint(8, 10, (N,), generator=gen)
 rec = torch.repeat_interleave(torch.arange(N), deg)
 M = rec.numel()
@@ -29,11 +29,14 @@ for it in range(3):
 lib.nlam_debug_fs_stamps(buf, 0)
 names_f = ["rows issued + landed, h store, silu -> planes", "barrier", "residual issue + GEMM",
            "LayerNorm (2 barriers, z_keep store)", "output tile + tables + barrier",
-           "aggregation + row stores"]
-vals = [buf[i] for i in range(6)]
+           "aggregation + row stores", "prologue: header -> indices -> tables + barrier",
+           "prologue: weight slice"]
+vals = [buf[i] for i in range(8)]
 tot = sum(vals)
-print(f"fs_tail_fwd (edge call + node call), M = {M}, B = {B}: cycles summed over workgroups")
+ntile = B * ((M + 63) // 64) + B * ((N + 63) // 64)
+nwg = min(256, B * ((M + 63) // 64)) + min(256, B * ((N + 63) // 64))
+print(f"fs_tail_fwd (edge call + node call), M = {M}, B = {B}: {ntile} tiles on {nwg} workgroups")
 for n, v in zip(names_f, vals):
-    print(f"  {n:48s} {100 * v / max(tot, 1):5.1f} %")
+    print(f"  {n:48s} {100 * v / max(tot, 1):5.1f} %  {v / nwg:9.0f} cycles / workgroup")
 ntile = B * ((M + 63) // 64) + B * ((N + 63) // 64)
 print(f"  total {tot / ntile:.0f} cycles per 64-row tile")
