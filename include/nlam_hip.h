@@ -697,7 +697,8 @@ int nlam_mfma_probe(float* out, void* stream);
  * update in its round-4 pipelined form (csrc/fused_edge2.hip) instead of the round-2 kernel.
  * Bits 8, 64 and 128 (16-row edge kernels) are retired.  Default: all of the above (or NLAM_K16 in
  * the environment).  Same entry points, slab layouts and results (to rounding) either way; used
- * to time both forms in one process. */
+ * to time both forms in one process.  Returns the mask that was in force before the call; a
+ * negative mask changes nothing (query). */
 int nlam_set_k16(int mask);
 
 #ifdef __cplusplus

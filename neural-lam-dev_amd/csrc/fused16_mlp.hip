@@ -26,8 +26,10 @@ bool nlam_k16_on(int family) {
   return (g_k16_mask & family) != 0;
 }
 extern "C" int nlam_set_k16(int mask) {
-  g_k16_mask = mask;
-  return 0;
+  (void)nlam_k16_on(0);   // (resolve the default / NLAM_K16 first)
+  const int prev = g_k16_mask;
+  if (mask >= 0) g_k16_mask = mask;
+  return prev;
 }
 
 // this lane's slice of a row [xa | xb] (column c0 = 16 fb + 4 g): unconditional loads from a

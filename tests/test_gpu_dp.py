@@ -205,10 +205,23 @@ def _one_rank_rccl_worker(rank, world, port, tmp, q, backend):
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     from neural_lam_amd import parallel, synthetic
 
-    out = {}
+    # the plain single-process step, in THIS process (same library state as the RCCL runs below:
+    # the parent may have run tests that switch kernel families or arithmetic modes)
+    model, n = _build(tmp)
+    model = model.cuda()
+    flat = parallel.FlatParams(model)
+    opt = parallel.FlatAdamW(flat, lr=1e-2)
+    full = synthetic.random_batch(4, 2, n, n_state=5, n_forcing_window=6, seed=3, device="cuda")
+    for _ in range(2):
+        flat.zero_grad()
+        model.training_step(full).backward()
+        flat.pack_grads()
+        opt.step(grad_scale=1.0)
+    torch.cuda.synchronize()
+    out = {"plain": (flat.grad.cpu(), flat.flat.cpu(), {})}
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     for overlap in (False, True):
         model, n = _build(tmp)
         model = model.cuda()
@@ -241,8 +254,6 @@ def test_one_rank_rccl_collectives_leave_the_step_unchanged():
     all-reduce + barrier (the bench's timing protocol).  A one-rank all-reduce returns its input,
     so gradients and weights after two optimiser steps must be BIT-identical to the plain
     single-process step's -- any mis-ordered stream wait or mis-sliced bucket view shows."""
-    from neural_lam_amd import parallel, synthetic
-
     with tempfile.TemporaryDirectory() as tmp:
         _make_graph(tmp)
         ctx = mp.get_context("spawn")
@@ -251,17 +262,8 @@ def test_one_rank_rccl_collectives_leave_the_step_unchanged():
                              args=("_one_rank_rccl_worker", 0, 1, _free_port(), tmp, q, "nccl"))]
         procs[0].start()
         res = _collect(procs, q, 1)[0][1]
-        model, n = _build(tmp)
-    model = model.cuda()
-    flat = parallel.FlatParams(model)
-    opt = parallel.FlatAdamW(flat, lr=1e-2)
-    full = synthetic.random_batch(4, 2, n, n_state=5, n_forcing_window=6, seed=3, device="cuda")
-    for _ in range(2):
-        flat.zero_grad()
-        model.training_step(full).backward()
-        flat.pack_grads()
-        opt.step(grad_scale=1.0)
-    want_g, want_w = flat.grad.cpu(), flat.flat.cpu()
+    want_g, want_w = torch.tensor(res["plain"][0]), torch.tensor(res["plain"][1])
+    assert want_g.abs().max() > 0
     for overlap in (False, True):
         g, w, stats = res[overlap]
         assert torch.equal(torch.tensor(g), want_g), overlap
