@@ -675,6 +675,11 @@ int nlam_debug_edge_bwd_stamps(unsigned long long* out, int reset);
 int nlam_debug_mlp_bwd_stamps(unsigned long long* out, int reset);
 /* The same for the hidden-256 tail kernels (16 values: forward phases 0..7, backward 8..15). */
 int nlam_debug_fs_stamps(unsigned long long* out, int reset);
+/* Host logic, no device needed: the workgroups-per-problem rule of the multi-problem launches
+ * (nlam_lin_fwd_multi / nlam_lin_bwd_data_multi at hidden 128 / 256).  rounds[k] = trip rounds of
+ * problem k (tiles / tiles per workgroup round); out[k] = its workgroups: proportional to the
+ * rounds, sum <= cap unless n > cap, 1 <= out[k] <= rounds[k]. */
+int nlam_debug_multi_shares(int n, const int64_t* rounds, int64_t cap, int64_t* out);
 /* Diagnostic (NLAM_TIMELINE=1 in the environment of the process): nlam_lin_fwd records
  * s_memrealtime (100 MHz) per workgroup at start / after the weight prologue / at exit;
  * out: host array of 3 * 1024 values (first 1024 workgroups of the last launch). */

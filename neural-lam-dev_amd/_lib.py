@@ -122,6 +122,7 @@ SIGNATURES = {
     "nlam_debug_edge_bwd_stamps": [_p, _i32],
     "nlam_debug_mlp_bwd_stamps": [_p, _i32],
     "nlam_debug_fs_stamps": [_p, _i32],
+    "nlam_debug_multi_shares": [_i32, _p, _i64, _p],
     "nlam_debug_lin_fwd_timeline": [_p],
     "nlam_debug_node_timeline": [_p],
     "nlam_mfma_probe": [_p, _p],

@@ -162,6 +162,37 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ tile, int ld, int
   }
 }
 
+// ---- workgroups per problem of a multi-problem launch (host side) ----------------
+// Proportional to the problems' WORK (rounds = tiles a workgroup takes per trip round), at most
+// `cap` in all -- one workgroup of these kernels is resident per CU (LDS), so a workgroup beyond
+// the 256th waits for a whole share to finish -- never more than a problem has rounds, at least
+// one each; what rounding down leaves over goes to the largest problem.  (Equal shares of capped
+// wants gave an edge problem and two node problems a third of the device each although the edge
+// rows are 8 x the node rows, and more than 256 workgroups queued the node problems behind the
+// edge problem: Hi-LAM-256 34.4 -> 32.9 ms when this replaced them.)
+static inline int64_t nlam_multi_shares(int n, const int64_t* rounds_in, int64_t* g, int64_t cap) {
+  int64_t sum = 0, used = 0, tot = 0;
+  int big = 0;
+  for (int k = 0; k < n; ++k) {
+    const int64_t r = rounds_in[k] < 1 ? 1 : rounds_in[k];
+    sum += r;
+    if (r > (rounds_in[big] < 1 ? 1 : rounds_in[big])) big = k;
+  }
+  for (int k = 0; k < n; ++k) {
+    const int64_t r = rounds_in[k] < 1 ? 1 : rounds_in[k];
+    g[k] = sum > cap ? (r * cap) / sum : r;
+    if (g[k] < 1) g[k] = 1;
+    used += g[k];
+  }
+  if (n > 0) {
+    const int64_t rb = rounds_in[big] < 1 ? 1 : rounds_in[big];
+    if (sum > cap && used < cap) g[big] += cap - used;
+    if (g[big] > rb) g[big] = rb;
+  }
+  for (int k = 0; k < n; ++k) tot += g[k];
+  return tot;
+}
+
 // ---- two-phase staging: issue every row load of a source first (they stay in
 // flight together), write the LDS tile afterwards.  Loads are unconditional --
 // slots >= nrows read a valid row (their index is clamped by the caller's

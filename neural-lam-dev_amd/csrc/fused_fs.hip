@@ -520,28 +520,10 @@ static unsigned fs_grid(int64_t ntiles) {
 // 512-thread workgroup is resident per CU)
 template <typename P, typename TilesOf>
 static unsigned fs_multi_grid(WideMulti<P>& m, TilesOf tiles_of) {
-  // Workgroups per problem: proportional to the problems' WORK (tile rounds), at most 256 in all
-  // -- one workgroup is resident per CU (LDS), so a 257th would wait for a whole share to finish
-  // -- never more than a problem has rounds, at least one each; what rounding leaves over goes
-  // to the largest problem.  (Equal shares of the capped wants gave an edge problem and two node
-  // problems a third of the device each although the edge rows are 8 x the node rows, and more
-  // than 256 workgroups queued the node problems behind the edge problem.)
-  int64_t rounds[NLAM_WIDE_MAXP], g[NLAM_WIDE_MAXP], sum = 0, used = 0;
-  int big = 0;
-  for (int k = 0; k < m.n; ++k) {
-    rounds[k] = (tiles_of(m.p[k]) + 1 - 1) / 1;
-    if (rounds[k] < 1) rounds[k] = 1;
-    sum += rounds[k];
-    if (rounds[k] > rounds[big]) big = k;
-  }
-  const int64_t cap = 256;
-  for (int k = 0; k < m.n; ++k) {
-    g[k] = sum > cap ? (rounds[k] * cap) / sum : rounds[k];
-    if (g[k] < 1) g[k] = 1;
-    used += g[k];
-  }
-  if (sum > cap && used < cap) g[big] += cap - used;
-  if (g[big] > rounds[big]) g[big] = rounds[big];
+  // shares proportional to work, one round of the device in all (fused_common.h)
+  int64_t rounds[NLAM_WIDE_MAXP], g[NLAM_WIDE_MAXP];
+  for (int k = 0; k < m.n; ++k) rounds[k] = (tiles_of(m.p[k]) + 1 - 1) / 1;
+  nlam_multi_shares(m.n, rounds, g, 256);
   m.first[0] = 0;
   for (int k = 0; k < m.n; ++k) m.first[k + 1] = m.first[k] + (int)g[k];
   for (int k = m.n; k < NLAM_WIDE_MAXP; ++k) m.first[k + 1] = m.first[m.n];

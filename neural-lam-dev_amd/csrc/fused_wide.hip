@@ -947,31 +947,12 @@ __global__ __launch_bounds__(256) void lin_bwd_data_kernel(WideMulti<LinBwdDataP
                                       smem);
 }
 
-// grid shares of the problems of a multi launch: wide_grid() each, scaled down to <= 512 in all
 template <typename P, typename TilesOf>
 static unsigned wide_multi_grid(WideMulti<P>& m, TilesOf tiles_of) {
-  // Workgroups per problem: proportional to the problems' WORK (tile rounds), at most 256 in all
-  // -- one workgroup is resident per CU (LDS), so a 257th would wait for a whole share to finish
-  // -- never more than a problem has rounds, at least one each; what rounding leaves over goes
-  // to the largest problem.  (Equal shares of the capped wants gave an edge problem and two node
-  // problems a third of the device each although the edge rows are 8 x the node rows, and more
-  // than 256 workgroups queued the node problems behind the edge problem.)
-  int64_t rounds[NLAM_WIDE_MAXP], g[NLAM_WIDE_MAXP], sum = 0, used = 0;
-  int big = 0;
-  for (int k = 0; k < m.n; ++k) {
-    rounds[k] = (tiles_of(m.p[k]) + 4 - 1) / 4;
-    if (rounds[k] < 1) rounds[k] = 1;
-    sum += rounds[k];
-    if (rounds[k] > rounds[big]) big = k;
-  }
-  const int64_t cap = 256;
-  for (int k = 0; k < m.n; ++k) {
-    g[k] = sum > cap ? (rounds[k] * cap) / sum : rounds[k];
-    if (g[k] < 1) g[k] = 1;
-    used += g[k];
-  }
-  if (sum > cap && used < cap) g[big] += cap - used;
-  if (g[big] > rounds[big]) g[big] = rounds[big];
+  // shares proportional to work, one round of the device in all (fused_common.h)
+  int64_t rounds[NLAM_WIDE_MAXP], g[NLAM_WIDE_MAXP];
+  for (int k = 0; k < m.n; ++k) rounds[k] = (tiles_of(m.p[k]) + 4 - 1) / 4;
+  nlam_multi_shares(m.n, rounds, g, 256);
   m.first[0] = 0;
   for (int k = 0; k < m.n; ++k) m.first[k + 1] = m.first[k] + (int)g[k];
   for (int k = m.n; k < NLAM_WIDE_MAXP; ++k) m.first[k + 1] = m.first[m.n];
@@ -1008,6 +989,14 @@ static int lin_bwd_data_fill(LinBwdDataParams& q, const float* gy, int64_t gy_bs
   q.gx = gx; q.gx_bstride = gx_bstride; q.gx_ld = gx_ld;
   q.gx_add = gx_add; q.ga_bstride = ga_bstride; q.ga_ld = ga_ld;
   q.rows = rows; q.B = (int)B;
+  return 0;
+}
+
+// the share rule of the multi-problem launches, callable without a device (tests/test_host_logic.py)
+extern "C" int nlam_debug_multi_shares(int n, const int64_t* rounds, int64_t cap, int64_t* out) {
+  NLAM_REQUIRE(n >= 1 && n <= NLAM_WIDE_MAXP && rounds != nullptr && out != nullptr && cap >= 1,
+               "nlam_debug_multi_shares: n %d out of [1, %d]", n, NLAM_WIDE_MAXP);
+  nlam_multi_shares(n, rounds, out, cap);
   return 0;
 }
 

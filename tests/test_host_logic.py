@@ -173,3 +173,42 @@ def test_graphgen_matches_reference_create_graph(path):
                 assert torch.equal(cfa, fb), name
         if not hier:
             assert not os.path.exists(os.path.join(tmp, "mesh_up_edge_index.pt"))
+
+
+def test_multi_problem_launch_shares_follow_the_work():
+    """Workgroups per problem of a multi-problem launch (hidden 128 / 256 projections): one round of
+    the device in all, proportional to the problems' trip rounds, at least one and never more than
+    a problem has rounds.  (Equal shares cost Hi-LAM-256 1.5 ms per step: DESIGN.md 4.10.)"""
+    import ctypes
+
+    from neural_lam_amd._lib import lib
+
+    def shares(rounds, cap=256):
+        n = len(rounds)
+        out = (ctypes.c_int64 * n)()
+        assert lib.nlam_debug_multi_shares(n, (ctypes.c_int64 * n)(*rounds), cap, out) == 0
+        return list(out)
+
+    # level-0 same-level net of Hi-LAM at hidden 256: edge rows 8 x the node rows (64-row tiles)
+    g = shares([3220, 410, 410])
+    assert sum(g) == 256 and g[1] == g[2] and 7.0 < g[0] / g[1] < 8.6, g
+    # everything fits: a workgroup per round
+    assert shares([10, 3, 1]) == [10, 3, 1]
+    # a tiny problem beside a huge one still gets a workgroup; the sum stays one round
+    g = shares([100000, 1])
+    assert g[1] == 1 and sum(g) == 256, g
+    # never more workgroups than rounds, even for the problem that takes the remainder
+    g = shares([300, 2, 2])
+    assert g[0] <= 300 and g[1] <= 2 and sum(g) <= 256, g
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        n = int(rng.integers(1, 9))
+        rounds = [int(x) for x in rng.integers(1, 20000, n)]
+        g = shares(rounds)
+        assert all(1 <= gi <= ri for gi, ri in zip(g, rounds)), (rounds, g)
+        assert sum(g) <= max(256, n), (rounds, g)
+        if sum(rounds) > 256:
+            assert sum(g) >= 256 - n, (rounds, g)   # (the device is filled)
+            big = max(range(n), key=lambda k: rounds[k])
+            for k in range(n):   # proportional within rounding
+                assert abs(g[k] - 256 * rounds[k] / sum(rounds)) <= (1 if k != big else n + 1), (rounds, g)
