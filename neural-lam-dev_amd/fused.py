@@ -288,8 +288,11 @@ def _base(t):
 class FusedInteractionNetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, send_rep, rec_rep, edge_rep, same, g, update_edges, mean,
-                W1, b1, W2, b2, gam, bet, V1, c1, V2, c2, gam2, bet2, take=None):
+                W1, b1, W2, b2, gam, bet, V1, c1, V2, c2, gam2, bet2, take=None, give=None):
         ctx.take = take   # glue.GradSlot: another consumer's gradient on send_rep, folded into g_send
+        # glue.GradSlot pair (receiver side, sender side): leave the gradient of rec_rep / send_rep
+        # there as well (glue.Tee: the other consumer's backward runs later and folds it in)
+        ctx.give = give
         with ops.tag(g.tag):
             dev = edge_rep.device
             d = W2.shape[0]
@@ -537,8 +540,21 @@ class FusedInteractionNetFunction(torch.autograd.Function):
                                       None, None, sum_gy_batch=fold_e)
             if not same and multi:
                 ops.fused_lin_bwd_multi(probs + outer_jobs)
+        _give_rec(ctx, g_rec_total, g_send)
         return (g_send, g_rec_total, g_edge, None, None, None, None,
-                dW1, db1, dW2, db2, dgam, dbet, dV1, dc1, dV2, dc2, dg2, db2n, None)
+                dW1, db1, dW2, db2, dgam, dbet, dV1, dc1, dV2, dc2, dg2, db2n, None, None)
+
+
+def _give_rec(ctx, g_rec, g_send=None):
+    """Leave the receiver-side (sender-side) input gradient in the Tee's slot for the other
+    consumer of that tensor (whose backward runs later and folds it into its own store)."""
+    if ctx.give is None or ctx.same:
+        return
+    slot_r, slot_s = ctx.give
+    if slot_r is not None and g_rec is not None:
+        slot_r.value = g_rec
+    if slot_s is not None and g_send is not None:
+        slot_s.value = g_send
 
 
 def _take_addend(ctx, g_send):
@@ -581,7 +597,8 @@ def _backward_seq(ctx, g_rec_out, g_edge_out):
                            add_s.data_ptr() if add_s is not None else None)
     ws = inet_seq.backward(sargs, grads, dev, ops.stream())
     del ws, bufs
-    return (g_send, g_rec, g_edge, None, None, None, None, *pg, None)
+    _give_rec(ctx, g_rec, g_send)
+    return (g_send, g_rec, g_edge, None, None, None, None, *pg, None, None)
 
 
 FusedInteractionNetFunction._backward_seq = staticmethod(_backward_seq)
@@ -598,7 +615,8 @@ def apply_inet(net, send_rep, rec_rep, edge_rep):
         s, r, e, same, net.tables, net.update_edges, net.aggr == "mean",
         el[0][0].weight, el[0][0].bias, el[0][1].weight, el[0][1].bias, el[1].weight, el[1].bias,
         al[0][0].weight, al[0][0].bias, al[0][1].weight, al[0][1].bias, al[1].weight, al[1].bias,
-        None if same else _sink(send_rep, "take"))
+        None if same else _sink(send_rep, "take"),
+        None if same else (_sink(rec_rep, "give"), _sink(send_rep, "give")))
     return out
 
 
