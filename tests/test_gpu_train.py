@@ -96,19 +96,24 @@ def test_graphlam_training_loss_decreases():
         loss.backward()
         flat.pack_grads()
         opt.step()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
     assert losses[-1] < 0.8 * losses[0], losses
 
 
-def test_ar_checkpointing_matches_plain_rollout():
+@pytest.mark.parametrize("model_name", ["graph_lam", "hi_lam"])
+def test_ar_checkpointing_matches_plain_rollout(model_name):
     """args.ar_checkpoint recomputes each predict_step in backward: same loss
-    and the same parameter gradients as the plain BPTT rollout (ar_model.py:220-267)."""
+    and the same parameter gradients as the plain BPTT rollout (ar_model.py:220-267).  Hi-LAM:
+    the level representations are joined through glue.tee inside the recomputed step as well."""
     from neural_lam_amd import graphgen, synthetic
-    from neural_lam_amd.models import GraphLAM
+    from neural_lam_amd.models import MODELS
     import numpy as np
 
+    GraphLAM = MODELS[model_name]
+    hier = model_name != "graph_lam"
     with tempfile.TemporaryDirectory() as tmp:
-        info = graphgen.create_graph(tmp + "/graph/g", graphgen.make_xy(30, 28, 5000.0), None, False)
+        info = graphgen.create_graph(tmp + "/graph/g", graphgen.make_xy(30, 28, 5000.0),
+                                     3 if hier else None, hier)
         n = info["num_grid"]
         gen = torch.Generator().manual_seed(0)
         ds = synthetic.SyntheticDatastore(
@@ -130,7 +135,7 @@ def test_ar_checkpointing_matches_plain_rollout():
         loss.backward()
         torch.cuda.synchronize()
         peaks.append(torch.cuda.max_memory_allocated() - base)
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
         grads.append({k: p.grad.clone() for k, p in m.named_parameters()})
     # ar_steps = 4: the recomputed rollout holds ONE step's activations at a time
     assert peaks[1] < 0.6 * peaks[0], peaks
