@@ -3,10 +3,15 @@ state residual (base_graph_model.py:174-177), boundary overwrite
 (ar_model.py:244-247) and the masked wmse/mse training loss (metrics.py:21-108,
 ar_model.py:294-298).  They replace ~15 eager elementwise / indexing launches
 per AR step, including a boolean-mask gather that synchronises the host."""
+import os
+
 import torch
 
 from . import ops
 from ._lib import lib
+
+
+_TEE = os.environ.get("NLAM_TEE", "1") != "0"   # 0: plain autograd sums (A/B switch)
 
 
 class GradSlot:
@@ -50,7 +55,7 @@ class Tee(torch.autograd.Function):
 def tee(x):
     """Two aliases of x (first: the consumer that runs its backward LAST and takes the other's
     gradient as an addend; second: the consumer whose backward runs first)."""
-    if not (x.is_cuda and x.requires_grad and torch.is_grad_enabled()):
+    if not (_TEE and x.is_cuda and x.requires_grad and torch.is_grad_enabled()):
         return x, x
     slot = GradSlot()
     a, b = Tee.apply(x, slot)

@@ -454,7 +454,9 @@ def inet_eligible(net, send_rep, rec_rep, edge_rep):
 class WideInteractionNetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, send_rep, rec_rep, edge_rep, same, g, update_edges, mean,
-                W1, b1, W2, b2, gam, bet, V1, c1, V2, c2, gam2, bet2):
+                W1, b1, W2, b2, gam, bet, V1, c1, V2, c2, gam2, bet2, take=None, give=None):
+        # glue.GradSlot side channels of a glue.Tee on send_rep / rec_rep (see fused.py)
+        ctx.take, ctx.give = take, give
         with ops.tag(g.tag):
             dev = edge_rep.device
             d = W2.shape[0]
@@ -591,10 +593,14 @@ class WideInteractionNetFunction(torch.autograd.Function):
                 lin_bwd_data(gpr_m, W1r, mat(g_send), mat(t4))
                 g_rec_total = None
             else:
+                from .fused import _give_rec, _take_addend
+
                 g_rec_total = _empty(rm.B, N_r, d, device=dev)
-                lin_bwd_data_multi([(gps_m, W1s, mat(g_send), None),
+                add_s = _take_addend(ctx, g_send)   # (another consumer's gradient on send_rep)
+                lin_bwd_data_multi([(gps_m, W1s, mat(g_send), mat(add_s) if add_s is not None else None),
                                     (gpr_m, W1r, mat(g_rec_total), mat(g_rec)),
                                     (dPe, W1e, mat(g_e), geo)])
+                _give_rec(ctx, g_rec_total, g_send)
             g_edge = g_e
             if ctx.update_edges and em.B == 1 and B > 1:
                 t5 = _empty(1, M, d, device=dev)
@@ -607,7 +613,7 @@ class WideInteractionNetFunction(torch.autograd.Function):
                     outer_multi(outers)
             lane.finish()
         return (g_send, g_rec_total, g_edge, None, None, None, None,
-                dW1, db1, dW2, db2, dgam, dbet, dV1, dc1, dV2, dc2, dg2, db2n)
+                dW1, db1, dW2, db2, dgam, dbet, dV1, dc1, dV2, dc2, dg2, db2n, None, None)
 
 
 def apply_inet(net, send_rep, rec_rep, edge_rep):
@@ -617,10 +623,14 @@ def apply_inet(net, send_rep, rec_rep, edge_rep):
     s, e = _base(send_rep), _base(edge_rep)
     r = s if same else _base(rec_rep)
     el, al = _mlp_parts(net.edge_mlp), _mlp_parts(net.aggr_mlp)
+    from .fused import _sink
+
     return WideInteractionNetFunction.apply(
         s, r, e, same, net.tables, net.update_edges, net.aggr == "mean",
         el[0][0].weight, el[0][0].bias, el[0][1].weight, el[0][1].bias, el[1].weight, el[1].bias,
-        al[0][0].weight, al[0][0].bias, al[0][1].weight, al[0][1].bias, al[1].weight, al[1].bias)
+        al[0][0].weight, al[0][0].bias, al[0][1].weight, al[0][1].bias, al[1].weight, al[1].bias,
+        None if same else _sink(send_rep, "take"),
+        None if same else (_sink(rec_rep, "give"), _sink(send_rep, "give")))
 
 
 # ------------------------------------------- InteractionNet with SplitMLPs (hidden 128 / 256)
