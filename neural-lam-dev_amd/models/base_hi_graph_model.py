@@ -2,7 +2,7 @@
 embedders, mesh-init up-sweep, hi_processor_step hook, read-out down-sweep."""
 from torch import nn
 
-from .. import utils
+from .. import glue, utils
 from ..interaction_net import InteractionNet
 from .base_graph_model import BaseGraphModel
 
@@ -83,8 +83,11 @@ class BaseHiGraphModel(BaseGraphModel):
         ]
         # mesh init: level l-1 -> l for l = 1..L-1
         for level_l, gnn in enumerate(self.mesh_init_gnns, start=1):
+            # (level l-1 is the sender here and an input of the processor later: glue.tee joins
+            # the two gradients inside this net's backward instead of a torch add)
+            snd, mesh_rep_levels[level_l - 1] = glue.tee(mesh_rep_levels[level_l - 1])
             mesh_rep_levels[level_l], mesh_up_rep[level_l - 1] = gnn(
-                mesh_rep_levels[level_l - 1], mesh_rep_levels[level_l], mesh_up_rep[level_l - 1]
+                snd, mesh_rep_levels[level_l], mesh_up_rep[level_l - 1]
             )
         mesh_rep_levels, _, _, mesh_down_rep = self.hi_processor_step(
             mesh_rep_levels, mesh_same_rep, mesh_up_rep, mesh_down_rep
