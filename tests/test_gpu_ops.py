@@ -161,3 +161,69 @@ def test_segment_sum_batch_folded(ops, d, B):
     gs = torch.full((B, n_send, d), float("nan"), device="cuda")
     ops.segment_sum(ops.mat(msg.cuda()), t.csc_colptr, t.csc_eid, ops.mat(gs))
     assert rel(gs, torch.zeros(B, n_send, d).index_add_(1, send, msg)) < 1e-6
+
+
+@pytest.mark.parametrize("case", ["vec4_large", "scalar_small", "unaligned_cols", "column_block_dst"])
+def test_slab_reduction_matches_a_plain_sum(case):
+    """nlam_reduce_slabs_batch (every weight gradient of a layer goes through it): segments of
+    per-workgroup slabs summed into their destinations.  Large float4-addressable layers take
+    16-byte lanes, everything else the 4-byte form -- same sums either way, and the same order of
+    summation run to run (bit-identical repeats)."""
+    from neural_lam_amd import ops
+
+    torch.manual_seed(0)
+    dev = "cuda"
+    if case == "vec4_large":        # a hidden-128 layer's seven 128 x 128 gradients + biases
+        nslabs, d = 160, 128
+        stride = d * d + d
+        segs = lambda slab, dsts: [(0, d, d, d, dsts[0]), (d * d, 1, d, d, dsts[1])]
+        shapes = [(d, d), (d,)]
+        reps = 7
+    elif case == "scalar_small":    # a hidden-64 layer: below the float4 threshold
+        nslabs, d = 37, 64
+        stride = d * d + d
+        segs = lambda slab, dsts: [(0, d, d, d, dsts[0]), (d * d, 1, d, d, dsts[1])]
+        shapes = [(d, d), (d,)]
+        reps = 2
+    elif case == "unaligned_cols":  # a 64 x 3 embedder gradient beside large aligned ones
+        nslabs, d = 64, 256
+        stride = d * d + 64 * 32 + 8
+        segs = lambda slab, dsts: [(0, d, d, d, dsts[0]), (d * d, 64, 3, 32, dsts[1])]
+        shapes = [(d, d), (64, 3)]
+        reps = 1
+    else:                           # destination = a column block of a wider matrix (dW1[:, d:2d])
+        nslabs, d = 96, 128
+        stride = d * d
+        segs = None
+        shapes = None
+        reps = 6
+    total = []
+    with ops.slab_batch():
+        for _ in range(reps):
+            slab = torch.randn(nslabs * stride, device=dev)
+            if case == "column_block_dst":
+                wide = torch.zeros(d, 3 * d, device=dev)
+                dst = wide[:, d : 2 * d]
+                ops.reduce_segments(slab, nslabs, stride, [(0, d, d, d, dst)])
+                total.append((slab, [(0, d, d, d, dst)], wide))
+            else:
+                dsts = [torch.empty(*s, device=dev) for s in shapes]
+                ops.reduce_segments(slab, nslabs, stride, segs(slab, dsts))
+                total.append((slab, segs(slab, dsts), None))
+    torch.cuda.synchronize()
+    for slab, sg, wide in total:
+        S = slab.view(nslabs, stride).double()
+        for off, r, c, ld, dst in sg:
+            idx = (off + torch.arange(r, device=dev)[:, None] * ld + torch.arange(c, device=dev)[None, :])
+            want = S[:, idx.reshape(-1)].sum(0).reshape(r, c).float()
+            got = dst.reshape(r, c)
+            assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max()), case
+        if wide is not None:        # nothing outside the column block was touched
+            assert float(wide[:, :d].abs().max()) == 0.0 and float(wide[:, 2 * d :].abs().max()) == 0.0
+    # deterministic: the same launch again gives the same bits
+    slab, sg, _ = total[0]
+    first = [s[4].clone() for s in sg]
+    ops.reduce_segments(slab, nslabs, stride, sg)
+    torch.cuda.synchronize()
+    for a, s in zip(first, sg):
+        assert torch.equal(a, s[4])
