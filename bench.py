@@ -89,6 +89,21 @@ def layer_roofline(stats, nprof, args, info, B, model):
                                       if k.endswith("@" + site)) / nprof / P}
 
 
+def sig(x, n=5):
+    """Every float of the JSON line at n significant digits (the line must fit the driver's 9 kB
+    stdout tail: tests/test_gpu_bench.py asserts < 8192 bytes)."""
+    if isinstance(x, float):
+        return float(f"{x:.{n}g}")
+    if isinstance(x, dict):
+        return {k: sig(v, n) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [sig(v, n) for v in x]
+    return x
+
+
+TOP_KERNELS = 12   # entries of the per-kernel table kept in the line (all of them: the side file)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -102,6 +117,9 @@ def parse():
     ap.add_argument("--windows", type=int, default=5,
                     help="timed windows of --steps steps each; the median one is reported")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-light", action="store_true",
+                    help="CPU baseline on B = 1 only, 1 warm-up + 3 timed steps (the other-config "
+                         "children: a stated baseline within the default run's time budget)")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="skip the per-kernel HIP-event pass (roofline = null)")
     ap.add_argument("--no-fp32-compare", action="store_true",
@@ -162,6 +180,10 @@ def spawn_ranks(args):
     import socket
     import subprocess
 
+    ndev = torch.cuda.device_count()   # (counting devices does not initialise the GPU)
+    if ndev < args.gpus and os.environ.get("NLAM_BENCH_BACKEND", "nccl") == "nccl":
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {ndev} GPU(s) visible; RCCL needs one "
+                         "device per rank (NLAM_BENCH_BACKEND=gloo rehearses the control flow on one)")
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
@@ -178,6 +200,10 @@ def spawn_ranks(args):
     sys.stdout.write(out0 or "")
     sys.stdout.flush()
     worst = max((abs(rc) for rc in rcs), default=0)
+    if worst != 0:   # one line saying why the run has no JSON line (the ranks' own stderr is above)
+        bad = ", ".join(f"rank {r}: exit {rc}" for r, rc in enumerate(rcs) if rc != 0)
+        sys.stderr.write(f"bench.py --gpus {args.gpus}: FAILED ({bad}); visible GPUs: "
+                         f"{torch.cuda.device_count()}\n")
     raise SystemExit(0 if worst == 0 else (worst if worst < 256 else 1))
 
 
@@ -260,30 +286,35 @@ def cpu_baseline(args, tmp, info, model):
         T = 1
         per_b = {}
         budget_t0 = time.perf_counter()
-        for B in (1, 4):
+        light = bool(getattr(args, "cpu_baseline_light", False))
+        nwarm = 1 if light else 2
+        for B in ((1,) if light else (1, 4)):
             init, target, forcing, _ = synthetic.random_batch(B, T, info["num_grid"])
             times = []
-            for it in range(7):
+            for it in range(4 if light else 7):
                 t0 = time.perf_counter()
                 loss, _ = orc.training_loss(sd, graph, cfg, data, init, target, forcing)
                 torch.autograd.grad(loss, list(sd.values()))
                 times.append(time.perf_counter() - t0)
                 # bounded: a slow host (or a wide model) stops after 3 timed steps / 60 s
+                # (light: after one timed step once 30 s are spent)
+                if light and it >= 1 and time.perf_counter() - budget_t0 > 30.0:
+                    break
                 if it >= 4 and time.perf_counter() - budget_t0 > 60.0:
                     break
-            timed = times[2:] if len(times) > 2 else times[-1:]
+            timed = times[nwarm:] if len(times) > nwarm else times[-1:]
             t = statistics.median(timed)
             upd = B * T * args.processor_layers * rec_updates_per_layer(args, info)
             per_b[B] = {"s_per_step": t, "value": upd / t, "timed_steps": len(timed)}
         bestB = max(per_b, key=lambda b: per_b[b]["value"])
+        per = ", ".join(f"B={b} {v['s_per_step']:.2f} s/step" for b, v in per_b.items())
         return {"value": per_b[bestB]["value"], "unit": "mesh node-updates/s", "cores": cores,
                 "kind": "port",
                 "per_batch": {str(b): v for b, v in per_b.items()},
                 "sample": f"oracle (pure-torch CPU restatement of the PyG path) full train step "
-                          f"fwd+loss+bwd, ar_steps={T}, B=1 and B=4, median of "
-                          f"{per_b[bestB]['timed_steps']} after 2 warm-ups "
-                          f"(B=1 {per_b[1]['s_per_step']:.2f} s/step, "
-                          f"B=4 {per_b[4]['s_per_step']:.2f} s/step; value = B={bestB}), "
+                          f"fwd+loss+bwd, ar_steps={T}, median of "
+                          f"{per_b[bestB]['timed_steps']} after {nwarm} warm-up(s) "
+                          f"({per}; value = B={bestB}), "
                           f"torch {torch.__version__}, {cores} threads"}
     finally:
         torch.set_num_threads(old)
@@ -293,13 +324,13 @@ def cpu_baseline(args, tmp, info, model):
 # the driver's one bench line witnesses them too (children, never a re-exec of this
 # GPU-initialised process).  Bounded in total; a failure is reported in the line, never fatal.
 OTHER_CONFIGS = (
-    ("hi_lam-128 (configs[2])", ["--model", "hi_lam", "--hidden-dim", "128"], {}),
+    ("hi_lam-128 (configs[2])", ["--model", "hi_lam", "--hidden-dim", "128", "--cpu-baseline-light"], {}),
     ("hi_lam-256 bf16 (configs[4], per GPU)", ["--model", "hi_lam", "--hidden-dim", "256"],
      {"NLAM_MFMA": "bf16"}),
     ("graph_lam-64 ar_steps=4 (configs[3], per GPU)", ["--ar-steps", "4"], {}),
     ("hi_lam-64", ["--model", "hi_lam", "--hidden-dim", "64"], {}),
 )
-OTHER_CONFIGS_BUDGET_S = 150.0
+OTHER_CONFIGS_BUDGET_S = 190.0   # (incl. ~40 s of CPU baseline for configs[2])
 
 
 def run_other_configs(args):
@@ -310,12 +341,13 @@ def run_other_configs(args):
     for name, extra, env in OTHER_CONFIGS:
         left = OTHER_CONFIGS_BUDGET_S - (time.perf_counter() - t_start)
         if left < 20.0:
-            out[name] = {"error": "skipped: the 150 s budget of the other configs is spent"}
+            out[name] = {"error": "skipped: the time budget of the other configs is spent"}
             continue
         cmd = [sys.executable, os.path.abspath(__file__), "--steps", "10", "--warmup", "3",
                "--windows", "3", "--batch", str(args.batch), "--processor-layers",
-               str(args.processor_layers), "--no-cpu-baseline", "--no-fp32-compare",
-               "--no-other-configs"] + extra
+               str(args.processor_layers), "--no-fp32-compare", "--no-other-configs"] + extra
+        if "--cpu-baseline-light" not in extra:
+            cmd.append("--no-cpu-baseline")
         try:
             r = subprocess.run(cmd, env=dict(os.environ, **env), capture_output=True, text=True,
                                timeout=left)
@@ -329,6 +361,11 @@ def run_other_configs(args):
                          "workload": j["config"]["workload"], "ar_steps": j["config"]["ar_steps"],
                          "batch_per_gpu": j["config"]["batch_per_gpu"],
                          "wall_s": time.perf_counter() - t_start}
+            cb = j.get("cpu_baseline")
+            if cb:
+                out[name]["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"],
+                                             "cores": cb["cores"], "kind": cb["kind"],
+                                             "sample": cb["sample"]}
         except Exception as e:  # noqa: BLE001 -- reported, never fatal for the bench line
             out[name] = {"error": repr(e)[:300]}
     return out
@@ -607,11 +644,30 @@ def main():
             "launches_per_step": (sum(v["calls_per_step"] for v in kernels.values())
                                   if kernels else None),
             "other_configs": other,
-            "kernels": kernels,
         }
         if cpu:
             out["speedup_vs_cpu_baseline"] = value / cpu["value"]
-        print(json.dumps(out), flush=True)
+        # the per-kernel table goes LAST and short (top entries by time, 4 significant digits:
+        # [calls, ms, GFLOP, MB] per step); the whole table is written to a side file that gpurun
+        # pulls back (gpurun_out/) -- the line itself stays under 8 kB so that the driver's stdout
+        # tail holds all of it
+        if kernels:
+            side = os.environ.get("NLAM_BENCH_KERNELS_FILE") or os.path.join(
+                ROOT, "gpurun_out", f"bench_kernels_{args.model}-{args.hidden_dim}"
+                                    f"{'' if T == 1 else f'-ar{T}'}.json")
+            try:
+                os.makedirs(os.path.dirname(side), exist_ok=True)
+                json.dump({"ms_per_step": ms, "kernels": kernels}, open(side, "w"), indent=0)
+                out["kernels_file"] = os.path.relpath(side, ROOT)
+            except OSError as e:
+                out["kernels_file"] = f"not written: {e!r}"[:120]
+            top = list(kernels.items())[:TOP_KERNELS]
+            out["kernels_top"] = {
+                "columns": ["calls", "ms", "gflop", "mb"], "per": "step",
+                "sum_ms_all": sum(v["ms_per_step"] for v in kernels.values()),
+                "rows": {k: sig([v["calls_per_step"], v["ms_per_step"], v["gflop_per_step"],
+                                 v["mb_per_step"]], 4) for k, v in top}}
+        print(json.dumps(sig(out), separators=(",", ":")), flush=True)
     if multi:
         dist.destroy_process_group()
     tmpdir.cleanup()

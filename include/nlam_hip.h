@@ -30,7 +30,10 @@ extern "C" {
 #endif
 
 const char* nlam_last_error(void);
-/* ABI version of this header; bumped on any signature change. */
+/* ABI version of this header; bumped on any signature change (2: nlam_inet_grads.g_send_add,
+ * nlam_set_k16 returns the previous mask; 3: round-5 entry points).  A binding compares it with
+ * the version it was written against and refuses a stale prebuilt library (_lib.py). */
+#define NLAM_ABI_VERSION 3
 int nlam_abi_version(void);
 /* GEMM arithmetic of the fused kernels: a property of a run, as the reference's `--precision`
  * (train_model.py:72-77,285).  Initial value: NLAM_MFMA in the environment (fp32 | bf16x3 | bf16,

@@ -153,6 +153,7 @@ class NlamError(RuntimeError):
     pass
 
 
+ABI_VERSION = 3   # include/nlam_hip.h NLAM_ABI_VERSION (tests/test_host_logic.py compares the two)
 MFMA_MODE_NAMES = ("fp32", "bf16x3", "b3", "bf16")
 
 
@@ -173,6 +174,12 @@ def _load():
             raise ImportError(f"{LIB_PATH} does not export {name}; rebuild it") from e
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, ctypes.c_int)
+    got = lib.nlam_abi_version()
+    if got != ABI_VERSION:
+        raise ImportError(
+            f"{LIB_PATH} has ABI version {got}, this binding was written against {ABI_VERSION} "
+            "(include/nlam_hip.h NLAM_ABI_VERSION): rebuild the library"
+        )
     return lib
 
 

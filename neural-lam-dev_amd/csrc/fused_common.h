@@ -187,6 +187,9 @@ static inline int64_t nlam_multi_shares(int n, const int64_t* rounds_in, int64_t
   if (n > 0) {
     const int64_t rb = rounds_in[big] < 1 ? 1 : rounds_in[big];
     if (sum > cap && used < cap) g[big] += cap - used;
+    // (the at-least-one bump of small problems can push the total past `cap`: the largest
+    // problem gives the excess back, so no workgroup queues behind a full device round)
+    if (sum > cap && used > cap) g[big] = g[big] - (used - cap) < 1 ? 1 : g[big] - (used - cap);
     if (g[big] > rb) g[big] = rb;
   }
   for (int k = 0; k < n; ++k) tot += g[k];

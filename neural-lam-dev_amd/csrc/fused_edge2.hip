@@ -814,7 +814,11 @@ static int launch_edge_bwd2(const EdgeBwdParams& q, hipStream_t s) {
 // backward's load otherwise.
 extern "C" int nlam_edge_bwd_forms_batch_sum(int64_t ntiles, int64_t B, int d) {
   if (d != D || B <= 1 || ntiles <= 0 || !nlam_mfma_b3() || !nlam_k16_on(K16_EDGE_BWD2)) return 0;
-  if (getenv("NLAM_STAMP") != nullptr) return 0;
+  // (the diagnostic builds -- phase stamps, the no-traffic ablation -- run the strided form and
+  // never write dPe: callers must not allocate it and feed it on)
+  if (getenv("NLAM_STAMP") != nullptr || getenv("NLAM_STAMP2") != nullptr ||
+      getenv("NLAM_ABL2") != nullptr)
+    return 0;
   const int64_t nw = 4 * nlam_bwd_grid(ntiles * B);
   const int64_t rounds_tiles = ((ntiles + nw - 1) / nw) * B;
   const double rounds_tasks = (double)ntiles * (double)B / (double)nw;

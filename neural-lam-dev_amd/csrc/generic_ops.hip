@@ -41,7 +41,7 @@ int nlam_enable_big_lds(const void* kern, const char* name) {
   done.emplace_back(kern, dev);
   return 0;
 }
-extern "C" int nlam_abi_version(void) { return 1; }
+extern "C" int nlam_abi_version(void) { return NLAM_ABI_VERSION; }
 
 // GEMM arithmetic of the fused kernels (see fused_bf16x3.h): NLAM_MFMA=fp32 | bf16x3
 #define NLAM_MFMA_DEFAULT_MODE 1

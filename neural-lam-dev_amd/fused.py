@@ -98,7 +98,7 @@ class FusedMLPFunction(torch.autograd.Function):
             gres = None
         gx_out = gx.reshape(ctx.x_shape) if need_gx else None
         if ctx.give is not None and gx_out is not None:
-            ctx.give.value = gx_out
+            ctx.give.put(gx_out)
         return (gx_out, gres, dW1, db1, dW2, db2, dg, dbt, None)
 
 
@@ -552,22 +552,18 @@ def _give_rec(ctx, g_rec, g_send=None):
         return
     slot_r, slot_s = ctx.give
     if slot_r is not None and g_rec is not None:
-        slot_r.value = g_rec
+        slot_r.put(g_rec)
     if slot_s is not None and g_send is not None:
-        slot_s.value = g_send
+        slot_s.put(g_send)
 
 
 def _take_addend(ctx, g_send):
     """The gradient another consumer of send_rep left in the Tee's slot (glue.Tee), if it can be
     folded into this layer's g_send store; marks the slot consumed."""
     slot = ctx.take
-    if slot is None or slot.value is None or ctx.same:
+    if slot is None or ctx.same:
         return None
-    v = slot.value
-    if v.shape != g_send.shape or not v.is_contiguous() or v.dtype != torch.float32:
-        return None
-    slot.consumed = True
-    return v
+    return slot.take(g_send.shape)
 
 
 def _backward_seq(ctx, g_rec_out, g_edge_out):

@@ -14,14 +14,36 @@ from ._lib import lib
 _TEE = os.environ.get("NLAM_TEE", "1") != "0"   # 0: plain autograd sums (A/B switch)
 
 
-class GradSlot:
-    """Side channel of a Tee: the first consumer's backward leaves its input gradient here, the
-    second consumer's backward kernel adds it to its own output (`gx_add`) and marks it consumed."""
+def _graph_task():
+    """Id of the backward pass that is running (-1 outside one): a value left in a slot by an
+    EARLIER pass (a pass that pruned the Tee node: retain_graph + autograd.grad on a sub-graph)
+    must never be folded into this one."""
+    f = getattr(torch._C, "_current_graph_task_id", None)
+    return f() if f is not None else -1
 
-    __slots__ = ("value", "consumed")
+
+class GradSlot:
+    """Side channel of a Tee: the first consumer's backward leaves its input gradient here
+    (`put`), the second consumer's backward kernel adds it to its own output (`gx_add`) and
+    records WHICH tensor it folded in (`take`)."""
+
+    __slots__ = ("value", "task", "folded")
 
     def __init__(self):
-        self.value, self.consumed = None, False
+        self.value, self.task, self.folded = None, -1, None
+
+    def put(self, v):
+        self.value, self.task = v, _graph_task()
+
+    def take(self, shape):
+        """The addend for a gradient of `shape`, or None; the slot remembers what was handed out."""
+        v = self.value
+        if v is None or self.task != _graph_task():
+            return None
+        if v.shape != shape or not v.is_contiguous() or v.dtype != torch.float32:
+            return None
+        self.value, self.folded = None, v
+        return v
 
 
 class Tee(torch.autograd.Function):
@@ -30,8 +52,9 @@ class Tee(torch.autograd.Function):
     grid_emb feeds the g2m InteractionNet (sender side) and the grid's own encoding MLP
     (base_graph_model.py:134-141): autograd summed the two gradients with a full-size
     elementwise add, the one torch kernel left inside a GraphLAM step (31.6 us of 2.6 ms).
-    Whatever the execution order, the result is the sum: if nobody consumed the slot the add
-    happens here."""
+    The result is the sum whatever the execution order and however many consumers the `give`
+    alias has: `ga` contains exactly the tensor `slot.folded` (if any); whatever else arrived on
+    the give alias -- `gb` is autograd's sum over ALL its consumers -- is added here."""
 
     @staticmethod
     def forward(ctx, x, slot):
@@ -41,15 +64,17 @@ class Tee(torch.autograd.Function):
     @staticmethod
     def backward(ctx, ga, gb):
         slot = ctx.slot
-        consumed = slot.consumed
-        slot.value, slot.consumed = None, False
-        if consumed:      # ga already contains gb (added inside the producer's kernel)
-            return ga, None
+        folded = slot.folded
+        slot.value, slot.folded, slot.task = None, None, -1
         if ga is None:
             return gb, None
-        if gb is None:
-            return ga, None
-        return ga + gb, None
+        if gb is None or gb is folded or (
+                folded is not None and gb.data_ptr() == folded.data_ptr()
+                and gb.shape == folded.shape and gb.stride() == folded.stride()):
+            return ga, None   # the give alias's only gradient is already inside ga
+        if folded is None:
+            return ga + gb, None
+        return ga + (gb - folded), None   # a second consumer of the give alias
 
 
 def tee(x):

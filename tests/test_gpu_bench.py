@@ -18,18 +18,22 @@ def test_bench_line_contract():
          "--windows", "1", "--no-fp32-compare"],
         capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
-    line = json.loads(out.stdout.strip().splitlines()[-1])
+    raw = out.stdout.strip().splitlines()[-1]
+    # the driver keeps a 9 kB tail of stdout: the whole line has to fit into it
+    assert len(raw) < 8192, len(raw)
+    line = json.loads(raw)
     for key, want in (("metric", "mesh node-updates/sec (fwd+bwd)"), ("unit", "mesh node-updates/s"),
                       ("n_gpus", 1), ("steps", 3), ("warmup", 1), ("higher_is_better", True),
                       ("scaling", "weak"), ("vs_baseline", None), ("data", "synthetic")):
         assert line[key] == want, (key, line[key])
     assert line["value"] > 1e6 and line["ms_per_step"] > 0
     # value = B * ar_steps * P * N_mesh / t_step
-    assert abs(line["value"] - 4 * 1 * 4 * 6561 / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-6
+    # (floats of the line carry 5 significant digits)
+    assert abs(line["value"] - 4 * 1 * 4 * 6561 / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-4
     assert "graph_lam" in line["config"]["workload"] and "model" not in line["config"]
     roof = line["roofline"]
     assert roof["bound"] in ("hbm", "mfma") and roof["unit"] in ("GB/s", "TFLOP/s")
-    assert 0 < roof["frac"] <= 1 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+    assert 0 < roof["frac"] <= 1 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-4
     assert roof["traffic"] is None or roof["traffic"] > 0
     cpu = line["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0 and cpu["sample"]
@@ -46,6 +50,15 @@ def test_bench_line_contract():
         assert ent["ms_per_step"] > 0 and ent["value"] > 0 and ent["roofline"]["kernel"], (name, ent)
         assert 0 < ent["roofline"]["frac"] <= 1
     assert other["hi_lam-256 bf16 (configs[4], per GPU)"]["dtype"] == "bf16"
+    # configs[2] carries its own stated CPU baseline (B = 1, bounded)
+    cb = other["hi_lam-128 (configs[2])"]["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
+    # the per-kernel table: top entries in the line, all of them in the side file
+    top = line["kernels_top"]
+    assert top["columns"] == ["calls", "ms", "gflop", "mb"] and 1 <= len(top["rows"]) <= 12
+    side = json.load(open(os.path.join(ROOT, line["kernels_file"])))
+    assert set(top["rows"]) <= set(side["kernels"]) and len(side["kernels"]) >= len(top["rows"])
+    assert roof["kernel"] in side["kernels"]
     assert other["graph_lam-64 ar_steps=4 (configs[3], per GPU)"]["ar_steps"] == 4
 
 
@@ -74,7 +87,7 @@ def test_two_rank_bench_control_flow_over_gloo():
     assert line["launch"]["mode"] in ("eager", "eager+overlapped_allreduce")
     assert line["scaling"] == "weak" and line["other_configs"] is None
     # value = world * B * ar_steps * P * N_mesh / t_step
-    assert abs(line["value"] - 2 * 4 * 1 * 4 * 6561 / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-6
+    assert abs(line["value"] - 2 * 4 * 1 * 4 * 6561 / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-4
 
 
 def test_gpus_1_is_the_default_path():

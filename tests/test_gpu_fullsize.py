@@ -116,7 +116,7 @@ def test_m2m_layer_vs_cpu_oracle_full_size_other_modes(mode, width):
 
 @pytest.mark.parametrize("which", ["g2m", "m2g"])
 def test_g2m_m2g_forward_vs_cpu_oracle_full_size(meps, which):
-    """The encoder / decoder InteractionNets (100,656 / 255,136 edges, update_edges=False,
+    """The encoder / decoder InteractionNets (79,236 / 255,136 edges, update_edges=False,
     batch-invariant edge and receiver-or-sender inputs) at full size vs the CPU oracle."""
     import nlam_oracle as orc
     from neural_lam_amd.interaction_net import InteractionNet
@@ -416,3 +416,140 @@ def test_hilam_training_step_vs_cpu_oracle_full_size(mode, kind, hidden):
                          text=True, timeout=900)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-2500:])
     assert f"mfma mode: {mode}" in out.stdout and "full-size model case passed" in out.stdout
+
+
+# ---- B = 4: the bench's per-GPU batch.  Every full-size oracle test above runs B = 1, where the
+# batch-inner form of the edge backward (fused_edge2.hip, edge_bwd2_kernel<..., BSUM = true>:
+# sum_b gh[b] formed in registers, dPe written by the kernel) is off; these run the forms the
+# timed region runs.
+@pytest.mark.parametrize("which,forms", [("m2g", 1), ("g2m", 0)])
+def test_grid_side_inets_b4_vs_cpu_oracle_full_size(meps, which, forms):
+    """The decoder (m2g: 255,136 edges) and encoder (g2m: 79,236 edges) InteractionNets at full MEPS
+    size with B = 4 exactly as base_graph_model.py:139,152 calls them: update_edges=False, the edge
+    embedding batch-invariant (stride-0 expand_to_batch), g2m's receivers (the mesh embedding)
+    batch-invariant too.  Forward and EVERY gradient -- senders, receivers, the batch-summed edge
+    gradient (dPe projected back through W1e) and all parameter gradients -- against the CPU oracle
+    (interaction_net.py:86-131).  m2g must take the batch-inner edge backward
+    (nlam_edge_bwd_forms_batch_sum == 1), g2m the strided one (== 0); both through the one-call
+    sequencer and launch by launch.  Bars: forward 1e-4, gradients 1e-3."""
+    import nlam_oracle as orc
+    from neural_lam_amd import inet_seq, ops
+    from neural_lam_amd.interaction_net import InteractionNet
+
+    B, d = 4, 64
+    torch.manual_seed(30)
+    ei = meps[f"{which}_edge_index"]
+    net = InteractionNet(ei, d, update_edges=False)
+    sd = {f"n.{k}": v.detach().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    net = net.cuda()
+    tb = net.tables
+    n_s, n_r, M = tb.n_send, tb.n_rec, ei.shape[1]
+    assert M == {"m2g": 255136, "g2m": 79236}[which]
+    assert ops.lib.nlam_edge_bwd_forms_batch_sum(tb.ntiles, B, d) == forms
+    gen = torch.Generator().manual_seed(31)
+    send = torch.randn(B, n_s, d, generator=gen)
+    rec = torch.randn(1 if which == "g2m" else B, n_r, d, generator=gen)
+    edge = torch.randn(1, M, d, generator=gen)
+    cot = torch.randn(B, n_r, d, generator=gen)
+    sc, rc, ec = (t.clone().requires_grad_(True) for t in (send, rec, edge))
+    want = orc.interaction_net(sd, "n", ei, sc, rc.expand(B, -1, -1), ec.expand(B, -1, -1),
+                               update_edges=False)
+    names = [k for k, _ in net.named_parameters()]
+    wg = torch.autograd.grad((want * cot).sum(), [sc, rc, ec] + [sd[f"n.{k}"] for k in names])
+    for seq in (True, False):
+        old = inet_seq.ENABLED
+        inet_seq.ENABLED = seq
+        try:
+            for p in net.parameters():
+                p.grad = None
+            sg, rg, eg = (t.cuda().requires_grad_(True) for t in (send, rec, edge))
+            got = net(sg, rg.expand(B, -1, -1), eg.expand(B, -1, -1))
+            (got * cot.cuda()).sum().backward()
+        finally:
+            inet_seq.ENABLED = old
+        assert rel(got.detach().cpu(), want.detach()) < 1e-4, seq
+        assert rel(sg.grad.cpu(), wg[0]) < 1e-3, seq
+        assert rel(rg.grad.cpu(), wg[1]) < 1e-3, seq
+        assert rel(eg.grad.cpu(), wg[2]) < 1e-3, seq
+        for (k, p), w in zip(net.named_parameters(), wg[3:]):
+            assert rel(p.grad.cpu(), w) < 1e-3, (seq, k)
+
+
+def test_edge_bwd_batch_inner_form_matches_the_strided_form(meps):
+    """The two forms of the no-edge-update backward on the SAME m2g launch, through the C ABI:
+    batch-inner (dPe = sum_b gh[b] written by the kernel) against strided + nlam_sum_batch.  gh,
+    gPr and the weight-gradient slabs' reductions must agree to fp32 rounding; dPe to the rounding
+    of a 4-term sum in another order."""
+    from neural_lam_amd import fused, ops
+    from neural_lam_amd.interaction_net import InteractionNet
+    from neural_lam_amd.ops import mat
+
+    B, d = 4, 64
+    torch.manual_seed(33)
+    net = InteractionNet(meps["m2g_edge_index"], d, update_edges=False).cuda()
+    g = net.tables
+    assert ops.lib.nlam_edge_bwd_forms_batch_sum(g.ntiles, B, d) == 1
+    M, n_r, n_s = g.M, g.n_rec, g.n_send
+    dev = "cuda"
+    Pe = torch.randn(1, M, d, device=dev)
+    Ps = torch.randn(B, n_s, d, device=dev)
+    Pr = torch.randn(B, n_r, d, device=dev)
+    g_agg = torch.randn(B, n_r, d, device=dev)
+    lin, ln = fused._mlp_parts(net.edge_mlp)
+    W2, b2, gam = lin[1].weight.detach(), lin[1].bias.detach(), ln.weight.detach()
+
+    def run(with_dpe):
+        gh = torch.empty(B, M, d, device=dev)
+        gPr = torch.empty(B, n_r, d, device=dev)
+        dPe = torch.empty(1, M, d, device=dev) if with_dpe else None
+        dW2, db2 = torch.empty_like(W2), torch.empty(d, device=dev)
+        dgam, dbet = torch.empty(d, device=dev), torch.empty(d, device=dev)
+        with ops.slab_batch():
+            ops.fused_edge_bwd(g, mat(Pe), False, mat(Ps), mat(Pr), None, W2, b2, gam, mat(g_agg),
+                               None, mat(gh), mat(gPr), mat(dPe) if with_dpe else None, False, d,
+                               None, dW2, db2, dgam, dbet)
+        if not with_dpe:
+            dPe = torch.empty(1, M, d, device=dev)
+            ops.sum_batch(gh, dPe)
+        return gh, gPr, dPe, dW2, db2, dgam, dbet
+
+    a, b = run(True), run(False)
+    assert torch.equal(a[0], b[0]) or rel(a[0], b[0]) < 1e-6
+    assert rel(a[1], b[1]) < 1e-6
+    assert rel(a[2], b[2]) < 1e-6
+    for x, y in zip(a[3:], b[3:]):
+        assert rel(x, y) < 1e-5
+
+
+def test_graphlam64_training_step_b4_vs_cpu_oracle_full_size():
+    """The bench's exact per-GPU workload -- BASELINE configs[1] at B = 4 (GraphLAM, hidden 64, 4
+    processor layers, MEPS 238 x 268) -- one training step: loss and EVERY parameter gradient
+    against the CPU oracle's step on the same four samples.  Bars: loss 1e-4, gradients 2e-3."""
+    import nlam_oracle as orc
+    from neural_lam_amd import ops, synthetic
+    from neural_lam_amd.models import GraphLAM
+
+    B = 4
+    with tempfile.TemporaryDirectory() as tmp:
+        ds, gname, info = synthetic.meps_setup(tmp)
+        torch.manual_seed(43)
+        model = GraphLAM(synthetic.model_args(graph=gname, hidden_dim=64, processor_layers=4),
+                         config=None, datastore=ds)
+        _, graph = orc.load_graph(tmp + "/graph/" + gname)
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()
+          if v.dtype.is_floating_point}
+    data = {k: getattr(model, k).detach().clone() for k in
+            ("grid_static_features", "diff_mean", "diff_std", "boundary_mask", "per_var_std")}
+    batch = synthetic.random_batch(B, 1, info["num_grid"], seed=8)
+    cfg = {"model": "graph_lam", "hidden_layers": 1, "processor_layers": 4, "mesh_aggr": "sum",
+           "loss": "wmse"}
+    want, _ = orc.training_loss(sd, graph, cfg, data, batch[0], batch[1], batch[2])
+    names = [k for k, _ in model.named_parameters()]
+    grads = torch.autograd.grad(want, [sd[k] for k in names])
+    model = model.cuda()
+    assert ops.lib.nlam_edge_bwd_forms_batch_sum(model.m2g_gnn.tables.ntiles, B, 64) == 1
+    loss = model.training_step(tuple(t.cuda() if t is not None else None for t in batch))
+    loss.backward()
+    assert abs(float(loss) - float(want)) < 1e-4 * abs(float(want))
+    for (k, p), g in zip(model.named_parameters(), grads):
+        assert rel(p.grad.cpu(), g) < 2e-3, k

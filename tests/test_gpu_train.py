@@ -292,3 +292,58 @@ def test_sum_many_matches_chain_of_adds(n, shape):
     (got * w).sum().backward()
     for t in terms:
         assert torch.equal(t.grad, w)
+
+
+@pytest.mark.parametrize("case", ["one_consumer", "two_consumers", "reversed_roles", "stale_value"])
+def test_tee_gradient_is_the_sum_in_every_usage(case):
+    """glue.tee hands a tensor to two consumers whose backward kernels fold the other branch's
+    gradient into their own store.  Whatever the usage -- the give alias consumed once (the
+    models' case: no torch add may be needed), consumed TWICE (autograd sums both on the give
+    alias, only one of them was folded), the aliases used the other way round (nothing can be
+    folded), a value left over by a backward pass that pruned the Tee node -- the gradient of the
+    teed tensor must equal the plain autograd sum."""
+    from neural_lam_amd import glue
+    from neural_lam_amd.interaction_net import InteractionNet
+    from neural_lam_amd.utils import make_mlp
+
+    torch.manual_seed(50)
+    gen = torch.Generator().manual_seed(51)
+    d, B, n_s, n_r, M = 64, 2, 90, 40, 300
+    ei = torch.stack((torch.randint(0, n_s, (M,), generator=gen) + n_r,
+                      torch.randint(0, n_r, (M,), generator=gen)))
+    ei[0, 0], ei[0, 1], ei[1, 2], ei[1, 3] = n_r, n_r + n_s - 1, 0, n_r - 1
+    net = InteractionNet(ei, d, update_edges=False).cuda()
+    mlp = make_mlp([d, d, d]).cuda()
+    x0 = torch.randn(B, n_s, d, generator=gen).cuda()
+    rec = torch.randn(B, n_r, d, generator=gen).cuda()
+    edge = torch.randn(B, M, d, generator=gen).cuda()
+    w = torch.randn(B, n_s, d, generator=gen).cuda()
+    c1 = torch.randn(B, n_r, d, generator=gen).cuda()
+    c2 = torch.randn(B, n_s, d, generator=gen).cuda()
+
+    def loss_of(a, b):
+        if case == "reversed_roles":
+            a, b = b, a
+        out = (net(a, rec, edge) * c1).sum() + (mlp(b, res=b) * c2).sum()
+        if case == "two_consumers":
+            out = out + (b * w).sum()
+        return out
+
+    xr = x0.clone().requires_grad_(True)
+    h = xr * 1.5
+    loss_of(h, h).backward()
+    want = xr.grad.clone()
+
+    xt = x0.clone().requires_grad_(True)
+    a, b = glue.tee(xt * 1.5)
+    assert a is not b
+    if case == "stale_value":
+        # a pass that stops at the give alias leaves the encoding MLP's input gradient in the
+        # slot; the next full pass must not fold that old tensor in a second time
+        side = (mlp(b, res=b) * c2).sum()
+        torch.autograd.grad(side, b, retain_graph=True)
+        (side + (net(a, rec, edge) * c1).sum()).backward()
+    else:
+        loss_of(a, b).backward()
+    err = float((xt.grad - want).abs().max() / want.abs().max())
+    assert err < 1e-5, (case, err)

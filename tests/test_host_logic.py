@@ -22,7 +22,10 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(_lib.lib, name), f"libnlam_hip.so does not export {name}"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert _lib.lib.nlam_abi_version() >= 1
+    # the header's version macro, the library's and the binding's agree (a stale prebuilt .so
+    # selected through NLAM_LIB_PATH is refused at import: _lib._load)
+    ver = int(re.search(r"#define\s+NLAM_ABI_VERSION\s+(\d+)", hdr).group(1))
+    assert _lib.lib.nlam_abi_version() == ver == _lib.ABI_VERSION
 
 
 def test_graph_tables_match_numpy():
@@ -200,6 +203,10 @@ def test_multi_problem_launch_shares_follow_the_work():
     # never more workgroups than rounds, even for the problem that takes the remainder
     g = shares([300, 2, 2])
     assert g[0] <= 300 and g[1] <= 2 and sum(g) <= 256, g
+    # the at-least-one bump of small problems must not push the total past the cap
+    for rounds in ([1000, 1, 1], [19000, 30, 40], [5000, 1, 1, 1, 1, 1, 1, 1]):
+        g = shares(rounds)
+        assert sum(g) <= 256 and min(g) >= 1, (rounds, g)
     rng = np.random.default_rng(0)
     for _ in range(200):
         n = int(rng.integers(1, 9))

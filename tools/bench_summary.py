@@ -10,6 +10,12 @@ r = j.get("roofline") or {}
 print("roofline:", {k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()
                     if k in ("kernel", "avg_launch_us", "frac", "frac_hbm", "frac_mfma", "bound")})
 ks = j.get("kernels", {})
+if not ks and j.get("kernels_file"):   # round 5: the full table lives in a side file
+    import os
+    for cand in (j["kernels_file"], os.path.join(os.path.dirname(path), os.path.basename(j["kernels_file"]))):
+        if os.path.exists(cand):
+            ks = json.load(open(cand))["kernels"]
+            break
 tot = collections.defaultdict(lambda: [0.0, 0.0])
 for k, v in ks.items():
     t = tot[k.split("@")[0]]
