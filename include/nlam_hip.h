@@ -301,6 +301,10 @@ typedef struct nlam_inet_args {
   float* agg;     /* (B, n_rec, 64) */
   float* e_out;   /* update_edges: (B, M, 64) */
   float* rec_out; /* (B, n_rec, 64) */
+  /* separate nodes: P (ps_given) / Pr (pr_given) already hold the sender / receiver projection
+   * of edge_mlp.0 -- written by nlam_grid_encode_fwd in the same pass as the rows they project --
+   * and nlam_inet_fwd skips that third of the projection launch */
+  int ps_given, pr_given;
 } nlam_inet_args;
 typedef struct nlam_inet_grads {
   const float* g_rec_out;            /* (B, n_rec, 64) contiguous, required */
@@ -647,6 +651,28 @@ int nlam_wide_outer_multi(int n, int d, const float* const* g, const int64_t* g_
  * batch-invariant static features). */
 int nlam_concat_rows(int nsrc, const float* const* src, const int64_t* bstride, const int64_t* ld,
                      const int32_t* width, float* out, int64_t B, int64_t N, void* stream);
+
+/* Grid-side encoder chain of predict_step in one pass over the grid rows (hidden 64; reference
+ * base_graph_model.py:116-143,157 and the grid-row thirds of interaction_net.py:121):
+ *   feat = cat(src_0 .. src_{nsrc-1})                 (B, rows, k_in <= 64)   [optional]
+ *   emb  = LayerNorm(W2 silu(W1 feat + b1) + b2)      grid_embedder
+ *   ps   = emb Ws^T                                   sender third of g2m_gnn.edge_mlp.0
+ *   rep  = emb + LayerNorm(E2 silu(E1 emb + e1) + e2) encoding_grid_mlp + residual
+ *   pr   = rep Wr^T + br                              receiver third of m2g_gnn.edge_mlp.0
+ * Sources as nlam_concat_rows (any alignment, bstride 0 = batch-invariant); outputs contiguous
+ * (B, rows, 64), 16-byte aligned.  Bitwise equal to nlam_concat_rows -> nlam_mlp_fwd ->
+ * nlam_lin_fwd -> nlam_mlp_fwd -> nlam_lin_fwd in the split-bf16 mode (the only mode it runs in:
+ * nlam_grid_encode_supported()). */
+int nlam_grid_encode_supported(void);
+int nlam_grid_encode_fwd(int nsrc, const float* const* src, const int64_t* src_bstride,
+                         const int64_t* src_ld, const int32_t* src_width, const float* W1,
+                         int64_t ldW1, const float* b1, const float* W2, int64_t ldW2,
+                         const float* b2, const float* gamma, const float* beta, const float* Ws,
+                         int64_t ldWs, const float* E1, int64_t ldE1, const float* e1,
+                         const float* E2, int64_t ldE2, const float* e2, const float* egamma,
+                         const float* ebeta, const float* Wr, int64_t ldWr, const float* br,
+                         float* feat, float* emb, float* ps, float* rep, float* pr, int64_t B,
+                         int64_t rows, void* stream);
 
 /* output_std head (reference base_graph_model.py:161-177 with args.output_std): net_out is
  * (rows, 2F); state = prev + net_out[:, :F] * scale + shift, pred_std = softplus(net_out[:, F:])

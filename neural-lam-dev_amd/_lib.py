@@ -110,6 +110,13 @@ SIGNATURES = {
     "nlam_lin_bwd_data_multi": [_i32, _i32] + [_p] * 13 + [_p],
     "nlam_wide_outer_multi": [_i32, _i32] + [_p] * 13 + [_p],
     "nlam_concat_rows": [_i32, _p, _p, _p, _p, _p, _i64, _i64, _p],
+    "nlam_grid_encode_supported": [],
+    "nlam_grid_encode_fwd": [_i32, _p, _p, _p, _p,                      # sources
+                             _p, _i64, _p, _p, _i64, _p, _p, _p,        # grid_embedder
+                             _p, _i64,                                  # Ws
+                             _p, _i64, _p, _p, _i64, _p, _p, _p,        # encoding MLP
+                             _p, _i64, _p,                              # Wr, br
+                             _p, _p, _p, _p, _p, _i64, _i64, _p],
     "nlam_state_step": [_p, _i64, _p, _p, _i64, _p, _p, _p, _p, _i64, _i64, _i32, _p],
     "nlam_state_step_bwd": [_p, _p, _p, _p, _p, _i64, _i64, _i32, _p],
     "nlam_sum_many": [_i32, _p, _p, _i64, _p],

@@ -99,7 +99,9 @@ extern "C" int nlam_inet_fwd(const nlam_inet_args* a, void* stream) {
     const float* bias[3] = {nullptr, w.b1, nullptr};
     float* out[3] = {a->P, a->Pr, a->Pe};
     const int64_t Bk[3] = {a->send.B, a->rec.B, a->edge.B};
-    const int64_t rows[3] = {N_s, N_r, M};
+    // (a problem with zero rows is skipped by the multi-problem launch: a projection the caller
+    // already holds -- nlam_grid_encode_fwd wrote it -- is not recomputed)
+    const int64_t rows[3] = {a->ps_given ? 0 : N_s, a->pr_given ? 0 : N_r, M};
     const int64_t obs[3] = {Bk[0] > 1 ? N_s * D : 0, Bk[1] > 1 ? N_r * D : 0, Bk[2] > 1 ? M * D : 0};
     const int64_t old_[3] = {D, D, D};
     rc = nlam_lin_fwd_multi(upd ? 2 : 3, D, x, xbs, xld, Wk, ldw, bias, out, obs, old_, Bk, rows, 0, stream);

@@ -56,20 +56,41 @@ def mlp_eligible(seq, x):
     return _bwd_shape_ok(k_in, n_out, ln is not None)
 
 
+# ------------------------------------------- forward outputs computed ahead of their module
+# A fused multi-stage forward kernel (grid_encode below) produces, in one pass, what several
+# modules of predict_step would each launch a kernel for.  It leaves those results here; the
+# module's own forward -- which still builds the autograd node whose backward recomputes from the
+# saved INPUT, unchanged -- adopts the result instead of launching, provided it is asked with the
+# very input buffer the result was computed from.  Keys: ("mlp", id(module)), ("ps" | "pr",
+# id(InteractionNet)), ("concat",).  Values: (data_ptr of the expected input, tensor).  The
+# producer clears the registry when its predict_step ends.
+PRE = {}
+
+
+def _pre_take(key, inp):
+    ent = PRE.pop(key, None) if PRE else None
+    if ent is None or ent[0] != inp.data_ptr():
+        return None
+    return ent[1]
+
+
 # --------------------------------------------------------------------- MLP
 class FusedMLPFunction(torch.autograd.Function):
     """y = [res +] [LN](W2 silu(W1 x + b1) + b2), x: (..., rows, k_in)."""
 
     @staticmethod
-    def forward(ctx, x, res, W1, b1, W2, b2, gamma, beta, give=None):
+    def forward(ctx, x, res, W1, b1, W2, b2, gamma, beta, give=None, pre_out=None):
         ctx.tag = ops._TAG[-1] if ops._TAG else "mlp"
         ctx.give = give   # glue.GradSlot: leave the input gradient there as well (glue.Tee)
         hid, n_out = W1.shape[0], W2.shape[0]
         xm = mat(x.detach())
         res_is_x = res is x
         rm = xm if res_is_x else (mat(res.detach()) if res is not None else None)
-        out = _empty(xm.B, xm.rows, n_out, device=x.device)
-        ops.fused_mlp_fwd(xm, None, W1, b1, W2, b2, gamma, beta, rm, mat(out), hid, n_out)
+        if pre_out is not None:   # computed by a fused multi-stage kernel from this very input
+            out = pre_out
+        else:
+            out = _empty(xm.B, xm.rows, n_out, device=x.device)
+            ops.fused_mlp_fwd(xm, None, W1, b1, W2, b2, gamma, beta, rm, mat(out), hid, n_out)
         ctx.save_for_backward(W1, b1, W2, b2, gamma)
         ctx.xm, ctx.x_shape = xm, x.shape
         ctx.res_mode = 0 if res is None else (1 if res_is_x else 2)
@@ -99,7 +120,7 @@ class FusedMLPFunction(torch.autograd.Function):
         gx_out = gx.reshape(ctx.x_shape) if need_gx else None
         if ctx.give is not None and gx_out is not None:
             ctx.give.put(gx_out)
-        return (gx_out, gres, dW1, db1, dW2, db2, dg, dbt, None)
+        return (gx_out, gres, dW1, db1, dW2, db2, dg, dbt, None, None)
 
 
 def _mlp_grad_dst(W1, W2, has_ln):
@@ -119,10 +140,13 @@ def _sink(t, role):
 
 def apply_mlp(seq, x, res=None):
     lin, ln = _mlp_parts(seq)
+    pre = _pre_take(("mlp", id(seq)), x) if (res is None or res is x) else None
+    if pre is not None and tuple(pre.shape) != (*x.shape[:-1], lin[1].weight.shape[0]):
+        pre = None
     return FusedMLPFunction.apply(
         x, res, lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias,
         ln.weight if ln is not None else None, ln.bias if ln is not None else None,
-        _sink(x, "give") if (res is None or res is x) else None)
+        _sink(x, "give") if (res is None or res is x) else None, pre)
 
 
 # ------------------------------------------- several embedder MLPs in one launch
@@ -288,7 +312,10 @@ def _base(t):
 class FusedInteractionNetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, send_rep, rec_rep, edge_rep, same, g, update_edges, mean,
-                W1, b1, W2, b2, gam, bet, V1, c1, V2, c2, gam2, bet2, take=None, give=None):
+                W1, b1, W2, b2, gam, bet, V1, c1, V2, c2, gam2, bet2, take=None, give=None,
+                ps_given=None, pr_given=None):
+        # ps_given / pr_given: the sender / receiver projection of edge_mlp.0, already computed
+        # from send_rep / rec_rep by a fused multi-stage kernel (grid_encode); separate nodes only
         ctx.take = take   # glue.GradSlot: another consumer's gradient on send_rep, folded into g_send
         # glue.GradSlot pair (receiver side, sender side): leave the gradient of rec_rep / send_rep
         # there as well (glue.Tee: the other consumer's backward runs later and folds it in)
@@ -314,13 +341,14 @@ class FusedInteractionNetFunction(torch.autograd.Function):
                     if same:
                         bufs["P"] = _empty(sm.B, N_s, 2 * d, device=dev)
                     else:
-                        bufs["P"] = _empty(sm.B, N_s, d, device=dev)
-                        bufs["Pr"] = _empty(rm.B, N_r, d, device=dev)
+                        bufs["P"] = ps_given if ps_given is not None else _empty(sm.B, N_s, d, device=dev)
+                        bufs["Pr"] = pr_given if pr_given is not None else _empty(rm.B, N_r, d, device=dev)
                     if update_edges:
                         bufs["e_out"] = _empty(B, M, d, device=dev)
                     else:
                         bufs["Pe"] = _empty(em.B, M, d, device=dev)
-                    sargs = inet_seq.make_args(g, sm, rm, em, same, update_edges, mean, B, weights, bufs)
+                    sargs = inet_seq.make_args(g, sm, rm, em, same, update_edges, mean, B, weights, bufs,
+                                               ps_given is not None, pr_given is not None)
                     inet_seq.forward(sargs, ops.stream())
                     # bet / bet2 are saved too: the backward rebuilds the weight block from
                     # saved_tensors, so an in-place change of a weight between forward and
@@ -342,15 +370,19 @@ class FusedInteractionNetFunction(torch.autograd.Function):
                 psm, prm = mat(P, 0, d), mat(P, d, d)
                 saved_proj = (P,)
             else:
-                Ps = _empty(sm.B, N_s, d, device=dev)
-                Pr = _empty(rm.B, N_r, d, device=dev)
+                Ps = ps_given if ps_given is not None else _empty(sm.B, N_s, d, device=dev)
+                Pr = pr_given if pr_given is not None else _empty(rm.B, N_r, d, device=dev)
                 psm, prm = mat(Ps), mat(Pr)
                 saved_proj = (Ps, Pr)
             Pe = None if update_edges else _empty(em.B, M, d, device=dev)
             # the sender / receiver / edge thirds of edge_mlp.0 that are separate row sets: one
             # multi-problem launch (they are independent; on the small mesh levels each would be
             # a launch of a few workgroups)
-            projs = [] if same else [(sm, W1s, None, psm), (rm, W1r, b1, prm)]
+            projs = []
+            if not same and ps_given is None:
+                projs.append((sm, W1s, None, psm))
+            if not same and pr_given is None:
+                projs.append((rm, W1r, b1, prm))
             if not update_edges:
                 projs.append((em, W1e, None, mat(Pe)))
             if len(projs) > 1 and ops.lin_multi_supported():
@@ -542,7 +574,7 @@ class FusedInteractionNetFunction(torch.autograd.Function):
                 ops.fused_lin_bwd_multi(probs + outer_jobs)
         _give_rec(ctx, g_rec_total, g_send)
         return (g_send, g_rec_total, g_edge, None, None, None, None,
-                dW1, db1, dW2, db2, dgam, dbet, dV1, dc1, dV2, dc2, dg2, db2n, None, None)
+                dW1, db1, dW2, db2, dgam, dbet, dV1, dc1, dV2, dc2, dg2, db2n, None, None, None, None)
 
 
 def _give_rec(ctx, g_rec, g_send=None):
@@ -594,7 +626,7 @@ def _backward_seq(ctx, g_rec_out, g_edge_out):
     ws = inet_seq.backward(sargs, grads, dev, ops.stream())
     del ws, bufs
     _give_rec(ctx, g_rec, g_send)
-    return (g_send, g_rec, g_edge, None, None, None, None, *pg, None, None)
+    return (g_send, g_rec, g_edge, None, None, None, None, *pg, None, None, None, None)
 
 
 FusedInteractionNetFunction._backward_seq = staticmethod(_backward_seq)
@@ -612,8 +644,87 @@ def apply_inet(net, send_rep, rec_rep, edge_rep):
         el[0][0].weight, el[0][0].bias, el[0][1].weight, el[0][1].bias, el[1].weight, el[1].bias,
         al[0][0].weight, al[0][0].bias, al[0][1].weight, al[0][1].bias, al[1].weight, al[1].bias,
         None if same else _sink(send_rep, "take"),
-        None if same else (_sink(rec_rep, "give"), _sink(send_rep, "give")))
+        None if same else (_sink(rec_rep, "give"), _sink(send_rep, "give")),
+        None if same else _pre_proj(("ps", id(net)), s, net),
+        None if same else _pre_proj(("pr", id(net)), r, net))
     return out
+
+
+def _pre_proj(key, x, net):
+    """A projection of edge_mlp.0 computed ahead by grid_encode from exactly this operand."""
+    pre = _pre_take(key, x)
+    if pre is None or tuple(pre.shape) != (x.shape[0], x.shape[1], net.hidden_dim):
+        return None
+    return pre
+
+
+# ------------------------------------------- grid-side encoder chain in one pass
+# predict_step (base_graph_model.py:116-143,157) per grid row: concatenate the inputs, embed them,
+# project the embedding as g2m sender, run the grid's own encoding MLP (+ residual), project the
+# result as m2g receiver.  Five launches that each stream a (B x N_grid)-row tensor become ONE pass
+# (csrc/fused16_grid.hip); the modules' autograd nodes are built as before, with the outputs
+# adopted through PRE, so every backward is the launch-by-launch one.
+def grid_encode_eligible(model, srcs):
+    if FORCE_GENERIC or not srcs[0].is_cuda or not ops.grid_encode_supported():
+        return False
+    if os.environ.get("NLAM_GRID_ENCODE", "1") == "0":
+        return False
+    if not (1 <= len(srcs) <= 4) or any(t.dim() != 3 or t.dtype != torch.float32 for t in srcs):
+        return False
+    k_in = sum(t.shape[-1] for t in srcs)
+    from .interaction_net import SplitMLPs
+
+    for m, k in ((model.grid_embedder, k_in), (model.encoding_grid_mlp, 64)):
+        lin, ln = _mlp_parts(m)
+        if len(lin) != 2 or ln is None or tuple(lin[0].weight.shape) != (64, k) or \
+                tuple(lin[1].weight.shape) != (64, 64):
+            return False
+    if k_in > 64:
+        return False
+    for net in (model.g2m_gnn, model.m2g_gnn):
+        if isinstance(net.edge_mlp, SplitMLPs) or isinstance(net.aggr_mlp, SplitMLPs):
+            return False
+        if net.hidden_layers != 1 or net.input_dim != 64 or net.hidden_dim != 64:
+            return False
+        if net.tables.ntiles <= 0 and net.tables.virtual is None:
+            return False
+    N = srcs[0].shape[1]
+    return (model.g2m_gnn.tables.n_send <= N and model.m2g_gnn.tables.n_rec == N
+            and all(t.shape[1] == N for t in srcs))
+
+
+def grid_encode(model, srcs):
+    """Launch the fused pass and leave its five outputs in PRE for the modules of this
+    predict_step.  Returns True if it ran (the caller clears PRE when the step ends)."""
+    d = 64
+    base = [_base(t.detach()) for t in srcs]
+    B = max(t.shape[0] for t in srcs)
+    N = srcs[0].shape[1]
+    mats = [mat(t) for t in base]
+    dev = srcs[0].device
+    k_in = sum(m.cols for m in mats)
+
+    def params(m):
+        lin, ln = _mlp_parts(m)
+        return (lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias, ln.weight, ln.bias)
+
+    emb_w, enc_w = params(model.grid_embedder), params(model.encoding_grid_mlp)
+    W1_g2m = _mlp_parts(model.g2m_gnn.edge_mlp)[0][0]
+    W1_m2g = _mlp_parts(model.m2g_gnn.edge_mlp)[0][0]
+    if any(w.stride(-1) != 1 for w in (emb_w[0], emb_w[2], enc_w[0], enc_w[2], W1_g2m.weight, W1_m2g.weight)):
+        return False
+    feat = _empty(B, N, k_in, device=dev)
+    emb, ps, rep, pr = (_empty(B, N, d, device=dev) for _ in range(4))
+    with ops.tag("grid_encode"):
+        ops.grid_encode_fwd(mats, [w.detach() for w in emb_w], W1_g2m.weight.detach()[:, d : 2 * d],
+                            [w.detach() for w in enc_w], W1_m2g.weight.detach()[:, 2 * d :],
+                            W1_m2g.bias.detach(), feat, emb, ps, rep, pr)
+    PRE[("concat",)] = (srcs[0].data_ptr(), feat)
+    PRE[("mlp", id(model.grid_embedder))] = (feat.data_ptr(), emb)
+    PRE[("ps", id(model.g2m_gnn))] = (emb.data_ptr(), ps)
+    PRE[("mlp", id(model.encoding_grid_mlp))] = (emb.data_ptr(), rep)
+    PRE[("pr", id(model.m2g_gnn))] = (rep.data_ptr(), pr)
+    return True
 
 
 # ------------------------------------------ chain of InteractionNets on shared nodes

@@ -304,15 +304,21 @@ class ConcatRows(torch.autograd.Function):
         N = srcs[0].shape[-2]
         mats = [ops.mat(t) for t in base]
         W = sum(m.cols for m in mats)
-        out = torch.empty(B, N, W, dtype=torch.float32, device=srcs[0].device)
-        n = len(mats)
-        ops._launch(
-            "nlam_concat_rows", lib.nlam_concat_rows,
-            (n, (ctypes.c_void_p * n)(*[m.ptr for m in mats]),
-             (ctypes.c_int64 * n)(*[m.bstride for m in mats]),
-             (ctypes.c_int64 * n)(*[m.ld for m in mats]),
-             (ctypes.c_int32 * n)(*[m.cols for m in mats]), out.data_ptr(), B, N, ops.stream()),
-            nbytes=8.0 * out.numel())
+        from . import fused
+
+        out = fused._pre_take(("concat",), srcs[0])   # written by fused.grid_encode in this step
+        if out is not None and tuple(out.shape) != (B, N, W):
+            out = None
+        if out is None:
+            out = torch.empty(B, N, W, dtype=torch.float32, device=srcs[0].device)
+            n = len(mats)
+            ops._launch(
+                "nlam_concat_rows", lib.nlam_concat_rows,
+                (n, (ctypes.c_void_p * n)(*[m.ptr for m in mats]),
+                 (ctypes.c_int64 * n)(*[m.bstride for m in mats]),
+                 (ctypes.c_int64 * n)(*[m.ld for m in mats]),
+                 (ctypes.c_int32 * n)(*[m.cols for m in mats]), out.data_ptr(), B, N, ops.stream()),
+                nbytes=8.0 * out.numel())
         ctx.widths = [m.cols for m in mats]
         return out
 

@@ -34,7 +34,8 @@ class Weights(ctypes.Structure):
 class Args(ctypes.Structure):
     _fields_ = [("g", Graph), ("w", Weights), ("send", View), ("rec", View), ("edge", View),
                 ("n_send_rows", _I64), ("B", _I64), ("d", _I), ("update_edges", _I), ("mean", _I),
-                ("P", _P), ("Pr", _P), ("Pe", _P), ("agg", _P), ("e_out", _P), ("rec_out", _P)]
+                ("P", _P), ("Pr", _P), ("Pe", _P), ("agg", _P), ("e_out", _P), ("rec_out", _P),
+                ("ps_given", _I), ("pr_given", _I)]
 
 
 class Grads(ctypes.Structure):
@@ -73,7 +74,8 @@ def weights_struct(weights):
                    bet2.data_ptr())
 
 
-def make_args(tables, sm, rm, em, same, update_edges, mean, B, weights, bufs):
+def make_args(tables, sm, rm, em, same, update_edges, mean, B, weights, bufs, ps_given=False,
+              pr_given=False):
     """weights: (W1, b1, W2, b2, gam, bet, V1, c1, V2, c2, gam2, bet2); bufs: dict of the
     caller-allocated tensors P, Pr, Pe, agg, e_out, rec_out (None where unused; an empty dict
     gives the shape-only block nlam_inet_supported() is asked with)."""
@@ -85,7 +87,7 @@ def make_args(tables, sm, rm, em, same, update_edges, mean, B, weights, bufs):
     return Args(graph_struct(tables), w, _view(sm), rec, _view(em), sm.rows, B, 64,
                 int(update_edges), int(mean), _ptr(bufs.get("P")), _ptr(bufs.get("Pr")),
                 _ptr(bufs.get("Pe")), _ptr(bufs.get("agg")), _ptr(bufs.get("e_out")),
-                _ptr(bufs.get("rec_out")))
+                _ptr(bufs.get("rec_out")), int(bool(ps_given)), int(bool(pr_given)))
 
 
 def supported(args):

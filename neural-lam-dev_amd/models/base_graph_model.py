@@ -82,12 +82,17 @@ class BaseGraphModel(ARModel):
             return self._predict_step(prev_state, prev_prev_state, forcing, boundary_truth)
         finally:
             self._static_emb = None
+            fused.PRE.clear()
 
     def _predict_step(self, prev_state, prev_prev_state, forcing, boundary_truth=None):
         batch_size = prev_state.shape[0]
         srcs = (prev_state, prev_prev_state, forcing,
                 self.expand_to_batch(self.grid_static_features, batch_size))
         if prev_state.is_cuda:
+            # the whole grid-side chain up to the m2g receiver projection in one pass over the grid
+            # rows (csrc/fused16_grid.hip); the modules below adopt its outputs (fused.PRE)
+            if fused.grid_encode_eligible(self, srcs):
+                fused.grid_encode(self, srcs)
             grid_features = glue.ConcatRows.apply(*srcs)   # one kernel, static features in place
         else:
             grid_features = torch.cat(srcs, dim=-1)

@@ -363,6 +363,37 @@ def fused_mlp_fwd(xa, xb, W1, b1, W2, b2, gamma, beta, res, out, hid, n_out):
     )
 
 
+def grid_encode_supported():
+    return bool(lib.nlam_grid_encode_supported())
+
+
+def grid_encode_fwd(srcs, emb_w, Ws, enc_w, Wr, br, feat, emb, ps, rep, pr):
+    """One pass over the grid rows (csrc/fused16_grid.hip): srcs = Mats of the grid features'
+    sources; emb_w / enc_w = (W1, b1, W2, b2, gamma, beta) of grid_embedder / encoding_grid_mlp;
+    Ws / (Wr, br) = the sender third of g2m's and the receiver third of m2g's first edge-MLP
+    Linear; feat (or None), emb, ps, rep, pr: contiguous (B, rows, .) output tensors."""
+    n = len(srcs)
+    B, rows = emb.shape[0], emb.shape[1]
+    k_in = sum(m.cols for m in srcs)
+    P, I64, I32 = ctypes.c_void_p * n, ctypes.c_int64 * n, ctypes.c_int32 * n
+    W1, b1, W2, b2, gam, bet = emb_w
+    E1, e1, E2, e2, egam, ebet = enc_w
+    _launch(
+        "nlam_grid_encode_fwd", lib.nlam_grid_encode_fwd,
+        (n, P(*[m.ptr for m in srcs]), I64(*[m.bstride for m in srcs]), I64(*[m.ld for m in srcs]),
+         I32(*[m.cols for m in srcs]),
+         W1.data_ptr(), W1.stride(0), b1.data_ptr(), W2.data_ptr(), W2.stride(0), b2.data_ptr(),
+         gam.data_ptr(), bet.data_ptr(), Ws.data_ptr(), Ws.stride(0),
+         E1.data_ptr(), E1.stride(0), e1.data_ptr(), E2.data_ptr(), E2.stride(0), e2.data_ptr(),
+         egam.data_ptr(), ebet.data_ptr(), Wr.data_ptr(), Wr.stride(0), _p(br),
+         _p(feat), emb.data_ptr(), ps.data_ptr(), rep.data_ptr(), pr.data_ptr(), B, rows, stream()),
+        flops=2.0 * B * rows * 64 * (k_in + 5 * 64),
+        # algorithmic bytes: the sources once, the five outputs once
+        nbytes=4.0 * rows * (sum((m.B if m.bstride else 1) * m.cols for m in srcs)
+                             + B * ((k_in if feat is not None else 0) + 4 * 64)),
+    )
+
+
 def fused_lin_fwd(x, WA, bA, WB, bB, out):
     """out[:, :nA] = x WA^T + bA ; out[:, nA:] = x WB^T + bB.  WA/WB: 2-D weight
     views (any row pitch)."""
