@@ -28,7 +28,6 @@
 #define G16_THREADS 512
 #define G16_MAXSRC 4
 #define G16_XLD 68      // fp32 staging tile [16][68]: 64 columns + 4 (conflict-free 16-byte access)
-#define G16_SLOTS 16    // dword loads per lane that cover 16 rows x <= 64 columns
 
 struct GridFwdParams {
   RowView src[G16_MAXSRC];    // (B | 1, rows, width_k); widths sum to k_in <= 64
@@ -50,33 +49,45 @@ struct GridFwdParams {
   int B;
 };
 
-// element e of a tile's concatenated rows (row-major [16][k_in]) -> where it comes from
-struct G16Slot {
-  int src;     // source index
-  int row;     // tile row 0..15
-  int c;       // column inside the source
-  int col;     // column of the concatenated row
-  bool live;
+// ---- source staging -----------------------------------------------------------------------
+// A tile's source elements arrive by COALESCED dword loads and change shape through the wave's
+// fp32 tile: source k's 16 x w_k block of a tile is one contiguous run of 16 w_k floats when its
+// rows are dense (ld == w_k: the state / forcing slices), so lane l of a source's slot u takes
+// element 64 u + l of that run.  Every source gets the same compile-time number S of slots
+// (S = ceil(max_k w_k / 4); slot (k, u) is statically source k), so the per-tile part of an
+// address is ONE scalar base per source (saddr form of global_load: no per-lane pointer
+// arithmetic, no selects) and the per-lane part -- dword offset inside the source's tile and LDS
+// offset, packed into one register per slot -- is computed once before the tile loop.  No
+// branches, no predicated loads or stores in the tile loop: lanes past a run's end re-read its
+// element 0 and park it in the tile's padding columns, and the last tile of a batch item is moved
+// back so that it is a full 16 rows (rows it shares with its neighbour are computed twice,
+// bit-identically).
+template <int S>
+struct G16Map {
+  int desc[G16_MAXSRC * S];    // per lane: dword offset | LDS offset << 20
 };
-__device__ __forceinline__ G16Slot g16_slot(const GridFwdParams& p, int e) {
-  G16Slot s;
-  s.live = e < NLAM_T16 * p.k_in;
-  const int ee = s.live ? e : 0;
-  s.row = ee / p.k_in;
-  s.col = ee - s.row * p.k_in;
-  int c = s.col, k = 0;
+template <int S>
+__device__ __forceinline__ void g16_make_map(G16Map<S>& m, const GridFwdParams& p, int lane) {
+  int col0 = 0;
 #pragma unroll
-  for (int j = 0; j + 1 < G16_MAXSRC; ++j) {
-    const bool next = k == j && j + 1 < p.nsrc && c >= p.src[j].width;
-    c = next ? c - p.src[j].width : c;
-    k = next ? j + 1 : k;
+  for (int k = 0; k < G16_MAXSRC; ++k) {
+    const int w = k < p.nsrc ? p.src[k].width : 0;
+    const int wd = w > 0 ? w : 1;
+#pragma unroll
+    for (int u = 0; u < S; ++u) {
+      const int e = 64 * u + lane;
+      const bool live = e < NLAM_T16 * w;
+      const int row = live ? e / wd : (lane & 15);
+      const int c = live ? e - row * w : 0;
+      const int off = live ? row * (int)p.src[k].ld + c : 0;
+      const int dst = live ? row * G16_XLD + col0 + c : row * G16_XLD + 64 + ((lane >> 4) & 3);
+      m.desc[k * S + u] = off | (dst << 20);
+    }
+    col0 += w;
   }
-  s.src = k;
-  s.c = c;
-  return s;
 }
 
-template <int TERMS>
+template <int TERMS, int S, bool FEAT>
 __global__ __launch_bounds__(G16_THREADS, 2) void grid_fwd16_kernel(GridFwdParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem16[];
   constexpr int D = 64;
@@ -119,90 +130,65 @@ __global__ __launch_bounds__(G16_THREADS, 2) void grid_fwd16_kernel(GridFwdParam
     w16_commit(l4, E2im, 0, p.E2, p.ldE2, D, D, D, D, tid, G16_THREADS);
     w16_commit(lr, Wrim, 0, p.Wr, p.ldWr, D, D, D, D, tid, G16_THREADS);
   }
-  // the staging tile's columns >= k_in stay zero for the life of the kernel
+  // the staging tile's columns >= k_in stay zero for the life of the kernel (its padding columns
+  // 64..67 take the parked elements and are never read)
   for (int i = lane; i < NLAM_T16 * G16_XLD; i += 64) XT[i] = 0.f;
+  constexpr int NSL = G16_MAXSRC * S;
+  G16Map<S> map;
+  g16_make_map<S>(map, p, lane);
   __syncthreads();
-
-  // per lane, once: where each of its G16_SLOTS elements of a tile comes from and goes to.
-  // desc = src | row << 2 | c << 6 | live << 12; dst = LDS float offset in the staging tile
-  int desc[G16_SLOTS], dst[G16_SLOTS];
-#pragma unroll
-  for (int j = 0; j < G16_SLOTS; ++j) {
-    const G16Slot s = g16_slot(p, lane + 64 * j);
-    desc[j] = s.src | (s.row << 2) | (s.c << 6) | ((s.live ? 1 : 0) << 12);
-    dst[j] = s.row * G16_XLD + s.col;
-  }
-  const int nslots = (NLAM_T16 * p.k_in + 63) >> 6;   // wave-uniform
 
   const int64_t tiles_per_b = (p.rows + NLAM_T16 - 1) / NLAM_T16;
   const int64_t ntiles = tiles_per_b * p.B;
   const int64_t stride = (int64_t)gridDim.x * G16_NW;
 
-  // request the source elements of tile tt (rows past the end re-read the tile's last valid row)
-  auto issue = [&](float (&v)[G16_SLOTS], int64_t tt) {
+  // request the source elements of tile tt
+  auto issue = [&](float (&v)[NSL], int64_t tt) {
     const int64_t b = tt / tiles_per_b;
-    const int64_t r0 = (tt - b * tiles_per_b) * NLAM_T16;
-    const int last = (int)((p.rows - r0) < NLAM_T16 ? (p.rows - r0) : NLAM_T16) - 1;
-    const float* base[G16_MAXSRC];
-    int64_t ld[G16_MAXSRC];
+    int64_t r0 = (tt - b * tiles_per_b) * NLAM_T16;
+    r0 = r0 + NLAM_T16 <= p.rows ? r0 : p.rows - NLAM_T16;   // the last tile is moved back: full
 #pragma unroll
     for (int k = 0; k < G16_MAXSRC; ++k) {
-      const int kk = k < p.nsrc ? k : 0;
-      base[k] = p.src[kk].ptr + b * p.src[kk].bstride + r0 * p.src[kk].ld;
-      ld[k] = p.src[kk].ld;
-    }
+      // (unused sources repeat source 0 in the parameter block: valid addresses, parked values)
+      const float* bp = p.src[k].ptr + b * p.src[k].bstride + r0 * p.src[k].ld;   // scalar
 #pragma unroll
-    for (int j = 0; j < G16_SLOTS; ++j) {
-      if (j < nslots) {   // wave-uniform
-        const int sidx = desc[j] & 3;
-        int row = (desc[j] >> 2) & 15;
-        row = row < last ? row : last;
-        const int c = (desc[j] >> 6) & 63;
-        const float* bp = sidx == 0 ? base[0] : (sidx == 1 ? base[1] : (sidx == 2 ? base[2] : base[3]));
-        const int64_t l = sidx == 0 ? ld[0] : (sidx == 1 ? ld[1] : (sidx == 2 ? ld[2] : ld[3]));
-        v[j] = bp[row * l + c];
-      }
+      for (int u = 0; u < S; ++u) v[k * S + u] = bp[map.desc[k * S + u] & 0xFFFFF];
     }
   };
 
-  float nx[G16_SLOTS];
+  float nx[NSL];
   int64_t tt = (int64_t)blockIdx.x * G16_NW + wave;
   if (tt < ntiles) issue(nx, tt);
+  // the loop is entered with nothing in flight: hipcc merges its wait counts over the loop's two
+  // entries, and with the first tile's loads still pending at the header every wait at the top of
+  // a tile also drained the previous tile's 20 row stores (fused_edge2.hip, same remedy)
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0); lgkmcnt / expcnt untouched
   for (; tt < ntiles; tt += stride) {
     const int64_t b = tt / tiles_per_b;
-    const int64_t r0 = (tt - b * tiles_per_b) * NLAM_T16;
-    const int nrows = (int)((p.rows - r0) < NLAM_T16 ? (p.rows - r0) : NLAM_T16);
-    const bool valid = t < nrows;
+    int64_t r0 = (tt - b * tiles_per_b) * NLAM_T16;
+    r0 = r0 + NLAM_T16 <= p.rows ? r0 : p.rows - NLAM_T16;
     const int64_t orow = b * p.rows + r0;    // first output row of the tile (outputs are contiguous)
 
     // ---- stage: registers -> this wave's fp32 tile, then accumulator layout
     wave_sync();   // (the previous tile's reads of XT are done)
 #pragma unroll
-    for (int j = 0; j < G16_SLOTS; ++j)
-      if (j < nslots && ((desc[j] >> 12) & 1)) XT[dst[j]] = nx[j];
+    for (int j = 0; j < NSL; ++j) XT[(unsigned)map.desc[j] >> 20] = nx[j];
     wave_sync();
-    if (tt + stride < ntiles) issue(nx, tt + stride);   // next tile's rows ride under this tile
+    // next tile's rows ride under this tile (a wave's last tile re-requests itself: no branch
+    // around loads, the values are never used)
+    issue(nx, tt + stride < ntiles ? tt + stride : tt);
     f32x4 x[4];
     tile_to_acc16<4>(x, XT, G16_XLD, lane);
-    if (p.feat != nullptr) {
-      // grid_features rows: 16 x k_in floats, contiguous in the output; float4 chunks (k_in % 4 == 0
-      // checked by the host side, else element stores)
+    if constexpr (FEAT) {
+      // grid_features rows: 16 x k_in floats, contiguous in the output (k_in % 4 == 0: float4)
       float* fo = p.feat + orow * p.k_in;
       const int cpr = p.k_in >> 2;
-      if ((p.k_in & 3) == 0) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int q = lane + 64 * j;
-          const int r = q / cpr, c4 = q - r * cpr;
-          if (q < nrows * cpr)
-            *reinterpret_cast<f32x4*>(fo + 4 * q) = *reinterpret_cast<const f32x4*>(XT + r * G16_XLD + 4 * c4);
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < G16_SLOTS; ++j) {
-          const int e = lane + 64 * j;
-          if (j < nslots && e < nrows * p.k_in) fo[e] = XT[dst[j]];
-        }
+      for (int j = 0; j < 4; ++j) {
+        int q = lane + 64 * j;
+        q = q < NLAM_T16 * cpr ? q : NLAM_T16 * cpr - 1;   // (clamped: duplicates store the same bytes)
+        const int r = q / cpr, c4 = q - r * cpr;
+        *reinterpret_cast<f32x4*>(fo + 4 * q) = *reinterpret_cast<const f32x4*>(XT + r * G16_XLD + 4 * c4);
       }
     }
 
@@ -220,13 +206,13 @@ __global__ __launch_bounds__(G16_THREADS, 2) void grid_fwd16_kernel(GridFwdParam
       gemm_acc16<4, 2, TERMS>(emb, W2im, 0, 0, h, lane);
       ln16_apply<4>(emb, gs, bs, lane);
     }
-    if (valid) store_row16<4>(p.emb + (orow + t) * D, emb, lane);
+    store_row16<4>(p.emb + (orow + t) * D, emb, lane);
     // ---- sender projection of the encoder GNN
     {
       f32x4 y[4];
       zero16<4>(y);
       gemm_acc16<4, 2, TERMS>(y, Wsim, 0, 0, emb, lane);
-      if (valid) store_row16<4>(p.ps + (orow + t) * D, y, lane);
+      store_row16<4>(p.ps + (orow + t) * D, y, lane);
     }
     // ---- encoding MLP with residual: rep = emb + LN(E2 silu(E1 emb + e1) + e2)
     f32x4 rep[4];
@@ -244,13 +230,13 @@ __global__ __launch_bounds__(G16_THREADS, 2) void grid_fwd16_kernel(GridFwdParam
 #pragma unroll
       for (int fb = 0; fb < 4; ++fb) rep[fb] += emb[fb];
     }
-    if (valid) store_row16<4>(p.rep + (orow + t) * D, rep, lane);
+    store_row16<4>(p.rep + (orow + t) * D, rep, lane);
     // ---- receiver projection of the decoder GNN
     {
       f32x4 y[4];
       vec_to_acc16<4>(y, brs, lane);
       gemm_acc16<4, 2, TERMS>(y, Wrim, 0, 0, rep, lane);
-      if (valid) store_row16<4>(p.pr + (orow + t) * D, y, lane);
+      store_row16<4>(p.pr + (orow + t) * D, y, lane);
     }
   }
 }
@@ -286,10 +272,15 @@ extern "C" int nlam_grid_encode_fwd(
       p.src[k] = RowView{nullptr, 0, 0, 0};
     }
   }
-  NLAM_REQUIRE(p.k_in <= 64, "nlam_grid_encode_fwd: %d input columns (max 64)", p.k_in);
-  NLAM_REQUIRE(nlam_aligned16(emb) && nlam_aligned16(ps) && nlam_aligned16(rep) && nlam_aligned16(pr) &&
-                   (feat == nullptr || nlam_aligned16(feat)),
-               "nlam_grid_encode_fwd: outputs must be 16-byte aligned");
+  NLAM_REQUIRE(p.k_in <= 64 && p.k_in % 4 == 0, "nlam_grid_encode_fwd: %d input columns (a multiple of 4, <= 64)", p.k_in);
+  NLAM_REQUIRE(rows >= NLAM_T16, "nlam_grid_encode_fwd: %lld rows (>= 16)", (long long)rows);
+  int wmax = 0;
+  for (int k = 0; k < nsrc; ++k) {
+    wmax = src_width[k] > wmax ? src_width[k] : wmax;
+    NLAM_REQUIRE(NLAM_T16 * src_ld[k] < (1 << 20), "nlam_grid_encode_fwd: source %d row pitch too large", k);
+  }
+  NLAM_REQUIRE(wmax <= 32, "nlam_grid_encode_fwd: a source of %d columns (max 32 per source)", wmax);
+  for (int k = nsrc; k < G16_MAXSRC; ++k) p.src[k] = RowView{src[0], src_bstride[0], src_ld[0], 0};
   p.W1 = W1; p.ldW1 = ldW1; p.b1 = b1; p.W2 = W2; p.ldW2 = ldW2; p.b2 = b2;
   p.gamma = gamma; p.beta = beta; p.Ws = Ws; p.ldWs = ldWs;
   p.E1 = E1; p.ldE1 = ldE1; p.e1 = e1; p.E2 = E2; p.ldE2 = ldE2; p.e2 = e2;
@@ -299,12 +290,27 @@ extern "C" int nlam_grid_encode_fwd(
   const size_t lds = 6 * w16_image_bytes(64, 64) + 9 * 64 * sizeof(float) +
                      (size_t)G16_NW * NLAM_T16 * G16_XLD * sizeof(float);
   NLAM_REQUIRE(lds <= 160 * 1024, "grid_fwd16: LDS footprint %zu B exceeds 160 KiB", lds);
-  auto kern = grid_fwd16_kernel<3>;
-  NLAM_BIG_LDS(kern, __func__);
   const int64_t ntiles = ((rows + NLAM_T16 - 1) / NLAM_T16) * B;
   int64_t g = (ntiles + G16_NW - 1) / G16_NW;
   if (g > 256) g = 256;   // one 8-wave workgroup per CU (LDS)
-  kern<<<(unsigned)g, G16_THREADS, lds, (hipStream_t)stream>>>(p);
+  // slots per source: ceil(wmax / 4), rounded up to an instantiated count
+#define G16_LAUNCH(SS)                                                              \
+  do {                                                                              \
+    if (feat != nullptr) {                                                          \
+      auto kern = grid_fwd16_kernel<3, SS, true>;                                   \
+      NLAM_BIG_LDS(kern, __func__);                                                 \
+      kern<<<(unsigned)g, G16_THREADS, lds, (hipStream_t)stream>>>(p);              \
+    } else {                                                                        \
+      auto kern = grid_fwd16_kernel<3, SS, false>;                                  \
+      NLAM_BIG_LDS(kern, __func__);                                                 \
+      kern<<<(unsigned)g, G16_THREADS, lds, (hipStream_t)stream>>>(p);              \
+    }                                                                               \
+  } while (0)
+  const int need = (wmax + 3) / 4;
+  if (need <= 3) G16_LAUNCH(3);
+  else if (need <= 5) G16_LAUNCH(5);
+  else G16_LAUNCH(8);
+#undef G16_LAUNCH
   NLAM_CHECK_LAUNCH("grid_fwd16_kernel");
   return 0;
 }

@@ -679,7 +679,7 @@ def grid_encode_eligible(model, srcs):
         if len(lin) != 2 or ln is None or tuple(lin[0].weight.shape) != (64, k) or \
                 tuple(lin[1].weight.shape) != (64, 64):
             return False
-    if k_in > 64:
+    if k_in > 64 or k_in % 4 != 0 or max(t.shape[-1] for t in srcs) > 32 or srcs[0].shape[1] < 16:
         return False
     for net in (model.g2m_gnn, model.m2g_gnn):
         if isinstance(net.edge_mlp, SplitMLPs) or isinstance(net.aggr_mlp, SplitMLPs):

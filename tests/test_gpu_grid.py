@@ -31,7 +31,8 @@ def _params(m):
 
 
 @pytest.mark.parametrize("widths,B,N", [((17, 17, 18, 4), 3, 1000), ((17, 17, 18, 4), 2, 16 * 40 + 5),
-                                        ((5, 5, 6, 1), 2, 333), ((64,), 1, 47), ((3, 8), 4, 16)])
+                                        ((5, 5, 6, 4), 2, 333), ((32, 32), 1, 47), ((1, 8, 3), 4, 16),
+                                        ((9, 9, 12, 2), 2, 90)])
 def test_grid_encode_kernel_matches_the_launch_sequence_bitwise(widths, B, N):
     from neural_lam_amd import glue, ops
     from neural_lam_amd.ops import mat
@@ -101,7 +102,7 @@ def test_training_step_is_unchanged_by_the_fused_grid_pass(model_name, monkeypat
         n = info["num_grid"]
         gen = torch.Generator().manual_seed(0)
         ds = synthetic.SyntheticDatastore(
-            tmp, torch.randn(n, 3, generator=gen).numpy(), np.zeros(7), np.ones(7), np.zeros(7),
+            tmp, torch.randn(n, 4, generator=gen).numpy(), np.zeros(7), np.ones(7), np.zeros(7),
             np.ones(7), (torch.rand(n, generator=gen) < 0.2).float().numpy(), n_forcing=2)
         torch.manual_seed(1)
         model = MODELS[model_name](synthetic.model_args(graph="g", hidden_dim=64, processor_layers=2),
