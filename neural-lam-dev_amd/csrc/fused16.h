@@ -32,18 +32,26 @@
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
 
 // ---- weight images -------------------------------------------------------------------
-// Two bf16 planes (hi, lo) in natural [n][k] order like fused_bf16x3.h, but with row pitch
-// K + 8 elements: with 16 rows x 2 k-groups per 32-lane half (instead of 32 rows) the 8-byte
-// row reads are conflict-free at K/2 + 4 dwords per row (tools/sim16.py bank_report).
-__host__ __device__ constexpr int w16_pitch(int k32) { return k32 + 8; }
-__host__ __device__ constexpr size_t w16_image_bytes(int n_pad, int k32) {
-  return (size_t)2 * n_pad * w16_pitch(k32) * sizeof(__bf16);
+// Two bf16 planes (hi, lo) in natural [n][k] order like fused_bf16x3.h.  Two layouts:
+//   plain    (forward-only kernels): row pitch K + 8 elements -- with 16 rows x 2 k-groups per
+//            32-lane half the 8-byte ROW reads of W . x are conflict-free at K/2 + 4 dwords per row;
+//            the transposed reads of W^T . g are 2-way conflicted there (rows 0 and 7 of a half
+//            wrap onto the same banks);
+//   swizzled (kernels that also read the image transposed: every backward): row pitch K + 16 and
+//            rows with bit 3 set start 8 elements later -- row reads AND transposed reads are both
+//            conflict-free (tools/sim16.py bank_report; SQ_LDS_BANK_CONFLICT was 0.36-0.45 of the
+//            LDS cycles of the 16-row backward kernels with the plain layout: VERDICT r4 2c).
+// The helpers take either: B3Image carries pitch and swizzle.
+__host__ __device__ constexpr int w16_pitch(int k32, bool swz = false) { return k32 + (swz ? 16 : 8); }
+__host__ __device__ constexpr size_t w16_image_bytes(int n_pad, int k32, bool swz = false) {
+  return (size_t)2 * (n_pad * w16_pitch(k32, swz) + (swz ? 8 : 0)) * sizeof(__bf16);
 }
-__device__ __forceinline__ B3Image w16_image(void* base, int n_pad, int k32) {
+__device__ __forceinline__ B3Image w16_image(void* base, int n_pad, int k32, bool swz = false) {
   B3Image im;
-  im.pitch = w16_pitch(k32);
+  im.pitch = w16_pitch(k32, swz);
+  im.swz = swz ? 8 : 0;
   im.hi = reinterpret_cast<__bf16*>(base);
-  im.lo = im.hi + n_pad * im.pitch;
+  im.lo = im.hi + n_pad * im.pitch + im.swz;
   return im;
 }
 
@@ -110,7 +118,7 @@ __device__ __forceinline__ void gemm_acc16(f32x4 (&out)[NO], const B3Image& W, i
     if constexpr (TERMS == 3) split16(in[2 * s], in[2 * s + 1], bh[s], bl[s]);
     else hi16(in[2 * s], in[2 * s + 1], bh[s]);
   }
-  const int base = (row0 + i) * W.pitch + col0 + 4 * g;
+  const int base = (row0 + i) * W.pitch + col0 + 4 * g + W.swz * ((i >> 3) & 1);   // (row0 % 16 == 0)
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
 #pragma unroll
@@ -144,7 +152,7 @@ __device__ __forceinline__ void gemm_acc16_wt(f32x4 (&out)[KO], const B3Image& W
     if constexpr (TERMS == 3) split16(gin[2 * s], gin[2 * s + 1], bh[s], bl[s]);
     else hi16(gin[2 * s], gin[2 * s + 1], bh[s]);
   }
-  const int base = (row0 + 4 * g + q) * W.pitch + col0 + 4 * p;
+  const int base = (row0 + 4 * g + q) * W.pitch + col0 + 4 * p + W.swz * (g >> 1);   // (row0 % 16 == 0)
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
 #pragma unroll
@@ -187,7 +195,7 @@ template <int NO, int KS, int TERMS = 3>
 __device__ __forceinline__ void gemm_frag16(f32x4 (&out)[NO], const B3Image& W, int row0, int col0,
                                             const Frag16<KS>& f, int lane) {
   const int i = lane & 15, g = lane >> 4;
-  const int base = (row0 + i) * W.pitch + col0 + 4 * g;
+  const int base = (row0 + i) * W.pitch + col0 + 4 * g + W.swz * ((i >> 3) & 1);   // (row0 % 16 == 0)
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
 #pragma unroll
@@ -210,7 +218,7 @@ template <int KO, int NS, int TERMS = 3>
 __device__ __forceinline__ void gemm_frag16_wt(f32x4 (&out)[KO], const B3Image& W, int row0,
                                                int col0, const Frag16<NS>& f, int lane) {
   const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
-  const int base = (row0 + 4 * g + q) * W.pitch + col0 + 4 * p;
+  const int base = (row0 + 4 * g + q) * W.pitch + col0 + 4 * p + W.swz * (g >> 1);   // (row0 % 16 == 0)
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
 #pragma unroll

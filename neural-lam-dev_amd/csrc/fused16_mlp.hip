@@ -104,10 +104,11 @@ __device__ __forceinline__ void mlp_bwd16_body(const MlpBwdParams& q, int wg, in
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
   const int t = lane & 15;
   char* cur = smem16;
-  const B3Image W1im = w16_image(cur, HID, KP32);
-  cur += w16_image_bytes(HID, KP32);
-  const B3Image W2im = w16_image(cur, NO, HID);
-  cur += w16_image_bytes(NO, HID);
+  // (both images are also read transposed: swizzled layout, fused16.h)
+  const B3Image W1im = w16_image(cur, HID, KP32, true);
+  cur += w16_image_bytes(HID, KP32, true);
+  const B3Image W2im = w16_image(cur, NO, HID, true);
+  cur += w16_image_bytes(NO, HID, true);
   float* b1s = reinterpret_cast<float*>(cur);
   float* b2s = b1s + HID;
   float* gs = b2s + NO;
@@ -358,7 +359,8 @@ static int launch_mlp_bwd16(const MlpBwdParams& q, hipStream_t s) {
   constexpr int HID = 64, NO = 32 * NOB, KP32 = 32 * KB;
   constexpr int PW0 = (!DEFER && KP32 > HID) ? KP32 : HID;
   constexpr int PW1 = HID > NO ? HID : NO;
-  size_t lds = w16_image_bytes(HID, KP32) + w16_image_bytes(NO, HID) + (HID + 2 * NO) * sizeof(float) +
+  size_t lds = w16_image_bytes(HID, KP32, true) + w16_image_bytes(NO, HID, true) +
+               (HID + 2 * NO) * sizeof(float) +
                K16_NW * (p16_bytes(PW0) + p16_bytes(PW1) +
                          (DEFER ? 0 : (size_t)NLAM_T16 * (HID + 4) * sizeof(float)));
   size_t fold = (size_t)K16_NW * HID * HID * sizeof(float);          // dW2 images
@@ -408,8 +410,8 @@ __device__ __forceinline__ void lin_bwd16_body(const LinBwdParams& q, int wg, in
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
   const int t = lane & 15;
-  const B3Image Wim = w16_image(smem16, NO, K);
-  char* mine = smem16 + w16_image_bytes(NO, K) + wave * (p16_bytes(NO) + p16_bytes(K));
+  const B3Image Wim = w16_image(smem16, NO, K, true);   // read transposed: swizzled layout
+  char* mine = smem16 + w16_image_bytes(NO, K, true) + wave * (p16_bytes(NO) + p16_bytes(K));
   const B3Tile Tg = p16_tile(mine, NO), Tx = p16_tile(mine + p16_bytes(NO), K);
   {
     WLoad16<NOB> la, lb;   // (NOB x 512 float4 cover up to 32 NOB rows of 64)
@@ -532,7 +534,7 @@ __global__ __launch_bounds__(K16_THREADS, 2) void lin_bwd16_multi_kernel(LinBwdM
 template <int NOB>
 static size_t lin_bwd16_lds() {
   constexpr int K = 64, NO = 32 * NOB;
-  size_t lds = w16_image_bytes(NO, K) + K16_NW * (p16_bytes(NO) + p16_bytes(K));
+  size_t lds = w16_image_bytes(NO, K, true) + K16_NW * (p16_bytes(NO) + p16_bytes(K));
   const size_t fold = (size_t)K16_NW * 64 * K * sizeof(float);
   return fold > lds ? fold : lds;
 }
@@ -978,7 +980,8 @@ int nlam_k16_mlp_bwd_multi(const MlpBwdParams* q, int n, hipStream_t s) {
   }
   for (int k = n; k < K16_MAXM; ++k) m.wg0[k + 1] = m.wg0[n];
   constexpr int HID = 64, NO = 64, KP32 = 32;
-  size_t lds = w16_image_bytes(HID, KP32) + w16_image_bytes(NO, HID) + (HID + 2 * NO) * sizeof(float) +
+  size_t lds = w16_image_bytes(HID, KP32, true) + w16_image_bytes(NO, HID, true) +
+               (HID + 2 * NO) * sizeof(float) +
                K16_NW * (p16_bytes(HID) + p16_bytes(HID) + (size_t)NLAM_T16 * (HID + 4) * sizeof(float));
   const size_t fold = (size_t)K16_NW * HID * HID * sizeof(float);
   if (fold > lds) lds = fold;

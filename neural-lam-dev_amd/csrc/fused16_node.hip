@@ -146,11 +146,14 @@ __global__ __launch_bounds__(K16_THREADS, 2) void node_bwd16_kernel(NodeBwdParam
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int t = lane & 15;
   char* cur = smem16;
-  const B3Image Wpim = w16_image(cur, 2 * D, D);
-  cur += w16_image_bytes(2 * D, D);
+  // swizzled (transposed reads conflict-free, fused16.h) where the 160 KiB allow it: with the node
+  // update below (HAS_A) the three images + planes leave 3 KB, enough for V2's 2 KB only
+  constexpr bool WP_SWZ = !HAS_A;
+  const B3Image Wpim = w16_image(cur, 2 * D, D, WP_SWZ);
+  cur += w16_image_bytes(2 * D, D, WP_SWZ);
   const B3Image V1im = w16_image(cur, D, 2 * D);
-  const B3Image V2im = w16_image(cur + w16_image_bytes(D, 2 * D), D, D);
-  if (HAS_A) cur += w16_image_bytes(D, 2 * D) + w16_image_bytes(D, D);
+  const B3Image V2im = w16_image(cur + w16_image_bytes(D, 2 * D), D, D, true);
+  if (HAS_A) cur += w16_image_bytes(D, 2 * D) + w16_image_bytes(D, D, true);
   float* c1s = reinterpret_cast<float*>(cur);
   float* c2s = c1s + D;
   float* gs = c2s + D;
@@ -320,8 +323,8 @@ extern "C" int64_t nlam_node_outer_grid(int64_t B, int64_t rows) { return node_g
 static int launch_node_bwd16(const NodeBwdParams& q, hipStream_t s) {
   constexpr int D = 64;
   const bool has_a = q.x.ptr != nullptr;
-  size_t lds = w16_image_bytes(2 * D, D) + 3 * D * sizeof(float) + (size_t)K16_NW * 2 * p16_bytes(D);
-  if (has_a) lds += w16_image_bytes(D, 2 * D) + w16_image_bytes(D, D);
+  size_t lds = w16_image_bytes(2 * D, D, !has_a) + 3 * D * sizeof(float) + (size_t)K16_NW * 2 * p16_bytes(D);
+  if (has_a) lds += w16_image_bytes(D, 2 * D) + w16_image_bytes(D, D, true);
   const size_t fold = (size_t)K16_NW * D * D * sizeof(float);
   if (has_a && fold > lds) lds = fold;
   NLAM_REQUIRE(lds <= 160 * 1024, "node_bwd16: LDS footprint %zu B exceeds 160 KiB", lds);

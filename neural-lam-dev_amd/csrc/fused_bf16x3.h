@@ -22,7 +22,12 @@ struct B3Image {
   __bf16* hi;
   __bf16* lo;
   int pitch;   // elements
+  int swz;     // rows with bit 3 set start `swz` elements later (16-row kernels: fused16.h); 0: none
 };
+// element offset of (row, col) in either plane of an image
+__device__ __forceinline__ int b3_at(const B3Image& im, int row, int col) {
+  return row * im.pitch + col + im.swz * ((row >> 3) & 1);
+}
 __host__ __device__ constexpr int b3_pitch(int k_pad32) { return k_pad32 + 4; }
 // bytes of one image with n_pad rows
 __host__ __device__ constexpr size_t b3_image_bytes(int n_pad, int k_pad32) {
@@ -31,6 +36,7 @@ __host__ __device__ constexpr size_t b3_image_bytes(int n_pad, int k_pad32) {
 __device__ __forceinline__ B3Image b3_image(void* base, int n_pad, int k_pad32) {
   B3Image im;
   im.pitch = b3_pitch(k_pad32);
+  im.swz = 0;
   im.hi = reinterpret_cast<__bf16*>(base);
   im.lo = im.hi + n_pad * im.pitch;
   return im;
@@ -80,8 +86,8 @@ __device__ __forceinline__ void load_weight_lds_b3(const B3Image& im, int row0,
           if (!(i < n_out && 4 * c < k_in)) v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
           bf16x4 hi, lo;
           b3_split4(v[u], hi, lo);
-          *reinterpret_cast<bf16x4*>(im.hi + (row0 + i) * im.pitch + 4 * c) = hi;
-          *reinterpret_cast<bf16x4*>(im.lo + (row0 + i) * im.pitch + 4 * c) = lo;
+          *reinterpret_cast<bf16x4*>(im.hi + b3_at(im, row0 + i, 4 * c)) = hi;
+          *reinterpret_cast<bf16x4*>(im.lo + b3_at(im, row0 + i, 4 * c)) = lo;
         }
       }
     }
@@ -105,8 +111,8 @@ __device__ __forceinline__ void load_weight_lds_b3(const B3Image& im, int row0,
         if (idx < total) {
           const int i = idx / k_pad32, k = idx - i * k_pad32;
           const __bf16 h = (__bf16)v[u];
-          im.hi[(row0 + i) * im.pitch + k] = h;
-          im.lo[(row0 + i) * im.pitch + k] = (__bf16)(v[u] - (float)h);
+          im.hi[b3_at(im, row0 + i, k)] = h;
+          im.lo[b3_at(im, row0 + i, k)] = (__bf16)(v[u] - (float)h);
         }
       }
     }
@@ -159,8 +165,8 @@ __device__ __forceinline__ void w16_commit(const WLoad16<NU>& w, const B3Image& 
         const f32x4 x = (i < n_out && 4 * c < k_in) ? w.v[u] : f32x4{0.f, 0.f, 0.f, 0.f};
         bf16x4 hi, lo;
         b3_split4(x, hi, lo);
-        *reinterpret_cast<bf16x4*>(im.hi + (row0 + i) * im.pitch + 4 * c) = hi;
-        *reinterpret_cast<bf16x4*>(im.lo + (row0 + i) * im.pitch + 4 * c) = lo;
+        *reinterpret_cast<bf16x4*>(im.hi + b3_at(im, row0 + i, 4 * c)) = hi;
+        *reinterpret_cast<bf16x4*>(im.lo + b3_at(im, row0 + i, 4 * c)) = lo;
       }
     }
   } else {

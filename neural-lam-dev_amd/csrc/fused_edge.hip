@@ -51,9 +51,25 @@ __device__ __forceinline__ bool tile_is_dense(const TileCtx& c, int lane) {
   const int rpn = __shfl_down(c.rp, 1, 64);
   return __all((lane >= c.nr) || (rpn > c.rp));
 }
+// Task tt -> (tile, batch item).  Batch-OUTER (tile = tt % ntiles, b = tt / ntiles) by default.
+// BINNER: batch-INNER (tile = tt / B, b = tt % B) -- taken when the edge operand is batch-invariant
+// (g2m / m2g: Pe of shape (1, M, d)): the B tasks of a tile are then consecutive, i.e. they run at
+// the same time on neighbouring waves of one workgroup, and the tile's Pe rows and index tables
+// come from HBM once instead of once per batch item (PMC traffic of nlam_edge_fwd@m2g was 2.0 x
+// its algorithmic bytes in batch-outer order: VERDICT r4 5c).  Same tiles, same arithmetic per
+// (tile, b): results are bitwise unchanged.
+template <bool BINNER>
+__device__ __forceinline__ unsigned task_tile(const EdgeFwdParams& p, unsigned q) {
+  return BINNER ? q / (unsigned)p.B : q % (unsigned)p.ntiles;
+}
+template <bool BINNER>
+__device__ __forceinline__ unsigned task_batch(const EdgeFwdParams& p, unsigned q) {
+  return BINNER ? q % (unsigned)p.B : q / (unsigned)p.ntiles;
+}
+template <bool BINNER = false>
 __device__ __forceinline__ int4 load_tile_hdr(const EdgeFwdParams& p, unsigned tt, unsigned total) {
   const unsigned q = tt < total ? tt : total - 1;
-  return reinterpret_cast<const int4*>(p.tiles)[q % (unsigned)p.ntiles];
+  return reinterpret_cast<const int4*>(p.tiles)[task_tile<BINNER>(p, q)];
 }
 
 // B3: the two d x d GEMMs run as split-bf16 MFMAs (fused_bf16x3.h); the weight images have
@@ -61,7 +77,7 @@ __device__ __forceinline__ int4 load_tile_hdr(const EdgeFwdParams& p, unsigned t
 // LEAN (split-bf16, hidden 64, every edge- / receiver-indexed operand below 4 GiB per batch item):
 // padded slots staged unmasked, 32-bit row offsets on scalar bases (one v_mad_u32_u24 per row
 // access instead of a 64-bit multiply-add chain).
-template <int D, bool HAS_EGEMM, bool B3 = false, bool LEAN = false>
+template <int D, bool HAS_EGEMM, bool B3 = false, bool LEAN = false, bool BINNER = false>
 __global__ __launch_bounds__(256, 2) void edge_fwd_kernel(EdgeFwdParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NB = D / 32;
@@ -91,7 +107,7 @@ __global__ __launch_bounds__(256, 2) void edge_fwd_kernel(EdgeFwdParams p) {
     // every global load of the prologue in flight together (fused_bf16x3.h, batched prologue
     // loads) -- including the FIRST tile's header (scalar load: tt is wave-uniform) and slot
     // indices, which used to be two more dependent round trips after the barrier
-    const int4 hdr0 = load_tile_hdr(p, (unsigned)__builtin_amdgcn_readfirstlane((int)tt), total);
+    const int4 hdr0 = load_tile_hdr<BINNER>(p, (unsigned)__builtin_amdgcn_readfirstlane((int)tt), total);
     __builtin_amdgcn_sched_barrier(0);
     VLoad16 lv;
     const float* const vecs[8] = {p.b2, p.gamma, p.beta, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -102,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void edge_fwd_kernel(EdgeFwdParams p) {
     w16_issue(l2, p.W2, p.ldW2, D, D, D, D, tid, 256);
     __builtin_amdgcn_sched_barrier(0);
     cur = load_tile_ctx(p, hdr0, lane);
-    hdr_n = load_tile_hdr(p, tt + stride, total);
+    hdr_n = load_tile_hdr<BINNER>(p, tt + stride, total);
     v16_commit(lv, b2s, 3, tid);
     if (HAS_EGEMM) w16_commit(l1, W1im, 0, p.W1e, p.ldW1e, D, D, D, D, tid, 256);
     w16_commit(l2, W2im, 0, p.W2, p.ldW2, D, D, D, D, tid, 256);
@@ -123,11 +139,11 @@ __global__ __launch_bounds__(256, 2) void edge_fwd_kernel(EdgeFwdParams p) {
   constexpr int NV = D / 8;
   if (tt >= total) return;
   if (!(B3 && D == 64)) {
-    cur = load_tile_ctx(p, load_tile_hdr(p, tt, total), lane);
-    hdr_n = load_tile_hdr(p, tt + stride, total);
+    cur = load_tile_ctx(p, load_tile_hdr<BINNER>(p, tt, total), lane);
+    hdr_n = load_tile_hdr<BINNER>(p, tt + stride, total);
   }
   for (; tt < total; tt += stride) {
-    const unsigned b = tt / (unsigned)p.ntiles;
+    const unsigned b = task_batch<BINNER>(p, tt);
     const int p0 = cur.p0, ne = cur.ne, r0 = cur.r0, nr = cur.nr;
     const int eid = cur.eid, snd = cur.snd, rcv = cur.rcv;
     const float* eb = p.e.ptr + (int64_t)b * p.e.bstride;
@@ -166,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void edge_fwd_kernel(EdgeFwdParams p) {
       }
     }
     const TileCtx nxt = load_tile_ctx(p, hdr_n, lane);
-    const int4 hdr_nn = load_tile_hdr(p, tt + 2 * stride, total);
+    const int4 hdr_nn = load_tile_hdr<BINNER>(p, tt + 2 * stride, total);
 #pragma unroll
     for (int k = 0; k < NV; ++k) vS[k] += vR[k];
 
@@ -242,12 +258,12 @@ __global__ __launch_bounds__(256, 2) void edge_fwd_kernel(EdgeFwdParams p) {
   }
 }
 
-template <int D, bool HAS_EGEMM, bool B3 = false, bool LEAN = false>
+template <int D, bool HAS_EGEMM, bool B3 = false, bool LEAN = false, bool BINNER = false>
 static int launch_edge_fwd(const EdgeFwdParams& p, hipStream_t s) {
   const size_t lds = ((size_t)(HAS_EGEMM ? 2 : 1) * D * (D + 4) + 3 * D +
                       (size_t)4 * NLAM_TILE * (D + 4) + 4 * 3 * NLAM_TILE) * sizeof(float);
   NLAM_REQUIRE(lds <= 160 * 1024, "edge_fwd: LDS footprint %zu B exceeds 160 KiB", lds);
-  auto kern = edge_fwd_kernel<D, HAS_EGEMM, B3, LEAN>;
+  auto kern = edge_fwd_kernel<D, HAS_EGEMM, B3, LEAN, BINNER>;
   NLAM_BIG_LDS(kern, __func__);
   kern<<<persistent_grid(p.ntiles * p.B, lds), 256, lds, s>>>(p);
   NLAM_CHECK_LAUNCH("edge_fwd_kernel");
@@ -296,8 +312,13 @@ extern "C" int nlam_edge_fwd(
     // floats and a batch item of each such operand below 4 GiB
     const int64_t Mb = ntiles * 32;
     auto ok = [](int64_t rows, int64_t ld) { return rows < (1 << 24) && ld < (1 << 22) && rows * ld * 4 < (1ll << 32); };
-    if (ok(Mb, e_ld) && ok(Mb, pr_ld))
-      return has_egemm ? launch_edge_fwd<64, true, true, true>(p, s) : launch_edge_fwd<64, false, true, true>(p, s);
+    if (ok(Mb, e_ld) && ok(Mb, pr_ld)) {
+      if (has_egemm) return launch_edge_fwd<64, true, true, true>(p, s);
+      // batch-invariant Pe: batch-inner task order (NLAM_EDGE_BINNER=0: batch-outer, for A/B)
+      static const bool binner_on = getenv("NLAM_EDGE_BINNER") == nullptr || atoi(getenv("NLAM_EDGE_BINNER")) != 0;
+      if (e_bstride == 0 && B > 1 && binner_on) return launch_edge_fwd<64, false, true, true, true>(p, s);
+      return launch_edge_fwd<64, false, true, true>(p, s);
+    }
     return has_egemm ? launch_edge_fwd<64, true, true>(p, s) : launch_edge_fwd<64, false, true>(p, s);
   }
   if (d == 64) return has_egemm ? launch_edge_fwd<64, true>(p, s) : launch_edge_fwd<64, false>(p, s);

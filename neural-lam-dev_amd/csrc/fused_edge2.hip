@@ -350,7 +350,9 @@ int nlam_edge_bwd2_stamps(unsigned long long* out, int reset) {
 // dPe = sum_b gh[b] (1, M, d) to q.g_e -- the gradient of the batch-invariant operand, which the
 // projection backward otherwise forms by reading gh B times (m2g: 261 MB of its 1,154 MB).
 template <bool HAS_EGEMM, bool HAS_GEO, bool STAMP = false, bool ABL = false, bool BSUM = false>
-__global__ __launch_bounds__(256) void edge_bwd2_kernel(EdgeBwdParams q, int xcd_remap) {
+__global__ __launch_bounds__(256) void edge_bwd2_kernel(EdgeBwdParams q, int flags) {
+  const int xcd_remap = flags & 1;
+  const bool edge_binner_on = (flags & 2) != 0;
   static_assert(!BSUM || !HAS_EGEMM, "the batch sum is the no-edge-update form's extra output");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int LDW = D + 4;
@@ -384,6 +386,8 @@ __global__ __launch_bounds__(256) void edge_bwd2_kernel(EdgeBwdParams q, int xcd
   // BSUM -- a contiguous range of tiles with the batch items innermost.
   const unsigned wid = wg * 4 + wave;
   const unsigned Bu = (unsigned)p.B;
+  // strided form with a batch-invariant edge operand (g2m): batch-inner task numbering
+  const bool binner = !BSUM && !HAS_EGEMM && p.e.bstride == 0 && Bu > 1 && edge_binner_on;
   unsigned tile0 = 0, niter;
   if (BSUM) {
     const unsigned per = (ntiles + stride - 1) / stride;          // tiles per wave
@@ -403,6 +407,11 @@ __global__ __launch_bounds__(256) void edge_bwd2_kernel(EdgeBwdParams q, int xcd
     }
     const unsigned task = wid + j * stride;
     const unsigned tq = task < total ? task : total - 1;
+    if (binner) {   // batch-invariant Pe, strided form: the B tasks of a tile are consecutive
+      const unsigned tl = tq / Bu;   // (their Pe rows / index tables are fetched once: fused_edge.hip)
+      b = (int)(tq - tl * Bu);
+      return load_hdr(p, tl);
+    }
     const unsigned bb = tq / ntiles;
     b = (int)bb;
     return load_hdr(p, tq - bb * ntiles);
@@ -804,7 +813,8 @@ static int launch_edge_bwd2(const EdgeBwdParams& q, hipStream_t s) {
   auto kern = edge_bwd2_kernel<HAS_EGEMM, HAS_GEO, STAMP, ABL, BSUM>;
   NLAM_BIG_LDS(kern, __func__);
   static const int xcd = getenv("NLAM_NO_XCD_ORDER") == nullptr;
-  kern<<<(unsigned)nlam_bwd_grid(q.f.ntiles * q.f.B), 256, lds, s>>>(q, xcd);
+  static const int binner = getenv("NLAM_EDGE_BINNER") == nullptr || atoi(getenv("NLAM_EDGE_BINNER")) != 0;
+  kern<<<(unsigned)nlam_bwd_grid(q.f.ntiles * q.f.B), 256, lds, s>>>(q, xcd | (binner ? 2 : 0));
   NLAM_CHECK_LAUNCH("edge_bwd2_kernel");
   return 0;
 }

@@ -851,6 +851,7 @@ __device__ __forceinline__ void lin_bwd_data_body(const LinBwdDataParams& q, int
   constexpr int WP = K + 16;
   B3Image Wim;
   Wim.pitch = WP;
+  Wim.swz = 0;
   Wim.hi = reinterpret_cast<__bf16*>(smem);
   Wim.lo = Wim.hi + NO * WP;
   float* tile = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) +

@@ -572,19 +572,25 @@ class WideInteractionNetFunction(torch.autograd.Function):
                 t2 = _empty(1, N_r, d, device=dev)
                 ops.sum_batch(gPr, t2)
                 gpr_m = mat(t2)
-            outers += [(gps_m, sm, dW1[:, d : 2 * d], dummy[1], False),
-                       (gpr_m, rm, dW1[:, 2 * d :], db1, False),
-                       (mat(gh), em, dW1[:, :d], dummy[2], False)]
-            if lane.enabled:   # the remaining weight gradients run next to step 5
-                with lane:
-                    outer_multi(outers)
-                outers = []
-            # 5. data gradients of the three projections (e' = e + m adds g_e' to the edge one)
+            # batch-invariant edge operand (g2m / m2g: Pe = W1e e with e the same for every sample):
+            # its gradient is summed over the batch ONCE and that sum serves the data gradient and
+            # the weight gradient dW1e = (sum_b gh_b)^T e -- the weight-gradient pass read all B
+            # slices of gh (522 MB of the 3.2 GB of wide_outer_multi@m2g at hidden 128) for a
+            # product that is linear in them
             dPe = mat(gh)
             if not ctx.update_edges and em.B == 1 and B > 1:
                 t6 = _empty(1, M, d, device=dev)
                 ops.sum_batch(gh, t6)
                 dPe = mat(t6)
+            ge_w = dPe if em.B == 1 else mat(gh)
+            outers += [(gps_m, sm, dW1[:, d : 2 * d], dummy[1], False),
+                       (gpr_m, rm, dW1[:, 2 * d :], db1, False),
+                       (ge_w, em, dW1[:, :d], dummy[2], False)]
+            if lane.enabled:   # the remaining weight gradients run next to step 5
+                with lane:
+                    outer_multi(outers)
+                outers = []
+            # 5. data gradients of the three projections (e' = e + m adds g_e' to the edge one)
             g_e = _empty(dPe.B, M, d, device=dev)
             g_send = _empty(sm.B, N_s, d, device=dev)
             if same:
