@@ -23,6 +23,7 @@ import re
 
 FAMILIES = [  # (kernel-name regex, family); the first match wins, template arguments included
     (r"^fs_lin_fwd_kernel<\d+, \d+, \d+, true>", "lin_bwd_data"),   # (transposed weights = data gradient)
+    (r"^grid_fwd16_kernel", "grid_encode_fwd"),
     (r"^node_fwd16_kernel", "node_fwd"), (r"^node_bwd16_kernel", "node_bwd"),
     (r"^node_outer16_kernel", "node_outer"),
     (r"^lin_fwd16_multi_kernel", "lin_fwd"), (r"^lin_bwd16_multi_kernel", "lin_bwd"),
