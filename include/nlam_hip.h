@@ -318,6 +318,10 @@ typedef struct nlam_inet_grads {
    * that reached send_rep through another consumer, added inside the projection backward */
   const float* g_send_add;
 } nlam_inet_grads;
+/* sizeof(nlam_inet_args) / sizeof(nlam_inet_grads) as this library was built: a binding that
+ * mirrors the structs (ctypes, cgo, JNI) checks its own layout against them at load time */
+int64_t nlam_sizeof_inet_args(void);
+int64_t nlam_sizeof_inet_grads(void);
 int nlam_inet_supported(const nlam_inet_args* a);
 int nlam_inet_fwd(const nlam_inet_args* a, void* stream);
 /* workspace (fp32 elements) of nlam_inet_bwd for this configuration; the workspace holds the

@@ -110,6 +110,8 @@ SIGNATURES = {
     "nlam_lin_bwd_data_multi": [_i32, _i32] + [_p] * 13 + [_p],
     "nlam_wide_outer_multi": [_i32, _i32] + [_p] * 13 + [_p],
     "nlam_concat_rows": [_i32, _p, _p, _p, _p, _p, _i64, _i64, _p],
+    "nlam_sizeof_inet_args": [],
+    "nlam_sizeof_inet_grads": [],
     "nlam_grid_encode_supported": [],
     "nlam_grid_encode_fwd": [_i32, _p, _p, _p, _p,                      # sources
                              _p, _i64, _p, _p, _i64, _p, _p, _p,        # grid_embedder
@@ -148,6 +150,8 @@ _RESTYPES = {
     "nlam_mlp_bwd_slab_stride": _i64,
     "nlam_outer_bwd_slab_stride": _i64,
     "nlam_inet_bwd_workspace": _i64,
+    "nlam_sizeof_inet_args": _i64,
+    "nlam_sizeof_inet_grads": _i64,
     "nlam_node_bwd_slab_stride": _i64,
     "nlam_node_bwd_grid": _i64,
     "nlam_node_outer_slab_stride": _i64,

@@ -66,6 +66,8 @@ int inet_case(const nlam_inet_args* a) {
 
 }  // namespace
 
+extern "C" int64_t nlam_sizeof_inet_args(void) { return (int64_t)sizeof(nlam_inet_args); }
+extern "C" int64_t nlam_sizeof_inet_grads(void) { return (int64_t)sizeof(nlam_inet_grads); }
 extern "C" int nlam_inet_supported(const nlam_inet_args* a) { return inet_case(a) != 0 ? 1 : 0; }
 
 extern "C" int nlam_inet_fwd(const nlam_inet_args* a, void* stream) {

@@ -45,6 +45,16 @@ class Grads(ctypes.Structure):
                 ("g_send_add", _P)]
 
 
+# the ctypes mirrors must have the layout the library was compiled with (a field added on one side
+# only shifts every later field: the advisor's round-4 finding on nlam_inet_grads)
+if ctypes.sizeof(Args) != int(lib.nlam_sizeof_inet_args()) or \
+        ctypes.sizeof(Grads) != int(lib.nlam_sizeof_inet_grads()):
+    raise ImportError(
+        f"inet_seq: struct layout mismatch with libnlam_hip.so (Args {ctypes.sizeof(Args)} vs "
+        f"{int(lib.nlam_sizeof_inet_args())}, Grads {ctypes.sizeof(Grads)} vs "
+        f"{int(lib.nlam_sizeof_inet_grads())}): rebuild the library or update include/nlam_hip.h's mirror")
+
+
 def graph_struct(t):
     """Graph struct of an EdgeTables (cached per device copy of its buffers)."""
     key = t.csr_rowptr.data_ptr()

@@ -28,6 +28,20 @@ def test_library_exports_every_declared_symbol():
     assert _lib.lib.nlam_abi_version() == ver == _lib.ABI_VERSION
 
 
+def test_ctypes_struct_mirrors_have_the_library_layout():
+    """inet_seq.Args / Grads mirror nlam_inet_args / nlam_inet_grads field by field: same size as
+    the C structs the library was compiled with (the import itself refuses a mismatch)."""
+    import ctypes
+
+    from neural_lam_amd import _lib, inet_seq
+
+    assert ctypes.sizeof(inet_seq.Args) == _lib.lib.nlam_sizeof_inet_args()
+    assert ctypes.sizeof(inet_seq.Grads) == _lib.lib.nlam_sizeof_inet_grads()
+    # the two flags added in round 5 are the last fields, after the six output pointers
+    names = [f[0] for f in inet_seq.Args._fields_]
+    assert names[-2:] == ["ps_given", "pr_given"] and names[-8:-2] == ["P", "Pr", "Pe", "agg", "e_out", "rec_out"]
+
+
 def test_graph_tables_match_numpy():
     from neural_lam_amd.graph import EdgeTables, normalise_edge_index
 
