@@ -67,10 +67,24 @@ __device__ __forceinline__ void store_cols16(float* __restrict__ row, const f32x
 }
 // narrow / unaligned rows: element loads from clamped addresses -- all loads first, the zeroing
 // of the columns past the end afterwards (a select next to each load serialises the loads)
-template <int NF>
+// N4: width <= 4 (the 2-3 wide static features of the embedders): only the first quad of the lanes
+// g == 0 holds live columns, so FOUR element loads per lane cover the row instead of 4 NF (twelve
+// of the embedders' sixteen loads per tile and row pass fetched a clamped column to zero it)
+template <int NF, bool N4 = false>
 __device__ __forceinline__ void load_narrow16(f32x4* __restrict__ a, const float* __restrict__ row,
                                               int width, int lane) {
   const int g = lane >> 4;
+  if constexpr (N4) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) a[0][r] = row[r < width ? r : 0];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (r >= width || g != 0) a[0][r] = 0.f;
+#pragma unroll
+    for (int fb = 1; fb < NF; ++fb) a[fb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    return;
+  }
 #pragma unroll
   for (int fb = 0; fb < NF; ++fb)
 #pragma unroll
@@ -95,8 +109,9 @@ __device__ __forceinline__ void load_narrow16(f32x4* __restrict__ a, const float
 //          KB == 2: one source, 16-byte aligned rows, width % 4 == 0;
 //          KB == 4: two sources of 64 columns each, 16-byte aligned.
 // gy: NOB == 2: 64 columns, 16-byte aligned; NOB == 1: any width <= 32 (element loads).
-template <int KB, int NOB, bool HAS_LN, bool DEFER, int TERMS>
+template <int KB, int NOB, bool HAS_LN, bool DEFER, int TERMS, bool N4 = false>
 __device__ __forceinline__ void mlp_bwd16_body(const MlpBwdParams& q, int wg, int nwg, char* smem16) {
+  static_assert(!N4 || KB == 1, "N4 is a form of the narrow-input (KB = 1) kernels");
   constexpr int HID = 64, NFH = 4, KF = 2 * KB, NFO = 2 * NOB, NO = 32 * NOB, KP32 = 32 * KB;
   constexpr int KBA = DEFER ? 1 : KB;
   const MlpParams& p = q.f;
@@ -175,7 +190,7 @@ __device__ __forceinline__ void mlp_bwd16_body(const MlpBwdParams& q, int wg, in
       const int64_t rw = opaque(row);
       const float* ra = p.src[0].ptr + b * p.src[0].bstride + rw * p.src[0].ld;
       const float* rb = KB == 4 ? p.src[1].ptr + b * p.src[1].bstride + rw * p.src[1].ld : ra;
-      if constexpr (KB == 1) load_narrow16<KF>(x, ra, p.src[0].width, lane);
+      if constexpr (KB == 1) load_narrow16<KF, N4>(x, ra, p.src[0].width, lane);
       else if constexpr (KB == 4) load_cat16<KF>(x, ra, 64, rb, 64, lane);
       else load_cat16<KF>(x, ra, p.src[0].width, ra, 0, lane);
     };
@@ -345,13 +360,13 @@ struct MlpBwdMulti {
   int n;
   int wg0[K16_MAXM + 1];
 };
-template <int TERMS>
+template <int TERMS, bool N4>
 __global__ __launch_bounds__(K16_THREADS, 2) void mlp_bwd16_multi_kernel(MlpBwdMulti m) {
   extern __shared__ __attribute__((aligned(16))) char smem16[];
   int k = 0;
   while (k + 1 < m.n && (int)blockIdx.x >= m.wg0[k + 1]) ++k;
-  mlp_bwd16_body<1, 2, true, false, TERMS>(m.q[k], (int)blockIdx.x - m.wg0[k], m.wg0[k + 1] - m.wg0[k],
-                                           smem16);
+  mlp_bwd16_body<1, 2, true, false, TERMS, N4>(m.q[k], (int)blockIdx.x - m.wg0[k],
+                                               m.wg0[k + 1] - m.wg0[k], smem16);
 }
 
 template <int KB, int NOB, bool HAS_LN, bool DEFER>
@@ -693,7 +708,7 @@ int nlam_k16_outer_bwd(const OuterParams& q, hipStream_t s) {
 // y = [res +] [LayerNorm](W2 silu(W1 [x_a | x_b] + b1) + b2): no row-contracting product, so no
 // LDS besides the weight images and ~100 registers: four or more waves per SIMD.  Sources as in
 // mlp_bwd16_kernel; NOB == 2: 64 outputs, 16-byte aligned (res, out); NOB == 1: any width <= 32.
-template <int KB, int NOB, bool HAS_LN, int TERMS>
+template <int KB, int NOB, bool HAS_LN, int TERMS, bool N4 = false>
 __device__ __forceinline__ void mlp_fwd16_body(const MlpParams& p, int wg, int nwg, char* smem16) {
   constexpr int HID = 64, NFH = 4, KF = 2 * KB, NFO = 2 * NOB, NO = 32 * NOB, KP32 = 32 * KB;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -742,7 +757,7 @@ __device__ __forceinline__ void mlp_fwd16_body(const MlpParams& p, int wg, int n
       f32x4 x[KF];
       const float* ra = p.src[0].ptr + b * p.src[0].bstride + row * p.src[0].ld;
       if constexpr (KB == 1) {
-        load_narrow16<KF>(x, ra, p.src[0].width, lane);
+        load_narrow16<KF, N4>(x, ra, p.src[0].width, lane);
       } else if constexpr (KB == 4) {
         const float* rb = p.src[1].ptr + b * p.src[1].bstride + row * p.src[1].ld;
         load_cat16<KF>(x, ra, 64, rb, 64, lane);
@@ -792,12 +807,13 @@ struct MlpFwdMulti {
   int n;
   int wg0[K16_MAXM + 1];
 };
-template <int TERMS>
+template <int TERMS, bool N4>
 __global__ __launch_bounds__(K16_THREADS, 2) void mlp_fwd16_multi_kernel(MlpFwdMulti m) {
   extern __shared__ __attribute__((aligned(16))) char smem16[];
   int k = 0;
   while (k + 1 < m.n && (int)blockIdx.x >= m.wg0[k + 1]) ++k;
-  mlp_fwd16_body<1, 2, true, TERMS>(m.p[k], (int)blockIdx.x - m.wg0[k], m.wg0[k + 1] - m.wg0[k], smem16);
+  mlp_fwd16_body<1, 2, true, TERMS, N4>(m.p[k], (int)blockIdx.x - m.wg0[k], m.wg0[k + 1] - m.wg0[k],
+                                        smem16);
 }
 
 template <int KB, int NOB, bool HAS_LN>
@@ -959,9 +975,17 @@ int nlam_k16_mlp_fwd_multi(const MlpParams* p, int n, hipStream_t s) {
   }
   for (int k = n; k < K16_MAXM; ++k) m.wg0[k + 1] = m.wg0[n];
   const size_t lds = w16_image_bytes(64, 32) + w16_image_bytes(64, 64) + (64 + 3 * 64) * sizeof(float);
-  auto kern = mlp_fwd16_multi_kernel<3>;
-  NLAM_BIG_LDS(kern, __func__);
-  kern<<<(unsigned)m.wg0[n], K16_THREADS, lds, s>>>(m);
+  bool n4 = true;   // every problem at most 4 columns wide (the static features are 2-3)
+  for (int k = 0; k < n; ++k) n4 = n4 && p[k].src[0].width <= 4;
+  if (n4) {
+    auto kern = mlp_fwd16_multi_kernel<3, true>;
+    NLAM_BIG_LDS(kern, __func__);
+    kern<<<(unsigned)m.wg0[n], K16_THREADS, lds, s>>>(m);
+  } else {
+    auto kern = mlp_fwd16_multi_kernel<3, false>;
+    NLAM_BIG_LDS(kern, __func__);
+    kern<<<(unsigned)m.wg0[n], K16_THREADS, lds, s>>>(m);
+  }
   NLAM_CHECK_LAUNCH("mlp_fwd16_multi_kernel");
   return 0;
 }
@@ -986,9 +1010,17 @@ int nlam_k16_mlp_bwd_multi(const MlpBwdParams* q, int n, hipStream_t s) {
   const size_t fold = (size_t)K16_NW * HID * HID * sizeof(float);
   if (fold > lds) lds = fold;
   NLAM_REQUIRE(lds <= 160 * 1024, "mlp_bwd16_multi: LDS footprint %zu B exceeds 160 KiB", lds);
-  auto kern = mlp_bwd16_multi_kernel<3>;
-  NLAM_BIG_LDS(kern, __func__);
-  kern<<<(unsigned)m.wg0[n], K16_THREADS, lds, s>>>(m);
+  bool n4 = true;
+  for (int k = 0; k < n; ++k) n4 = n4 && q[k].f.src[0].width <= 4;
+  if (n4) {
+    auto kern = mlp_bwd16_multi_kernel<3, true>;
+    NLAM_BIG_LDS(kern, __func__);
+    kern<<<(unsigned)m.wg0[n], K16_THREADS, lds, s>>>(m);
+  } else {
+    auto kern = mlp_bwd16_multi_kernel<3, false>;
+    NLAM_BIG_LDS(kern, __func__);
+    kern<<<(unsigned)m.wg0[n], K16_THREADS, lds, s>>>(m);
+  }
   NLAM_CHECK_LAUNCH("mlp_bwd16_multi_kernel");
   return 0;
 }
