@@ -315,7 +315,7 @@ __device__ __forceinline__ void ln16_apply(f32x4 (&z)[NF], const float* __restri
 // LayerNorm backward in place: z (pre-norm) -> xhat, g (dL/dy) -> dL/dz.  The dgamma summand
 // g * xhat goes straight to the bf16 planes P (no register copy); the dbeta summand is g
 // itself, taken by the caller before the call.
-template <int NF, int TERMS = 3>
+template <int NF, int TERMS = 3, bool WRITE_P = true>
 __device__ __forceinline__ void ln16_bwd(f32x4 (&z)[NF], f32x4 (&g)[NF], const B3Tile& P,
                                          const float* __restrict__ gamma, int lane) {
   constexpr float inv_d = 1.0f / (16.0f * NF);
@@ -337,11 +337,13 @@ __device__ __forceinline__ void ln16_bwd(f32x4 (&z)[NF], f32x4 (&g)[NF], const B
       s1 += gv;
       s2 += gv * xh;
     }
-    bf16x4 hi, lo;
-    b3_split4(prod, hi, lo);
-    const int off = t * P.pitch + 16 * fb + 4 * gq;
-    *reinterpret_cast<bf16x4*>(P.hi + off) = hi;
-    if constexpr (TERMS == 3) *reinterpret_cast<bf16x4*>(P.lo + off) = lo;
+    if constexpr (WRITE_P) {
+      bf16x4 hi, lo;
+      b3_split4(prod, hi, lo);
+      const int off = t * P.pitch + 16 * fb + 4 * gq;
+      *reinterpret_cast<bf16x4*>(P.hi + off) = hi;
+      if constexpr (TERMS == 3) *reinterpret_cast<bf16x4*>(P.lo + off) = lo;
+    }
   }
   const float m1 = row_sum16(s1) * inv_d, m2 = row_sum16(s2) * inv_d;
 #pragma unroll

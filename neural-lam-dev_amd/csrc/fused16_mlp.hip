@@ -16,6 +16,10 @@
 
 #define K16_NW 8
 #define K16_THREADS 512
+#ifndef MLP_BWD16_NODW
+#define MLP_BWD16_NODW 0   // diagnostic build (-DMLP_BWD16_NODW=1): the data path only, no weight / bias / LayerNorm gradients
+#endif
+constexpr bool NODW = MLP_BWD16_NODW != 0;
 
 static int g_k16_mask = -2;
 bool nlam_k16_on(int family) {
@@ -131,10 +135,11 @@ __device__ __forceinline__ void mlp_bwd16_body(const MlpBwdParams& q, int wg, in
   constexpr int PW0 = (!DEFER && KP32 > HID) ? KP32 : HID;   // S planes, later X planes
   constexpr int PW1 = HID > NO ? HID : NO;                   // g / prod / GZ planes, later GA
   constexpr size_t HST = DEFER ? 0 : (size_t)NLAM_T16 * (HID + 4) * sizeof(float);   // h stash
-  char* mine = cur + wave * (p16_bytes(PW0) + p16_bytes(PW1) + HST);
+  constexpr size_t PL0 = NODW ? 0 : p16_bytes(PW0), PL1 = NODW ? 0 : p16_bytes(PW1);   // (NODW: no planes)
+  char* mine = cur + wave * (PL0 + PL1 + HST);
   void* R0 = mine;
-  void* R1 = mine + p16_bytes(PW0);
-  float* HS = reinterpret_cast<float*>(mine + p16_bytes(PW0) + p16_bytes(PW1));
+  void* R1 = mine + PL0;
+  float* HS = reinterpret_cast<float*>(mine + PL0 + PL1);
 
   {   // every global load of the prologue in flight together (fused16.h, batched prologue loads)
     VLoad16 lv;
@@ -229,21 +234,25 @@ __device__ __forceinline__ void mlp_bwd16_body(const MlpBwdParams& q, int wg, in
       } else {
         acc16_to_tile<NFH>(hpre, HS, HID + 4, lane);          // silu'(h): back from LDS later
       }
-      acc16_to_planes<NFH, TERMS>(sact, Ts, 0, lane);         // S stays in R0 until dW2 is formed
+      if constexpr (!NODW) acc16_to_planes<NFH, TERMS>(sact, Ts, 0, lane);         // S stays in R0 until dW2 is formed
       if constexpr (HAS_LN) {
         f32x4 z[NFO];
         vec_to_acc16<NFO>(z, b2s, lane);
         gemm_acc16<NFO, 2, TERMS>(z, W2im, 0, 0, sact, lane);
         __builtin_amdgcn_sched_barrier(0);
         mask16<NFO>(g, valid);   // padded rows carry a zero gradient: every sum below ignores them
-        acc16_to_planes<NFO, TERMS>(g, Tz, 0, lane);          // dbeta summand: gy
-        wave_sync();
-        colsum16<1, TERMS>(dbet, Tz, 0, lane);
-        wave_sync();
-        ln16_bwd<NFO, TERMS>(z, g, Tz, gs, lane);             // g: gy -> gz; gy * xhat -> planes
-        wave_sync();
-        colsum16<1, TERMS>(dgam, Tz, 0, lane);
-        wave_sync();
+        if constexpr (!NODW) {
+          acc16_to_planes<NFO, TERMS>(g, Tz, 0, lane);          // dbeta summand: gy
+          wave_sync();
+          colsum16<1, TERMS>(dbet, Tz, 0, lane);
+          wave_sync();
+        }
+        ln16_bwd<NFO, TERMS, !NODW>(z, g, Tz, gs, lane);      // g: gy -> gz; gy * xhat -> planes
+        if constexpr (!NODW) {
+          wave_sync();
+          colsum16<1, TERMS>(dgam, Tz, 0, lane);
+          wave_sync();
+        }
       } else {
         if constexpr (NOB == 1) load_narrow16<NFO>(g, rg, p.n_out, lane);
         mask16<NFO>(g, valid);
@@ -251,17 +260,19 @@ __device__ __forceinline__ void mlp_bwd16_body(const MlpBwdParams& q, int wg, in
     }
     __builtin_amdgcn_sched_barrier(0);
     // ---- second layer's weight gradient: dW2 += gz (x) s, db2 += gz
-    acc16_to_planes<NFO, TERMS>(g, Tz, 0, lane);
-    wave_sync();
-    if constexpr (NOB == 1) colsum16_32<TERMS>(db2[0], Tz, 0, lane);
-    else colsum16<1, TERMS>(db2, Tz, 0, lane);
-    outer_accum16<NOB, 2, TERMS>(dW2, Tz, 0, Ts, 0, lane);
+    if constexpr (!NODW) {
+      acc16_to_planes<NFO, TERMS>(g, Tz, 0, lane);
+      wave_sync();
+      if constexpr (NOB == 1) colsum16_32<TERMS>(db2[0], Tz, 0, lane);
+      else colsum16<1, TERMS>(db2, Tz, 0, lane);
+      outer_accum16<NOB, 2, TERMS>(dW2, Tz, 0, Ts, 0, lane);
+    }
     __builtin_amdgcn_sched_barrier(0);
     // ---- ga = (W2^T gz) * silu'(h)
     // (the x rows of the first layer's weight gradient and the residual's gy rows are requested
     // here: L2-hot re-reads whose round trip rides under the next two GEMMs instead of being
     // exposed where the values are first used)
-    constexpr bool X2_EARLY = !DEFER && KB == 1;   // (KB = 2: 16 more live registers spill)
+    constexpr bool X2_EARLY = !DEFER && KB == 1 && !NODW;   // (KB = 2: 16 more live registers spill)
     f32x4 x2[DEFER ? 1 : KF];
     if constexpr (X2_EARLY) load_x(x2);
     // (the residual's rows early only where the registers allow it: the K = 128 node update, which
@@ -293,13 +304,15 @@ __device__ __forceinline__ void mlp_bwd16_body(const MlpBwdParams& q, int wg, in
       // ---- first layer's weight gradient: dW1 += ga (x) x, db1 += ga (x re-read: L2-hot)
       wave_sync();
       const B3Tile Ta = p16_tile(R1, HID), Tx = p16_tile(R0, KP32);
-      acc16_to_planes<NFH, TERMS>(ga, Ta, 0, lane);
-      if constexpr (!X2_EARLY) load_x(x2);
-      acc16_to_planes<KF, TERMS>(x2, Tx, 0, lane);
-      wave_sync();
-      colsum16<1, TERMS>(db1, Ta, 0, lane);
-      outer_accum16<2, KB, TERMS>(dW1, Ta, 0, Tx, 0, lane);
-      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (!NODW) {
+        acc16_to_planes<NFH, TERMS>(ga, Ta, 0, lane);
+        if constexpr (!X2_EARLY) load_x(x2);
+        acc16_to_planes<KF, TERMS>(x2, Tx, 0, lane);
+        wave_sync();
+        colsum16<1, TERMS>(db1, Ta, 0, lane);
+        outer_accum16<2, KB, TERMS>(dW1, Ta, 0, Tx, 0, lane);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     // ---- input gradient gx = W1^T ga (+ gy: the residual taken from source a)
     if (want_gx) {
@@ -328,6 +341,7 @@ __device__ __forceinline__ void mlp_bwd16_body(const MlpBwdParams& q, int wg, in
     wave_sync();   // the planes are rewritten by the next tile
   }
 
+  if constexpr (NODW) return;   // (diagnostic build: nothing was accumulated)
   // ---- fold the eight waves' partials in LDS (fixed order) and write the slab
   __syncthreads();
   float* img = reinterpret_cast<float*>(smem16);   // weights and planes are dead
@@ -376,17 +390,23 @@ static int launch_mlp_bwd16(const MlpBwdParams& q, hipStream_t s) {
   constexpr int PW1 = HID > NO ? HID : NO;
   size_t lds = w16_image_bytes(HID, KP32, true) + w16_image_bytes(NO, HID, true) +
                (HID + 2 * NO) * sizeof(float) +
-               K16_NW * (p16_bytes(PW0) + p16_bytes(PW1) +
+               K16_NW * ((NODW ? 0 : p16_bytes(PW0) + p16_bytes(PW1)) +
                          (DEFER ? 0 : (size_t)NLAM_T16 * (HID + 4) * sizeof(float)));
   size_t fold = (size_t)K16_NW * HID * HID * sizeof(float);          // dW2 images
   if (!DEFER && (size_t)K16_NW * HID * KP32 * sizeof(float) > fold)
     fold = (size_t)K16_NW * HID * KP32 * sizeof(float);
-  if (fold > lds) lds = fold;
+  if (fold > lds && !NODW) lds = fold;
   NLAM_REQUIRE(lds <= 160 * 1024, "mlp_bwd16: LDS footprint %zu B exceeds 160 KiB", lds);
   auto kern = mlp_bwd16_kernel<KB, NOB, HAS_LN, DEFER, 3>;
   NLAM_BIG_LDS(kern, __func__);
   const int64_t ntiles32 = ((q.f.rows + 31) / 32) * q.f.B;
-  kern<<<(unsigned)nlam_bwd_grid(ntiles32), K16_THREADS, lds, s>>>(q);
+  unsigned grid = (unsigned)nlam_bwd_grid(ntiles32);
+  if (NODW) {   // diagnostic: NLAM_NODW_WGS workgroups per CU (the slab fold then overruns: timing only)
+    static const int per = getenv("NLAM_NODW_WGS") ? atoi(getenv("NLAM_NODW_WGS")) : 1;
+    grid = grid * (per > 1 ? per : 1);
+    if (grid > 256u * per) grid = 256u * per;
+  }
+  kern<<<grid, K16_THREADS, lds, s>>>(q);
   NLAM_CHECK_LAUNCH("mlp_bwd16_kernel");
   return 0;
 }
