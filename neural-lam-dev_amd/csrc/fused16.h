@@ -567,6 +567,76 @@ __device__ __forceinline__ void outer_accum16(f32x16 (&dW)[NI][NJ], const B3Tile
     }
   }
 }
+// The same products plus the column sums of G (db = colsum(G): the bias gradient that goes with
+// dW = G^T X) from the A fragments the outer product loads anyway: D = ones (32 x 16) . G (16 x 32)
+// holds the 32 column sums of a block in every row, so lane l & 31 reads them in register 0 --
+// lanes = features, the layout of the per-lane accumulators -- with no plane store, no transposed
+// read and no sync of its own (colsum16 cost 16 transposed reads + 8 MFMAs per call; profiles/
+// r05_experiments.txt item 8: the row-contracting products are 30-43 % of an MLP backward).
+template <int NI, int NJ, int TERMS = 3>
+__device__ __forceinline__ void outer_accum16_cs(f32x16 (&dW)[NI][NJ], float (&csum)[NI / 2],
+                                                 const B3Tile& G, int gcol0, const B3Tile& X, int xcol0,
+                                                 int lane) {
+  static_assert(NI == 2 || NI == 4, "64 or 128 gradient columns");
+  bf16x8 ah[NI], al[NI];
+#pragma unroll
+  for (int ib = 0; ib < NI; ++ib) {
+    ah[ib] = b3_tr_frag_rows(G.hi, G.pitch, 0, gcol0 + 32 * ib, lane);
+    if constexpr (TERMS == 3) al[ib] = b3_tr_frag_rows(G.lo, G.pitch, 0, gcol0 + 32 * ib, lane);
+  }
+  {
+    bf16x8 ones;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ones[i] = (__bf16)1.0f;
+#pragma unroll
+    for (int j = 0; j < NI / 2; ++j) {
+      float v[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        f32x16 c;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c[r] = 0.f;
+        c = B3_MFMA(ones, ah[2 * j + h], c);
+        if constexpr (TERMS == 3) c = B3_MFMA(ones, al[2 * j + h], c);
+        v[h] = c[0];
+      }
+      csum[j] += (lane < 32) ? v[0] : v[1];
+    }
+  }
+#pragma unroll
+  for (int jb = 0; jb < NJ; ++jb) {
+    const bf16x8 bh = b3_tr_frag_rows(X.hi, X.pitch, 0, xcol0 + 32 * jb, lane);
+    bf16x8 bl;
+    if constexpr (TERMS == 3) bl = b3_tr_frag_rows(X.lo, X.pitch, 0, xcol0 + 32 * jb, lane);
+#pragma unroll
+    for (int ib = 0; ib < NI; ++ib) {
+      dW[ib][jb] = B3_MFMA(ah[ib], bh, dW[ib][jb]);
+      if constexpr (TERMS == 3) {
+        dW[ib][jb] = B3_MFMA(ah[ib], bl, dW[ib][jb]);
+        dW[ib][jb] = B3_MFMA(al[ib], bh, dW[ib][jb]);
+      }
+    }
+  }
+}
+// column sums of a 64-wide plane pair on the 32 x 32 x 16 product (K = the 16 tile rows exactly:
+// 4 transposed reads + 2 MFMAs per 32 columns and plane; colsum16 below pads K to 32)
+template <int TERMS = 3>
+__device__ __forceinline__ void colsum16_64(float& acc, const B3Tile& X, int xcol0, int lane) {
+  bf16x8 ones;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ones[i] = (__bf16)1.0f;
+  float v[2];
+#pragma unroll
+  for (int blk = 0; blk < 2; ++blk) {
+    f32x16 c;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c[r] = 0.f;
+    c = B3_MFMA(ones, b3_tr_frag_rows(X.hi, X.pitch, 0, xcol0 + 32 * blk, lane), c);
+    if constexpr (TERMS == 3) c = B3_MFMA(ones, b3_tr_frag_rows(X.lo, X.pitch, 0, xcol0 + 32 * blk, lane), c);
+    v[blk] = c[0];
+  }
+  acc += (lane < 32) ? v[0] : v[1];
+}
 // acc[j] (lanes = features xcol0 + 64 j + lane) += column sums of the 16 plane rows (rows of
 // padded slots must hold zeros), as ones-vector products on the 16x16x32 MFMA: B[k = row][n =
 // feature] by transposed reads (k slots 16..31 are zero fragments), A = ones, so every result

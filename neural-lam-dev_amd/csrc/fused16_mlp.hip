@@ -244,13 +244,13 @@ __device__ __forceinline__ void mlp_bwd16_body(const MlpBwdParams& q, int wg, in
         if constexpr (!NODW) {
           acc16_to_planes<NFO, TERMS>(g, Tz, 0, lane);          // dbeta summand: gy
           wave_sync();
-          colsum16<1, TERMS>(dbet, Tz, 0, lane);
+          colsum16_64<TERMS>(dbet[0], Tz, 0, lane);
           wave_sync();
         }
         ln16_bwd<NFO, TERMS, !NODW>(z, g, Tz, gs, lane);      // g: gy -> gz; gy * xhat -> planes
         if constexpr (!NODW) {
           wave_sync();
-          colsum16<1, TERMS>(dgam, Tz, 0, lane);
+          colsum16_64<TERMS>(dgam[0], Tz, 0, lane);
           wave_sync();
         }
       } else {
@@ -263,9 +263,12 @@ __device__ __forceinline__ void mlp_bwd16_body(const MlpBwdParams& q, int wg, in
     if constexpr (!NODW) {
       acc16_to_planes<NFO, TERMS>(g, Tz, 0, lane);
       wave_sync();
-      if constexpr (NOB == 1) colsum16_32<TERMS>(db2[0], Tz, 0, lane);
-      else colsum16<1, TERMS>(db2, Tz, 0, lane);
-      outer_accum16<NOB, 2, TERMS>(dW2, Tz, 0, Ts, 0, lane);
+      if constexpr (NOB == 1) {
+        colsum16_32<TERMS>(db2[0], Tz, 0, lane);
+        outer_accum16<NOB, 2, TERMS>(dW2, Tz, 0, Ts, 0, lane);
+      } else {
+        outer_accum16_cs<2, 2, TERMS>(dW2, db2, Tz, 0, Ts, 0, lane);   // db2 from dW2's own A fragments
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
     // ---- ga = (W2^T gz) * silu'(h)
@@ -309,8 +312,7 @@ __device__ __forceinline__ void mlp_bwd16_body(const MlpBwdParams& q, int wg, in
         if constexpr (!X2_EARLY) load_x(x2);
         acc16_to_planes<KF, TERMS>(x2, Tx, 0, lane);
         wave_sync();
-        colsum16<1, TERMS>(db1, Ta, 0, lane);
-        outer_accum16<2, KB, TERMS>(dW1, Ta, 0, Tx, 0, lane);
+        outer_accum16_cs<2, KB, TERMS>(dW1, db1, Ta, 0, Tx, 0, lane);   // db1 from dW1's own A fragments
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -511,8 +513,7 @@ __device__ __forceinline__ void lin_bwd16_body(const LinBwdParams& q, int wg, in
     acc16_to_planes<NFO, TERMS>(g, Tg, 0, lane);
     acc16_to_planes<KF, TERMS>(x, Tx, 0, lane);
     wave_sync();
-    colsum16<NV, TERMS>(db, Tg, 0, lane);
-    outer_accum16<NOB, 2, TERMS>(dW, Tg, 0, Tx, 0, lane);
+    outer_accum16_cs<NOB, 2, TERMS>(dW, db, Tg, 0, Tx, 0, lane);   // (db from dW's own A fragments)
     if (q.gx != nullptr) {
       f32x4 gx[KF];
       zero16<KF>(gx);
@@ -680,8 +681,7 @@ __device__ __forceinline__ void outer_bwd16_body(const OuterParams& q, int wg, i
     acc16_to_planes<4, TERMS>(g, Tg, 0, lane);
     acc16_to_planes<KF, TERMS>(x, Tx, 0, lane);
     wave_sync();
-    colsum16<1, TERMS>(db, Tg, 0, lane);
-    outer_accum16<2, NXB, TERMS>(dW, Tg, 0, Tx, 0, lane);
+    outer_accum16_cs<2, NXB, TERMS>(dW, db, Tg, 0, Tx, 0, lane);
     wave_sync();
   }
   __syncthreads();

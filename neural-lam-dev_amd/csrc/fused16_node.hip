@@ -260,18 +260,17 @@ __global__ __launch_bounds__(K16_THREADS, 2) void node_bwd16_kernel(NodeBwdParam
         for (int fb = 0; fb < 4; ++fb) g[fb] = G[fb];
         acc16_to_planes<4, TERMS>(g, Tz, 0, lane);
         wave_sync();
-        colsum16<1, TERMS>(dbet, Tz, 0, lane);
+        colsum16_64<TERMS>(dbet[0], Tz, 0, lane);
         wave_sync();
         ln16_bwd<4, TERMS>(z, g, Tz, gs, lane);
         wave_sync();
-        colsum16<1, TERMS>(dgam, Tz, 0, lane);
+        colsum16_64<TERMS>(dgam[0], Tz, 0, lane);
         wave_sync();
       }
       __builtin_amdgcn_sched_barrier(0);
       acc16_to_planes<4, TERMS>(g, Tz, 0, lane);
       wave_sync();
-      colsum16<1, TERMS>(dc2, Tz, 0, lane);
-      outer_accum16<2, 2, TERMS>(dV2, Tz, 0, Ts, 0, lane);
+      outer_accum16_cs<2, 2, TERMS>(dV2, dc2, Tz, 0, Ts, 0, lane);
       __builtin_amdgcn_sched_barrier(0);
       f32x4 ga[4];
       zero16<4>(ga);
@@ -390,8 +389,7 @@ __global__ __launch_bounds__(K16_THREADS, 2) void node_outer16_kernel(NodeOuterP
       acc16_to_planes<4, TERMS>(g, Tg, 0, lane);
       acc16_to_planes<8, TERMS>(x, Tx, 0, lane);
       wave_sync();
-      colsum16<1, TERMS>(db, Tg, 0, lane);
-      outer_accum16<2, 4, TERMS>(dW, Tg, 0, Tx, 0, lane);
+      outer_accum16_cs<2, 4, TERMS>(dW, db, Tg, 0, Tx, 0, lane);
       wave_sync();
     }
     __syncthreads();
@@ -422,8 +420,7 @@ __global__ __launch_bounds__(K16_THREADS, 2) void node_outer16_kernel(NodeOuterP
       acc16_to_planes<8, TERMS>(g, Tg, 0, lane);
       acc16_to_planes<4, TERMS>(x, Tx, 0, lane);
       wave_sync();
-      colsum16<2, TERMS>(db, Tg, 0, lane);
-      outer_accum16<4, 2, TERMS>(dW, Tg, 0, Tx, 0, lane);
+      outer_accum16_cs<4, 2, TERMS>(dW, db, Tg, 0, Tx, 0, lane);
       wave_sync();
     }
     __syncthreads();
