@@ -318,13 +318,17 @@ __device__ __forceinline__ void mlp_bwd16_body(const MlpBwdParams& q, int wg, in
     }
     // ---- input gradient gx = W1^T ga (+ gy: the residual taken from source a)
     if (want_gx) {
+      // (the residual's gy rows -- an L2-hot re-read -- are requested in front of the W1^T product
+      // instead of behind it: x2 is dead here, so the four quads fit, and the round trip rides
+      // under the 24 MFMAs)
+      if (!GY2_EARLY && add_gy)
+        load_row16<4>(gy2, q.gy.ptr + b * q.gy.bstride + opaque(row) * q.gy.ld, lane);
       f32x4 gx[KF];
       zero16<KF>(gx);
       gemm_acc16_wt<KF, 2, TERMS>(gx, W1im, 0, 0, ga, lane);
       const int wa = p.src[0].width;
       if (q.gxa != nullptr) {
         if (q.add_gy_to_gxa) {   // n_out == wa == 64 (checked by the host side)
-          if (!GY2_EARLY) load_row16<4>(gy2, q.gy.ptr + b * q.gy.bstride + opaque(row) * q.gy.ld, lane);
 #pragma unroll
           for (int fb = 0; fb < 4 && fb < KF; ++fb) gx[fb] += gy2[fb];
         }
