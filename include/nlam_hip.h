@@ -678,6 +678,23 @@ int nlam_grid_encode_fwd(int nsrc, const float* const* src, const int64_t* src_b
                          float* feat, float* emb, float* ps, float* rep, float* pr, int64_t B,
                          int64_t rows, void* stream);
 
+/* State step AND the training loss term of the same AR step in one pass (the loss target of step
+ * t is the boundary truth of step t; reference ar_model.py:244-247,294-298, base_graph_model.py:
+ * 174-177, metrics.py:21-84): out = mask ? truth : prev + net_out * scale + shift (as
+ * nlam_state_step) and loss[0] = lscale * sum_{b,n,f} keep[n] w[f] (out - truth)^2 (as nlam_wmse_fwd;
+ * partial: nlam_state_step_wmse_blocks() floats of scratch; N * F < 2^31).  Backward: g = g_state (NULL = 0) + 2 lscale
+ * gloss[0] keep w (pred - truth);  gx = (1 - mask) g scale[f];  gprev (optional) = (1 - mask) g. */
+int nlam_state_step_wmse_blocks(void);
+int nlam_state_step_wmse_fwd(const float* prev, int64_t prev_bstride, const float* net_out,
+                             const float* truth, int64_t truth_bstride, const float* mask,
+                             const float* scale, const float* shift, const float* keep, const float* w,
+                             float* out, float* partial, float* loss, float lscale, int64_t B,
+                             int64_t N, int F, void* stream);
+int nlam_state_step_wmse_bwd(const float* pred, const float* truth, int64_t truth_bstride,
+                             const float* mask, const float* scale, const float* keep, const float* w,
+                             const float* gloss, float lscale, const float* g_state, float* gx,
+                             float* gprev, int64_t B, int64_t N, int F, void* stream);
+
 /* output_std head (reference base_graph_model.py:161-177 with args.output_std): net_out is
  * (rows, 2F); state = prev + net_out[:, :F] * scale + shift, pred_std = softplus(net_out[:, F:])
  * (beta 1, threshold 20, as torch.nn.functional.softplus).  The backward takes either incoming

@@ -121,6 +121,10 @@ SIGNATURES = {
                              _p, _p, _p, _p, _p, _i64, _i64, _p],
     "nlam_state_step": [_p, _i64, _p, _p, _i64, _p, _p, _p, _p, _i64, _i64, _i32, _p],
     "nlam_state_step_bwd": [_p, _p, _p, _p, _p, _i64, _i64, _i32, _p],
+    "nlam_state_step_wmse_blocks": [],
+    "nlam_state_step_wmse_fwd": [_p, _i64, _p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _f, _i64, _i64,
+                                 _i32, _p],
+    "nlam_state_step_wmse_bwd": [_p, _p, _i64, _p, _p, _p, _p, _p, _f, _p, _p, _p, _i64, _i64, _i32, _p],
     "nlam_sum_many": [_i32, _p, _p, _i64, _p],
     "nlam_pack_chunk": [],
     "nlam_pack_segments": [_p, _i32, _i64, _p, _p],

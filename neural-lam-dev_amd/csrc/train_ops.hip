@@ -220,6 +220,170 @@ extern "C" int nlam_wmse_fwd(const float* pred, const float* target, const float
   NLAM_CHECK_LAUNCH("wmse_final");
   return 0;
 }
+// ---- state step + training loss in one pass (ar_model.py:244-247 + base_graph_model.py:174-177 +
+// metrics.py:21-84 under ar_model.py:294-298).  The rollout's new state and the loss term of the
+// same AR step read the same tensors -- the loss target of step t IS the boundary truth of step t
+// -- so: new = mask ? truth : prev + x * scale + shift;  loss_t = lscale * sum keep[n] w[f] (new -
+// truth)^2.  The loss's own pass over prediction and target (35 MB at the MEPS size, one launch)
+// disappears: 69 MB instead of 104 MB; the backward (one launch instead of two) forms
+//   g = g_state + 2 lscale gloss keep w (new - truth),  gx = (1 - mask) g scale[f],  gprev = (1 - mask) g.
+// Block partials go through ssl_final_kernel (a second, one-block launch: a last-block-done
+// ticket needs a device-scope fence per block, and on this 8-L2 part each fence writes the
+// block's XCD L2 back -- measured 110 us for the pass instead of 17).
+// Layout of both launches: grid (chunks, B); a block walks 1024-element chunks of one batch
+// element's N * F plane, each thread four elements a chunk apart by 256 with their loads issued
+// together (the (node, feature) split is one 32-bit division per element: N * F < 2^31 is
+// required).
+constexpr int SSL_MAX_BLOCKS = 8192;
+// fixed-shape tree over up to SSL_MAX_BLOCKS partials: 1024 threads, at most 8 loads each
+__global__ __launch_bounds__(1024) void ssl_final_kernel(const float* __restrict__ partial, int n,
+                                                         float scale, float* __restrict__ out) {
+  __shared__ float red[1024];
+  float v[SSL_MAX_BLOCKS / 1024];
+#pragma unroll
+  for (int u = 0; u < SSL_MAX_BLOCKS / 1024; ++u) {
+    const int i = u * 1024 + (int)threadIdx.x;
+    v[u] = i < n ? partial[i] : 0.f;
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int u = 0; u < SSL_MAX_BLOCKS / 1024; ++u) s += v[u];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = red[0] * scale;
+}
+extern "C" int nlam_state_step_wmse_blocks(void) { return SSL_MAX_BLOCKS; }
+__global__ __launch_bounds__(256) void state_step_wmse_kernel(
+    const float* __restrict__ prev, int64_t prev_bstride, const float* __restrict__ x,
+    const float* __restrict__ truth, int64_t truth_bstride, const float* __restrict__ mask,
+    const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ keep, const float* __restrict__ w, float* __restrict__ out,
+    float* __restrict__ partial, unsigned per, unsigned F) {
+  __shared__ float red[256];
+  const unsigned b = blockIdx.y;
+  prev += (int64_t)b * prev_bstride;
+  truth += (int64_t)b * truth_bstride;
+  x += (int64_t)b * per;
+  out += (int64_t)b * per;
+  float s = 0.f;
+  for (unsigned base = blockIdx.x * 1024u; base < per; base += gridDim.x * 1024u) {
+    float tr[4], pv[4], xv[4], m[4], kp[4], sc[4], sh[4], wf[4];
+    bool ok[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const unsigned j = base + u * 256u + threadIdx.x;
+      ok[u] = j < per;
+      const unsigned jj = ok[u] ? j : 0u;
+      const unsigned node = jj / F, f = jj - node * F;
+      tr[u] = truth[jj]; pv[u] = prev[jj]; xv[u] = x[jj];
+      m[u] = mask[node]; kp[u] = keep[node];
+      sc[u] = scale[f]; sh[u] = shift[f]; wf[u] = w[f];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float pr = pv[u] + xv[u] * sc[u] + sh[u];
+      const float nw = m[u] * tr[u] + (1.0f - m[u]) * pr;
+      const float d = nw - tr[u];
+      if (ok[u]) {
+        out[base + u * 256u + threadIdx.x] = nw;
+        s += kp[u] * wf[u] * d * d;
+      }
+    }
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = red[0];
+}
+__global__ __launch_bounds__(256) void state_step_wmse_bwd_kernel(
+    const float* __restrict__ pred, const float* __restrict__ truth, int64_t truth_bstride,
+    const float* __restrict__ mask, const float* __restrict__ scale, const float* __restrict__ keep,
+    const float* __restrict__ w, const float* __restrict__ gloss, float lscale,
+    const float* __restrict__ g_state, float* __restrict__ gx, float* __restrict__ gprev, unsigned per,
+    unsigned F) {
+  const unsigned b = blockIdx.y;
+  truth += (int64_t)b * truth_bstride;
+  pred += (int64_t)b * per;
+  gx += (int64_t)b * per;
+  if (g_state) g_state += (int64_t)b * per;
+  if (gprev) gprev += (int64_t)b * per;
+  const float c = gloss ? 2.0f * lscale * gloss[0] : 0.0f;
+  for (unsigned base = blockIdx.x * 1024u; base < per; base += gridDim.x * 1024u) {
+    float tr[4], pd[4], gs[4], m[4], kp[4], sc[4], wf[4];
+    bool ok[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const unsigned j = base + u * 256u + threadIdx.x;
+      ok[u] = j < per;
+      const unsigned jj = ok[u] ? j : 0u;
+      const unsigned node = jj / F, f = jj - node * F;
+      tr[u] = truth[jj]; pd[u] = pred[jj];
+      gs[u] = g_state ? g_state[jj] : 0.0f;
+      m[u] = mask[node]; kp[u] = keep[node];
+      sc[u] = scale[f]; wf[u] = w[f];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float g = c * kp[u] * wf[u] * (pd[u] - tr[u]) + gs[u];
+      const float gp = (1.0f - m[u]) * g;
+      if (ok[u]) {
+        const unsigned j = base + u * 256u + threadIdx.x;
+        gx[j] = gp * sc[u];
+        if (gprev) gprev[j] = gp;
+      }
+    }
+  }
+}
+extern "C" int nlam_state_step_wmse_fwd(const float* prev, int64_t prev_bstride, const float* net_out,
+                                        const float* truth, int64_t truth_bstride, const float* mask,
+                                        const float* scale, const float* shift, const float* keep,
+                                        const float* w, float* out, float* partial, float* loss,
+                                        float lscale, int64_t B, int64_t N, int F, void* stream) {
+  const int64_t per = N * F;
+  NLAM_REQUIRE(B > 0 && per > 0, "nlam_state_step_wmse_fwd: empty input");
+  NLAM_REQUIRE(per < (int64_t(1) << 31) && B <= 65535, "nlam_state_step_wmse_fwd: N * F or B too large");
+  NLAM_REQUIRE(prev && net_out && truth && mask && scale && shift && keep && w && out && partial && loss,
+               "nlam_state_step_wmse_fwd: null operand");
+  NLAM_REQUIRE(prev_bstride >= per && truth_bstride >= per,
+               "nlam_state_step_wmse_fwd: batch pitch below N * F");
+  int64_t chunks = (per + 1023) / 1024, cap = SSL_MAX_BLOCKS / B;
+  if (cap < 1) cap = 1;   // (B <= SSL_MAX_BLOCKS is implied by the partial buffer: checked next)
+  NLAM_REQUIRE(B <= SSL_MAX_BLOCKS, "nlam_state_step_wmse_fwd: B above nlam_state_step_wmse_blocks()");
+  if (chunks > cap) chunks = cap;
+  state_step_wmse_kernel<<<dim3((unsigned)chunks, (unsigned)B), 256, 0, (hipStream_t)stream>>>(
+      prev, prev_bstride, net_out, truth, truth_bstride, mask, scale, shift, keep, w, out, partial,
+      (unsigned)per, (unsigned)F);
+  NLAM_CHECK_LAUNCH("state_step_wmse");
+  ssl_final_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(partial, (int)(chunks * B), lscale, loss);
+  NLAM_CHECK_LAUNCH("state_step_wmse_final");
+  return 0;
+}
+extern "C" int nlam_state_step_wmse_bwd(const float* pred, const float* truth, int64_t truth_bstride,
+                                        const float* mask, const float* scale, const float* keep,
+                                        const float* w, const float* gloss, float lscale,
+                                        const float* g_state, float* gx, float* gprev, int64_t B,
+                                        int64_t N, int F, void* stream) {
+  const int64_t per = N * F;
+  if (B <= 0 || per <= 0) return 0;
+  NLAM_REQUIRE(per < (int64_t(1) << 31) && B <= 65535, "nlam_state_step_wmse_bwd: N * F or B too large");
+  NLAM_REQUIRE(pred && truth && mask && scale && keep && w && gx, "nlam_state_step_wmse_bwd: null operand");
+  NLAM_REQUIRE(truth_bstride >= per, "nlam_state_step_wmse_bwd: batch pitch below N * F");
+  int64_t chunks = (per + 1023) / 1024;
+  if (chunks > 2048) chunks = 2048;
+  state_step_wmse_bwd_kernel<<<dim3((unsigned)chunks, (unsigned)B), 256, 0, (hipStream_t)stream>>>(
+      pred, truth, truth_bstride, mask, scale, keep, w, gloss, lscale, g_state, gx, gprev, (unsigned)per,
+      (unsigned)F);
+  NLAM_CHECK_LAUNCH("state_step_wmse_bwd");
+  return 0;
+}
+
 // g_pred = gloss[0] * 2 scale keep w (pred - target)
 __global__ void wmse_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ target,
                                 const float* __restrict__ keep, const float* __restrict__ w,

@@ -188,6 +188,49 @@ class StateStep(torch.autograd.Function):
         return gprev, gx, None, None, None, None
 
 
+class StateStepLoss(torch.autograd.Function):
+    """StateStep AND the training-loss term of the same AR step in one pass each way (the loss
+    target of AR step t is the boundary truth of step t: ar_model.py:244-247 with 294-298):
+    returns (new_state, lscale * sum keep w (new_state - truth)^2).  Forward reads what StateStep
+    reads and nothing more; backward folds MaskedWMSE's and StateStep's into one kernel."""
+
+    @staticmethod
+    def forward(ctx, prev_state, net_out, truth, mask, diff_std, diff_mean, keep, w, lscale):
+        net_out = net_out.contiguous()
+        ops._require_dev(net_out, "net_out")
+        B, N, F = net_out.shape
+        prev_state, pb = _batch_view(prev_state)
+        truth, tb = _batch_view(truth)
+        out = torch.empty_like(net_out)
+        partial = torch.empty(lib.nlam_state_step_wmse_blocks(), dtype=torch.float32, device=out.device)
+        loss = torch.empty(1, dtype=torch.float32, device=out.device)
+        ops._launch("nlam_state_step_wmse_fwd", lib.nlam_state_step_wmse_fwd,
+                    (prev_state.data_ptr(), pb, net_out.data_ptr(), truth.data_ptr(), tb,
+                     mask.data_ptr(), diff_std.data_ptr(), diff_mean.data_ptr(), keep.data_ptr(),
+                     w.data_ptr(), out.data_ptr(), partial.data_ptr(), loss.data_ptr(), lscale,
+                     B, N, F, ops.stream()), nbytes=16.0 * net_out.numel())
+        ctx.save_for_backward(out, truth, mask, diff_std, keep, w)
+        ctx.tb, ctx.lscale = tb, lscale
+        ctx.set_materialize_grads(False)
+        return out, loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g_state, g_loss):
+        out, truth, mask, diff_std, keep, w = ctx.saved_tensors
+        B, N, F = out.shape
+        g_state = g_state.contiguous() if g_state is not None else None
+        gl = g_loss.reshape(1).contiguous() if g_loss is not None else None
+        gx = torch.empty_like(out)
+        gprev = torch.empty_like(out) if ctx.needs_input_grad[0] else None
+        ops._launch("nlam_state_step_wmse_bwd", lib.nlam_state_step_wmse_bwd,
+                    (out.data_ptr(), truth.data_ptr(), ctx.tb, mask.data_ptr(), diff_std.data_ptr(),
+                     keep.data_ptr(), w.data_ptr(), gl.data_ptr() if gl is not None else None,
+                     ctx.lscale, g_state.data_ptr() if g_state is not None else None, gx.data_ptr(),
+                     gprev.data_ptr() if gprev is not None else None, B, N, F, ops.stream()),
+                    nbytes=(12.0 + 4.0 * (g_state is not None) + 4.0 * (gprev is not None)) * out.numel())
+        return gprev, gx, None, None, None, None, None, None, None
+
+
 class MaskedWMSE(torch.autograd.Function):
     """mean over the leading dims of sum_f mean_{kept n} (pred - target)^2 * w_f."""
 

@@ -6,6 +6,7 @@ Validation / test / plotting / W&B stay with the reference (out of scope).
 It is a pytorch_lightning.LightningModule when Lightning is installed and a
 plain nn.Module otherwise; the method names and batch layout are Lightning's.
 """
+import os
 import torch
 import torch.utils.checkpoint
 from torch import nn
@@ -204,18 +205,41 @@ class ARModel(_Base):
         prediction, pred_std = self.unroll_prediction(init_states, forcing_features, target_states)
         return prediction, target_states, pred_std, batch_times
 
+    def _masked_loss_consts(self, device):
+        if not hasattr(self, "_loss_consts") or self._loss_consts[0].device != device:
+            keep = self.interior_mask[:, 0].contiguous()
+            w = (
+                1.0 / self.per_var_std**2 if self.loss is metrics.wmse
+                else torch.ones_like(self.per_var_std)
+            ).contiguous()
+            self._loss_consts = (keep, w, float(keep.sum().item()))
+        return self._loss_consts
+
     def training_step(self, batch):
-        prediction, target, pred_std, _ = self.common_step(batch)
-        if not self.output_std and self.loss in (metrics.wmse, metrics.mse):
+        init_states, forcing = batch[0], batch[2]
+        wmse_like = not self.output_std and self.loss in (metrics.wmse, metrics.mse)
+        # the loss target of AR step t is the boundary truth of the same step: on the device path
+        # each predict_step hands back its loss term from the state-step kernel itself
+        # (glue.StateStepLoss; NLAM_FUSE_LOSS=0: the separate loss kernel over the stacked prediction)
+        tap = (wmse_like and init_states.is_cuda and not getattr(self, "ar_checkpoint", False)
+               and os.environ.get("NLAM_FUSE_LOSS", "1") != "0")
+        if tap:
+            keep, w, n_keep = self._masked_loss_consts(init_states.device)
+            self._loss_tap = (keep, w, 1.0 / (n_keep * init_states.shape[0] * forcing.shape[1]))
+            self._loss_terms = []
+        try:
+            prediction, target, pred_std, _ = self.common_step(batch)
+            terms = self._loss_terms if tap else []
+        finally:
+            self._loss_tap, self._loss_terms = None, []
+        if terms:
+            assert len(terms) == forcing.shape[1]
+            batch_loss = terms[0]
+            for t in terms[1:]:
+                batch_loss = batch_loss + t
+        elif wmse_like:
             # fused masked loss kernel (no boolean-mask gather, no host sync)
-            if not hasattr(self, "_loss_consts") or self._loss_consts[0].device != prediction.device:
-                keep = self.interior_mask[:, 0].contiguous()
-                w = (
-                    1.0 / self.per_var_std**2 if self.loss is metrics.wmse
-                    else torch.ones_like(self.per_var_std)
-                ).contiguous()
-                self._loss_consts = (keep, w, float(keep.sum().item()))
-            keep, w, n_keep = self._loss_consts
+            keep, w, n_keep = self._masked_loss_consts(prediction.device)
             lead = prediction.numel() // (prediction.shape[-1] * prediction.shape[-2])
             batch_loss = glue.MaskedWMSE.apply(prediction, target, keep, w, 1.0 / (n_keep * lead))
         elif self.output_std and self.loss is metrics.nll and prediction.is_cuda:

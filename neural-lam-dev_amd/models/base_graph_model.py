@@ -118,6 +118,15 @@ class BaseGraphModel(ARModel):
         if self.output_std:
             # chunk + softplus + rescale + residual in one kernel (glue.StdHead)
             return glue.StdHead.apply(prev_state, net_output, self.diff_std, self.diff_mean)
+        tap = getattr(self, "_loss_tap", None)
+        if boundary_truth is not None and tap is not None:
+            # training: this AR step's loss term from the same pass (ARModel.training_step sums them)
+            keep, w, lscale = tap
+            new_state, term = glue.StateStepLoss.apply(
+                prev_state, net_output, boundary_truth, self.boundary_mask, self.diff_std,
+                self.diff_mean, keep, w, lscale)
+            self._loss_terms.append(term)
+            return new_state, None
         if boundary_truth is not None:
             return glue.StateStep.apply(prev_state, net_output, boundary_truth, self.boundary_mask,
                                         self.diff_std, self.diff_mean), None

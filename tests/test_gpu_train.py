@@ -274,6 +274,113 @@ def test_state_step_matches_residual_then_boundary_mix(prev_grad):
         assert torch.allclose(g_prev, prev.grad, rtol=1e-6, atol=1e-7)
 
 
+@pytest.mark.parametrize("prev_grad,use_state,use_loss,N", [(False, False, True, 517), (True, True, True, 517),
+                                                             (False, True, False, 33), (True, True, True, 70001)])
+def test_state_step_loss_matches_state_step_then_masked_wmse(prev_grad, use_state, use_loss, N):
+    """glue.StateStepLoss (state step + this AR step's loss term, one kernel each way) against
+    (a) glue.StateStep followed by glue.MaskedWMSE and (b) the torch expression in float64;
+    values and gradients, with the new state and / or the loss term feeding the objective (the
+    last rollout step has no consumer of its state; a term may go unused), twice in a row (the
+    last-block ticket of the loss reduction must re-arm itself)."""
+    from neural_lam_amd import glue
+
+    gen = torch.Generator().manual_seed(6)
+    B, F = 3, 17
+    init = torch.randn(B, 2, N, F, generator=gen).cuda()
+    targets = torch.randn(B, 4, N, F, generator=gen).cuda()
+    mask = (torch.rand(N, 1, generator=gen) < 0.3).float().cuda()
+    keep = (1.0 - mask[:, 0]).contiguous()
+    wf = (torch.rand(F, generator=gen) + 0.2).cuda()
+    std, mean = (torch.rand(F, generator=gen) + 0.5).cuda(), torch.randn(F, generator=gen).cuda()
+    cot = torch.randn(B, N, F, generator=gen).cuda()
+    lscale = 1.0 / (float(keep.sum()) * B * 2)
+
+    def run(kind):
+        net = torch.randn(B, N, F, generator=torch.Generator().manual_seed(7)).cuda().requires_grad_(True)
+        prev = init[:, 1].clone().requires_grad_(True) if prev_grad else init[:, 1]
+        truth = targets[:, 2]
+        if kind == "fused":
+            new, loss = glue.StateStepLoss.apply(prev, net, truth, mask, std, mean, keep, wf, lscale)
+        elif kind == "split":
+            new = glue.StateStep.apply(prev, net, truth, mask, std, mean)
+            loss = glue.MaskedWMSE.apply(new, truth, keep, wf, lscale)
+        else:
+            new = mask.double() * truth.double() + (1.0 - mask.double()) * (
+                prev.double() + net.double() * std.double() + mean.double())
+            loss = (keep.double()[None, :, None] * wf.double() * (new - truth.double()) ** 2).sum() * lscale
+        obj = (3.0 * loss if use_loss else 0.0) + ((new * cot).sum() if use_state else 0.0)
+        obj.backward()
+        return new.detach(), loss.detach(), net.grad, (prev.grad if prev_grad else None)
+
+    for _ in range(2):
+        got, split, want = run("fused"), run("split"), run("f64")
+        assert torch.equal(got[0], split[0])
+        assert torch.allclose(got[0].double(), want[0], rtol=1e-6, atol=1e-6)
+        assert abs(float(got[1]) - float(want[1])) <= 2e-6 * abs(float(want[1]))
+        assert abs(float(split[1]) - float(want[1])) <= 2e-6 * abs(float(want[1]))
+        for a, b, c in zip(got[2:], split[2:], want[2:]):
+            if a is None:
+                assert b is None and c is None
+                continue
+            scale = float(c.abs().max()) + 1e-30
+            assert float((a.double() - c.double()).abs().max()) <= 2e-6 * scale
+            assert float((a - b).abs().max()) <= 2e-6 * scale
+
+
+@pytest.mark.parametrize("model_name,ar_steps", [("graph_lam", 1), ("graph_lam", 3), ("hi_lam", 2)])
+def test_training_step_is_unchanged_by_the_fused_loss_term(model_name, ar_steps, monkeypatch):
+    """One training step with each AR step's loss term taken from the state-step kernel
+    (NLAM_FUSE_LOSS default) and with the separate loss kernel over the stacked prediction: the
+    same loss and parameter gradients to fp32 summation-order accuracy, fewer launches."""
+    import tempfile
+
+    import numpy as np
+
+    from neural_lam_amd import graphgen, ops, synthetic
+    from neural_lam_amd.models import MODELS
+
+    hier = model_name != "graph_lam"
+    with tempfile.TemporaryDirectory() as tmp:
+        info = graphgen.create_graph(tmp + "/graph/g", graphgen.make_xy(38, 35, 5000.0),
+                                     3 if hier else None, hier)
+        n = info["num_grid"]
+        gen = torch.Generator().manual_seed(0)
+        ds = synthetic.SyntheticDatastore(
+            tmp, torch.randn(n, 4, generator=gen).numpy(), np.zeros(7), np.ones(7), np.zeros(7),
+            np.ones(7), (torch.rand(n, generator=gen) < 0.2).float().numpy(), n_forcing=2)
+        torch.manual_seed(1)
+        model = MODELS[model_name](synthetic.model_args(graph="g", hidden_dim=64, processor_layers=2),
+                                   config=None, datastore=ds).cuda()
+    batch = synthetic.random_batch(2, ar_steps, n, n_state=7, n_forcing_window=6, device="cuda")
+
+    def run(on):
+        monkeypatch.setenv("NLAM_FUSE_LOSS", "1" if on else "0")
+        for p in model.parameters():
+            p.grad = None
+        ops.PROFILER = ops.KernelProfiler()
+        try:
+            loss = model.training_step(batch)
+            loss.backward()
+            stats = ops.PROFILER.collect()
+        finally:
+            ops.PROFILER = None
+        assert model._loss_tap is None and not model._loss_terms
+        return float(loss.detach()), [p.grad.clone() for p in model.parameters()], stats
+
+    l_on, g_on, s_on = run(True)
+    l_off, g_off, s_off = run(False)
+    assert sum(v["calls"] for k, v in s_on.items() if k.startswith("nlam_state_step_wmse_fwd")) == ar_steps
+    assert not [k for k in s_on if k.split("@")[0] in ("nlam_state_step", "nlam_state_step_bwd",
+                                                        "nlam_wmse_fwd", "nlam_wmse_bwd")], sorted(s_on)
+    assert not any(k.startswith("nlam_state_step_wmse") for k in s_off)
+    n_on, n_off = (sum(v["calls"] for v in s.values()) for s in (s_on, s_off))
+    assert n_on <= n_off - 2, (n_on, n_off)   # (the separate loss is one entry over the stacked prediction)
+    assert abs(l_on - l_off) <= 2e-6 * abs(l_off)
+    for (k, _), a, b in zip(model.named_parameters(), g_on, g_off):
+        scale = float(b.abs().max()) + 1e-30
+        assert float((a - b).abs().max()) <= 2e-5 * scale, (k, float((a - b).abs().max()) / scale)
+
+
 @pytest.mark.parametrize("n,shape", [(2, (3, 50, 64)), (7, (4, 737, 64)), (11, (2, 33, 5))])
 def test_sum_many_matches_chain_of_adds(n, shape):
     """glue.sum_many (nlam_sum_many: one pass over up to 8 terms, chained beyond) against the

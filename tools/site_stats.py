@@ -36,6 +36,7 @@ FAMILIES = [  # (kernel-name regex, family); the first match wins, template argu
     (r"^reduce_slabs_multi_kernel", "reduce_slabs_multi"), (r"^reduce_slabs_kernel", "reduce_slabs"),
     (r"^segment_sum_", "segment_sum"), (r"^sum_batch", "sum_batch"), (r"^concat_rows", "concat_rows"),
     (r"^boundary_mix", "boundary_mix"), (r"^affine_residual", "affine_residual"),
+    (r"^state_step_wmse_bwd", "state_step_wmse_bwd"), (r"^(state_step_wmse|ssl_final)", "state_step_wmse_fwd"),
     (r"^state_step_bwd", "state_step_bwd"), (r"^state_step", "state_step"),
     (r"^pack_segments", "pack_segments"),
     (r"^scale_cols", "scale_cols"), (r"^wmse_(partial|final)", "wmse_fwd"), (r"^wmse_bwd", "wmse_bwd"),
