@@ -540,6 +540,22 @@ int nlam_tail_fwd(const int32_t* tiles, int64_t ntiles, int64_t rows, const int3
                   const float* res, int64_t res_bstride, int64_t res_ld,
                   float* agg, int64_t agg_bstride, int64_t agg_ld, const float* inv_deg,
                   int64_t B, int d, int io_bf16, void* stream);
+/* The node update with its aggregate projection inside the tail (reference interaction_net.py:
+ * 127-131: aggr_mlp(cat(rec_rep, edge_rep_aggr)) + residual):  h = a + pre . preW^T  (preW (d, d),
+ * e.g. the aggregate columns V1[:, d:] of the first Linear; `a` holds the receiver part and the
+ * bias), y = res + LN(W2 silu(h) + b2), h kept in h_out.  The same products as nlam_lin_fwd(pre,
+ * preW) followed by nlam_tail_fwd(a, b = that product), accumulated ONTO a instead of summed
+ * beside it (fp32 rounding-order differences only); one launch and no round trip of the product.
+ * Hidden 128, contiguous rows, and
+ * B * ceil(rows / 32) <= 1024 (one row tile per wave: the workgroup holds preW's split-bf16 image
+ * first and W2's after it); nlam_tail_fwd_pre_supported says whether a shape qualifies. */
+int nlam_tail_fwd_pre_supported(int d, int64_t B, int64_t rows);
+int nlam_tail_fwd_pre(int64_t rows, const float* a, int64_t a_bstride, int64_t a_ld,
+                      const float* pre, int64_t pre_bstride, int64_t pre_ld, const float* preW,
+                      int64_t ldpreW, const float* W2, int64_t ldW2, const float* b2,
+                      const float* gamma, const float* beta, float* h_out, int64_t h_bstride,
+                      float* y, int64_t y_bstride, int64_t y_ld, const float* res,
+                      int64_t res_bstride, int64_t res_ld, int64_t B, int d, void* stream);
 /* Backward of nlam_tail_fwd from the kept h:  g[p] = scale1[idx_g1[p]] * g1[idx_g1[p]] +
  * g2[idx_g2[p]] is the gradient of m[p];  gz = LN'(z; g) (= g without LayerNorm) is written to
  * gz_out (B, rows, ceil32(n_out)) for the weight-gradient pass;  gh[idx_gh[p]] =

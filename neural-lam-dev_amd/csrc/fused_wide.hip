@@ -158,10 +158,14 @@ struct TailFwdParams {
   int B;
   int vec_y;                             // y / res rows 16-byte aligned, n_out % 4 == 0
   int stamp;                             // NLAM_STAMP_WIDE=1
+  // optional projection in front of the tail (node update: h = a + pre . preW^T, preW (D, D)):
+  // one-tile-per-wave problems only -- the workgroup holds preW's image first and W2's after it
+  RowView pre; const float* preW; int64_t ldpreW;
 };
 
-template <int D, int NOUTB, bool HAS_LN, int TERMS, bool STAMP = false>
+template <int D, int NOUTB, bool HAS_LN, int TERMS, bool STAMP = false, bool PRE = false>
 __global__ __launch_bounds__(256) void tail_fwd_kernel(TailFwdParams p) {
+  static_assert(!PRE || (HAS_LN && 32 * NOUTB == D), "PRE: the node update (n_out == D, LayerNorm)");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NB = D / 32, NV = D / 8, NO = 32 * NOUTB;
   constexpr int LDT = D + 4;
@@ -213,14 +217,27 @@ __global__ __launch_bounds__(256) void tail_fwd_kernel(TailFwdParams p) {
     float* const vdst[3] = {b2s, gs, bs};
     vecs_issue(lv, vsrc, p.n_out, tid);
     WLoad16<16> lw;
-    w16_issue(lw, p.W2, p.ldW2, p.n_out, D, NO, D, tid, 256);
+    const float* const W0 = PRE ? p.preW : p.W2;
+    const int64_t ldW0 = PRE ? p.ldpreW : p.ldW2;
+    w16_issue(lw, W0, ldW0, p.n_out, D, NO, D, tid, 256);
     __builtin_amdgcn_sched_barrier(0);
     cur = load_idx(wide_tile_decode(p.tl, k0, hdr0));
-    w16_commit(lw, W2im, 0, p.W2, p.ldW2, p.n_out, D, NO, D, tid, 256);
+    w16_commit(lw, W2im, 0, W0, ldW0, p.n_out, D, NO, D, tid, 256);
     vecs_commit(lv, vdst, NO, tid);
   }
   __syncthreads();
-  if (tt >= total) return;
+  // PRE: every wave of the workgroup swaps the weight image once (between the two barriers)
+  auto swap_to_W2 = [&]() {
+    __syncthreads();
+    WLoad16<16> lw;
+    w16_issue(lw, p.W2, p.ldW2, p.n_out, D, NO, D, tid, 256);
+    w16_commit(lw, W2im, 0, p.W2, p.ldW2, p.n_out, D, NO, D, tid, 256);
+    __syncthreads();
+  };
+  if (tt >= total) {
+    if constexpr (PRE) swap_to_W2();
+    return;
+  }
   unsigned long long wst[STAMP ? 8 : 1] = {0};
   unsigned long long wprev = STAMP ? __builtin_amdgcn_s_memtime() : 0;
   for (; tt < total; tt += tstride) {
@@ -270,13 +287,38 @@ __global__ __launch_bounds__(256) void tail_fwd_kernel(TailFwdParams p) {
     // (requested AFTER the gathers were waited for: memory operations retire in order, and the
     // residual rows are not needed before the end of the tile)
     if (res_rows) load_rows_i<NV>(vRes, p.res.ptr + b * p.res.bstride, p.res.ld, iy, D, lane);
-    if (p.h_out != nullptr)
+    f32x4 vP[PRE ? NV : 1];
+    if constexpr (PRE) {   // (contiguous rows p0 .. p0 + ne - 1 of the projected operand)
+      const float* pb = p.pre.ptr + b * p.pre.bstride + (int64_t)w.p0 * p.pre.ld;
+      const int last = ne > 0 ? ne - 1 : 0;
+      load_rows_v<NV>(vP, D, lane, [&](int s2) { return pb + (int64_t)(s2 < last ? s2 : last) * p.pre.ld; });
+    }
+    if (!PRE && p.h_out != nullptr)
       store_rows_regs<NV>(p.h_out + b * p.h_bstride + (int64_t)w.p0 * D, D, D, ne, lane, vA);
     WSTAMP(0)   // slot tables, row gathers a / b / c issued + landed + summed, h rows stored
     put_rows_v<NV, false>(tile, LDT, 0, D, ne, lane, vA);
     wave_sync();
     f32x16 a1[NB];
     tile_to_acc<NB>(a1, tile, LDT, lane);
+    if constexpr (PRE) {
+      // h = a + pre . preW^T with preW's image in LDS, then W2's image takes its place
+      wave_sync();
+      put_rows_v<NV, false>(tile, LDT, 0, D, ne, lane, vP);
+      wave_sync();
+      {
+        f32x16 xa[NB];
+        tile_to_acc<NB>(xa, tile, LDT, lane);
+        gemm_acc_b3<NB, NB, TERMS>(a1, W2im, 0, xa, lane);
+      }
+      swap_to_W2();
+      if (p.h_out != nullptr) {
+        acc_to_tile<NB>(a1, tile, LDT, lane);
+        wave_sync();
+        float* hb = p.h_out + b * p.h_bstride + (int64_t)w.p0 * D;
+        store_rows<true>(tile, LDT, 0, D, ne, lane, [&](int s2) { return hb + (int64_t)s2 * D; });
+        wave_sync();
+      }
+    }
     WSTAMP(1)   // h tile staged + back in accumulator layout
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
@@ -381,6 +423,9 @@ static int launch_tail_fwd(const TailFwdParams& p, hipStream_t s) {
   NLAM_REQUIRE(lds <= 160 * 1024, "tail_fwd: LDS footprint %zu B exceeds 160 KiB", lds);
   auto kern = tail_fwd_kernel<D, NOUTB, HAS_LN, TERMS>;
   if (HAS_LN && TERMS == 3 && p.stamp) kern = tail_fwd_kernel<D, NOUTB, HAS_LN, TERMS, HAS_LN && TERMS == 3>;
+  if constexpr (HAS_LN && 32 * NOUTB == D) {
+    if (p.preW != nullptr) kern = tail_fwd_kernel<D, NOUTB, HAS_LN, TERMS, false, true>;
+  }
   NLAM_BIG_LDS(kern, "tail_fwd_kernel");
   kern<<<wide_grid(p.tl.ntiles * p.B), 256, lds, s>>>(p);
   NLAM_CHECK_LAUNCH("tail_fwd_kernel");
@@ -390,6 +435,26 @@ static int launch_tail_fwd(const TailFwdParams& p, hipStream_t s) {
 static bool wide_view_ok(const float* ptr, int64_t bstride, int64_t ld, int d) {
   return view_vec_ok(ptr, bstride, ld, d);
 }
+
+// the node update's second projection inside the tail: one-tile-per-wave problems at hidden 128
+extern "C" int nlam_tail_fwd_pre_supported(int d, int64_t B, int64_t rows) {
+  return d == 128 && nlam_mfma_terms() != 0 && B >= 1 && rows >= 1 &&
+         B * ((rows + NLAM_TILE - 1) / NLAM_TILE) <= 4 * 256;
+}
+
+static int tail_fwd_impl(
+    const int32_t* tiles, int64_t ntiles, int64_t rows, const int32_t* csr_rec,
+    const int32_t* csr_rowptr,
+    const float* a, int64_t a_bstride, int64_t a_ld, const int32_t* idx_a,
+    const float* b, int64_t b_bstride, int64_t b_ld, const int32_t* idx_b,
+    const float* c, int64_t c_bstride, int64_t c_ld, const int32_t* idx_c,
+    const float* W2, int64_t ldW2, const float* b2, const float* gamma, const float* beta,
+    int n_out, float* h_out, int64_t h_bstride, void* z_keep, int64_t z_bstride,
+    float* y, int64_t y_bstride, int64_t y_ld, const int32_t* idx_y,
+    const float* res, int64_t res_bstride, int64_t res_ld,
+    float* agg, int64_t agg_bstride, int64_t agg_ld, const float* inv_deg,
+    int64_t B, int d, int io_bf16, void* stream,
+    const float* pre, int64_t pre_bstride, int64_t pre_ld, const float* preW, int64_t ldpreW);
 
 extern "C" int nlam_tail_fwd(
     const int32_t* tiles, int64_t ntiles, int64_t rows, const int32_t* csr_rec,
@@ -403,6 +468,45 @@ extern "C" int nlam_tail_fwd(
     const float* res, int64_t res_bstride, int64_t res_ld,
     float* agg, int64_t agg_bstride, int64_t agg_ld, const float* inv_deg,
     int64_t B, int d, int io_bf16, void* stream) {
+  return tail_fwd_impl(tiles, ntiles, rows, csr_rec, csr_rowptr, a, a_bstride, a_ld, idx_a, b, b_bstride,
+                       b_ld, idx_b, c, c_bstride, c_ld, idx_c, W2, ldW2, b2, gamma, beta, n_out, h_out,
+                       h_bstride, z_keep, z_bstride, y, y_bstride, y_ld, idx_y, res, res_bstride, res_ld,
+                       agg, agg_bstride, agg_ld, inv_deg, B, d, io_bf16, stream, nullptr, 0, 0, nullptr, 0);
+}
+
+extern "C" int nlam_tail_fwd_pre(
+    int64_t rows, const float* a, int64_t a_bstride, int64_t a_ld,
+    const float* pre, int64_t pre_bstride, int64_t pre_ld, const float* preW, int64_t ldpreW,
+    const float* W2, int64_t ldW2, const float* b2, const float* gamma, const float* beta,
+    float* h_out, int64_t h_bstride, float* y, int64_t y_bstride, int64_t y_ld,
+    const float* res, int64_t res_bstride, int64_t res_ld, int64_t B, int d, void* stream) {
+  if (B <= 0 || rows <= 0) return 0;
+  NLAM_REQUIRE(nlam_tail_fwd_pre_supported(d, B, rows),
+               "nlam_tail_fwd_pre: hidden 128 and at most 1024 row tiles (B * ceil(rows / 32))");
+  NLAM_REQUIRE(pre != nullptr && preW != nullptr && gamma != nullptr && beta != nullptr,
+               "nlam_tail_fwd_pre: null operand");
+  NLAM_REQUIRE(view_vec_ok(pre, pre_bstride, pre_ld, d) && nlam_aligned16(preW) && ldpreW % 4 == 0,
+               "nlam_tail_fwd_pre: projected rows / weights must be 16-byte aligned, pitch %% 4 == 0");
+  return tail_fwd_impl(nullptr, (rows + NLAM_TILE - 1) / NLAM_TILE, rows, nullptr, nullptr, a, a_bstride,
+                       a_ld, nullptr, nullptr, 0, 0, nullptr, nullptr, 0, 0, nullptr, W2, ldW2, b2, gamma,
+                       beta, d, h_out, h_bstride, nullptr, 0, y, y_bstride, y_ld, nullptr, res, res_bstride,
+                       res_ld, nullptr, 0, 0, nullptr, B, d, 0, stream, pre, pre_bstride, pre_ld, preW,
+                       ldpreW);
+}
+
+static int tail_fwd_impl(
+    const int32_t* tiles, int64_t ntiles, int64_t rows, const int32_t* csr_rec,
+    const int32_t* csr_rowptr,
+    const float* a, int64_t a_bstride, int64_t a_ld, const int32_t* idx_a,
+    const float* b, int64_t b_bstride, int64_t b_ld, const int32_t* idx_b,
+    const float* c, int64_t c_bstride, int64_t c_ld, const int32_t* idx_c,
+    const float* W2, int64_t ldW2, const float* b2, const float* gamma, const float* beta,
+    int n_out, float* h_out, int64_t h_bstride, void* z_keep, int64_t z_bstride,
+    float* y, int64_t y_bstride, int64_t y_ld, const int32_t* idx_y,
+    const float* res, int64_t res_bstride, int64_t res_ld,
+    float* agg, int64_t agg_bstride, int64_t agg_ld, const float* inv_deg,
+    int64_t B, int d, int io_bf16, void* stream,
+    const float* pre, int64_t pre_bstride, int64_t pre_ld, const float* preW, int64_t ldpreW) {
   if (B <= 0 || rows <= 0) return 0;
   NLAM_REQUIRE(io_bf16 == 0 || d == 256, "nlam_tail_fwd: bf16 rows exist at hidden 256 only");
   if (d == 256)
@@ -442,6 +546,9 @@ extern "C" int nlam_tail_fwd(
   p.vec_y = (y != nullptr && view_vec_ok(y, y_bstride, y_ld, n_out) &&
              (res == nullptr || view_vec_ok(res, res_bstride, res_ld, n_out))) ? 1 : 0;
   p.stamp = wide_stamp_flag();
+  p.pre = RowView{pre, pre_bstride, pre_ld, d}; p.preW = preW; p.ldpreW = ldpreW;
+  NLAM_REQUIRE(preW == nullptr || (d == 128 && tiles == nullptr && ntiles * B <= 4 * 256),
+               "nlam_tail_fwd: the fused projection needs one row tile per wave at hidden 128");
   NLAM_REQUIRE(idx_y == nullptr || y == nullptr || (p.vec_y && n_out == d),
                "nlam_tail_fwd: scattered output rows must be 16-byte aligned and d wide");
   hipStream_t s = (hipStream_t)stream;

@@ -154,6 +154,27 @@ def tail_fwd(tl, a, idx_a, b, idx_b, c, idx_c, W2, b2, gamma, beta, h_out, y, id
     )
 
 
+def tail_fwd_pre_ok(d, B, rows, *mats):
+    """The node update's aggregate projection inside its tail launch (nlam_tail_fwd_pre):
+    hidden 128, one row tile per wave, fp32 rows; NLAM_TAIL_PRE=0 keeps the two launches."""
+    return (os.environ.get("NLAM_TAIL_PRE", "1") != "0" and not bf16_rows(d)
+            and bool(lib.nlam_tail_fwd_pre_supported(d, B, rows))
+            and all(m is not None and not is_bf16(m) and _aligned(m) for m in mats))
+
+
+def tail_fwd_pre(rows, a, pre, preW, W2, b2, gamma, beta, h_out, y, res, B, d):
+    """h = a + pre preW^T;  y = res + LN(W2 silu(h) + b2);  h kept."""
+    _launch(
+        "nlam_tail_fwd_pre", lib.nlam_tail_fwd_pre,
+        (rows, a.ptr, a.bstride, a.ld, pre.ptr, pre.bstride, pre.ld, preW.data_ptr(), preW.stride(0),
+         W2.data_ptr(), W2.stride(0), _p(b2), _p(gamma), _p(beta), h_out.data_ptr(), h_out.stride(0),
+         y.ptr, y.bstride, y.ld, res.ptr if res is not None else None,
+         res.bstride if res is not None else 0, res.ld if res is not None else 0, B, d, stream()),
+        flops=4.0 * B * rows * d * d,
+        nbytes=4.0 * B * rows * d * (4 + (res is not None)),
+    )
+
+
 def tail_bwd(tl, h, g1, idx_g1, scale1, g2, idx_g2, W2, b2, gamma, gz_out, gh, idx_gh, gpr, B, d,
              dgamma, dbeta, z_keep=None):
     n_out = W2.shape[0]
@@ -486,13 +507,18 @@ class WideInteractionNetFunction(torch.autograd.Function):
                 fold_virtual(g, agg_k, mat(agg), g.inv_deg if mean else None)
             del Pe, Ps, Pr
             # node update x_r + LN(V2 silu(V1 [x_r | agg] + c1) + c2)
-            hn2 = _inter(d, B, N_r, d, device=dev)
-            _first_linear(mat(agg), V1[:, d:], None, _m(hn2))
             h_n = _inter(d, B, N_r, d, device=dev)
             rec_out = _empty(B, N_r, d, device=dev)
             z_n = keep_z(B, N_r, d, gam2, dev)
-            tail_fwd(Tiling(N_r), _m(hn1), None, _m(hn2), None, None, None, V2, c2, gam2, bet2,
-                     h_n, mat(rec_out), None, rm, None, None, B, d, z_n)
+            if z_n is None and tail_fwd_pre_ok(d, B, N_r, _m(hn1), mat(agg), mat(rec_out), rm):
+                # (mesh-sized receiver sets: the aggregate's projection rides inside the tail)
+                tail_fwd_pre(N_r, _m(hn1), mat(agg), V1[:, d:], V2, c2, gam2, bet2, h_n,
+                             mat(rec_out), rm, B, d)
+            else:
+                hn2 = _inter(d, B, N_r, d, device=dev)
+                _first_linear(mat(agg), V1[:, d:], None, _m(hn2))
+                tail_fwd(Tiling(N_r), _m(hn1), None, _m(hn2), None, None, None, V2, c2, gam2, bet2,
+                         h_n, mat(rec_out), None, rm, None, None, B, d, z_n)
             ctx.save_for_backward(W1, b1, W2, b2, gam, V1, c1, V2, c2, gam2, h_e, h_n, agg, z_e, z_n)
             ctx.set_materialize_grads(False)
             ctx.g, ctx.same, ctx.update_edges, ctx.mean = g, same, update_edges, mean

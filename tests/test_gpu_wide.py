@@ -271,9 +271,57 @@ def test_wide_paths_are_taken_at_hidden_128():
     finally:
         ops.PROFILER = None
     names = {k.split("@")[0] for k in stats}
-    assert {"nlam_lin_fwd_multi", "nlam_lin_fwd", "nlam_tail_fwd", "nlam_tail_bwd",
+    assert {"nlam_lin_fwd_multi", "nlam_tail_fwd", "nlam_tail_fwd_pre", "nlam_tail_bwd",
             "nlam_lin_bwd_data_multi", "nlam_wide_outer_multi", "nlam_segment_sum"} <= names
-    # launch budget of one wide InteractionNet (forward 4, backward 9 incl. the slab reduction)
-    assert sum(v["calls"] for v in stats.values()) <= 14, stats
-    assert "nlam_gemm" not in names and "nlam_layernorm_fwd" not in names
-    assert stats["nlam_tail_fwd@inet"]["calls"] == 2 and stats["nlam_tail_bwd@inet"]["calls"] == 2
+    # launch budget of one wide InteractionNet (forward 3: the node update's aggregate projection
+    # rides inside its tail launch; backward 9 incl. the slab reduction)
+    assert sum(v["calls"] for v in stats.values()) <= 13, stats
+    assert "nlam_gemm" not in names and "nlam_layernorm_fwd" not in names and "nlam_lin_fwd" not in names
+    assert stats["nlam_tail_fwd@inet"]["calls"] == 1 and stats["nlam_tail_fwd_pre@inet"]["calls"] == 1
+    assert stats["nlam_tail_bwd@inet"]["calls"] == 2
+
+
+@pytest.mark.skipif(D != 128, reason="hidden 128 only")
+@pytest.mark.parametrize("B,n_r,expect_pre", [(2, 30, True), (4, 8192, True), (1, 32 * 1024 - 5, True),
+                                              (4, 8193, False), (3, 517, True)])
+def test_node_update_with_the_projection_inside_the_tail(B, n_r, expect_pre, monkeypatch):
+    """nlam_tail_fwd_pre (h = a + agg V1b^T inside the node tail; one row tile per wave, i.e. at
+    most 1024 tiles) against the two-launch sequence it replaces (nlam_lin_fwd + nlam_tail_fwd):
+    outputs and every gradient of an InteractionNet to fp32 rounding order (the product is
+    accumulated onto `a` instead of beside it), at the tile-count boundary on both sides, with a
+    batch-invariant receiver operand, and the fall-back above the boundary."""
+    from neural_lam_amd import ops
+    from neural_lam_amd.interaction_net import InteractionNet
+
+    gen = torch.Generator().manual_seed(n_r)
+    M = 4 * n_r if n_r < 10000 else n_r + 100
+    rec = torch.arange(M) % n_r
+    send = torch.randint(0, n_r, (M,), generator=gen)
+    torch.manual_seed(3)
+    net = InteractionNet(torch.stack((send, rec)), 128).cuda()
+    x = torch.randn(1 if B == 3 else B, n_r, 128, device="cuda", generator=torch.Generator("cuda").manual_seed(1))
+    e = torch.randn(B, M, 128, device="cuda", generator=torch.Generator("cuda").manual_seed(2))
+
+    def run(on):
+        monkeypatch.setenv("NLAM_TAIL_PRE", "1" if on else "0")
+        for p in net.parameters():
+            p.grad = None
+        xs, es = x.clone().requires_grad_(True), e.clone().requires_grad_(True)
+        ops.PROFILER = ops.KernelProfiler()
+        try:
+            o_x, o_e = net(xs.expand(B, -1, -1) if xs.shape[0] == 1 else xs, xs.expand(B, -1, -1)
+                           if xs.shape[0] == 1 else xs, es)
+            (o_x.square().sum() + o_e.sum()).backward()
+            stats = ops.PROFILER.collect()
+        finally:
+            ops.PROFILER = None
+        return (o_x.detach(), o_e.detach(), xs.grad, es.grad, *[p.grad.clone() for p in net.parameters()]), stats
+
+    got, s_on = run(True)
+    want, s_off = run(False)
+    assert any(k.startswith("nlam_tail_fwd_pre") for k in s_on) == expect_pre
+    assert not any(k.startswith("nlam_tail_fwd_pre") for k in s_off)
+    if expect_pre:
+        assert sum(v["calls"] for v in s_on.values()) == sum(v["calls"] for v in s_off.values()) - 1
+    for a, b in zip(got, want):
+        assert rel(a.cpu(), b.cpu()) < 2e-5, rel(a.cpu(), b.cpu())
