@@ -62,6 +62,8 @@ def entry_family(entry):
     e = e[5:] if e.startswith("nlam_") else e
     if e != "reduce_slabs_multi" and e.endswith("_multi"):
         e = e[:-6]
+    if e == "tail_fwd_pre":   # (nlam_tail_fwd_pre launches tail_fwd_kernel<..., PRE = true>)
+        e = "tail_fwd"
     return e
 
 
