@@ -33,7 +33,7 @@ const char* nlam_last_error(void);
 /* ABI version of this header; bumped on any signature change (2: nlam_inet_grads.g_send_add,
  * nlam_set_k16 returns the previous mask; 3: round-5 entry points).  A binding compares it with
  * the version it was written against and refuses a stale prebuilt library (_lib.py). */
-#define NLAM_ABI_VERSION 3
+#define NLAM_ABI_VERSION 4
 int nlam_abi_version(void);
 /* GEMM arithmetic of the fused kernels: a property of a run, as the reference's `--precision`
  * (train_model.py:72-77,285).  Initial value: NLAM_MFMA in the environment (fp32 | bf16x3 | bf16,
@@ -277,6 +277,8 @@ typedef struct nlam_inet_graph {     /* device tables: nlam_graph_build_host + n
   const float* inv_deg;
   const int32_t* csc_colptr; const int32_t* csc_eid;
   int64_t n_send, n_rec, M;
+  /* optional (all three or none; nlam_edge_bwd_parts below): per-tile sender partial sums */
+  const int32_t* part_slot; const int32_t* pcsc_colptr; const int32_t* pcsc_rows;
 } nlam_inet_graph;
 typedef struct nlam_inet_view {      /* (B, rows, 64) fp32 input; B = 1: batch-invariant */
   const float* ptr; int64_t B, bstride, ld;
@@ -433,6 +435,34 @@ int nlam_edge_bwd(const int32_t* tiles, int64_t ntiles,
                   float* gpr, int64_t gpr_bstride, int64_t gpr_ld,
                   float* g_e, int64_t ge_bstride, int64_t ge_ld,
                   float* slab, int64_t slab_stride, int64_t B, int d, void* stream);
+
+/* nlam_edge_bwd without an edge update and with a batch-invariant first-layer edge term pe (M, d)
+ * (the grid-side nets: reference base_graph_model.py:139,152 with expand_to_batch), B > 1, when the
+ * gh rows are wanted ONLY for the sender-side sums of the projection backward: the kernel writes,
+ * instead of gh (B, M, d), the sums of each tile's gh rows per distinct sender.
+ *   part_slot (M, CSR position order): rank of the position's sender among the distinct senders of
+ *     its tile (every tile must have at most 16);
+ *   gpart (B, 16 ntiles, d): row 16 t + s = sum of the gh rows of tile t whose part_slot is s (rows
+ *     of unused slots are not written);
+ *   dpe (M, d) = sum_b gh[b] as nlam_edge_bwd's g_e in this form; gpr as there.
+ * The sender sums are then  gPs[b][n] = sum of gpart[b][r] over the rows r listed for sender n
+ * (pcsc_colptr / pcsc_rows, the CSC of the (tile, sender) pairs; nlam_lin_bwd_multi's gather takes
+ * them in place of csc_colptr / csc_eid): m2g of the MEPS graph has 76 k pairs for 255 k edges.
+ * Arithmetic: the indicator product that forms the receiver sums (fp32 accumulation of the split
+ * hi + lo bf16 planes of gh).  nlam_edge_bwd_parts_supported(): hidden 64, split-bf16 mode, and
+ * nlam_edge_bwd_forms_batch_sum(ntiles, B, d) = 1. */
+int nlam_edge_bwd_parts_supported(int64_t ntiles, int64_t B, int d);
+int nlam_edge_bwd_parts(const int32_t* tiles, int64_t ntiles,
+                        const int32_t* csr_rowptr, const int32_t* csr_eid,
+                        const int32_t* csr_send, const int32_t* csr_rec, const float* inv_deg,
+                        const float* pe, int64_t pe_ld,
+                        const float* ps, int64_t ps_bstride, int64_t ps_ld,
+                        const float* pr, int64_t pr_bstride, int64_t pr_ld,
+                        const float* W2, int64_t ldW2, const float* b2, const float* gamma,
+                        const float* g_agg, int64_t gagg_bstride, int64_t gagg_ld,
+                        const int32_t* part_slot, float* gpart, int64_t gpart_bstride,
+                        float* gpr, int64_t gpr_bstride, int64_t gpr_ld, float* dpe, int64_t dpe_ld,
+                        float* slab, int64_t slab_stride, int64_t B, int d, void* stream);
 
 /* One AdamW step over a flat fp32 parameter buffer (decoupled weight decay,
  * bias correction; torch.optim.AdamW semantics, ar_model.py:191-195).

@@ -96,6 +96,10 @@ SIGNATURES = {
                       _p, _i64, _p, _p, _p, _i32, _p, _i64, _p, _i64,
                       _p, _i64, _i64, _p, _p, _i64, _i64,
                       _p, _i64, _i64, _p, _i64, _i32, _i32, _p],
+    "nlam_edge_bwd_parts_supported": [_i64, _i64, _i32],
+    "nlam_edge_bwd_parts": [_p, _i64, _p, _p, _p, _p, _p, _p, _i64, _p, _i64, _i64, _p, _i64, _i64,
+                            _p, _i64, _p, _p, _p, _i64, _i64, _p, _p, _i64, _p, _i64, _i64, _p, _i64,
+                            _p, _i64, _i64, _i32, _p],
     "nlam_tail_fwd_pre_supported": [_i32, _i64, _i64],
     "nlam_tail_fwd_pre": [_i64, _p, _i64, _i64, _p, _i64, _i64, _p, _i64, _p, _i64, _p, _p, _p,
                           _p, _i64, _p, _i64, _i64, _p, _i64, _i64, _i64, _i32, _p],
@@ -171,7 +175,7 @@ class NlamError(RuntimeError):
     pass
 
 
-ABI_VERSION = 3   # include/nlam_hip.h NLAM_ABI_VERSION (tests/test_host_logic.py compares the two)
+ABI_VERSION = 4   # include/nlam_hip.h NLAM_ABI_VERSION (tests/test_host_logic.py compares the two)
 MFMA_MODE_NAMES = ("fp32", "bf16x3", "b3", "bf16")
 
 

@@ -747,6 +747,22 @@ static int launch_edge_bwd(const EdgeBwdParams& q, hipStream_t s) {
 
 extern "C" int64_t nlam_edge_bwd_slab_stride(int d) { return 2 * (int64_t)d * d + 3 * d; }
 
+static int edge_bwd_impl(
+    const int32_t* tiles, int64_t ntiles, const int32_t* csr_rowptr, const int32_t* csr_eid,
+    const int32_t* csr_send, const int32_t* csr_rec, const float* inv_deg,
+    const float* e, int64_t e_bstride, int64_t e_ld, int has_egemm,
+    const float* ps, int64_t ps_bstride, int64_t ps_ld,
+    const float* pr, int64_t pr_bstride, int64_t pr_ld,
+    const float* W1e, int64_t ldW1e, const float* W2, int64_t ldW2, const float* b2,
+    const float* gamma,
+    const float* g_agg, int64_t gagg_bstride, int64_t gagg_ld,
+    const float* g_eout, int64_t geo_bstride, int64_t geo_ld,
+    float* gh_out, int64_t gh_bstride,
+    float* gpr, int64_t gpr_bstride, int64_t gpr_ld,
+    float* g_e, int64_t ge_bstride, int64_t ge_ld,
+    float* slab, int64_t slab_stride, int64_t B, int d, void* stream,
+    const int32_t* part_slot, float* gpart, int64_t gpart_bstride);
+
 extern "C" int nlam_edge_bwd(
     const int32_t* tiles, int64_t ntiles, const int32_t* csr_rowptr, const int32_t* csr_eid,
     const int32_t* csr_send, const int32_t* csr_rec, const float* inv_deg,
@@ -761,12 +777,63 @@ extern "C" int nlam_edge_bwd(
     float* gpr, int64_t gpr_bstride, int64_t gpr_ld,
     float* g_e, int64_t ge_bstride, int64_t ge_ld,
     float* slab, int64_t slab_stride, int64_t B, int d, void* stream) {
+  return edge_bwd_impl(tiles, ntiles, csr_rowptr, csr_eid, csr_send, csr_rec, inv_deg, e, e_bstride, e_ld,
+                       has_egemm, ps, ps_bstride, ps_ld, pr, pr_bstride, pr_ld, W1e, ldW1e, W2, ldW2, b2, gamma,
+                       g_agg, gagg_bstride, gagg_ld, g_eout, geo_bstride, geo_ld, gh_out, gh_bstride, gpr,
+                       gpr_bstride, gpr_ld, g_e, ge_bstride, ge_ld, slab, slab_stride, B, d, stream, nullptr,
+                       nullptr, 0);
+}
+
+// Sender partials instead of gh rows (include/nlam_hip.h): the batch-sum form of fused_edge2.hip only
+extern "C" int nlam_edge_bwd_parts_supported(int64_t ntiles, int64_t B, int d) {
+  return d == 64 && B > 1 && nlam_mfma_b3() && getenv("NLAM_STAMP") == nullptr &&
+         nlam_k16_on(K16_EDGE_BWD2) && ntiles * 16 * 64 * 4 < (1ll << 32) &&
+         nlam_edge_bwd_forms_batch_sum(ntiles, B, d) != 0;
+}
+extern "C" int nlam_edge_bwd_parts(
+    const int32_t* tiles, int64_t ntiles, const int32_t* csr_rowptr, const int32_t* csr_eid,
+    const int32_t* csr_send, const int32_t* csr_rec, const float* inv_deg,
+    const float* pe, int64_t pe_ld,
+    const float* ps, int64_t ps_bstride, int64_t ps_ld,
+    const float* pr, int64_t pr_bstride, int64_t pr_ld,
+    const float* W2, int64_t ldW2, const float* b2, const float* gamma,
+    const float* g_agg, int64_t gagg_bstride, int64_t gagg_ld,
+    const int32_t* part_slot, float* gpart, int64_t gpart_bstride,
+    float* gpr, int64_t gpr_bstride, int64_t gpr_ld, float* dpe, int64_t dpe_ld,
+    float* slab, int64_t slab_stride, int64_t B, int d, void* stream) {
+  if (B <= 0 || ntiles <= 0) return 0;
+  NLAM_REQUIRE(nlam_edge_bwd_parts_supported(ntiles, B, d),
+               "nlam_edge_bwd_parts: shape / mode not taken (nlam_edge_bwd_parts_supported())");
+  NLAM_REQUIRE(part_slot != nullptr && gpart != nullptr && nlam_aligned16(gpart) && dpe != nullptr &&
+                   gpart_bstride >= ntiles * 16 * d && gpart_bstride % 4 == 0,
+               "nlam_edge_bwd_parts: partial-sum operands");
+  return edge_bwd_impl(tiles, ntiles, csr_rowptr, csr_eid, csr_send, csr_rec, inv_deg, pe, 0, pe_ld, 0, ps,
+                       ps_bstride, ps_ld, pr, pr_bstride, pr_ld, nullptr, 0, W2, ldW2, b2, gamma, g_agg,
+                       gagg_bstride, gagg_ld, nullptr, 0, 0, nullptr, 0, gpr, gpr_bstride, gpr_ld, dpe, 0,
+                       dpe_ld, slab, slab_stride, B, d, stream, part_slot, gpart, gpart_bstride);
+}
+
+static int edge_bwd_impl(
+    const int32_t* tiles, int64_t ntiles, const int32_t* csr_rowptr, const int32_t* csr_eid,
+    const int32_t* csr_send, const int32_t* csr_rec, const float* inv_deg,
+    const float* e, int64_t e_bstride, int64_t e_ld, int has_egemm,
+    const float* ps, int64_t ps_bstride, int64_t ps_ld,
+    const float* pr, int64_t pr_bstride, int64_t pr_ld,
+    const float* W1e, int64_t ldW1e, const float* W2, int64_t ldW2, const float* b2,
+    const float* gamma,
+    const float* g_agg, int64_t gagg_bstride, int64_t gagg_ld,
+    const float* g_eout, int64_t geo_bstride, int64_t geo_ld,
+    float* gh_out, int64_t gh_bstride,
+    float* gpr, int64_t gpr_bstride, int64_t gpr_ld,
+    float* g_e, int64_t ge_bstride, int64_t ge_ld,
+    float* slab, int64_t slab_stride, int64_t B, int d, void* stream,
+    const int32_t* part_slot, float* gpart, int64_t gpart_bstride) {
   if (B <= 0 || ntiles <= 0) return 0;
   NLAM_REQUIRE(d == 64, "nlam_edge_bwd: d=%d not supported (64 only)", d);
   NLAM_REQUIRE(view_vec_ok(e, e_bstride, e_ld, d) && view_vec_ok(ps, ps_bstride, ps_ld, d) &&
                    view_vec_ok(pr, pr_bstride, pr_ld, d) &&
                    view_vec_ok(g_agg, gagg_bstride, gagg_ld, d) &&
-                   view_vec_ok(gh_out, gh_bstride, d, d),
+                   (gpart != nullptr || view_vec_ok(gh_out, gh_bstride, d, d)),
                "nlam_edge_bwd: operand rows must be 16-byte aligned with pitch %% 4 == 0");
   NLAM_REQUIRE(g_eout == nullptr || view_vec_ok(g_eout, geo_bstride, geo_ld, d),
                "nlam_edge_bwd: bad g_eout view");
@@ -793,7 +860,13 @@ extern "C" int nlam_edge_bwd(
   q.gpr = gpr; q.gpr_bstride = gpr_bstride; q.gpr_ld = gpr_ld;
   q.g_e = g_e; q.ge_bstride = ge_bstride; q.ge_ld = ge_ld;
   q.slab = slab; q.slab_stride = slab_stride;
+  q.part_slot = part_slot; q.gpart = gpart; q.gpart_bstride = gpart_bstride;
   hipStream_t s = (hipStream_t)stream;
+  if (gpart != nullptr) {   // (only the batch-sum form of fused_edge2.hip writes the partials)
+    const int r2 = nlam_edge_bwd2(q, has_egemm, s);
+    NLAM_REQUIRE(r2 >= 0, "nlam_edge_bwd_parts: the batch-sum kernel did not take this call (%d)", r2);
+    return r2;
+  }
   // Without an edge update a non-NULL g_e asks for dPe = sum_b gh[b], (1, M, d): the gradient of a
   // batch-invariant first-layer edge term.  Where the kernel that runs does not form it in its
   // registers (fused_edge2.hip, batch-inner form), one more launch does.

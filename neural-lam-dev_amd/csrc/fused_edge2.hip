@@ -68,6 +68,7 @@ struct Ctx {
   int b;            // batch item (wave-uniform)
   int eid, snd, rcv;
   float sc;
+  int slot;         // PART: rank of the slot's sender among the tile's distinct senders
 };
 
 __device__ __forceinline__ Hdr load_hdr(const EdgeFwdParams& p, unsigned tile) {
@@ -78,7 +79,9 @@ __device__ __forceinline__ Hdr load_hdr(const EdgeFwdParams& p, unsigned tile) {
   h.p0 = v.x; h.ne = v.y - v.x; h.r0 = v.z; h.nr = v.w - v.z;
   return h;
 }
-__device__ __forceinline__ Ctx load_ctx(const EdgeFwdParams& p, const Hdr& h, int b, int lane) {
+template <bool PART = false>
+__device__ __forceinline__ Ctx load_ctx(const EdgeFwdParams& p, const Hdr& h, int b, int lane,
+                                        const int32_t* __restrict__ part_slot = nullptr) {
   Ctx c;
   c.h = h; c.b = b;
   const int t = lane & 31;
@@ -90,6 +93,8 @@ __device__ __forceinline__ Ctx load_ctx(const EdgeFwdParams& p, const Hdr& h, in
   c.snd = p.csr_send[pos];
   c.rcv = p.csr_rec[pos];
   c.sc = 1.0f;   // (mean aggregation: 1 / deg follows one tile later, load_scale)
+  c.slot = 0;
+  if constexpr (PART) c.slot = part_slot[pos];
   return c;
 }
 // 1 / deg of the slots' receivers, requested a tile after the receiver ids themselves so that no
@@ -349,11 +354,16 @@ int nlam_edge_bwd2_stamps(unsigned long long* out, int reset) {
 // and runs their B batch items back to back, sums gh over the batch in registers and writes
 // dPe = sum_b gh[b] (1, M, d) to q.g_e -- the gradient of the batch-invariant operand, which the
 // projection backward otherwise forms by reading gh B times (m2g: 261 MB of its 1,154 MB).
-template <bool HAS_EGEMM, bool HAS_GEO, bool STAMP = false, bool ABL = false, bool BSUM = false>
+// PART (with BSUM): the gh rows are not written; each tile emits the sums of its gh rows per distinct
+// sender instead (a second indicator product on the matrix cores, <= 16 rows per tile): what the
+// sender-side reduction of the projection backward needs, in a third of the rows.
+template <bool HAS_EGEMM, bool HAS_GEO, bool STAMP = false, bool ABL = false, bool BSUM = false,
+          bool PART = false>
 __global__ __launch_bounds__(256) void edge_bwd2_kernel(EdgeBwdParams q, int flags) {
   const int xcd_remap = flags & 1;
   const bool edge_binner_on = (flags & 2) != 0;
   static_assert(!BSUM || !HAS_EGEMM, "the batch sum is the no-edge-update form's extra output");
+  static_assert(!PART || BSUM, "sender partials exist in the batch-sum form");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int LDW = D + 4;
   constexpr int WSTRIDE = 3 * NLAM_TILE * LDT;
@@ -430,8 +440,8 @@ __global__ __launch_bounds__(256) void edge_bwd2_kernel(EdgeBwdParams q, int fla
   if (HAS_EGEMM) w16_issue(l1, p.W1e, p.ldW1e, D, D, D, D, tid, 256);
   w16_issue(l2, p.W2, p.ldW2, D, D, D, D, tid, 256);
   __builtin_amdgcn_sched_barrier(0);
-  Ctx cur = load_ctx(p, h0, b0, lane);
-  Ctx nxt = load_ctx(p, h1, b1, lane);
+  Ctx cur = load_ctx<PART>(p, h0, b0, lane, q.part_slot);
+  Ctx nxt = load_ctx<PART>(p, h1, b1, lane, q.part_slot);
   cur.sc = load_scale(p, cur);
   nxt.sc = load_scale(p, nxt);
   v16_commit(lv, b2s, 2, tid);
@@ -667,7 +677,7 @@ __global__ __launch_bounds__(256) void edge_bwd2_kernel(EdgeBwdParams q, int fla
     STAMP2(2)   // gm assembled, LayerNorm backward, dgamma / dbeta partial sums, GZ planes
     // ================================================================ P3: dW2, db2, gh
     // indices of the tile after next (consumed one tile from now: no wait in this tile)
-    Ctx nn = load_ctx(p, hdr2, b2i, lane);
+    Ctx nn = load_ctx<PART>(p, hdr2, b2i, lane, q.part_slot);
     nxt.sc = load_scale(p, nxt);   // (nxt.rcv landed a tile ago; the prologue's value is the same)
     hdr2 = task_hdr(j + 3, b2i);
     outer_cb(dW2, T1p, T2p, lane, [&](int st_) { fetch_S(2 * st_); fetch_S(2 * st_ + 1); });
@@ -742,8 +752,10 @@ __global__ __launch_bounds__(256) void edge_bwd2_kernel(EdgeBwdParams q, int fla
     } else {
       f32x16 seg[NB];
       seg_mfma(seg, ind, T1p, lane);
+      if constexpr (!PART) {
 #pragma unroll
-      for (int k = 0; k < NVR; ++k) store_gh(k);
+        for (int k = 0; k < NVR; ++k) store_gh(k);
+      }
       if constexpr (BSUM) {
         // dPe = sum over the batch items of this tile (b runs innermost; first item: plain copy)
         const float keep = b == 0 ? 0.0f : 1.0f;
@@ -765,6 +777,20 @@ __global__ __launch_bounds__(256) void edge_bwd2_kernel(EdgeBwdParams q, int fla
       }
       wave_sync();   // (the gh rows of T2 are read)
       seg_store(seg, T2, nr, gb, (uint32_t)r0 * ldGP, ldGP, lane);
+      if constexpr (PART) {
+        // sums of the tile's gh rows per distinct sender: Ind2[s][k] = (slot(k) == s)
+        int ns = (lane < NLAM_TILE && lane < ne) ? cur.slot + 1 : 0;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) ns = max(ns, __shfl_xor(ns, o, 64));
+        ns = __builtin_amdgcn_readfirstlane(ns);
+        wave_sync();
+        ind_build(ind, cur.slot, lane);
+        wave_sync();
+        seg_mfma(seg, ind, T1p, lane);
+        wave_sync();
+        const unsigned tile_id = tile0 + j / Bu;   // (BSUM task numbering: batch items innermost)
+        seg_store(seg, T2, ns, q.gpart + b * q.gpart_bstride, 4u * D * (16u * tile_id), 4u * D, lane);
+      }
     }
     wave_sync();
     __builtin_amdgcn_sched_barrier(0);
@@ -805,12 +831,13 @@ __global__ __launch_bounds__(256) void edge_bwd2_kernel(EdgeBwdParams q, int fla
   }
 }
 
-template <bool HAS_EGEMM, bool HAS_GEO, bool STAMP = false, bool ABL = false, bool BSUM = false>
+template <bool HAS_EGEMM, bool HAS_GEO, bool STAMP = false, bool ABL = false, bool BSUM = false,
+          bool PART = false>
 static int launch_edge_bwd2(const EdgeBwdParams& q, hipStream_t s) {
   const size_t lds = ((size_t)(HAS_EGEMM ? 2 : 1) * D * (D + 4) + 2 * D +
                       (size_t)4 * 3 * NLAM_TILE * LDT + 4 * 4 * NLAM_TILE) * sizeof(float) +
                      (size_t)4 * NLAM_TILE * IND_PITCH * sizeof(__bf16);
-  auto kern = edge_bwd2_kernel<HAS_EGEMM, HAS_GEO, STAMP, ABL, BSUM>;
+  auto kern = edge_bwd2_kernel<HAS_EGEMM, HAS_GEO, STAMP, ABL, BSUM, PART>;
   NLAM_BIG_LDS(kern, __func__);
   static const int xcd = getenv("NLAM_NO_XCD_ORDER") == nullptr;
   static const int binner = getenv("NLAM_EDGE_BINNER") == nullptr || atoi(getenv("NLAM_EDGE_BINNER")) != 0;
@@ -862,8 +889,10 @@ int nlam_edge_bwd2(const EdgeBwdParams& q, int has_egemm, hipStream_t s) {
     // = 4 each, 16 rounds against 12.5 -- there the strided form runs and the caller sums)
     if (q.g_e != nullptr) {
       if (!(p.e.bstride == 0 && p.B > 1 && ok(M, q.ge_ld))) return -1;
-      if (nlam_edge_bwd_forms_batch_sum(p.ntiles, p.B, D))
+      if (nlam_edge_bwd_forms_batch_sum(p.ntiles, p.B, D)) {
+        if (q.gpart != nullptr) return launch_edge_bwd2<false, false, false, false, true, true>(q, s);
         return launch_edge_bwd2<false, false, false, false, true>(q, s);
+      }
       return -2;   // (this kernel WITHOUT the batch sum: see nlam_edge_bwd)
     }
     return launch_edge_bwd2<false, false>(q, s);

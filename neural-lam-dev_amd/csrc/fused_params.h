@@ -97,6 +97,12 @@ struct EdgeBwdParams {
   float* gpr; int64_t gpr_bstride; int64_t gpr_ld;            // (B, N_r, d)
   float* g_e; int64_t ge_bstride; int64_t ge_ld;              // (B, M, d) original order (has_egemm)
   float* slab; int64_t slab_stride;
+  // optional (batch-sum form only): per-tile sender partial sums of gh INSTEAD of the gh rows.
+  // part_slot[pos] = rank of the slot's sender among the tile's distinct senders (< 16, CSR
+  // position order); row 16 * tile + slot of gpart (B, 16 * ntiles, d) receives the sum of the
+  // tile's gh rows of that sender.  The sender-side reduction then reads one row per (tile, sender)
+  // pair instead of one per edge (m2g: 76 k instead of 255 k per sample).
+  const int32_t* part_slot; float* gpart; int64_t gpart_bstride;
 };
 
 // ---- node-side kernels of a chain of InteractionNets on shared nodes (fused16_node.hip)

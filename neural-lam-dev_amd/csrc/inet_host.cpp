@@ -208,7 +208,12 @@ static int64_t inet_bwd_plan(const nlam_inet_args* a, const nlam_inet_grads* gr,
   }
 
   // 2. edge backward
-  float* gh = c.take(B * M * D);
+  // (grid-side nets with a batch-invariant edge term: per-tile sender partials instead of gh rows)
+  const bool parts = !same && !upd && Be == 1 && B > 1 && g.part_slot != nullptr &&
+                     g.pcsc_colptr != nullptr && g.pcsc_rows != nullptr &&
+                     nlam_edge_bwd_parts_supported(g.ntiles, B, D) != 0;
+  float* gh = parts ? c.take(B * g.ntiles * 16 * D) : c.take(B * M * D);
+  const int64_t gh_bs = parts ? g.ntiles * 16 * D : M * D;
   float* gP = c.take(B * N_r * (same ? 2 * D : D));     // same: [gPs | gPr]; else gPr
   float* gpr = same ? gP + D : gP;
   const int64_t gpr_bs = N_r * (same ? 2 * D : D), gpr_ld = same ? 2 * D : D;
@@ -230,6 +235,10 @@ static int64_t inet_bwd_plan(const nlam_inet_args* a, const nlam_inet_grads* gr,
                       a->edge.ptr, a->edge.bstride, a->edge.ld, 1, ps, ps_bs, ps_ld, pr, pr_bs, pr_ld, W1e,
                       w.ldW1, w.W2, w.ldW2, w.b2, w.gam, g_agg, N_r * D, D, gr->g_edge_out, M * D, D, gh,
                       M * D, gpr, gpr_bs, gpr_ld, g_e, M * D, D, slab2, st2, B, D, stream));
+  } else if (parts) {
+    RUN(nlam_edge_bwd_parts(g.tiles, g.ntiles, g.csr_rowptr, g.csr_eid, g.csr_send, g.csr_rec, inv_deg, a->Pe,
+                            D, ps, ps_bs, ps_ld, pr, pr_bs, pr_ld, w.W2, w.ldW2, w.b2, w.gam, g_agg, N_r * D, D,
+                            g.part_slot, gh, gh_bs, gpr, gpr_bs, gpr_ld, dPe1, D, slab2, st2, B, D, stream));
   } else {
     // batch-invariant edge term: dPe = sum_b gh[b] comes out of the edge kernel (nlam_hip.h)
     RUN(nlam_edge_bwd(g.tiles, g.ntiles, g.csr_rowptr, g.csr_eid, g.csr_send, g.csr_rec, inv_deg, a->Pe,
@@ -283,8 +292,9 @@ static int64_t inet_bwd_plan(const nlam_inet_args* a, const nlam_inet_grads* gr,
       x[n] = x_; xbs[n] = xbs_; xld[n] = xld_; xb[n] = xb_; xbbs[n] = xbbs_; xbld[n] = D;
       gy[n] = gy_; gybs[n] = gybs_; gyld[n] = D; Wk[n] = W_; ldw[n] = w.ldW1;
       gx[n] = gx_; gxbs[n] = gxbs_; gxld[n] = D; gxa[n] = ga_; gabs[n] = gabs_; gald[n] = D;
-      nsum[n] = nsum_; sstr[n] = sstr_; ghp[n] = gh_; ghbs[n] = M * D;
-      colp[n] = gh_ ? g.csc_colptr : nullptr; eidp[n] = gh_ ? g.csc_eid : nullptr; nsend[n] = gh_ ? g.n_send : 0;
+      nsum[n] = nsum_; sstr[n] = sstr_; ghp[n] = gh_; ghbs[n] = gh_bs;
+      colp[n] = gh_ ? (parts ? g.pcsc_colptr : g.csc_colptr) : nullptr;
+      eidp[n] = gh_ ? (parts ? g.pcsc_rows : g.csc_eid) : nullptr; nsend[n] = gh_ ? g.n_send : 0;
       slab[n] = sl; sst[n] = st; Bk[n] = Bk_; rows[n] = rows_;
       segs.add(sl, ns, st, 0, D, kcols, kcols, dW, dW_ld);
       segs.add(sl, ns, st, (int64_t)D * kcols, 1, D, D, db, D);

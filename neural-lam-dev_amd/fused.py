@@ -452,7 +452,14 @@ class FusedInteractionNetFunction(torch.autograd.Function):
             dW2, db2 = torch.empty_like(W2), _empty(d, device=dev)
             dgam, dbet = _empty(d, device=dev), _empty(d, device=dev)
             # 2. edge backward
-            gh = _empty(B, M, d, device=dev)
+            # grid-side nets (batch-invariant edge term, separate nodes): per-tile sender partial
+            # sums instead of the gh rows (nlam_edge_bwd_parts, include/nlam_hip.h)
+            from . import inet_seq
+
+            parts = (not same and not ctx.update_edges and em.B == 1 and B > 1 and g.virtual is None
+                     and inet_seq.sender_parts_on(g) and ops.lin_multi_supported()
+                     and bool(ops.lib.nlam_edge_bwd_parts_supported(g.ntiles, B, d)))
+            gh = _empty(B, 16 * g.ntiles if parts else M, d, device=dev)
             if same:
                 gP = _empty(B, N_r, 2 * d, device=dev)
                 gpr_m = mat(gP, d, d)
@@ -473,8 +480,12 @@ class FusedInteractionNetFunction(torch.autograd.Function):
                 if em.B == 1 and B > 1 and g.virtual is None and \
                         ops.lib.nlam_edge_bwd_forms_batch_sum(g.ntiles, B, d):
                     dPe1 = _empty(1, M, d, device=dev)
-                _edge_bwd_any(g, mat(Pe), False, psm, prm, None, W2, b2, gam, g_agg, None, gh, gpr_m,
-                              dPe1, ctx.mean, d, None, dW2, db2, dgam, dbet, dev)
+                if parts:
+                    ops.fused_edge_bwd_parts(g, mat(Pe), psm, prm, W2, b2, gam, mat(g_agg), mat(gh),
+                                             gpr_m, mat(dPe1), ctx.mean, d, dW2, db2, dgam, dbet)
+                else:
+                    _edge_bwd_any(g, mat(Pe), False, psm, prm, None, W2, b2, gam, g_agg, None, gh, gpr_m,
+                                  dPe1, ctx.mean, d, None, dW2, db2, dgam, dbet, dev)
             # 3. sender-side reduction of gh (rows in the original edge order, sender lists of edge ids)
             if same and node_path:
                 # sender gather + projections backward in one data pass (csrc/fused16_node.hip),
@@ -526,7 +537,9 @@ class FusedInteractionNetFunction(torch.autograd.Function):
                     fold_s = sm.B == 1 and B > 1
                     add_s = _take_addend(ctx, g_send)
                     probs = [
-                        {"x": sm, "W": W1s, "gather": (mat(gh), g.csc_colptr, g.csc_eid, g.n_send),
+                        {"x": sm, "W": W1s,
+                         "gather": ((mat(gh), g.pcsc_colptr, g.pcsc_rows, g.n_send) if parts else
+                                    (mat(gh), g.csc_colptr, g.csc_eid, g.n_send)),
                          "nsum": B if fold_s else 1, "gx": mat(g_send), "dW": dW1[:, d : 2 * d],
                          "gx_add": mat(add_s) if add_s is not None else None},
                         {"x": rm, "gy": gpr_in, "W": W1r, "nsum": B if fold_r else 1,

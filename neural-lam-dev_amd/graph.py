@@ -73,6 +73,7 @@ class EdgeTables(torch.nn.Module):
             self.register_buffer(
                 "tiles", torch.from_numpy(tiles[: 4 * nt].copy()).view(nt, 4), persistent=False
             )
+            self._sender_parts(tiles[: 4 * nt].reshape(nt, 4), out["csr_send"], n_send)
         else:
             # a receiver with more than 32 in-edges does not fit one receiver-aligned tile: its
             # segment is cut into VIRTUAL receivers of <= 32 consecutive CSR positions; the fused
@@ -82,6 +83,43 @@ class EdgeTables(torch.nn.Module):
             # still falls back to the generic kernels for such graphs, with a RuntimeWarning.
             self.tiles = None
             self.virtual = VirtualReceivers(out, n_rec, M)
+
+
+    # Tables of nlam_edge_bwd_parts (include/nlam_hip.h): the distinct senders of every tile get
+    # the slots 0, 1, ... in ascending sender order; `part_slot` holds the slot of every CSR
+    # position, `pcsc_colptr` / `pcsc_rows` list, per sender, the partial rows 16 * tile + slot that
+    # carry its sums (ascending tile order: the reduction order is fixed).  Graphs with a tile of
+    # more than 16 distinct senders do not get them (has_sender_parts = False).
+    PART_SLOTS = 16
+
+    def _sender_parts(self, tiles, csr_send, n_send):
+        self.has_sender_parts = False
+        nt = tiles.shape[0]
+        ne = (tiles[:, 1] - tiles[:, 0]).astype(np.int64)
+        if nt == 0 or int(ne.sum()) != self.M:
+            return
+        tile_of_pos = np.repeat(np.arange(nt, dtype=np.int64), ne)
+        pos = (np.repeat(tiles[:, 0].astype(np.int64), ne) + np.arange(self.M, dtype=np.int64)
+               - np.repeat(np.cumsum(ne) - ne, ne))               # CSR positions, tile by tile
+        key = tile_of_pos * int(n_send) + csr_send[pos].astype(np.int64)
+        pairs, inverse = np.unique(key, return_inverse=True)       # sorted by (tile, sender)
+        pair_tile = pairs // int(n_send)
+        pair_send = pairs - pair_tile * int(n_send)
+        first = np.searchsorted(pair_tile, np.arange(nt, dtype=np.int64), side="left")
+        pair_slot = np.arange(len(pairs), dtype=np.int64) - first[pair_tile]
+        if len(pairs) == 0 or int(pair_slot.max()) >= self.PART_SLOTS:
+            return
+        part_slot = np.zeros(self.M, np.int32)
+        part_slot[pos] = pair_slot[inverse].astype(np.int32)
+        order = np.lexsort((pair_tile, pair_send))                  # by sender, then tile
+        colptr = np.zeros(int(n_send) + 1, np.int64)
+        np.cumsum(np.bincount(pair_send, minlength=int(n_send)), out=colptr[1:])
+        rows = (self.PART_SLOTS * pair_tile + pair_slot)[order]
+        self.n_sender_parts = int(len(pairs))
+        for k, v in (("part_slot", part_slot), ("pcsc_colptr", colptr.astype(np.int32)),
+                     ("pcsc_rows", rows.astype(np.int32))):
+            self.register_buffer(k, torch.from_numpy(np.ascontiguousarray(v)), persistent=False)
+        self.has_sender_parts = True
 
 
 class VirtualReceivers(torch.nn.Module):

@@ -18,7 +18,8 @@ ENABLED = os.environ.get("NLAM_INET_SEQ", "1") != "0"
 class Graph(ctypes.Structure):
     _fields_ = [("tiles", _P), ("ntiles", _I64), ("csr_rowptr", _P), ("csr_eid", _P),
                 ("csr_send", _P), ("csr_rec", _P), ("inv_deg", _P), ("csc_colptr", _P),
-                ("csc_eid", _P), ("n_send", _I64), ("n_rec", _I64), ("M", _I64)]
+                ("csc_eid", _P), ("n_send", _I64), ("n_rec", _I64), ("M", _I64),
+                ("part_slot", _P), ("pcsc_colptr", _P), ("pcsc_rows", _P)]
 
 
 class View(ctypes.Structure):
@@ -55,15 +56,24 @@ if ctypes.sizeof(Args) != int(lib.nlam_sizeof_inet_args()) or \
         f"{int(lib.nlam_sizeof_inet_grads())}): rebuild the library or update include/nlam_hip.h's mirror")
 
 
+def sender_parts_on(t):
+    """Per-tile sender partials instead of gh rows in the edge backward of the grid-side nets
+    (nlam_edge_bwd_parts); NLAM_SENDER_PARTS=0: the gh rows and the per-edge sender lists."""
+    return bool(getattr(t, "has_sender_parts", False)) and os.environ.get("NLAM_SENDER_PARTS", "1") != "0"
+
+
 def graph_struct(t):
     """Graph struct of an EdgeTables (cached per device copy of its buffers)."""
-    key = t.csr_rowptr.data_ptr()
+    key = (t.csr_rowptr.data_ptr(), sender_parts_on(t))
     cached = getattr(t, "_inet_graph", None)
     if cached is not None and cached[0] == key:
         return cached[1]
+    parts = sender_parts_on(t)
     g = Graph(t.tiles.data_ptr(), t.ntiles, t.csr_rowptr.data_ptr(), t.csr_eid.data_ptr(),
               t.csr_send.data_ptr(), t.csr_rec.data_ptr(), t.inv_deg.data_ptr(),
-              t.csc_colptr.data_ptr(), t.csc_eid.data_ptr(), t.n_send, t.n_rec, t.M)
+              t.csc_colptr.data_ptr(), t.csc_eid.data_ptr(), t.n_send, t.n_rec, t.M,
+              t.part_slot.data_ptr() if parts else None, t.pcsc_colptr.data_ptr() if parts else None,
+              t.pcsc_rows.data_ptr() if parts else None)
     t._inet_graph = (key, g)
     return g
 

@@ -809,7 +809,8 @@ def fused_lin_bwd_multi(problems):
     flops = sum(2.0 * max(B, pr.get("nsum", 1)) * r * d * d * (2 if pr.get("gx") is not None else 1)
                 for (B, r), pr in zip(rowsB, problems))
     nbytes = sum(4.0 * max(B, pr.get("nsum", 1)) * r * d * 2 for (B, r), pr in zip(rowsB, problems))
-    nbytes += sum(4.0 * g[0].B * g[0].rows * d for g in gath if g is not None)
+    # (gathered rows: one per list entry -- edges, or the (tile, sender) pairs of the sender partials)
+    nbytes += sum(4.0 * g[0].B * min(g[0].rows, g[2].numel()) * d for g in gath if g is not None)
     _launch(
         "nlam_lin_bwd_multi", lib.nlam_lin_bwd_multi,
         (n, d, P(*[pr["x"].ptr for pr in problems]), I64(*[pr["x"].bstride for pr in problems]),
@@ -924,6 +925,32 @@ def node_outer(ga, xa, xb, gP, xl, dV1, dc1, dWA, dWB, dbB):
     if has_a:
         segs += [(0, d, 2 * d, 2 * d, dV1), (2 * d * d, 1, d, d, dc1)]
     reduce_segments(slab, nslabs, stride, segs)
+
+
+def fused_edge_bwd_parts(g, pe, ps, pr, W2, b2, gamma, g_agg, gpart, gpr, dpe, mean, d, dW2, db2,
+                         dgamma, dbeta):
+    """nlam_edge_bwd_parts: no edge update, batch-invariant edge term pe (1, M, d); gpart
+    (B, 16 ntiles, d) receives the per-tile sender partial sums of gh, dpe (1, M, d) its batch sum."""
+    B = g_agg.B
+    stride = lib.nlam_edge_bwd_slab_stride(d)
+    nslabs = lib.nlam_bwd_grid(B * g.ntiles)
+    slab = torch.empty(nslabs * stride, dtype=torch.float32, device=W2.device)
+    _launch(
+        "nlam_edge_bwd", lib.nlam_edge_bwd_parts,
+        (g.tiles.data_ptr(), g.ntiles, g.csr_rowptr.data_ptr(), g.csr_eid.data_ptr(),
+         g.csr_send.data_ptr(), g.csr_rec.data_ptr(), g.inv_deg.data_ptr() if mean else None,
+         pe.ptr, pe.ld, ps.ptr, ps.bstride, ps.ld, pr.ptr, pr.bstride, pr.ld, W2.data_ptr(),
+         W2.stride(0), b2.data_ptr(), gamma.data_ptr(), g_agg.ptr, g_agg.bstride, g_agg.ld,
+         g.part_slot.data_ptr(), gpart.ptr, gpart.bstride, gpr.ptr, gpr.bstride, gpr.ld,
+         dpe.ptr, dpe.ld, slab.data_ptr(), stride, B, d, stream()),
+        flops=2.0 * B * g.M * d * d * 3,
+        # algorithmic bytes: pe once, the sender partials (one row per (tile, sender) pair and
+        # sample) and dpe out; node-side rows (ps, pr, g_agg, gpr) once; indices
+        nbytes=4.0 * d * (2 * g.M + B * g.n_sender_parts + B * (ps.rows + 3 * pr.rows)) + 20.0 * g.M,
+    )
+    dd = d * d
+    reduce_segments(slab, nslabs, stride, [(dd, d, d, d, dW2), (2 * dd, 1, d, d, db2),
+                                           (2 * dd + d, 1, d, d, dgamma), (2 * dd + 2 * d, 1, d, d, dbeta)])
 
 
 def fused_edge_bwd(g, e, has_egemm, ps, pr, W1e, W2, b2, gamma, g_agg, g_eout, gh_out, gpr, g_e,

@@ -307,3 +307,52 @@ def test_fused_path_is_taken_for_split_mlps():
     assert {"nlam_edge_fwd", "nlam_edge_bwd", "nlam_mlp_fwd", "nlam_mlp_bwd"} <= names
     assert "nlam_gemm" not in names
     assert stats["nlam_edge_fwd@inet"]["calls"] == 3 and stats["nlam_mlp_fwd@inet"]["calls"] == 2
+
+
+def test_sender_partials_match_the_gh_rows_form(monkeypatch):
+    """nlam_edge_bwd_parts (per-tile sender partial sums of gh instead of the gh rows, gathered by
+    the projection backward through the (tile, sender) lists) against the gh-rows form
+    (NLAM_SENDER_PARTS=0) on an m2g-like layer: no edge update, batch-invariant edge operand and
+    receivers' Pr, separate nodes, B = 4 (the batch-sum form must be the one that runs), through
+    the C++ sequencer and launch by launch; every gradient to split-bf16 summation accuracy
+    (the partial sums come from the indicator product that also forms the receiver sums)."""
+    from neural_lam_amd import inet_seq, ops
+    from neural_lam_amd.interaction_net import InteractionNet
+
+    gen = torch.Generator().manual_seed(11)
+    n_r, n_s, B = 65536, 7000, 4      # (8,192 tiles: the batch-sum form is balanced from ~8 tiles per wave)
+    rec = torch.arange(4 * n_r) // 4                     # four in-edges per receiver (create_graph.py:508)
+    send = ((rec // 9) + torch.randint(0, 3, (4 * n_r,), generator=gen)) % n_s
+    torch.manual_seed(5)
+    net = InteractionNet(torch.stack((send + n_r, rec)), 64, update_edges=False).cuda()
+    t = net.tables
+    assert t.has_sender_parts and t.n_sender_parts < t.M
+    assert ops.lib.nlam_edge_bwd_parts_supported(t.ntiles, B, 64) == 1
+    xs = torch.randn(B, n_s, 64, device="cuda", generator=torch.Generator("cuda").manual_seed(1))
+    xr = torch.randn(B, n_r, 64, device="cuda", generator=torch.Generator("cuda").manual_seed(2))
+    e1 = torch.randn(1, 4 * n_r, 64, device="cuda", generator=torch.Generator("cuda").manual_seed(3))
+    cot = torch.randn(B, n_r, 64, device="cuda", generator=torch.Generator("cuda").manual_seed(4))
+
+    def run(parts, seq):
+        monkeypatch.setenv("NLAM_SENDER_PARTS", "1" if parts else "0")
+        monkeypatch.setattr(inet_seq, "ENABLED", seq)
+        for p in net.parameters():
+            p.grad = None
+        a, b, c = (v.clone().requires_grad_(True) for v in (xs, xr, e1))
+        ops.PROFILER = None if seq else ops.KernelProfiler()
+        try:
+            out = net(a, b, c.expand(B, -1, -1))
+            (out * cot).sum().backward()
+            stats = ops.PROFILER.collect() if ops.PROFILER is not None else {}
+        finally:
+            ops.PROFILER = None
+        return [out.detach(), a.grad, b.grad, c.grad] + [p.grad.clone() for p in net.parameters()], stats
+
+    want, _ = run(False, True)
+    for seq in (True, False):
+        got, stats = run(True, seq)
+        for a, b in zip(got, want):
+            scale = float(b.abs().max()) + 1e-30
+            assert float((a - b).abs().max()) <= 2e-5 * scale, float((a - b).abs().max()) / scale
+    # byte accounting of the launch-by-launch form: the gather reads one row per (tile, sender) pair
+    assert any(k.startswith("nlam_edge_bwd") for k in stats)
