@@ -233,3 +233,34 @@ def test_multi_problem_launch_shares_follow_the_work():
             big = max(range(n), key=lambda k: rounds[k])
             for k in range(n):   # proportional within rounding
                 assert abs(g[k] - 256 * rounds[k] / sum(rounds)) <= (1 if k != big else n + 1), (rounds, g)
+
+
+def test_sender_partial_tables_against_a_brute_force_walk():
+    """EdgeTables._sender_parts (the tables of nlam_edge_bwd_parts): every CSR position's slot is
+    the rank of its sender among the distinct senders of its tile; every sender's list holds
+    exactly the rows 16 * tile + slot of the tiles it appears in, ascending; a graph with a tile
+    of more than 16 distinct senders gets no tables."""
+    import torch
+
+    from neural_lam_amd.graph import EdgeTables
+
+    gen = torch.Generator().manual_seed(0)
+    n_r, n_s, M = 500, 60, 2000
+    rec = torch.arange(M) % n_r
+    send = (rec // 10 + torch.randint(0, 3, (M,), generator=gen)) % n_s
+    t = EdgeTables(send, rec, n_s, n_r)
+    assert t.has_sender_parts and 0 < t.n_sender_parts < M
+    tiles, cs, ps = t.tiles.numpy(), t.csr_send.numpy(), t.part_slot.numpy()
+    for p0, p1, _, _ in tiles:
+        u = sorted(set(cs[p0:p1].tolist()))
+        assert len(u) <= EdgeTables.PART_SLOTS
+        assert [int(ps[p]) for p in range(p0, p1)] == [u.index(cs[p]) for p in range(p0, p1)]
+    colptr, rows = t.pcsc_colptr.numpy(), t.pcsc_rows.numpy()
+    assert colptr[0] == 0 and colptr[-1] == t.n_sender_parts == len(rows)
+    for s in range(n_s):
+        want = sorted({16 * ti + int(ps[p]) for ti, (p0, p1, _, _) in enumerate(tiles)
+                       for p in range(p0, p1) if cs[p] == s})
+        assert rows[colptr[s]:colptr[s + 1]].tolist() == want
+    # random senders: 32-edge tiles with ~30 distinct senders -> no tables
+    t2 = EdgeTables(torch.randint(0, 1000, (M,), generator=gen), rec, 1000, n_r)
+    assert not t2.has_sender_parts and not hasattr(t2, "part_slot")
