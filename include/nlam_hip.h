@@ -31,7 +31,8 @@ extern "C" {
 
 const char* nlam_last_error(void);
 /* ABI version of this header; bumped on any signature change (2: nlam_inet_grads.g_send_add,
- * nlam_set_k16 returns the previous mask; 3: round-5 entry points).  A binding compares it with
+ * nlam_set_k16 returns the previous mask; 3: round-5 entry points; 4: nlam_inet_graph carries the
+ * sender-partial tables of nlam_edge_bwd_parts).  A binding compares it with
  * the version it was written against and refuses a stale prebuilt library (_lib.py). */
 #define NLAM_ABI_VERSION 4
 int nlam_abi_version(void);
