@@ -100,7 +100,9 @@ __global__ __launch_bounds__(256, 2) void edge_fwd_kernel(EdgeFwdParams p) {
   // every round's tiles instead of every eighth tile
   const unsigned G = gridDim.x;
   const unsigned wg = (LEAN && (G & 7u) == 0) ? (blockIdx.x & 7u) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x;
-  unsigned tt = wg * 4 + wave;
+  // wave-major numbering (no batch-inner order): the tasks of the last, partial round go to one
+  // wave of as many workgroups instead of every wave of a few (fused_edge2.hip)
+  unsigned tt = (LEAN && !BINNER && p.wave_major) ? (unsigned)wave * G + wg : wg * 4 + wave;
   TileCtx cur;
   int4 hdr_n;
   if (B3 && D == 64) {
@@ -270,6 +272,11 @@ static int launch_edge_fwd(const EdgeFwdParams& p, hipStream_t s) {
   return 0;
 }
 
+static int edge_fwd_wave_major() {   // (NLAM_EDGE_WAVE_MAJOR bit 1; default on)
+  static const int on = getenv("NLAM_EDGE_WAVE_MAJOR") == nullptr || (atoi(getenv("NLAM_EDGE_WAVE_MAJOR")) & 2) != 0;
+  return on;
+}
+
 static bool rows_vec_ok(const float* ptr, int64_t bstride, int64_t ld, int d) {
   return view_vec_ok(ptr, bstride, ld, d);
 }
@@ -306,6 +313,7 @@ extern "C" int nlam_edge_fwd(
   p.agg = agg; p.agg_bstride = agg_bstride; p.agg_ld = agg_ld;
   p.e_out = e_out; p.eo_bstride = eo_bstride; p.eo_ld = eo_ld;
   p.B = (int)B;
+  p.wave_major = edge_fwd_wave_major();
   hipStream_t s = (hipStream_t)stream;
   if (d == 64 && nlam_mfma_b3()) {   // (unaligned weights take the scalar image loader)
     // 32-bit row offsets: edge / receiver ids are below 32 * ntiles; ids < 2^24, pitches < 2^22
@@ -854,6 +862,7 @@ static int edge_bwd_impl(
   p.gamma = gamma; p.beta = nullptr;
   p.agg = nullptr; p.agg_bstride = 0; p.agg_ld = 0; p.e_out = nullptr; p.eo_bstride = 0; p.eo_ld = 0;
   p.B = (int)B;
+  p.wave_major = edge_fwd_wave_major();
   q.g_agg = RowView{g_agg, gagg_bstride, gagg_ld, d};
   q.g_eout = g_eout; q.geo_bstride = geo_bstride; q.geo_ld = geo_ld;
   q.gh_out = gh_out; q.gh_bstride = gh_bstride;

@@ -394,10 +394,12 @@ __global__ __launch_bounds__(256) void edge_bwd2_kernel(EdgeBwdParams q, int fla
   const unsigned wg = (xcd_remap && (G & 7u) == 0) ? (blockIdx.x & 7u) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x;
   // Tasks of this wave, numbered j = 0, 1, ...: strided over the (batch item, tile) pairs, or --
   // BSUM -- a contiguous range of tiles with the batch items innermost.
-  const unsigned wid = wg * 4 + wave;
+  // (strided form) wave-major numbering: the waves that own a task of the last, partial round are
+  // then wave 0 of as many workgroups -- one per CU -- instead of all four waves of a few CUs
   const unsigned Bu = (unsigned)p.B;
   // strided form with a batch-invariant edge operand (g2m): batch-inner task numbering
   const bool binner = !BSUM && !HAS_EGEMM && p.e.bstride == 0 && Bu > 1 && edge_binner_on;
+  const unsigned wid = (!BSUM && !binner && (flags & 8)) ? (unsigned)wave * G + wg : wg * 4 + wave;
   unsigned tile0 = 0, niter;
   if (BSUM) {
     const unsigned per = (ntiles + stride - 1) / stride;          // tiles per wave
@@ -841,7 +843,9 @@ static int launch_edge_bwd2(const EdgeBwdParams& q, hipStream_t s) {
   NLAM_BIG_LDS(kern, __func__);
   static const int xcd = getenv("NLAM_NO_XCD_ORDER") == nullptr;
   static const int binner = getenv("NLAM_EDGE_BINNER") == nullptr || atoi(getenv("NLAM_EDGE_BINNER")) != 0;
-  kern<<<(unsigned)nlam_bwd_grid(q.f.ntiles * q.f.B), 256, lds, s>>>(q, xcd | (binner ? 2 : 0));
+  // (NLAM_EDGE_WAVE_MAJOR: bit 0 = this kernel, bit 1 = edge_fwd; default 3)
+  static const int wmajor = getenv("NLAM_EDGE_WAVE_MAJOR") == nullptr || (atoi(getenv("NLAM_EDGE_WAVE_MAJOR")) & 1) != 0;
+  kern<<<(unsigned)nlam_bwd_grid(q.f.ntiles * q.f.B), 256, lds, s>>>(q, xcd | (binner ? 2 : 0) | (wmajor ? 8 : 0));
   NLAM_CHECK_LAUNCH("edge_bwd2_kernel");
   return 0;
 }

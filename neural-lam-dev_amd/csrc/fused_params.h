@@ -87,6 +87,7 @@ struct EdgeFwdParams {
   float* agg; int64_t agg_bstride; int64_t agg_ld;
   float* e_out; int64_t eo_bstride; int64_t eo_ld;   // HAS_EGEMM only
   int B;
+  int wave_major;             // edge_fwd: task numbering of the persistent waves (see the kernel)
 };
 
 struct EdgeBwdParams {
