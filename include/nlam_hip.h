@@ -441,8 +441,9 @@ int nlam_edge_bwd(const int32_t* tiles, int64_t ntiles,
  * (the grid-side nets: reference base_graph_model.py:139,152 with expand_to_batch), B > 1, when the
  * gh rows are wanted ONLY for the sender-side sums of the projection backward: the kernel writes,
  * instead of gh (B, M, d), the sums of each tile's gh rows per distinct sender.
- *   part_slot (M, CSR position order): rank of the position's sender among the distinct senders of
- *     its tile (every tile must have at most 16);
+ *   part_slot (M, CSR position order): bits 0-7 = rank of the position's sender among the distinct
+ *     senders of its tile (every tile must have at most 16), bits 8-15 = that number of distinct
+ *     senders (the same on every position of a tile);
  *   gpart (B, 16 ntiles, d): row 16 t + s = sum of the gh rows of tile t whose part_slot is s (rows
  *     of unused slots are not written);
  *   dpe (M, d) = sum_b gh[b] as nlam_edge_bwd's g_e in this form; gpr as there.

@@ -781,12 +781,10 @@ __global__ __launch_bounds__(256) void edge_bwd2_kernel(EdgeBwdParams q, int fla
       seg_store(seg, T2, nr, gb, (uint32_t)r0 * ldGP, ldGP, lane);
       if constexpr (PART) {
         // sums of the tile's gh rows per distinct sender: Ind2[s][k] = (slot(k) == s)
-        int ns = (lane < NLAM_TILE && lane < ne) ? cur.slot + 1 : 0;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) ns = max(ns, __shfl_xor(ns, o, 64));
-        ns = __builtin_amdgcn_readfirstlane(ns);
+        // (part_slot packs the slot [bits 0-7] and the tile's number of distinct senders [bits 8-15])
+        const int ns = ne > 0 ? (__builtin_amdgcn_readfirstlane(cur.slot) >> 8) : 0;
         wave_sync();
-        ind_build(ind, cur.slot, lane);
+        ind_build(ind, cur.slot & 255, lane);
         wave_sync();
         seg_mfma(seg, ind, T1p, lane);
         wave_sync();

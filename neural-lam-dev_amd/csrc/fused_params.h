@@ -100,7 +100,7 @@ struct EdgeBwdParams {
   float* slab; int64_t slab_stride;
   // optional (batch-sum form only): per-tile sender partial sums of gh INSTEAD of the gh rows.
   // part_slot[pos] = rank of the slot's sender among the tile's distinct senders (< 16, CSR
-  // position order); row 16 * tile + slot of gpart (B, 16 * ntiles, d) receives the sum of the
+  // position order) | number of distinct senders of the tile << 8; row 16 * tile + slot of gpart (B, 16 * ntiles, d) receives the sum of the
   // tile's gh rows of that sender.  The sender-side reduction then reads one row per (tile, sender)
   // pair instead of one per edge (m2g: 76 k instead of 255 k per sample).
   const int32_t* part_slot; float* gpart; int64_t gpart_bstride;

@@ -87,7 +87,7 @@ class EdgeTables(torch.nn.Module):
 
     # Tables of nlam_edge_bwd_parts (include/nlam_hip.h): the distinct senders of every tile get
     # the slots 0, 1, ... in ascending sender order; `part_slot` holds the slot of every CSR
-    # position, `pcsc_colptr` / `pcsc_rows` list, per sender, the partial rows 16 * tile + slot that
+    # position (bits 0-7; bits 8-15: the number of distinct senders of its tile), `pcsc_colptr` / `pcsc_rows` list, per sender, the partial rows 16 * tile + slot that
     # carry its sums (ascending tile order: the reduction order is fixed).  Graphs with a tile of
     # more than 16 distinct senders do not get them (has_sender_parts = False).
     PART_SLOTS = 16
@@ -109,8 +109,11 @@ class EdgeTables(torch.nn.Module):
         pair_slot = np.arange(len(pairs), dtype=np.int64) - first[pair_tile]
         if len(pairs) == 0 or int(pair_slot.max()) >= self.PART_SLOTS:
             return
+        # (packed with the tile's number of distinct senders in bits 8-15: the kernel reads it
+        # from the first slot instead of reducing over the wave)
+        ns_tile = np.bincount(pair_tile, minlength=nt)
         part_slot = np.zeros(self.M, np.int32)
-        part_slot[pos] = pair_slot[inverse].astype(np.int32)
+        part_slot[pos] = (pair_slot[inverse] | (ns_tile[tile_of_pos] << 8)).astype(np.int32)
         order = np.lexsort((pair_tile, pair_send))                  # by sender, then tile
         colptr = np.zeros(int(n_send) + 1, np.int64)
         np.cumsum(np.bincount(pair_send, minlength=int(n_send)), out=colptr[1:])

@@ -254,11 +254,12 @@ def test_sender_partial_tables_against_a_brute_force_walk():
     for p0, p1, _, _ in tiles:
         u = sorted(set(cs[p0:p1].tolist()))
         assert len(u) <= EdgeTables.PART_SLOTS
-        assert [int(ps[p]) for p in range(p0, p1)] == [u.index(cs[p]) for p in range(p0, p1)]
+        assert [int(ps[p]) & 255 for p in range(p0, p1)] == [u.index(cs[p]) for p in range(p0, p1)]
+        assert all(int(ps[p]) >> 8 == len(u) for p in range(p0, p1))
     colptr, rows = t.pcsc_colptr.numpy(), t.pcsc_rows.numpy()
     assert colptr[0] == 0 and colptr[-1] == t.n_sender_parts == len(rows)
     for s in range(n_s):
-        want = sorted({16 * ti + int(ps[p]) for ti, (p0, p1, _, _) in enumerate(tiles)
+        want = sorted({16 * ti + (int(ps[p]) & 255) for ti, (p0, p1, _, _) in enumerate(tiles)
                        for p in range(p0, p1) if cs[p] == s})
         assert rows[colptr[s]:colptr[s + 1]].tolist() == want
     # random senders: 32-edge tiles with ~30 distinct senders -> no tables
