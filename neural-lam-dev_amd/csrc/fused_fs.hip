@@ -191,13 +191,14 @@ struct FsPlanes {
 };
 
 // acc[rb] += A . X^T for the two 32-row blocks of the shared tile
-template <int K, int TERMS>
+// (KSTEPS < K / 16: only the first 16 KSTEPS columns of X are non-zero -- the narrow head's backward)
+template <int K, int TERMS, int KSTEPS = K / 16>
 __device__ __forceinline__ void fs_gemm(f32x16 (&acc)[2], const FsW<K, TERMS>& A,
                                         const FsPlanes<K, TERMS>& X, int lane) {
   const int t = lane & 31, h = lane >> 5;
   constexpr int P = FsPlanes<K, TERMS>::P;
 #pragma unroll
-  for (int s = 0; s < K / 16; ++s) {
+  for (int s = 0; s < KSTEPS; ++s) {
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
       const int xo = (32 * rb + t) * P + 16 * s + 4 * h;
@@ -915,7 +916,9 @@ __global__ __launch_bounds__(2 * D) void fs_tail_fwd_kernel(FsTailFwdParams p) {
     f32x16 z[2];
     z[0] = fs_vec_block(p.b2, p.n_out, wave, lane);
     z[1] = z[0];
-    fs_gemm<D, TERMS>(z, A, S, lane);
+    // (narrow head without LayerNorm: the waves whose 32 output features lie past n_out have no
+    // product to form -- seven of the eight on the 17-wide output map)
+    if (HAS_LN || 32 * wave < p.n_out) fs_gemm<D, TERMS>(z, A, S, lane);
     FSSTAMP(2)   // residual issue + GEMM
     if (HAS_LN) {
       // The Linear output is a bf16 tensor, as under the reference's autocast (LayerNorm then
@@ -1324,8 +1327,10 @@ __global__ __launch_bounds__(2 * D) void fs_tail_bwd_kernel(FsTailBwdParams q) {
           }
         }
       } else {
-        for (int idx = tid; idx < FS_R * D; idx += NT) {
-          const int r = idx / D, cc = idx - r * D;
+        // (scalar path = the narrow head: only its first 32 columns are ever read again)
+        constexpr int CW = HAS_LN ? D : 32;
+        for (int idx = tid; idx < FS_R * CW; idx += NT) {
+          const int r = idx / CW, cc = idx - r * CW;
           const int rb = r >> 5;
           float v = 0.f;
           if ((r & 31) < sub.ne(rb) && cc < q.n_out) {
@@ -1477,7 +1482,9 @@ __global__ __launch_bounds__(2 * D) void fs_tail_bwd_kernel(FsTailBwdParams q) {
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) gh[rb][r] = 0.f;
-    fs_gemm<D, TERMS>(gh, A2, S, lane);
+    // (no LayerNorm = the narrow head, n_out <= 32: gz has two non-zero 16-column steps, not D / 16)
+    if constexpr (HAS_LN) fs_gemm<D, TERMS>(gh, A2, S, lane);
+    else fs_gemm<D, TERMS, 2>(gh, A2, S, lane);
     if constexpr (TERMS == 3) {
       f32x4 hv[2][4];
 #pragma unroll

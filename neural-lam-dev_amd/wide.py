@@ -389,8 +389,9 @@ class WideMLPFunction(torch.autograd.Function):
     """y = [res +] [LN](W2 silu(W1 x + b1) + b2), x: (..., rows, k_in), hidden 128 / 256."""
 
     @staticmethod
-    def forward(ctx, x, res, W1, b1, W2, b2, gamma, beta):
+    def forward(ctx, x, res, W1, b1, W2, b2, gamma, beta, give=None):
         ctx.tag = ops._TAG[-1] if ops._TAG else "mlp"
+        ctx.give = give   # glue.GradSlot: leave the input gradient there as well (glue.Tee)
         dev = x.device
         hid, n_out = W1.shape[0], W2.shape[0]
         xm = mat(x.detach())
@@ -439,16 +440,21 @@ class WideMLPFunction(torch.autograd.Function):
         gres = gy if ctx.res_mode == 2 else None
         if gx is not None:
             gx = gx.reshape(ctx.x_shape)
-        return (gx, gres, dW1, db1, dW2, db2, dg, dbt)
+            if ctx.give is not None:
+                ctx.give.put(gx)
+        return (gx, gres, dW1, db1, dW2, db2, dg, dbt, None)
 
 
 def apply_mlp(seq, x, res=None):
     from .fused import _mlp_parts
 
+    from .fused import _sink
+
     lin, ln = _mlp_parts(seq)
     return WideMLPFunction.apply(
         x, res, lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias,
-        ln.weight if ln is not None else None, ln.bias if ln is not None else None)
+        ln.weight if ln is not None else None, ln.bias if ln is not None else None,
+        _sink(x, "give") if (res is None or res is x) else None)
 
 
 # ---------------------------------------------------------- InteractionNet
@@ -585,8 +591,9 @@ class WideInteractionNetFunction(torch.autograd.Function):
                 fold_virtual(g, gPr_k, mat(gPr))
             outers.append((_m(gz_e), _m(h_e), dW2, db2, True))
             # 3. sender-side reduction of gh (edge order; sender lists of edge ids)
-            gPs = (torch.zeros if N_s > g.n_send else torch.empty)(
-                B, N_s, d, dtype=torch.float32, device=dev)
+            gPs = _empty(B, N_s, d, device=dev)
+            if N_s > g.n_send:   # (rows of nodes past the last sender: no edge, zero gradient)
+                gPs[:, g.n_send :].zero_()
             ops.segment_sum(mat(gh), g.csc_colptr, g.csc_eid, mat(gPs[:, : g.n_send]))
             # 4. projections backward (batch-invariant operands: gradients summed over B first)
             gps_m, gpr_m = mat(gPs), mat(gPr)
