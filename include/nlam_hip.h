@@ -143,6 +143,19 @@ int nlam_segment_sum(const float* src, int64_t src_bstride, int64_t ldsrc,
                      int64_t ldout, int accumulate, int64_t B, int64_t n_out,
                      int64_t d, void* stream);
 
+/* nlam_segment_sum (scale = 1, no accumulate) and, from the same pass over src, the batch sum of
+ * every listed row:  bsum[pos[p]][0:d] = sum_b src[b][pos[p]][0:d]  for every p of every segment
+ * (rows listed in no segment are not written; a row listed twice gets the same value twice).  The
+ * backward of an InteractionNet whose first-layer edge term is batch-invariant needs both the
+ * per-sender sums of the edge gradients and their sum over the batch: every edge is in exactly
+ * one sender's list, so one walk over the lists serves both (reference interaction_net.py:121
+ * under expand_to_batch, base_graph_model.py:139,152).  d in {64, 128, 256}, B * d <= 1024,
+ * 16-byte aligned rows.  Summation order: list order per sample, sample order per row. */
+int nlam_segment_sum_bsum(const float* src, int64_t src_bstride, int64_t ldsrc,
+                          const int32_t* rowptr, const int32_t* pos, float* out,
+                          int64_t out_bstride, int64_t ldout, float* bsum, int64_t ldbsum,
+                          int64_t B, int64_t n_out, int64_t d, void* stream);
+
 /* out[r][0:d] = a[r][0:d] + b[r][0:d]  (strided 2-D add; cat-slice grads). */
 int nlam_add_rows(const float* a, int64_t lda, const float* b, int64_t ldb,
                   float* out, int64_t ldout, int64_t rows, int64_t d,

@@ -34,6 +34,7 @@ SIGNATURES = {
     "nlam_colsum": [_p, _i64, _p, _i32, _p, _i64, _i64, _p],
     "nlam_gather_rows": [_p, _i64, _i64, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _p],
     "nlam_segment_sum": [_p, _i64, _i64, _p, _p, _p, _p, _i64, _i64, _i32, _i64, _i64, _i64, _p],
+    "nlam_segment_sum_bsum": [_p, _i64, _i64, _p, _p, _p, _i64, _i64, _p, _i64, _i64, _i64, _i64, _p],
     "nlam_add_rows": [_p, _i64, _p, _i64, _p, _i64, _i64, _i64, _p],
     "nlam_copy_rows": [_p, _i64, _i64, _p, _i64, _i64, _i64, _i64, _i64, _p],
     "nlam_sum_batch": [_p, _i64, _p, _i64, _i64, _p],

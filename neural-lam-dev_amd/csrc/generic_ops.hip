@@ -815,6 +815,105 @@ __global__ __launch_bounds__(256) void segment_sum_bfold_kernel(
   }
 }
 
+// Segment sums of every sample AND the batch sum of every listed row in one pass over src (the
+// sender-side sums gPs[b][n] = sum of gh[b][e] over the out-edges of n, and dPe[e] = sum_b gh[b][e],
+// the gradient of a batch-invariant edge term: every edge is in exactly one sender's list, so the
+// walk over the lists reads each row of each sample once).  One wavefront per output row; its
+// R = 64 / LPR sub-groups take the samples b = sub, sub + R, ...; eight list entries per trip.
+// Sums in list order per sample, in sample order per row: deterministic.
+template <int LPR, int NB>   // NB = ceil(B / R) <= 4
+__global__ __launch_bounds__(256) void segment_sum_bsum_kernel(
+    const float* __restrict__ src, int64_t src_bstride, int64_t ldsrc,
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ pos,
+    float* __restrict__ out, int64_t out_bstride, int64_t ldout,
+    float* __restrict__ bsum, int64_t ldbsum, int64_t B, int64_t n_out) {
+  constexpr int R = 64 / LPR;
+  constexpr int U = 8;
+  const int lane = threadIdx.x & 63;
+  const int sub = lane / LPR, c4 = lane % LPR;
+  const int64_t i = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+  if (i >= n_out) return;
+  const int beg = rowptr[i], end = rowptr[i + 1];
+  f32x4 acc[NB];
+#pragma unroll
+  for (int k = 0; k < NB; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int p = beg; p < end; p += U) {
+    int64_t r[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int pp = p + u < end ? p + u : end - 1;
+      r[u] = pos ? (int64_t)pos[pp] : pp;
+    }
+    f32x4 es[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) es[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+      const int64_t b = (int64_t)k * R + sub;
+      const bool valid = b < B;
+      const float* sb = src + (valid ? b : B - 1) * src_bstride;
+      f32x4 v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = reinterpret_cast<const f32x4*>(sb + r[u] * ldsrc)[c4];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (valid && p + u < end) {
+          acc[k] += v[u];
+          es[u] += v[u];
+        }
+      }
+    }
+    // samples of the other sub-groups (fixed order: xor LPR, 2 LPR, ...)
+#pragma unroll
+    for (int o = LPR; o < 64; o <<= 1)
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) es[u][c] += __shfl_xor(es[u][c], o, 64);
+    if (sub == 0) {
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (p + u < end) reinterpret_cast<f32x4*>(bsum + r[u] * ldbsum)[c4] = es[u];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NB; ++k) {
+    const int64_t b = (int64_t)k * R + sub;
+    if (b < B) reinterpret_cast<f32x4*>(out + b * out_bstride + i * ldout)[c4] = acc[k];
+  }
+}
+
+extern "C" int nlam_segment_sum_bsum(const float* src, int64_t src_bstride, int64_t ldsrc,
+                                     const int32_t* rowptr, const int32_t* pos, float* out,
+                                     int64_t out_bstride, int64_t ldout, float* bsum, int64_t ldbsum,
+                                     int64_t B, int64_t n_out, int64_t d, void* stream) {
+  if (B <= 0 || n_out <= 0) return 0;
+  NLAM_REQUIRE(rowptr != nullptr && src != nullptr && out != nullptr && bsum != nullptr,
+               "segment_sum_bsum: null operand");
+  NLAM_REQUIRE((d == 64 || d == 128 || d == 256) && B * d <= 4 * 256,
+               "segment_sum_bsum: d %ld (64, 128, 256) with B %ld (B * d <= 1024)", (long)d, (long)B);
+  NLAM_REQUIRE((ldsrc % 4 == 0) && (ldout % 4 == 0) && (ldbsum % 4 == 0) && (src_bstride % 4 == 0) &&
+                   (out_bstride % 4 == 0) && nlam_aligned16(src) && nlam_aligned16(out) &&
+                   nlam_aligned16(bsum),
+               "segment_sum_bsum: rows must be 16-byte aligned, pitches %% 4 == 0");
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned grid = (unsigned)((n_out + 3) / 4);
+#define SEG_BSUM(LPR, NB)                                                                          \
+  segment_sum_bsum_kernel<LPR, NB><<<grid, 256, 0, s>>>(src, src_bstride, ldsrc, rowptr, pos, out, \
+                                                        out_bstride, ldout, bsum, ldbsum, B, n_out)
+  const int R = (int)(256 / d), nb = (int)((B + R - 1) / R);
+  if (d == 64) {
+    if (nb <= 1) SEG_BSUM(16, 1); else if (nb == 2) SEG_BSUM(16, 2); else SEG_BSUM(16, 4);
+  } else if (d == 128) {
+    if (nb <= 1) SEG_BSUM(32, 1); else if (nb == 2) SEG_BSUM(32, 2); else SEG_BSUM(32, 4);
+  } else {
+    if (nb <= 1) SEG_BSUM(64, 1); else if (nb == 2) SEG_BSUM(64, 2); else SEG_BSUM(64, 4);
+  }
+#undef SEG_BSUM
+  NLAM_CHECK_LAUNCH("segment_sum_bsum");
+  return 0;
+}
+
 __global__ __launch_bounds__(256) void segment_sum_scalar_kernel(
     const float* __restrict__ src, int64_t src_bstride, int64_t ldsrc,
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ pos,

@@ -332,6 +332,26 @@ def segment_sum(src, rowptr, pos, out, scale=None, accumulate=False):
     )
 
 
+def segment_sum_bsum_ok(src, out, bsum):
+    d = out.cols
+    return (d in (64, 128, 256) and out.B * d <= 1024 and src.B == out.B and bsum.B == 1
+            and all(m.ptr % 16 == 0 and m.ld % 4 == 0 and m.bstride % 4 == 0 for m in (src, out, bsum))
+            and os.environ.get("NLAM_SEGSUM_BSUM", "1") != "0")
+
+
+def segment_sum_bsum(src, rowptr, pos, out, bsum):
+    """segment_sum AND bsum[pos[p]] = sum_b src[b][pos[p]] for every listed row, one pass."""
+    if rowptr.numel() != out.rows + 1 or rowptr.dtype != torch.int32:
+        raise ValueError(f"segment_sum_bsum: rowptr has {rowptr.numel()} entries for {out.rows} output rows")
+    _launch(
+        "nlam_segment_sum", lib.nlam_segment_sum_bsum,
+        (src.ptr, src.bstride, src.ld, rowptr.data_ptr(), pos.data_ptr() if pos is not None else None,
+         out.ptr, out.bstride, out.ld, bsum.ptr, bsum.ld, out.B, out.rows, out.cols, stream()),
+        nbytes=out.B * (4.0 * out.cols * (src.rows + out.rows) + 4.0 * src.rows + 4.0 * (out.rows + 1))
+        + 4.0 * out.cols * src.rows,
+    )
+
+
 def mfma_probe():
     out = torch.empty(32, 32, dtype=torch.float32, device="cuda")
     check(lib.nlam_mfma_probe(out.data_ptr(), stream()), "nlam_mfma_probe")

@@ -594,7 +594,17 @@ class WideInteractionNetFunction(torch.autograd.Function):
             gPs = _empty(B, N_s, d, device=dev)
             if N_s > g.n_send:   # (rows of nodes past the last sender: no edge, zero gradient)
                 gPs[:, g.n_send :].zero_()
-            ops.segment_sum(mat(gh), g.csc_colptr, g.csc_eid, mat(gPs[:, : g.n_send]))
+            # (batch-invariant edge term: its gradient -- the sum of gh over the batch -- comes out of
+            # the same walk over the sender lists, every edge being in exactly one of them)
+            t6 = None
+            if not ctx.update_edges and em.B == 1 and B > 1:
+                t6 = _empty(1, M, d, device=dev)
+                if not ops.segment_sum_bsum_ok(mat(gh), mat(gPs[:, : g.n_send]), mat(t6)):
+                    t6 = None
+            if t6 is not None:
+                ops.segment_sum_bsum(mat(gh), g.csc_colptr, g.csc_eid, mat(gPs[:, : g.n_send]), mat(t6))
+            else:
+                ops.segment_sum(mat(gh), g.csc_colptr, g.csc_eid, mat(gPs[:, : g.n_send]))
             # 4. projections backward (batch-invariant operands: gradients summed over B first)
             gps_m, gpr_m = mat(gPs), mat(gPr)
             if sm.B == 1 and B > 1:
@@ -611,7 +621,9 @@ class WideInteractionNetFunction(torch.autograd.Function):
             # slices of gh (522 MB of the 3.2 GB of wide_outer_multi@m2g at hidden 128) for a
             # product that is linear in them
             dPe = mat(gh)
-            if not ctx.update_edges and em.B == 1 and B > 1:
+            if t6 is not None:
+                dPe = mat(t6)
+            elif not ctx.update_edges and em.B == 1 and B > 1:
                 t6 = _empty(1, M, d, device=dev)
                 ops.sum_batch(gh, t6)
                 dPe = mat(t6)

@@ -227,3 +227,34 @@ def test_slab_reduction_matches_a_plain_sum(case):
     torch.cuda.synchronize()
     for a, s in zip(first, sg):
         assert torch.equal(a, s[4])
+
+
+@pytest.mark.parametrize("d,B,n_out,M", [(128, 4, 300, 2500), (64, 4, 77, 900), (256, 3, 50, 640),
+                                         (128, 5, 40, 333), (64, 16, 30, 200), (256, 1, 20, 100)])
+def test_segment_sum_bsum_matches_segment_sum_and_a_batch_sum(d, B, n_out, M):
+    """nlam_segment_sum_bsum: the per-sample segment sums of nlam_segment_sum AND the batch sum of
+    every listed row from one pass (every row listed exactly once, as the out-edge lists of the
+    senders list every edge once; segments of 0, 1 and > 8 entries)."""
+    from neural_lam_amd import ops
+    from neural_lam_amd.ops import mat
+
+    gen = torch.Generator().manual_seed(d + B + M)
+    owner = torch.randint(0, n_out, (M,), generator=gen)
+    owner[:20] = 3                                   # a long list
+    owner[owner == 5] = 6                            # an empty one
+    order = torch.argsort(owner, stable=True)
+    rowptr = torch.zeros(n_out + 1, dtype=torch.int32)
+    rowptr[1:] = torch.cumsum(torch.bincount(owner, minlength=n_out), 0).int()
+    src = torch.randn(B, M, d, generator=gen).cuda()
+    pos = order.int().cuda()
+    out = torch.full((B, n_out, d), float("nan"), device="cuda")
+    bsum = torch.full((1, M, d), float("nan"), device="cuda")
+    assert ops.segment_sum_bsum_ok(mat(src), mat(out), mat(bsum))
+    ops.segment_sum_bsum(mat(src), rowptr.cuda(), pos, mat(out), mat(bsum))
+    want = torch.zeros(B, n_out, d, dtype=torch.float64)
+    want.index_add_(1, owner, src.cpu().double())
+    assert torch.allclose(out.cpu().double(), want, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(bsum[0].cpu().double(), src.cpu().double().sum(0), rtol=1e-6, atol=1e-6)
+    ref = torch.empty_like(out)
+    ops.segment_sum(mat(src), rowptr.cuda(), pos, mat(ref))
+    assert torch.equal(out, ref)                     # (same list order per sample)
