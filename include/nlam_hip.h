@@ -570,7 +570,8 @@ int nlam_wmse_bwd(const float* pred, const float* target, const float* keep,
  * bf16 elements (multiples of 8: a lane moves 16 bytes) and the rows are 256 wide.
  *   nlam_lin_fwd: out_bf16 (nlam_lin_fwd_multi: bit k = problem k);
  *   nlam_tail_fwd: io_bf16 != 0 = a, b, c AND h_out are bf16 (h is rounded to bf16 before the SiLU);
- *   nlam_tail_bwd: io_bf16 != 0 = h AND gz_out are bf16 (LayerNorm form);
+ *   nlam_tail_bwd: io_bf16 != 0 = h AND (LayerNorm form) gz_out are bf16; without LayerNorm (the
+ *     narrow heads, n_out <= 32) gz_out stays fp32, 32 wide;
  *   nlam_wide_outer[_multi]: bit 0 = g, bit 1 = x.
  * 0 everywhere = all fp32 (the only form at hidden 64 / 128). */
 int nlam_tail_fwd(const int32_t* tiles, int64_t ntiles, int64_t rows, const int32_t* csr_rec,

@@ -1451,7 +1451,7 @@ __global__ __launch_bounds__(2 * D) void fs_tail_bwd_kernel(FsTailBwdParams q) {
       }
     }
     __syncthreads();
-    if constexpr (IO16) {   // (NO == D here: checked on the host)
+    if constexpr (IO16 && HAS_LN) {   // (NO == D here: checked on the host; the narrow head's gz stays fp32)
       const int c8 = tid % (D / 8), rh = tid / (D / 8);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -1580,8 +1580,8 @@ int nlam_fs_tail_bwd_256(
     float* gpr, int64_t gpr_bstride, int64_t gpr_ld,
     float* slab, int64_t slab_stride, int64_t B, unsigned grid, int io_bf16, void* stream) {
   constexpr int d = 256;
-  NLAM_REQUIRE(!io_bf16 || (gamma != nullptr && n_out == d && h_bstride % 8 == 0 && gz_bstride % 8 == 0),
-               "nlam_tail_bwd: bf16 h / gz rows exist for the LayerNorm form (n_out == d) only");
+  NLAM_REQUIRE(!io_bf16 || (h_bstride % 8 == 0 && (gamma == nullptr || (n_out == d && gz_bstride % 8 == 0))),
+               "nlam_tail_bwd: bf16 h rows (and, with LayerNorm, n_out == d bf16 gz rows): pitches %% 8 == 0");
   NLAM_REQUIRE(gamma == nullptr || (z_keep != nullptr && (reinterpret_cast<uintptr_t>(z_keep) & 7u) == 0 &&
                                     z_bstride % 4 == 0),
                "nlam_tail_bwd: hidden 256 with LayerNorm needs the z_keep rows of nlam_tail_fwd");
@@ -1608,7 +1608,9 @@ int nlam_fs_tail_bwd_256(
   q.vec_g = (n_out == d && view_vec_ok(g1, g1_bstride, g1_ld, n_out) &&
              (g2 == nullptr || view_vec_ok(g2, g2_bstride, g2_ld, n_out))) ? 1 : 0;
   hipStream_t s = (hipStream_t)stream;
-  if (io_bf16) return launch_fs_tail_bwd<256, true, 1, true>(q, s, grid);
+  if (io_bf16)
+    return gamma != nullptr ? launch_fs_tail_bwd<256, true, 1, true>(q, s, grid)
+                            : launch_fs_tail_bwd<256, false, 1, true>(q, s, grid);
   if (terms_ == 3)
     return gamma != nullptr ? launch_fs_tail_bwd<256, true, 3>(q, s, grid)
                             : launch_fs_tail_bwd<256, false, 3>(q, s, grid);

@@ -179,7 +179,8 @@ def tail_bwd(tl, h, g1, idx_g1, scale1, g2, idx_g2, W2, b2, gamma, gz_out, gh, i
              dgamma, dbeta, z_keep=None):
     n_out = W2.shape[0]
     dev = W2.device
-    assert (h.dtype == torch.bfloat16) == (gz_out.dtype == torch.bfloat16)
+    # (bf16 rows: h and, in the LayerNorm form, gz; the narrow head's 32-wide gz stays fp32)
+    assert (gz_out.dtype == torch.bfloat16) == (h.dtype == torch.bfloat16 and gamma is not None)
     stride = int(lib.nlam_tail_bwd_slab_stride(n_out))
     nslabs = int(lib.nlam_bwd_grid(B * tl.ntiles))
     slab = torch.empty(nslabs * stride, dtype=torch.float32, device=dev) if gamma is not None else None
@@ -428,9 +429,8 @@ class WideMLPFunction(torch.autograd.Function):
         dbt = _empty(n_out, device=dev) if has_ln else None
         need_gx = ctx.needs_input_grad[0]
         with ops.tag(ctx.tag), ops.slab_batch():
-            if h.dtype == torch.bfloat16 and not has_ln:
-                h = h.float()     # (narrow heads, e.g. the 17-wide output map: fp32 form of the kernel)
-            gz = torch.empty(B, rows, no, dtype=h.dtype, device=dev)
+            gz = torch.empty(B, rows, no, device=dev,
+                             dtype=h.dtype if has_ln else torch.float32)   # (narrow heads: fp32 gz)
             ga = _empty(B, rows, hid, device=dev)
             tail_bwd(Tiling(rows), h, gym, None, None, None, None, W2, b2, gamma, gz, mat(ga),
                      None, None, B, hid, dg, dbt, zk)
