@@ -188,6 +188,21 @@ class StateStep(torch.autograd.Function):
         return gprev, gx, None, None, None, None
 
 
+class DeferGrad(torch.autograd.Function):
+    """Identity on a set of parameters whose backward runs ops.flush_deferred() before handing the
+    gradients on (see ops.slab_batch).  Created once per predict_step, before any layer runs."""
+
+    @staticmethod
+    def forward(ctx, *ws):
+        ctx.set_materialize_grads(False)   # (a parameter no layer used keeps a None gradient)
+        return tuple(w.view_as(w) for w in ws)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        ops.flush_deferred()
+        return gs
+
+
 class StateStepLoss(torch.autograd.Function):
     """StateStep AND the training-loss term of the same AR step in one pass each way (the loss
     target of AR step t is the boundary truth of step t: ar_model.py:244-247 with 294-298):

@@ -3,7 +3,7 @@ same sub-module names, construction order (=> same default-init RNG stream)
 and predict_step contract; the GNN / MLP blocks are the HIP modules."""
 import torch
 
-from .. import fused, glue, utils
+from .. import fused, glue, utils, wide
 from ..interaction_net import InteractionNet
 from .ar_model import ARModel
 
@@ -73,6 +73,10 @@ class BaseGraphModel(ARModel):
         (device path without output_std only: the rollout's use), the boundary overwrite of
         ar_model.py:244-247 is applied in the same kernel as the state residual and the returned
         state is the rollout's new state."""
+        defer = (prev_state.is_cuda and torch.is_grad_enabled() and self.training
+                 and not getattr(self, "ar_checkpoint", False))
+        if defer:   # (hidden 128 / 256: one slab-reduction flush per AR step, wide.defer_begin)
+            wide.defer_begin(self)
         shared = getattr(self, "_static_emb_rollout", None)   # set by a multi-step rollout
         if shared is not None:
             self._static_emb = shared
@@ -83,6 +87,8 @@ class BaseGraphModel(ARModel):
         finally:
             self._static_emb = None
             fused.PRE.clear()
+            if defer:
+                wide.defer_end()
 
     def _predict_step(self, prev_state, prev_prev_state, forcing, boundary_truth=None):
         batch_size = prev_state.shape[0]

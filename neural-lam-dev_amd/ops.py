@@ -465,9 +465,47 @@ _SLAB_BATCH = []   # stack of pending (slab, nslabs, stride, src_off, rows, cols
 MAX_SEGS = 64
 
 
+# Slab reductions handed on to the end of an AR step's backward (slab_batch(defer=True)): the
+# weight gradients of a layer feed nothing inside the backward, so the reductions of ALL layers of
+# one predict_step can run as a few large launches instead of one small launch per layer.  Safe
+# only when nothing reads the destinations before flush_deferred(): the layers that defer take
+# their parameters through glue.DeferGrad (an identity node created at the START of predict_step;
+# the autograd engine runs ready nodes latest-created first, so its backward -- the flush -- runs
+# after every layer of the step and before anything that touches the gradients: input-buffer sums,
+# AccumulateGrad).  An engine callback flushes at the end of the pass as well (a node that never ran).
+_DEFERRED = []
+_DEFER_TASK = [None]
+# gradient reducers that overlap their bucket all-reduces with the backward through per-parameter
+# hooks (parallel.GradAllReduce): while their hooks are live the deferral stays off -- it would make
+# every gradient of the deferring layers "ready" only at the end of the AR step's backward
+OVERLAP_REDUCERS = []
+
+
+def deferral_allowed():
+    live = [r() for r in OVERLAP_REDUCERS]
+    return not any(r is not None and r.hooks_enabled and r.active and r.overlap for r in live)
+
+
+def flush_deferred():
+    if _DEFERRED:
+        entries = list(_DEFERRED)
+        del _DEFERRED[:]
+        with tag("deferred"):
+            _flush_segments(entries)
+
+
+def _end_of_pass_flush():
+    _DEFER_TASK[0] = None
+    flush_deferred()
+
+
 class slab_batch:
     """Collect the slab reductions issued inside the block and finish them with ONE
-    launch at exit (the destinations must not be read before that)."""
+    launch at exit (the destinations must not be read before that); defer=True: hand them on to
+    flush_deferred() instead (see above)."""
+
+    def __init__(self, defer=False):
+        self.defer = bool(defer)
 
     def __enter__(self):
         _SLAB_BATCH.append([])
@@ -475,8 +513,16 @@ class slab_batch:
 
     def __exit__(self, et, ev, tb):
         pending = _SLAB_BATCH.pop()
-        if et is None:
+        if et is not None:
+            return False
+        task = torch._C._current_graph_task_id() if self.defer else -1
+        if task == -1:
             _flush_segments(pending)
+            return False
+        _DEFERRED.extend(pending)
+        if _DEFER_TASK[0] != task:
+            _DEFER_TASK[0] = task
+            torch.autograd.Variable._execution_engine.queue_callback(_end_of_pass_flush)
         return False
 
 

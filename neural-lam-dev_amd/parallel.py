@@ -197,6 +197,11 @@ class GradAllReduce:
         # collectives then (reduce(packed=True) issues every bucket after the replay instead)
         self.hooks_enabled = True
         if self.overlap:
+            from . import ops
+
+            import weakref
+
+            ops.OVERLAP_REDUCERS.append(weakref.ref(self))   # (ops.deferral_allowed)
             self._bucket_of = {}
             self._pending = []
             for bi, (lo, hi) in enumerate(self.ranges):

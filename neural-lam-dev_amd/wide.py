@@ -52,6 +52,68 @@ import os
 SIDE_LANE_ROWS = int(os.environ.get("NLAM_SIDE_ROWS", "0"))
 
 
+# Slab reductions of the hidden-128 layers at the end of an AR step's backward instead of one
+# launch per layer (ops.slab_batch(defer=True); NLAM_DEFER_REDUCE=0: per layer, =2: at hidden 256
+# as well -- measured there it LOSES, 30.27 -> 30.48 ms: a layer's slabs, up to 67 MB, are read
+# back out of the 256 MB Infinity Cache when the reduction follows the launch that wrote them, and
+# out of HBM when it comes at the end of the step).  PROXY:
+# id(parameter) -> its glue.DeferGrad output for the predict_step in flight; a parameter is handed
+# out ONCE per predict_step (a second use of a layer gets the parameters themselves and the
+# undeferred path: two gradients into one proxy would be summed by the engine before the flush).
+PROXY = {}
+
+
+def defer_begin(model):
+    """Called at the start of predict_step (device path, gradients on, training)."""
+    PROXY.clear()
+    if os.environ.get("NLAM_DEFER_REDUCE", "1") == "0" or not ops.deferral_allowed():
+        return
+    widths = WIDE_HIDDEN if os.environ.get("NLAM_DEFER_REDUCE", "1") == "2" else (128,)
+    mods = getattr(model, "_wide_defer_mods", None)
+    if mods is not None and mods[0] != widths:
+        mods = None
+    if mods is None:
+        from .interaction_net import InteractionNet, SplitMLPs
+        from .utils import HipMLP
+
+        mods = []
+        for m in model.modules():
+            if isinstance(m, InteractionNet):
+                if (m.hidden_dim in widths and m.hidden_layers == 1
+                        and not isinstance(m.edge_mlp, SplitMLPs) and not isinstance(m.aggr_mlp, SplitMLPs)):
+                    mods.append(m)
+            elif isinstance(m, HipMLP):
+                lin = [l for l in m if isinstance(l, torch.nn.Linear)]
+                if len(lin) == 2 and lin[0].weight.shape[0] in widths:
+                    mods.append(m)
+        mods = (widths, mods)
+        model._wide_defer_mods = mods
+    seen, params = set(), []
+    for m in mods[1]:
+        for p in m.parameters():
+            if p.requires_grad and p.is_cuda and id(p) not in seen:
+                seen.add(id(p))
+                params.append(p)
+    if not params:
+        return
+    from . import glue
+
+    for p, q in zip(params, glue.DeferGrad.apply(*params)):
+        PROXY[id(p)] = q
+
+
+def defer_end():
+    PROXY.clear()
+
+
+def _proxies(params):
+    """The DeferGrad outputs of `params` (None entries pass through) if every parameter has an
+    unused one, else None."""
+    if not PROXY or not torch.is_grad_enabled() or any(p is not None and id(p) not in PROXY for p in params):
+        return None
+    return [PROXY.pop(id(p)) if p is not None else None for p in params]
+
+
 def _empty(*shape, device):
     return torch.empty(*shape, dtype=torch.float32, device=device)
 
@@ -390,9 +452,10 @@ class WideMLPFunction(torch.autograd.Function):
     """y = [res +] [LN](W2 silu(W1 x + b1) + b2), x: (..., rows, k_in), hidden 128 / 256."""
 
     @staticmethod
-    def forward(ctx, x, res, W1, b1, W2, b2, gamma, beta, give=None):
+    def forward(ctx, x, res, W1, b1, W2, b2, gamma, beta, give=None, deferred=False):
         ctx.tag = ops._TAG[-1] if ops._TAG else "mlp"
         ctx.give = give   # glue.GradSlot: leave the input gradient there as well (glue.Tee)
+        ctx.deferred = deferred   # the parameters are glue.DeferGrad outputs (ops.slab_batch)
         dev = x.device
         hid, n_out = W1.shape[0], W2.shape[0]
         xm = mat(x.detach())
@@ -428,7 +491,7 @@ class WideMLPFunction(torch.autograd.Function):
         dg = _empty(n_out, device=dev) if has_ln else None
         dbt = _empty(n_out, device=dev) if has_ln else None
         need_gx = ctx.needs_input_grad[0]
-        with ops.tag(ctx.tag), ops.slab_batch():
+        with ops.tag(ctx.tag), ops.slab_batch(defer=ctx.deferred):
             gz = torch.empty(B, rows, no, device=dev,
                              dtype=h.dtype if has_ln else torch.float32)   # (narrow heads: fp32 gz)
             ga = _empty(B, rows, hid, device=dev)
@@ -442,7 +505,7 @@ class WideMLPFunction(torch.autograd.Function):
             gx = gx.reshape(ctx.x_shape)
             if ctx.give is not None:
                 ctx.give.put(gx)
-        return (gx, gres, dW1, db1, dW2, db2, dg, dbt, None)
+        return (gx, gres, dW1, db1, dW2, db2, dg, dbt, None, None)
 
 
 def apply_mlp(seq, x, res=None):
@@ -451,10 +514,12 @@ def apply_mlp(seq, x, res=None):
     from .fused import _sink
 
     lin, ln = _mlp_parts(seq)
+    params = [lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias,
+              ln.weight if ln is not None else None, ln.bias if ln is not None else None]
+    prox = _proxies(params)
     return WideMLPFunction.apply(
-        x, res, lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias,
-        ln.weight if ln is not None else None, ln.bias if ln is not None else None,
-        _sink(x, "give") if (res is None or res is x) else None)
+        x, res, *(prox if prox is not None else params),
+        _sink(x, "give") if (res is None or res is x) else None, prox is not None)
 
 
 # ---------------------------------------------------------- InteractionNet
@@ -481,9 +546,11 @@ def inet_eligible(net, send_rep, rec_rep, edge_rep):
 class WideInteractionNetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, send_rep, rec_rep, edge_rep, same, g, update_edges, mean,
-                W1, b1, W2, b2, gam, bet, V1, c1, V2, c2, gam2, bet2, take=None, give=None):
+                W1, b1, W2, b2, gam, bet, V1, c1, V2, c2, gam2, bet2, take=None, give=None,
+                deferred=False):
         # glue.GradSlot side channels of a glue.Tee on send_rep / rec_rep (see fused.py)
         ctx.take, ctx.give = take, give
+        ctx.deferred = deferred   # the parameters are glue.DeferGrad outputs (ops.slab_batch)
         with ops.tag(g.tag):
             dev = edge_rep.device
             d = W2.shape[0]
@@ -536,7 +603,7 @@ class WideInteractionNetFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_rec_out, g_edge_out=None):
-        with ops.tag(ctx.g.tag), ops.slab_batch():
+        with ops.tag(ctx.g.tag), ops.slab_batch(defer=ctx.deferred):
             W1, b1, W2, b2, gam, V1, c1, V2, c2, gam2, h_e, h_n, agg, z_e, z_n = ctx.saved_tensors
             g = ctx.g
             sm, rm, em = ctx.mats
@@ -664,7 +731,7 @@ class WideInteractionNetFunction(torch.autograd.Function):
                     outer_multi(outers)
             lane.finish()
         return (g_send, g_rec_total, g_edge, None, None, None, None,
-                dW1, db1, dW2, db2, dgam, dbet, dV1, dc1, dV2, dc2, dg2, db2n, None, None)
+                dW1, db1, dW2, db2, dgam, dbet, dV1, dc1, dV2, dc2, dg2, db2n, None, None, None)
 
 
 def apply_inet(net, send_rep, rec_rep, edge_rep):
@@ -676,12 +743,14 @@ def apply_inet(net, send_rep, rec_rep, edge_rep):
     el, al = _mlp_parts(net.edge_mlp), _mlp_parts(net.aggr_mlp)
     from .fused import _sink
 
+    params = [el[0][0].weight, el[0][0].bias, el[0][1].weight, el[0][1].bias, el[1].weight, el[1].bias,
+              al[0][0].weight, al[0][0].bias, al[0][1].weight, al[0][1].bias, al[1].weight, al[1].bias]
+    prox = _proxies(params)
     return WideInteractionNetFunction.apply(
         s, r, e, same, net.tables, net.update_edges, net.aggr == "mean",
-        el[0][0].weight, el[0][0].bias, el[0][1].weight, el[0][1].bias, el[1].weight, el[1].bias,
-        al[0][0].weight, al[0][0].bias, al[0][1].weight, al[0][1].bias, al[1].weight, al[1].bias,
+        *(prox if prox is not None else params),
         None if same else _sink(send_rep, "take"),
-        None if same else (_sink(rec_rep, "give"), _sink(send_rep, "give")))
+        None if same else (_sink(rec_rep, "give"), _sink(send_rep, "give")), prox is not None)
 
 
 # ------------------------------------------- InteractionNet with SplitMLPs (hidden 128 / 256)

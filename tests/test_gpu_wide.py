@@ -325,3 +325,57 @@ def test_node_update_with_the_projection_inside_the_tail(B, n_r, expect_pre, mon
         assert sum(v["calls"] for v in s_on.values()) == sum(v["calls"] for v in s_off.values()) - 1
     for a, b in zip(got, want):
         assert rel(a.cpu(), b.cpu()) < 2e-5, rel(a.cpu(), b.cpu())
+
+
+@pytest.mark.skipif(D != 128, reason="model-level check at hidden 128")
+@pytest.mark.parametrize("ar_steps", [1, 2])
+def test_deferred_slab_reductions_leave_the_training_step_unchanged(ar_steps, monkeypatch):
+    """Hi-LAM-128 training step with the slab reductions of the hidden-128 layers flushed once per
+    AR step (glue.DeferGrad + ops.slab_batch(defer=True)) and with one reduction launch per layer
+    (NLAM_DEFER_REDUCE=0): identical loss, parameter gradients equal to fp32 summation order (the
+    same reductions, later), fewer reduction launches, nothing left pending, and no parameter without a gradient."""
+    import tempfile
+
+    import numpy as np
+
+    from neural_lam_amd import graphgen, ops, synthetic, wide
+    from neural_lam_amd.models import MODELS
+
+    with tempfile.TemporaryDirectory() as tmp:
+        info = graphgen.create_graph(tmp + "/graph/g", graphgen.make_xy(38, 35, 5000.0), 3, True)
+        n = info["num_grid"]
+        gen = torch.Generator().manual_seed(0)
+        ds = synthetic.SyntheticDatastore(
+            tmp, torch.randn(n, 4, generator=gen).numpy(), np.zeros(7), np.ones(7), np.zeros(7),
+            np.ones(7), (torch.rand(n, generator=gen) < 0.2).float().numpy(), n_forcing=2)
+        torch.manual_seed(1)
+        model = MODELS["hi_lam"](synthetic.model_args(graph="g", hidden_dim=128, processor_layers=2),
+                                 config=None, datastore=ds).cuda()
+    batch = synthetic.random_batch(2, ar_steps, n, n_state=7, n_forcing_window=6, device="cuda")
+
+    def run(on):
+        monkeypatch.setenv("NLAM_DEFER_REDUCE", "1" if on else "0")
+        for p in model.parameters():
+            p.grad = None
+        ops.PROFILER = ops.KernelProfiler()
+        try:
+            loss = model.training_step(batch)
+            assert not wide.PROXY
+            loss.backward()
+            stats = ops.PROFILER.collect()
+        finally:
+            ops.PROFILER = None
+        assert not ops._DEFERRED
+        assert all(p.grad is not None for p in model.parameters())
+        n_red = sum(v["calls"] for k, v in stats.items() if k.startswith("nlam_reduce_slabs"))
+        return float(loss.detach()), [p.grad.clone() for p in model.parameters()], n_red
+
+    l_on, g_on, r_on = run(True)
+    l_off, g_off, r_off = run(False)
+    assert r_on < r_off / 2, (r_on, r_off)   # (a multi-step rollout embeds the static features up front, undeferred)
+    assert l_on == l_off
+    # (the same slab sums; which reduction kernel form takes a segment depends on what shares its
+    # launch, so the order of the fp32 additions -- not the set of addends -- may differ)
+    for (k, _), a, b in zip(model.named_parameters(), g_on, g_off):
+        scale = float(b.abs().max()) + 1e-30
+        assert float((a - b).abs().max()) <= 2e-6 * scale, (k, float((a - b).abs().max()) / scale)
