@@ -61,6 +61,7 @@ SIDE_LANE_ROWS = int(os.environ.get("NLAM_SIDE_ROWS", "0"))
 # out ONCE per predict_step (a second use of a layer gets the parameters themselves and the
 # undeferred path: two gradients into one proxy would be summed by the engine before the flush).
 PROXY = {}
+DEFER_WIDTHS = (128,)   # (hidden 64, through the Python-level MLP / chain functions: measured neutral)
 
 
 def defer_begin(model):
@@ -68,7 +69,7 @@ def defer_begin(model):
     PROXY.clear()
     if os.environ.get("NLAM_DEFER_REDUCE", "1") == "0" or not ops.deferral_allowed():
         return
-    widths = WIDE_HIDDEN if os.environ.get("NLAM_DEFER_REDUCE", "1") == "2" else (128,)
+    widths = WIDE_HIDDEN if os.environ.get("NLAM_DEFER_REDUCE", "1") == "2" else DEFER_WIDTHS
     mods = getattr(model, "_wide_defer_mods", None)
     if mods is not None and mods[0] != widths:
         mods = None
