@@ -637,7 +637,8 @@ int nlam_wide_outer(const float* g, int64_t g_bstride, int64_t g_ld, int ng,
                     float* slab, int64_t slab_stride, int64_t B, int64_t rows, int io_bf16,
                     void* stream);
 
-/* Several INDEPENDENT problems of one kind in one launch (n <= 8; arrays of n entries): the small
+/* Several INDEPENDENT problems of one kind in one launch (n <= 8, nlam_wide_outer_multi: n <= 24;
+ * arrays of n entries): the small
  * mesh levels of Hi-LAM (reference hi_lam.py:82-207: 10 InteractionNets per processor layer on
  * 81 ... 6,561-node levels) are bound by the latency of their launches, not by their work.
  * nlam_lin_fwd_multi: out_k = x_k W_k^T + bias_k (bias_k may be NULL), all d -> d; d = 64 (n <= 4,

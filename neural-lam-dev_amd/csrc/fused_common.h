@@ -809,14 +809,17 @@ __device__ __forceinline__ void fold_vec_lds(const float (&v)[NV], float* __rest
 // Workgroup b serves problem k with first[k] <= b < first[k + 1] as block b - first[k] of
 // first[k + 1] - first[k].
 #define NLAM_WIDE_MAXP 8
-template <typename P>
+// (the weight-gradient launches take more: the small layers' problems of a whole AR step are merged
+// at the end of its backward -- they feed nothing in between; the argument block stays under 4 KB)
+#define NLAM_WIDE_MAXP_OUTER 24
+template <typename P, int N = NLAM_WIDE_MAXP>
 struct WideMulti {
   int n;
-  int first[NLAM_WIDE_MAXP + 1];
-  P p[NLAM_WIDE_MAXP];
+  int first[N + 1];
+  P p[N];
 };
-template <typename P>
-__device__ __forceinline__ int wide_multi_find(const WideMulti<P>& m, int b) {
+template <typename P, int N>
+__device__ __forceinline__ int wide_multi_find(const WideMulti<P, N>& m, int b) {
   int k = 0;
   while (k + 1 < m.n && b >= m.first[k + 1]) ++k;
   return k;

@@ -1833,7 +1833,7 @@ __device__ __forceinline__ void fs_outer_body(const FsOuterParams& q, const int 
 }
 
 template <int GW, int NXB, int TERMS>
-__global__ __launch_bounds__(512) void fs_outer_kernel(WideMulti<FsOuterParams> m) {
+__global__ __launch_bounds__(512) void fs_outer_kernel(WideMulti<FsOuterParams, NLAM_WIDE_MAXP_OUTER> m) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int k = wide_multi_find(m, blockIdx.x);
   fs_outer_body<GW, NXB, TERMS>(m.p[k], blockIdx.x - m.first[k], m.first[k + 1] - m.first[k], smem);
@@ -1841,7 +1841,7 @@ __global__ __launch_bounds__(512) void fs_outer_kernel(WideMulti<FsOuterParams> 
 
 // m.first[] = the slab counts the caller sized its buffers for (one workgroup per slab)
 template <int GW, int NXB, int TERMS>
-static int launch_fs_outer(const WideMulti<FsOuterParams>& m, hipStream_t s) {
+static int launch_fs_outer(const WideMulti<FsOuterParams, NLAM_WIDE_MAXP_OUTER>& m, hipStream_t s) {
   const size_t lds = FsPlanes<GW, TERMS, 16>::bytes + FsPlanes<32 * NXB, TERMS, 16>::bytes;
   auto kern = fs_outer_kernel<GW, NXB, TERMS>;
   NLAM_BIG_LDS(kern, "fs_outer_kernel");
@@ -1851,11 +1851,11 @@ static int launch_fs_outer(const WideMulti<FsOuterParams>& m, hipStream_t s) {
 }
 template <int GW, int NXB, int TERMS>
 static int launch_fs_outer(const FsOuterParams& q, hipStream_t s, unsigned grid) {
-  WideMulti<FsOuterParams> m;
+  WideMulti<FsOuterParams, NLAM_WIDE_MAXP_OUTER> m;
   m.n = 1;
   m.p[0] = q;
   m.first[0] = 0;
-  for (int k = 0; k < NLAM_WIDE_MAXP; ++k) m.first[k + 1] = (int)grid;
+  for (int k = 0; k < NLAM_WIDE_MAXP_OUTER; ++k) m.first[k + 1] = (int)grid;
   return launch_fs_outer<GW, NXB, TERMS>(m, s);
 }
 
@@ -1915,7 +1915,7 @@ int nlam_fs_outer_multi_256(int n, const float* const* g, const int64_t* g_bstri
   int any16 = 0;
   for (int k = 0; k < n && io_bf16; ++k) any16 |= io_bf16[k];
   FS_TERMS("nlam_wide_outer_multi", any16);
-  WideMulti<FsOuterParams> m;
+  WideMulti<FsOuterParams, NLAM_WIDE_MAXP_OUTER> m;
   m.n = 0;
   m.first[0] = 0;
   for (int k = 0; k < n; ++k) {
@@ -1927,7 +1927,7 @@ int nlam_fs_outer_multi_256(int n, const float* const* g, const int64_t* g_bstri
     ++m.n;
   }
   if (m.n == 0) return 0;
-  for (int k = m.n; k < NLAM_WIDE_MAXP; ++k) m.first[k + 1] = m.first[m.n];
+  for (int k = m.n; k < NLAM_WIDE_MAXP_OUTER; ++k) m.first[k + 1] = m.first[m.n];
   return terms_ == 3 ? launch_fs_outer<256, 8, 3>(m, (hipStream_t)stream)
                      : launch_fs_outer<256, 8, 1>(m, (hipStream_t)stream);
 }

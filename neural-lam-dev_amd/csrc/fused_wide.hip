@@ -1261,7 +1261,7 @@ __device__ __forceinline__ void wide_outer_body(const WideOuterParams& q, int bi
 }
 
 template <int NGB, int NXB, int TERMS>
-__global__ __launch_bounds__(256) void wide_outer_kernel(WideMulti<WideOuterParams> m) {
+__global__ __launch_bounds__(256) void wide_outer_kernel(WideMulti<WideOuterParams, NLAM_WIDE_MAXP_OUTER> m) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int k = wide_multi_find(m, blockIdx.x);
   wide_outer_body<NGB, NXB, TERMS>(m.p[k], blockIdx.x - m.first[k], m.first[k + 1] - m.first[k],
@@ -1270,7 +1270,7 @@ __global__ __launch_bounds__(256) void wide_outer_kernel(WideMulti<WideOuterPara
 
 // counts: slabs (= workgroups) per problem; NULL = nlam_bwd_grid(tiles) each (single launches)
 template <int NGB, int NXB, int TERMS>
-static int launch_wide_outer(WideMulti<WideOuterParams>& m, hipStream_t s,
+static int launch_wide_outer(WideMulti<WideOuterParams, NLAM_WIDE_MAXP_OUTER>& m, hipStream_t s,
                              const int* counts = nullptr) {
   constexpr int NG = 32 * NGB, NX = 32 * NXB;
   size_t lds = (size_t)4 * NLAM_TILE * (NG + 16 + NX + 16) * sizeof(float);
@@ -1283,7 +1283,7 @@ static int launch_wide_outer(WideMulti<WideOuterParams>& m, hipStream_t s,
   m.first[0] = 0;
   for (int k = 0; k < m.n; ++k)
     m.first[k + 1] = m.first[k] + (counts ? counts[k] : (int)wide_grid(((m.p[k].rows + NLAM_TILE - 1) / NLAM_TILE) * m.p[k].B));
-  for (int k = m.n; k < NLAM_WIDE_MAXP; ++k) m.first[k + 1] = m.first[m.n];
+  for (int k = m.n; k < NLAM_WIDE_MAXP_OUTER; ++k) m.first[k + 1] = m.first[m.n];
   kern<<<(unsigned)m.first[m.n], 256, lds, s>>>(m);
   NLAM_CHECK_LAUNCH("wide_outer_kernel");
   return 0;
@@ -1317,7 +1317,7 @@ extern "C" int nlam_wide_outer(const float* g, int64_t g_bstride, int64_t g_ld, 
                              B, rows, wide_grid(((rows + NLAM_TILE - 1) / NLAM_TILE) * B), io_bf16,
                              stream);
   NLAM_REQUIRE(io_bf16 == 0, "nlam_wide_outer: bf16 rows exist at hidden 256 only");
-  WideMulti<WideOuterParams> m;
+  WideMulti<WideOuterParams, NLAM_WIDE_MAXP_OUTER> m;
   m.n = 1;
   if (wide_outer_fill(m.p[0], g, g_bstride, g_ld, ng, x, x_bstride, x_ld, nx, silu_x, slab,
                       slab_stride, B, rows))
@@ -1338,14 +1338,14 @@ extern "C" int nlam_wide_outer_multi(int n, int d, const float* const* g, const 
                                      const int64_t* slab_stride, const int64_t* B,
                                      const int64_t* rows, const int32_t* nslabs,
                                      const int32_t* io_bf16, void* stream) {
-  NLAM_REQUIRE(n >= 1 && n <= NLAM_WIDE_MAXP, "nlam_wide_outer_multi: n %d out of [1, %d]", n,
-               NLAM_WIDE_MAXP);
+  NLAM_REQUIRE(n >= 1 && n <= NLAM_WIDE_MAXP_OUTER, "nlam_wide_outer_multi: n %d out of [1, %d]", n,
+               NLAM_WIDE_MAXP_OUTER);
   NLAM_REQUIRE(nlam_mfma_terms() != 0, "nlam_wide_outer_multi: needs NLAM_MFMA=bf16x3|bf16");
   for (int k = 0; k < n; ++k)
     NLAM_REQUIRE(nslabs != nullptr && nslabs[k] >= 1 && nslabs[k] <= 1024,
                  "nlam_wide_outer_multi: nslabs[%d] out of [1, 1024]", k);
   if (d == 256) {
-    unsigned grid[NLAM_WIDE_MAXP];
+    unsigned grid[NLAM_WIDE_MAXP_OUTER];
     for (int k = 0; k < n; ++k) grid[k] = (unsigned)nslabs[k];
     return nlam_fs_outer_multi_256(n, g, g_bstride, g_ld, x, x_bstride, x_ld, silu_x, slab,
                                    slab_stride, B, rows, grid, io_bf16, stream);
@@ -1354,8 +1354,8 @@ extern "C" int nlam_wide_outer_multi(int n, int d, const float* const* g, const 
     NLAM_REQUIRE(io_bf16 == nullptr || io_bf16[k] == 0,
                  "nlam_wide_outer_multi: bf16 rows exist at hidden 256 only");
   NLAM_REQUIRE(d == 128, "nlam_wide_outer_multi: width %d unsupported (128, 256)", d);
-  WideMulti<WideOuterParams> m;
-  int counts[NLAM_WIDE_MAXP];
+  WideMulti<WideOuterParams, NLAM_WIDE_MAXP_OUTER> m;
+  int counts[NLAM_WIDE_MAXP_OUTER];
   m.n = 0;
   for (int k = 0; k < n; ++k) {
     if (B[k] <= 0 || rows[k] <= 0) continue;

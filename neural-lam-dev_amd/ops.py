@@ -486,7 +486,24 @@ def deferral_allowed():
     return not any(r is not None and r.hooks_enabled and r.active and r.overlap for r in live)
 
 
+_FLUSH_HOOKS = []   # work that must run before the deferred reductions (wide.flush_deferred_outers)
+
+
+def on_flush(fn):
+    """Run fn() at the next flush_deferred() (and make sure one comes at the end of this pass)."""
+    if fn not in _FLUSH_HOOKS:
+        _FLUSH_HOOKS.append(fn)
+    task = torch._C._current_graph_task_id()
+    if task != -1 and _DEFER_TASK[0] != task:
+        _DEFER_TASK[0] = task
+        torch.autograd.Variable._execution_engine.queue_callback(_end_of_pass_flush)
+
+
 def flush_deferred():
+    hooks = list(_FLUSH_HOOKS)
+    del _FLUSH_HOOKS[:]
+    for fn in hooks:
+        fn()
     if _DEFERRED:
         entries = list(_DEFERRED)
         del _DEFERRED[:]

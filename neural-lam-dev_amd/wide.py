@@ -61,7 +61,9 @@ SIDE_LANE_ROWS = int(os.environ.get("NLAM_SIDE_ROWS", "0"))
 # out ONCE per predict_step (a second use of a layer gets the parameters themselves and the
 # undeferred path: two gradients into one proxy would be summed by the engine before the flush).
 PROXY = {}
-DEFER_WIDTHS = (128,)   # (hidden 64, through the Python-level MLP / chain functions: measured neutral)
+# widths whose LARGE layers defer their reductions as well (hidden 256: measured slower, see above;
+# hidden 64, through the Python-level MLP / chain functions: measured neutral, not wired)
+DEFER_WIDTHS = (128, 256) if os.environ.get("NLAM_DEFER_REDUCE", "1") == "2" else (128,)
 
 
 def defer_begin(model):
@@ -69,7 +71,7 @@ def defer_begin(model):
     PROXY.clear()
     if os.environ.get("NLAM_DEFER_REDUCE", "1") == "0" or not ops.deferral_allowed():
         return
-    widths = WIDE_HIDDEN if os.environ.get("NLAM_DEFER_REDUCE", "1") == "2" else DEFER_WIDTHS
+    widths = WIDE_HIDDEN
     mods = getattr(model, "_wide_defer_mods", None)
     if mods is not None and mods[0] != widths:
         mods = None
@@ -362,9 +364,45 @@ _OUTER_FLOOR = int(os.environ.get("NLAM_OUTER_FLOOR", "64"))
 _OUTER_MIN_TILES = int(os.environ.get("NLAM_OUTER_MIN_TILES", "8"))   # 32-row tiles per slab, at least
 
 
+OUTER_MAXP = 24   # csrc/fused_common.h NLAM_WIDE_MAXP_OUTER
+
+# Weight-gradient problems handed on to the end of the AR step's backward (glue.DeferGrad ->
+# flush_deferred_outers): the products feed nothing before the optimizer; a small layer's launch is
+# all latency (20 - 60 us for a few MB), and merged 24 to a launch -- workgroups shared out by work --
+# the problems of a whole step run side by side; each merged launch is followed by the reduction of
+# ITS slabs while the Infinity Cache still has them.  Measured (same box, layers of at most 60 k /
+# 250 k / any number of edge rows deferred): Hi-LAM-128 19.20 -> 18.65 / 18.14 / 18.06 ms, Hi-LAM-256
+# (bf16) 30.36 -> 29.89 / 29.66 / 29.64 ms.  NLAM_DEFER_OUTER_ROWS caps the size of a layer that
+# defers (0: none); the problems hold their operands alive until the flush (a few GB at B = 4).
+DEFER_OUTER_ROWS = int(os.environ.get("NLAM_DEFER_OUTER_ROWS", str(1 << 40)))
+SMALL_LAYER_ROWS = 60000   # (a hidden-256 layer up to this size defers its remaining slab reductions too)
+_DEFERRED_OUTERS = []
+
+
+def defer_outers(problems):
+    _DEFERRED_OUTERS.extend(problems)
+    ops.on_flush(flush_deferred_outers)
+
+
+def flush_deferred_outers():
+    if not _DEFERRED_OUTERS:
+        return
+    problems = list(_DEFERRED_OUTERS)
+    del _DEFERRED_OUTERS[:]
+    by_d = {}
+    for pr in problems:
+        by_d.setdefault(pr[0].cols, []).append(pr)
+    with ops.tag("deferred"):
+        for prs in by_d.values():
+            for i in range(0, len(prs), OUTER_MAXP):
+                # (each merged launch's slabs are reduced at once, while the Infinity Cache has them)
+                with ops.slab_batch():
+                    outer_multi(prs[i : i + OUTER_MAXP])
+
+
 def outer_multi(problems):
     """[(g Mat (.., d), x Mat (.., d), dW view, db, silu_x)] -> one launch + the layer's slab
-    reduction (all d x d)."""
+    reduction (all d x d; at most OUTER_MAXP problems)."""
     import ctypes
     d = problems[0][0].cols
     I64, I32 = ctypes.c_int64, ctypes.c_int32
@@ -409,8 +447,9 @@ def _first_linear(x, W, b, out):
     ops.fused_lin_fwd(x, W, b, None, None, out)
 
 
-def _first_linear_bwd(x, ga, W, need_gx, gx_add, dW, db, dev):
-    """Backward of out = x W^T + b given ga = dL/dout: returns gx (or None), fills dW / db."""
+def _first_linear_bwd(x, ga, W, need_gx, gx_add, dW, db, dev, deferred=False):
+    """Backward of out = x W^T + b given ga = dL/dout: returns gx (or None), fills dW / db
+    (deferred: the d x d weight-gradient product joins the step's merged launches)."""
     k_in = W.shape[1]
     gx = None
     wide_ok = k_in == ga.cols and _aligned(x)
@@ -422,7 +461,9 @@ def _first_linear_bwd(x, ga, W, need_gx, gx_add, dW, db, dev):
             ops.linear_bwd_data(ga, W, mat(gx))
             if gx_add is not None:
                 ops.add_rows(mat(gx), gx_add, mat(gx))
-    if wide_ok or k_in <= 64:
+    if deferred and wide_ok and ga.B * ga.rows <= DEFER_OUTER_ROWS:
+        defer_outers([(ga, x, dW, db, False)])
+    elif wide_ok or k_in <= 64:
         outer(ga, x, dW, db)    # (narrow / unaligned static features: scalar staging, K padded)
     else:
         ops.linear_bwd_weight(ga, x, dW, db)   # generic split-K GEMM
@@ -492,15 +533,19 @@ class WideMLPFunction(torch.autograd.Function):
         dg = _empty(n_out, device=dev) if has_ln else None
         dbt = _empty(n_out, device=dev) if has_ln else None
         need_gx = ctx.needs_input_grad[0]
-        with ops.tag(ctx.tag), ops.slab_batch(defer=ctx.deferred):
+        defer_red = ctx.deferred and (hid in DEFER_WIDTHS or B * rows <= SMALL_LAYER_ROWS)
+        with ops.tag(ctx.tag), ops.slab_batch(defer=defer_red):
             gz = torch.empty(B, rows, no, device=dev,
                              dtype=h.dtype if has_ln else torch.float32)   # (narrow heads: fp32 gz)
             ga = _empty(B, rows, hid, device=dev)
             tail_bwd(Tiling(rows), h, gym, None, None, None, None, W2, b2, gamma, gz, mat(ga),
                      None, None, B, hid, dg, dbt, zk)
-            outer(_m(gz), _m(h), dW2, db2, silu_x=True, rows_out=n_out)
+            if ctx.deferred and has_ln and n_out == hid and B * rows <= DEFER_OUTER_ROWS:
+                defer_outers([(_m(gz), _m(h), dW2, db2, True)])   # (a small embedder: merged later)
+            else:
+                outer(_m(gz), _m(h), dW2, db2, silu_x=True, rows_out=n_out)
             gx_add = gym if (ctx.res_mode == 1 and need_gx) else None
-            gx = _first_linear_bwd(xm, mat(ga), W1, need_gx, gx_add, dW1, db1, dev)
+            gx = _first_linear_bwd(xm, mat(ga), W1, need_gx, gx_add, dW1, db1, dev, ctx.deferred)
         gres = gy if ctx.res_mode == 2 else None
         if gx is not None:
             gx = gx.reshape(ctx.x_shape)
@@ -604,7 +649,10 @@ class WideInteractionNetFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_rec_out, g_edge_out=None):
-        with ops.tag(ctx.g.tag), ops.slab_batch(defer=ctx.deferred):
+        # (reductions at the end of the step: hidden 128 always, hidden 256 for small layers only)
+        defer_red = ctx.deferred and (ctx.dims[4] in DEFER_WIDTHS
+                                      or ctx.dims[0] * ctx.dims[3] <= SMALL_LAYER_ROWS)
+        with ops.tag(ctx.g.tag), ops.slab_batch(defer=defer_red):
             W1, b1, W2, b2, gam, V1, c1, V2, c2, gam2, h_e, h_n, agg, z_e, z_n = ctx.saved_tensors
             g = ctx.g
             sm, rm, em = ctx.mats
@@ -727,7 +775,9 @@ class WideInteractionNetFunction(torch.autograd.Function):
                 g_edge = t5
             # 6. every weight / bias gradient of the layer: one streaming launch (small layers
             #    have issued theirs on the weight-gradient lane already: only the join is left)
-            if outers:
+            if outers and ctx.deferred and not lane.enabled and B * M <= DEFER_OUTER_ROWS:
+                defer_outers(outers)   # (merged with the other small layers' at the end of the step)
+            elif outers:
                 with lane:
                     outer_multi(outers)
             lane.finish()

@@ -353,8 +353,9 @@ def test_deferred_slab_reductions_leave_the_training_step_unchanged(ar_steps, mo
                                  config=None, datastore=ds).cuda()
     batch = synthetic.random_batch(2, ar_steps, n, n_state=7, n_forcing_window=6, device="cuda")
 
-    def run(on):
+    def run(on, outer_rows=1 << 40):
         monkeypatch.setenv("NLAM_DEFER_REDUCE", "1" if on else "0")
+        monkeypatch.setattr(wide, "DEFER_OUTER_ROWS", outer_rows)
         for p in model.parameters():
             p.grad = None
         ops.PROFILER = ops.KernelProfiler()
@@ -365,13 +366,21 @@ def test_deferred_slab_reductions_leave_the_training_step_unchanged(ar_steps, mo
             stats = ops.PROFILER.collect()
         finally:
             ops.PROFILER = None
-        assert not ops._DEFERRED
+        assert not ops._DEFERRED and not wide._DEFERRED_OUTERS and not ops._FLUSH_HOOKS
         assert all(p.grad is not None for p in model.parameters())
         n_red = sum(v["calls"] for k, v in stats.items() if k.startswith("nlam_reduce_slabs"))
         return float(loss.detach()), [p.grad.clone() for p in model.parameters()], n_red
 
     l_on, g_on, r_on = run(True)
     l_off, g_off, r_off = run(False)
+    # the weight-gradient problems of the step merged 24 to a launch (default) against one launch
+    # per layer: the same products (a slab count per problem that depends on what shares its
+    # launch: fp32 summation order only)
+    l_lay, g_lay, _ = run(True, outer_rows=0)
+    assert l_lay == l_on
+    for (k, _), a, b in zip(model.named_parameters(), g_on, g_lay):
+        scale = float(b.abs().max()) + 1e-30
+        assert float((a - b).abs().max()) <= 5e-6 * scale, (k, float((a - b).abs().max()) / scale)
     assert r_on < r_off / 2, (r_on, r_off)   # (a multi-step rollout embeds the static features up front, undeferred)
     assert l_on == l_off
     # (the same slab sums; which reduction kernel form takes a segment depends on what shares its
