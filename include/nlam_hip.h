@@ -712,6 +712,14 @@ int nlam_wide_outer_multi(int n, int d, const float* const* g, const int64_t* g_
                           const int64_t* slab_stride, const int64_t* B, const int64_t* rows,
                           const int32_t* nslabs, const int32_t* io_bf16,
                           void* stream);
+/* The same for narrow x operands (first Linears of static-feature embedders and of the grid
+ * embedder: dW (d x nx[k]) = g^T x, db = colsum g): every problem d x nx[k] with nx[k] <= 64; all
+ * slabs of one launch have rows of 32 ceil(max_k nx[k] / 32) columns: [dW (d x that) | db (d)]. */
+int nlam_wide_outer_multi_nx(int n, int d, const float* const* g, const int64_t* g_bstride,
+                             const int64_t* g_ld, const float* const* x, const int64_t* x_bstride,
+                             const int64_t* x_ld, const int32_t* nx, float* const* slab,
+                             const int64_t* slab_stride, const int64_t* B, const int64_t* rows,
+                             const int32_t* nslabs, void* stream);
 
 /* Grid feature rows of predict_step (reference base_graph_model.py:116-124): out (B, N, sum w) =
  * concatenation of up to four (B | 1, N, w_k) sources along the feature axis (bstride 0 =

@@ -117,6 +117,7 @@ SIGNATURES = {
     "nlam_lin_fwd_multi": [_i32, _i32] + [_p] * 11 + [_i32, _p],
     "nlam_lin_bwd_data_multi": [_i32, _i32] + [_p] * 13 + [_p],
     "nlam_wide_outer_multi": [_i32, _i32] + [_p] * 13 + [_p],
+    "nlam_wide_outer_multi_nx": [_i32, _i32] + [_p] * 12 + [_p],
     "nlam_concat_rows": [_i32, _p, _p, _p, _p, _p, _i64, _i64, _p],
     "nlam_sizeof_inet_args": [],
     "nlam_sizeof_inet_grads": [],

@@ -54,4 +54,4 @@ int nlam_fs_outer_multi_256(int n, const float* const* g, const int64_t* g_bstri
                             const int64_t* g_ld, const float* const* x, const int64_t* x_bstride,
                             const int64_t* x_ld, const int32_t* silu_x, float* const* slab,
                             const int64_t* slab_stride, const int64_t* B, const int64_t* rows,
-                            const unsigned* grid, const int32_t* io_bf16, void* stream);
+                            const unsigned* grid, const int32_t* io_bf16, void* stream, const int32_t* nx);

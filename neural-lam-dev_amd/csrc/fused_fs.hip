@@ -1906,12 +1906,14 @@ int nlam_fs_outer_256(const float* g, int64_t g_bstride, int64_t g_ld, int ng,
   return launch_fs_outer<256, 8, 1>(q, s, grid);
 }
 
-// all problems 256 x 256; grid[k] = slab count of problem k
+// all problems 256 x nx[k] with nx[k] = 256 for all k, or nx[k] <= 64 for all k (nx == NULL: 256);
+// grid[k] = slab count of problem k
 int nlam_fs_outer_multi_256(int n, const float* const* g, const int64_t* g_bstride,
                             const int64_t* g_ld, const float* const* x, const int64_t* x_bstride,
                             const int64_t* x_ld, const int32_t* silu_x, float* const* slab,
                             const int64_t* slab_stride, const int64_t* B, const int64_t* rows,
-                            const unsigned* grid, const int32_t* io_bf16, void* stream) {
+                            const unsigned* grid, const int32_t* io_bf16, void* stream,
+                            const int32_t* nx) {
   int any16 = 0;
   for (int k = 0; k < n && io_bf16; ++k) any16 |= io_bf16[k];
   FS_TERMS("nlam_wide_outer_multi", any16);
@@ -1920,14 +1922,21 @@ int nlam_fs_outer_multi_256(int n, const float* const* g, const int64_t* g_bstri
   m.first[0] = 0;
   for (int k = 0; k < n; ++k) {
     if (B[k] <= 0 || rows[k] <= 0) continue;
-    if (fs_outer_fill(m.p[m.n], g[k], g_bstride[k], g_ld[k], 256, x[k], x_bstride[k], x_ld[k], 256,
-                      silu_x[k], slab[k], slab_stride[k], B[k], rows[k], io_bf16 ? io_bf16[k] : 0))
+    if (fs_outer_fill(m.p[m.n], g[k], g_bstride[k], g_ld[k], 256, x[k], x_bstride[k], x_ld[k],
+                      nx ? nx[k] : 256, silu_x[k], slab[k], slab_stride[k], B[k], rows[k],
+                      io_bf16 ? io_bf16[k] : 0))
       return 1;
     m.first[m.n + 1] = m.first[m.n] + (int)grid[k];
     ++m.n;
   }
   if (m.n == 0) return 0;
   for (int k = m.n; k < NLAM_WIDE_MAXP_OUTER; ++k) m.first[k + 1] = m.first[m.n];
-  return terms_ == 3 ? launch_fs_outer<256, 8, 3>(m, (hipStream_t)stream)
-                     : launch_fs_outer<256, 8, 1>(m, (hipStream_t)stream);
+  int nxmax = 0;
+  for (int k = 0; k < n; ++k) nxmax = nx ? (nx[k] > nxmax ? nx[k] : nxmax) : 256;
+  hipStream_t s = (hipStream_t)stream;
+  if (nxmax <= 32) return terms_ == 3 ? launch_fs_outer<256, 1, 3>(m, s) : launch_fs_outer<256, 1, 1>(m, s);
+  if (nxmax <= 64) return terms_ == 3 ? launch_fs_outer<256, 2, 3>(m, s) : launch_fs_outer<256, 2, 1>(m, s);
+  for (int k = 0; k < n; ++k)
+    NLAM_REQUIRE(!nx || nx[k] == 256, "nlam_wide_outer_multi: x widths of one launch: all 256, or all <= 64");
+  return terms_ == 3 ? launch_fs_outer<256, 8, 3>(m, s) : launch_fs_outer<256, 8, 1>(m, s);
 }

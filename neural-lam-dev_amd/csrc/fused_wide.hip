@@ -1330,7 +1330,15 @@ extern "C" int nlam_wide_outer(const float* g, int64_t g_bstride, int64_t g_ld, 
   return t3 ? launch_wide_outer<4, 4, 3>(m, s) : launch_wide_outer<4, 4, 1>(m, s);
 }
 
-// all problems 128 x 128
+static int wide_outer_multi_impl(int n, int d, const float* const* g, const int64_t* g_bstride,
+                                 const int64_t* g_ld, const float* const* x,
+                                 const int64_t* x_bstride, const int64_t* x_ld,
+                                 const int32_t* silu_x, float* const* slab,
+                                 const int64_t* slab_stride, const int64_t* B,
+                                 const int64_t* rows, const int32_t* nslabs,
+                                 const int32_t* io_bf16, void* stream, const int32_t* nx);
+
+// all problems d x d
 extern "C" int nlam_wide_outer_multi(int n, int d, const float* const* g, const int64_t* g_bstride,
                                      const int64_t* g_ld, const float* const* x,
                                      const int64_t* x_bstride, const int64_t* x_ld,
@@ -1338,6 +1346,32 @@ extern "C" int nlam_wide_outer_multi(int n, int d, const float* const* g, const 
                                      const int64_t* slab_stride, const int64_t* B,
                                      const int64_t* rows, const int32_t* nslabs,
                                      const int32_t* io_bf16, void* stream) {
+  return wide_outer_multi_impl(n, d, g, g_bstride, g_ld, x, x_bstride, x_ld, silu_x, slab, slab_stride, B,
+                               rows, nslabs, io_bf16, stream, nullptr);
+}
+// all problems d x nx[k], nx[k] <= 64 (narrow first Linears: static-feature embedders, the grid
+// embedder): every slab row has 32 ceil(max_k nx[k] / 32) columns
+extern "C" int nlam_wide_outer_multi_nx(int n, int d, const float* const* g, const int64_t* g_bstride,
+                                        const int64_t* g_ld, const float* const* x,
+                                        const int64_t* x_bstride, const int64_t* x_ld,
+                                        const int32_t* nx, float* const* slab,
+                                        const int64_t* slab_stride, const int64_t* B,
+                                        const int64_t* rows, const int32_t* nslabs, void* stream) {
+  NLAM_REQUIRE(nx != nullptr && n >= 1 && n <= NLAM_WIDE_MAXP_OUTER, "nlam_wide_outer_multi_nx: bad n / nx");
+  int32_t zeros[NLAM_WIDE_MAXP_OUTER] = {0};
+  for (int k = 0; k < n; ++k)
+    NLAM_REQUIRE(nx[k] >= 1 && nx[k] <= 64, "nlam_wide_outer_multi_nx: nx[%d] = %d out of [1, 64]", k, nx[k]);
+  return wide_outer_multi_impl(n, d, g, g_bstride, g_ld, x, x_bstride, x_ld, zeros, slab, slab_stride, B,
+                               rows, nslabs, nullptr, stream, nx);
+}
+
+static int wide_outer_multi_impl(int n, int d, const float* const* g, const int64_t* g_bstride,
+                                 const int64_t* g_ld, const float* const* x,
+                                 const int64_t* x_bstride, const int64_t* x_ld,
+                                 const int32_t* silu_x, float* const* slab,
+                                 const int64_t* slab_stride, const int64_t* B,
+                                 const int64_t* rows, const int32_t* nslabs,
+                                 const int32_t* io_bf16, void* stream, const int32_t* nx) {
   NLAM_REQUIRE(n >= 1 && n <= NLAM_WIDE_MAXP_OUTER, "nlam_wide_outer_multi: n %d out of [1, %d]", n,
                NLAM_WIDE_MAXP_OUTER);
   NLAM_REQUIRE(nlam_mfma_terms() != 0, "nlam_wide_outer_multi: needs NLAM_MFMA=bf16x3|bf16");
@@ -1348,7 +1382,7 @@ extern "C" int nlam_wide_outer_multi(int n, int d, const float* const* g, const 
     unsigned grid[NLAM_WIDE_MAXP_OUTER];
     for (int k = 0; k < n; ++k) grid[k] = (unsigned)nslabs[k];
     return nlam_fs_outer_multi_256(n, g, g_bstride, g_ld, x, x_bstride, x_ld, silu_x, slab,
-                                   slab_stride, B, rows, grid, io_bf16, stream);
+                                   slab_stride, B, rows, grid, io_bf16, stream, nx);
   }
   for (int k = 0; k < n; ++k)
     NLAM_REQUIRE(io_bf16 == nullptr || io_bf16[k] == 0,
@@ -1359,16 +1393,26 @@ extern "C" int nlam_wide_outer_multi(int n, int d, const float* const* g, const 
   m.n = 0;
   for (int k = 0; k < n; ++k) {
     if (B[k] <= 0 || rows[k] <= 0) continue;
-    if (wide_outer_fill(m.p[m.n], g[k], g_bstride[k], g_ld[k], 128, x[k], x_bstride[k], x_ld[k], 128,
-                        silu_x[k], slab[k], slab_stride[k], B[k], rows[k]))
+    if (wide_outer_fill(m.p[m.n], g[k], g_bstride[k], g_ld[k], 128, x[k], x_bstride[k], x_ld[k],
+                        nx ? nx[k] : 128, silu_x[k], slab[k], slab_stride[k], B[k], rows[k]))
       return 1;
     counts[m.n] = nslabs[k];
     ++m.n;
   }
   if (m.n == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
-  return nlam_mfma_terms() == 3 ? launch_wide_outer<4, 4, 3>(m, s, counts)
-                                : launch_wide_outer<4, 4, 1>(m, s, counts);
+  const bool t3 = nlam_mfma_terms() == 3;
+  if (nx != nullptr) {
+    int nxmax = 0;
+    for (int k = 0; k < n; ++k) nxmax = nx[k] > nxmax ? nx[k] : nxmax;
+    // (wide_outer_fill checked every slab against ITS nx; the kernel writes 32 NXB columns per row)
+    const int nxp = nxmax <= 32 ? 32 : 64;
+    for (int k = 0; k < n; ++k)
+      NLAM_REQUIRE(slab_stride[k] >= (int64_t)128 * nxp + 128, "nlam_wide_outer_multi_nx: slab %d too small", k);
+    if (nxmax <= 32) return t3 ? launch_wide_outer<4, 1, 3>(m, s, counts) : launch_wide_outer<4, 1, 1>(m, s, counts);
+    return t3 ? launch_wide_outer<4, 2, 3>(m, s, counts) : launch_wide_outer<4, 2, 1>(m, s, counts);
+  }
+  return t3 ? launch_wide_outer<4, 4, 3>(m, s, counts) : launch_wide_outer<4, 4, 1>(m, s, counts);
 }
 
 // ===================================== projections (first Linear), several per launch ===

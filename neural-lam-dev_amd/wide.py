@@ -389,15 +389,47 @@ def flush_deferred_outers():
         return
     problems = list(_DEFERRED_OUTERS)
     del _DEFERRED_OUTERS[:]
-    by_d = {}
+    by_kind = {}   # (d, 0) = d x d problems; (d, 32 | 64) = narrow x, by slab row width
     for pr in problems:
-        by_d.setdefault(pr[0].cols, []).append(pr)
+        d, nx = pr[0].cols, pr[1].cols
+        by_kind.setdefault((d, 0 if nx == d else (32 if nx <= 32 else 64)), []).append(pr)
     with ops.tag("deferred"):
-        for prs in by_d.values():
+        for (d, nxp), prs in by_kind.items():
             for i in range(0, len(prs), OUTER_MAXP):
                 # (each merged launch's slabs are reduced at once, while the Infinity Cache has them)
                 with ops.slab_batch():
-                    outer_multi(prs[i : i + OUTER_MAXP])
+                    (outer_multi if nxp == 0 else outer_multi_nx)(prs[i : i + OUTER_MAXP])
+
+
+def outer_multi_nx(problems):
+    """[(g Mat (.., d), x Mat (.., nx <= 64), dW (d, nx) view, db, _)] -> one launch + its slab
+    reduction (narrow first Linears; slab rows of 32 ceil(max nx / 32) columns)."""
+    import ctypes
+    d = problems[0][0].cols
+    I64, I32 = ctypes.c_int64, ctypes.c_int32
+    n = len(problems)
+    dev = problems[0][2].device
+    nxp = 32 if max(x.cols for _, x, _, _, _ in problems) <= 32 else 64
+    stride = d * nxp + d
+    ns = [int(lib.nlam_bwd_grid(g.B * ((g.rows + 31) // 32))) for g, _, _, _, _ in problems]
+    slabs = [torch.empty(nsl * stride, dtype=torch.float32, device=dev) for nsl in ns]
+    _launch(
+        "nlam_wide_outer_multi", lib.nlam_wide_outer_multi_nx,
+        (n, d, _parr([g.ptr for g, _, _, _, _ in problems]),
+         _arr(I64, [g.bstride for g, _, _, _, _ in problems]),
+         _arr(I64, [g.ld for g, _, _, _, _ in problems]),
+         _parr([x.ptr for _, x, _, _, _ in problems]),
+         _arr(I64, [x.bstride for _, x, _, _, _ in problems]),
+         _arr(I64, [x.ld for _, x, _, _, _ in problems]),
+         _arr(I32, [x.cols for _, x, _, _, _ in problems]),
+         _parr([sl.data_ptr() for sl in slabs]), _arr(I64, [stride] * n),
+         _arr(I64, [g.B for g, _, _, _, _ in problems]),
+         _arr(I64, [g.rows for g, _, _, _, _ in problems]), _arr(I32, ns), stream()),
+        flops=sum(2.0 * g.B * g.rows * d * x.cols for g, x, _, _, _ in problems),
+        nbytes=sum(1.0 * g.B * g.rows * (d * _esz(g) + x.cols * _esz(x)) for g, x, _, _, _ in problems),
+    )
+    for (g, x, dW, db, _), sl, nsl in zip(problems, slabs, ns):
+        ops.reduce_segments(sl, nsl, stride, [(0, d, x.cols, nxp, dW), (d * nxp, 1, d, d, db)])
 
 
 def outer_multi(problems):
@@ -461,8 +493,9 @@ def _first_linear_bwd(x, ga, W, need_gx, gx_add, dW, db, dev, deferred=False):
             ops.linear_bwd_data(ga, W, mat(gx))
             if gx_add is not None:
                 ops.add_rows(mat(gx), gx_add, mat(gx))
-    if deferred and wide_ok and ga.B * ga.rows <= DEFER_OUTER_ROWS:
-        defer_outers([(ga, x, dW, db, False)])
+    if deferred and (wide_ok or k_in <= 64) and not is_bf16(ga) and not is_bf16(x) \
+            and ga.B * ga.rows <= DEFER_OUTER_ROWS:
+        defer_outers([(ga, x, dW, db, False)])   # (d x d, or a narrow first Linear: its own merged launches)
     elif wide_ok or k_in <= 64:
         outer(ga, x, dW, db)    # (narrow / unaligned static features: scalar staging, K padded)
     else:

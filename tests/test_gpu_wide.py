@@ -381,7 +381,9 @@ def test_deferred_slab_reductions_leave_the_training_step_unchanged(ar_steps, mo
     for (k, _), a, b in zip(model.named_parameters(), g_on, g_lay):
         scale = float(b.abs().max()) + 1e-30
         assert float((a - b).abs().max()) <= 5e-6 * scale, (k, float((a - b).abs().max()) / scale)
-    assert r_on < r_off / 2, (r_on, r_off)   # (a multi-step rollout embeds the static features up front, undeferred)
+    # (every merged weight-gradient launch is followed by the reduction of its own slabs; a
+    # multi-step rollout embeds the static features up front, undeferred)
+    assert r_on <= 0.6 * r_off, (r_on, r_off)
     assert l_on == l_off
     # (the same slab sums; which reduction kernel form takes a segment depends on what shares its
     # launch, so the order of the fp32 additions -- not the set of addends -- may differ)
