@@ -469,10 +469,13 @@ MAX_SEGS = 64
 # weight gradients of a layer feed nothing inside the backward, so the reductions of ALL layers of
 # one predict_step can run as a few large launches instead of one small launch per layer.  Safe
 # only when nothing reads the destinations before flush_deferred(): the layers that defer take
-# their parameters through glue.DeferGrad (an identity node created at the START of predict_step;
-# the autograd engine runs ready nodes latest-created first, so its backward -- the flush -- runs
-# after every layer of the step and before anything that touches the gradients: input-buffer sums,
-# AccumulateGrad).  An engine callback flushes at the end of the pass as well (a node that never ran).
+# their parameters through glue.DeferGrad, an identity node between the parameters and the layers,
+# created at the START of predict_step: every gradient of a deferring layer reaches its parameter
+# (input-buffer sums, AccumulateGrad, hooks) only THROUGH that node, whose backward -- the flush --
+# cannot run before every layer that took parameters from it has run (the engine's dependency
+# count), and, being the earliest-created node of the step, is not run before the step's other
+# ready nodes either.  An engine callback flushes at the end of the pass as well (a node that
+# never ran: nobody asked for parameter gradients).
 _DEFERRED = []
 _DEFER_TASK = [None]
 # gradient reducers that overlap their bucket all-reduces with the backward through per-parameter
