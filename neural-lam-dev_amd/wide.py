@@ -361,6 +361,7 @@ def lin_bwd_data_multi(problems):
 # slabs of a weight-gradient launch: in all / average floor per problem (tunables; see outer_multi)
 _OUTER_BUDGET = int(os.environ.get("NLAM_OUTER_BUDGET", "256"))
 _OUTER_FLOOR = int(os.environ.get("NLAM_OUTER_FLOOR", "64"))
+_OUTER_FLOOR_MERGED = int(os.environ.get("NLAM_OUTER_FLOOR_MERGED", "16"))
 _OUTER_MIN_TILES = int(os.environ.get("NLAM_OUTER_MIN_TILES", "8"))   # 32-row tiles per slab, at least
 
 
@@ -447,7 +448,9 @@ def outer_multi(problems):
     # 19.89 / 32.19; an average below 64 per problem 20.7 / 33.8
     tiles = [g.B * ((g.rows + 31) // 32) for g, _, _, _, _ in problems]
     total = max(1, sum(tiles))
-    budget = max(_OUTER_BUDGET, _OUTER_FLOOR * n)
+    # (merged end-of-step launches, n up to 24: an average of 16 slabs per problem -- measured on
+    # Hi-LAM-256 / -128 for 64 / 32 / 16 / 8: 29.37 / 29.28 / 29.19 / 30.5 ms and 17.77 / 17.70 / 17.71 / 18.1)
+    budget = max(_OUTER_BUDGET, (_OUTER_FLOOR if n <= 8 else _OUTER_FLOOR_MERGED) * n)
     slabs, ns = [], []
     for t in tiles:
         nsl = max(1, min(int(lib.nlam_bwd_grid(t)), -(-budget * t // total), -(-t // _OUTER_MIN_TILES)))
