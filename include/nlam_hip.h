@@ -602,6 +602,24 @@ int nlam_tail_fwd_pre(int64_t rows, const float* a, int64_t a_bstride, int64_t a
                       const float* gamma, const float* beta, float* h_out, int64_t h_bstride,
                       float* y, int64_t y_bstride, int64_t y_ld, const float* res,
                       int64_t res_bstride, int64_t res_ld, int64_t B, int d, void* stream);
+/* Several independent MLP tails in one launch (n <= 8): y_k = LN(W2_k silu(h_k) + b2_k) for
+ * contiguous h_k, y_k (B_k, rows_k, 128) -- the static-feature embedders of a model (reference
+ * base_graph_model.py:127-130, base_hi_graph_model.py:137-166: ten small, mutually independent MLPs
+ * at the start of every Hi-LAM step); backward: gz_k = LN'(z_k; gy_k) and gh_k = (W2_k^T gz_k) *
+ * silu'(h_k) as nlam_tail_bwd, dgamma / dbeta partials in slab_k (nslabs[k] =
+ * nlam_mlp_tail_multi_shares slabs of nlam_tail_bwd_slab_stride(128) floats).  The kernels are the
+ * bodies of nlam_tail_fwd / nlam_tail_bwd compiled a second time around a per-problem block
+ * range (csrc/tail_fwd_body.h, tail_bwd_body.h): the same arithmetic in the same order. */
+int nlam_mlp_tail_multi_shares(int n, const int64_t* B, const int64_t* rows, int32_t* shares);
+int nlam_mlp_tail_fwd_multi(int n, int d, const float* const* h, const float* const* W2,
+                            const int64_t* ldW2, const float* const* b2, const float* const* gamma,
+                            const float* const* beta, float* const* y, const int64_t* B,
+                            const int64_t* rows, void* stream);
+int nlam_mlp_tail_bwd_multi(int n, int d, const float* const* h, const float* const* gy,
+                            const float* const* W2, const int64_t* ldW2, const float* const* b2,
+                            const float* const* gamma, float* const* gz_out, float* const* gh,
+                            float* const* slab, const int32_t* nslabs, const int64_t* B,
+                            const int64_t* rows, void* stream);
 /* Backward of nlam_tail_fwd from the kept h:  g[p] = scale1[idx_g1[p]] * g1[idx_g1[p]] +
  * g2[idx_g2[p]] is the gradient of m[p];  gz = LN'(z; g) (= g without LayerNorm) is written to
  * gz_out (B, rows, ceil32(n_out)) for the weight-gradient pass;  gh[idx_gh[p]] =

@@ -104,6 +104,9 @@ SIGNATURES = {
     "nlam_tail_fwd_pre_supported": [_i32, _i64, _i64],
     "nlam_tail_fwd_pre": [_i64, _p, _i64, _i64, _p, _i64, _i64, _p, _i64, _p, _i64, _p, _p, _p,
                           _p, _i64, _p, _i64, _i64, _p, _i64, _i64, _i64, _i32, _p],
+    "nlam_mlp_tail_multi_shares": [_i32, _p, _p, _p],
+    "nlam_mlp_tail_fwd_multi": [_i32, _i32] + [_p] * 9 + [_p],
+    "nlam_mlp_tail_bwd_multi": [_i32, _i32] + [_p] * 12 + [_p],
     "nlam_tail_bwd_slab_stride": [_i32],
     "nlam_tail_bwd": [_p, _i64, _i64, _p, _p, _p, _i64, _p, _i64,
                       _p, _i64, _i64, _p, _p, _p, _i64, _i64, _p,

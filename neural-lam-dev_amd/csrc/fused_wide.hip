@@ -165,247 +165,27 @@ struct TailFwdParams {
 
 template <int D, int NOUTB, bool HAS_LN, int TERMS, bool STAMP = false, bool PRE = false>
 __global__ __launch_bounds__(256) void tail_fwd_kernel(TailFwdParams p) {
-  static_assert(!PRE || (HAS_LN && 32 * NOUTB == D), "PRE: the node update (n_out == D, LayerNorm)");
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int NB = D / 32, NV = D / 8, NO = 32 * NOUTB;
-  constexpr int LDT = D + 4;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float* W2s = smem;
-  float* b2s = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + b3_image_bytes(NO, D));
-  float* gs = b2s + NO;
-  float* bs = gs + NO;
-  float* tile = bs + NO + wave * (NLAM_TILE * LDT);
-  // per-wave slot-index tables [a | b | c | y] (see lane_row_index)
-  int* itab = reinterpret_cast<int*>(bs + NO + 4 * (NLAM_TILE * LDT)) + wave * (4 * NLAM_TILE);
-  const B3Image W2im = b3_image(W2s, NO, D);
-  // slot indices of a tile (lanes 0..31), fetched ONE TILE AHEAD so that the row gathers do
-  // not wait for an index load
-  struct Ctx { WTile w; int ia, ib, ic, iy, rcv; };
-  auto load_hdr = [&](int64_t task, int64_t total) {
-    const int64_t tq = task < total ? task : total - 1;
-    const int64_t bq = tq / p.tl.ntiles;
-    return wide_tile(p.tl, tq - bq * p.tl.ntiles);
-  };
-  auto load_idx = [&](const WTile& w) {
-    Ctx c;
-    c.w = w;
-    c.rcv = p.tl.csr_rec ? wide_index(p.tl.csr_rec, c.w, lane) : 0;
-    c.ia = wide_index(p.idx_a, c.w, lane);
-    c.ib = p.b.ptr ? wide_index(p.idx_b, c.w, lane) : 0;
-    c.ic = p.c.ptr ? wide_index(p.idx_c, c.w, lane) : 0;
-    c.iy = wide_index(p.idx_y, c.w, lane);
-    return c;
-  };
-  auto load_ctx = [&](int64_t task, int64_t total) { return load_idx(load_hdr(task, total)); };
-  const int64_t total = p.tl.ntiles * p.B;
-  const int64_t tstride = (int64_t)gridDim.x * 4;
-  int64_t tt = (int64_t)blockIdx.x * 4 + wave;
-  // Prologue as ONE chain of overlapping round trips (most launches of the hierarchical models
-  // are one tile per wave, i.e. all prologue): first tile's header, then the weights and vectors
-  // (in flight), then the slot indices as soon as the header is there, then the LDS images.
-  Ctx cur;
-  {
-    static_assert(NO <= 256, "one vector entry per thread");
-    const int64_t tq0 = tt < total ? tt : total - 1;
-    // (wave-uniform by construction; readfirstlane lets the header come through the scalar
-    // cache, on its own counter, so waiting for it does not wait for the weight loads)
-    const int64_t k0 = __builtin_amdgcn_readfirstlane((int)(tq0 - (tq0 / p.tl.ntiles) * p.tl.ntiles));
-    const int4 hdr0 = wide_tile_raw(p.tl, k0);
-    __builtin_amdgcn_sched_barrier(0);
-    VecLoads<3> lv;
-    const float* const vsrc[3] = {p.b2, p.gamma, p.beta};
-    float* const vdst[3] = {b2s, gs, bs};
-    vecs_issue(lv, vsrc, p.n_out, tid);
-    WLoad16<16> lw;
-    const float* const W0 = PRE ? p.preW : p.W2;
-    const int64_t ldW0 = PRE ? p.ldpreW : p.ldW2;
-    w16_issue(lw, W0, ldW0, p.n_out, D, NO, D, tid, 256);
-    __builtin_amdgcn_sched_barrier(0);
-    cur = load_idx(wide_tile_decode(p.tl, k0, hdr0));
-    w16_commit(lw, W2im, 0, W0, ldW0, p.n_out, D, NO, D, tid, 256);
-    vecs_commit(lv, vdst, NO, tid);
-  }
-  __syncthreads();
-  // PRE: every wave of the workgroup swaps the weight image once (between the two barriers)
-  auto swap_to_W2 = [&]() {
-    __syncthreads();
-    WLoad16<16> lw;
-    w16_issue(lw, p.W2, p.ldW2, p.n_out, D, NO, D, tid, 256);
-    w16_commit(lw, W2im, 0, p.W2, p.ldW2, p.n_out, D, NO, D, tid, 256);
-    __syncthreads();
-  };
-  if (tt >= total) {
-    if constexpr (PRE) swap_to_W2();
-    return;
-  }
-  unsigned long long wst[STAMP ? 8 : 1] = {0};
-  unsigned long long wprev = STAMP ? __builtin_amdgcn_s_memtime() : 0;
-  for (; tt < total; tt += tstride) {
-    const int64_t b = tt / p.tl.ntiles;
-    const WTile w = cur.w;
-    const int ne = w.ne;
-    const int rcv = cur.rcv;
-    stash_slot_index(itab, cur.ia, lane);
-    stash_slot_index(itab + NLAM_TILE, cur.ib, lane);
-    stash_slot_index(itab + 2 * NLAM_TILE, cur.ic, lane);
-    stash_slot_index(itab + 3 * NLAM_TILE, cur.iy, lane);
-    wave_sync();
-    int iy[NV];
-    lane_row_index<NV>(iy, itab + 3 * NLAM_TILE, D, lane);
-    f32x4 vA[NV];
-    {
-      int ia[NV];
-      lane_row_index<NV>(ia, itab, D, lane);
-      load_rows_i<NV>(vA, p.a.ptr + b * p.a.bstride, p.a.ld, ia, D, lane);
-    }
-    // residual rows of the output (e' = e + m): requested with the gathers, used at the very end
-    // of the tile -- their HBM round trip rides under the whole tile.  (Inside the store loop
-    // each load was its own basic block with a full wait: 16 serialized round trips per tile,
-    // half of the kernel's time: tools/stamp_wide.py.)  Padded slots carry the clamped index
-    // of the tile's last row.
-    const bool res_rows = p.y != nullptr && p.res.ptr != nullptr && p.vec_y && NO == D;
-    f32x4 vRes[NV];
-    const Ctx nxt = load_ctx(tt + tstride, total);   // (lands during this tile's work)
-    if (p.b.ptr) {
-      f32x4 vB[NV];
-      {
-        int ib[NV];
-        lane_row_index<NV>(ib, itab + NLAM_TILE, D, lane);
-        load_rows_i<NV>(vB, p.b.ptr + b * p.b.bstride, p.b.ld, ib, D, lane);
-      }
-      if (p.c.ptr) {
-        f32x4 vC[NV];
-        int ic[NV];
-        lane_row_index<NV>(ic, itab + 2 * NLAM_TILE, D, lane);
-        load_rows_i<NV>(vC, p.c.ptr + b * p.c.bstride, p.c.ld, ic, D, lane);
-#pragma unroll
-        for (int k = 0; k < NV; ++k) vB[k] += vC[k];
-      }
-#pragma unroll
-      for (int k = 0; k < NV; ++k) vA[k] += vB[k];
-    }
-    // (requested AFTER the gathers were waited for: memory operations retire in order, and the
-    // residual rows are not needed before the end of the tile)
-    if (res_rows) load_rows_i<NV>(vRes, p.res.ptr + b * p.res.bstride, p.res.ld, iy, D, lane);
-    f32x4 vP[PRE ? NV : 1];
-    if constexpr (PRE) {   // (contiguous rows p0 .. p0 + ne - 1 of the projected operand)
-      const float* pb = p.pre.ptr + b * p.pre.bstride + (int64_t)w.p0 * p.pre.ld;
-      const int last = ne > 0 ? ne - 1 : 0;
-      load_rows_v<NV>(vP, D, lane, [&](int s2) { return pb + (int64_t)(s2 < last ? s2 : last) * p.pre.ld; });
-    }
-    if (!PRE && p.h_out != nullptr)
-      store_rows_regs<NV>(p.h_out + b * p.h_bstride + (int64_t)w.p0 * D, D, D, ne, lane, vA);
-    WSTAMP(0)   // slot tables, row gathers a / b / c issued + landed + summed, h rows stored
-    put_rows_v<NV, false>(tile, LDT, 0, D, ne, lane, vA);
-    wave_sync();
-    f32x16 a1[NB];
-    tile_to_acc<NB>(a1, tile, LDT, lane);
-    if constexpr (PRE) {
-      // h = a + pre . preW^T with preW's image in LDS, then W2's image takes its place
-      wave_sync();
-      put_rows_v<NV, false>(tile, LDT, 0, D, ne, lane, vP);
-      wave_sync();
-      {
-        f32x16 xa[NB];
-        tile_to_acc<NB>(xa, tile, LDT, lane);
-        gemm_acc_b3<NB, NB, TERMS>(a1, W2im, 0, xa, lane);
-      }
-      swap_to_W2();
-      if (p.h_out != nullptr) {
-        acc_to_tile<NB>(a1, tile, LDT, lane);
-        wave_sync();
-        float* hb = p.h_out + b * p.h_bstride + (int64_t)w.p0 * D;
-        store_rows<true>(tile, LDT, 0, D, ne, lane, [&](int s2) { return hb + (int64_t)s2 * D; });
-        wave_sync();
-      }
-    }
-    WSTAMP(1)   // h tile staged + back in accumulator layout
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) a1[nb][r] = nlam_silu(a1[nb][r]);
-    f32x16 m[NOUTB];
-    vec_to_acc<NOUTB>(m, b2s, lane);
-    WSTAMP(2)   // silu
-    gemm_acc_b3<NOUTB, NB, TERMS>(m, W2im, 0, a1, lane);
-    WSTAMP(3)   // GEMM (W2 silu(h) + b2)
-    if (HAS_LN) ln_apply<NOUTB>(m, gs, bs, lane);
-    wave_sync();
-    acc_to_tile<NOUTB>(m, tile, LDT, lane);
-    wave_sync();
-    WSTAMP(4)   // LayerNorm + message tile
-    if (p.agg != nullptr) {
-      float* aggb = p.agg + b * p.agg_bstride;
-      const int t = lane & 31;
-      // lane i <= nr: segment boundaries of the tile's receivers (edge mode only)
-      const int ri = w.r0 + (lane < w.nr ? lane : w.nr);
-      const int rp = p.tl.csr_rowptr[ri] - w.p0;
-      const float invd = p.inv_deg ? p.inv_deg[w.r0 + (lane < w.nr ? lane : 0)] : 1.0f;
-      const int rpn = __shfl_down(rp, 1, 64);
-      const bool dense = __all((lane >= w.nr) || (rpn > rp));
-      (void)t;
-      if (dense) {
-        tile_segment_sums<NO>(tile, LDT, ne, rcv, lane, [&](int r, int f0, float acc) {
-          const float sc = __shfl(invd, r - w.r0, 64);
-          aggb[(int64_t)r * p.agg_ld + f0 + lane] = acc * sc;
-        });
-      } else {
-        for (int i = 0; i < w.nr; ++i) {
-          const int beg = __shfl(rp, i, 64), end = __shfl(rp, i + 1, 64);
-          const float sc = __shfl(invd, i, 64);
-#pragma unroll
-          for (int f0 = 0; f0 < NO; f0 += 64) {
-            float acc = 0.f;
-            for (int s = beg; s < end; ++s) acc += tile[s * LDT + f0 + lane];
-            aggb[(int64_t)(w.r0 + i) * p.agg_ld + f0 + lane] = acc * sc;
-          }
-        }
-      }
-    }
-    WSTAMP(5)   // receiver sums
-    if (p.y != nullptr) {
-      // scattered rows (idx_y) are float4-only (checked on the host); narrow outputs are
-      // contiguous rows and take the scalar path
-      float* yb = p.y + b * p.y_bstride;
-      const float* rb = p.res.ptr ? p.res.ptr + b * p.res.bstride : nullptr;
-      if (p.vec_y && NO == D) {
-        if (rb) {
-          // (residual rows: requested at the top of the tile)
-          constexpr int lpr = D >> 2, rpi = 64 / lpr;
-          const int sub = lane / lpr, c4 = lane - sub * lpr;
-#pragma unroll
-          for (int k = 0; k < NV; ++k) {
-            const int tr = sub + k * rpi;
-            if (tr < ne) {
-              const f32x4 x = *(reinterpret_cast<const f32x4*>(tile + tr * LDT) + c4) + vRes[k];
-              reinterpret_cast<f32x4*>(yb + (int64_t)iy[k] * p.y_ld)[c4] = x;
-            }
-          }
-        } else {
-          store_rows_i<NV, false>(tile, LDT, 0, D, ne, lane, yb, p.y_ld, iy);
-        }
-      } else {
-        auto y_row = [&](int s) { return yb + (int64_t)(w.p0 + s) * p.y_ld; };
-        auto r_row = [&](int s) { return rb + (int64_t)(w.p0 + s) * p.res.ld; };
-        if (rb) {
-          if (p.vec_y) store_rows_res<true>(tile, LDT, 0, p.n_out, ne, lane, y_row, r_row);
-          else store_rows_res<false>(tile, LDT, 0, p.n_out, ne, lane, y_row, r_row);
-        } else {
-          if (p.vec_y) store_rows<true>(tile, LDT, 0, p.n_out, ne, lane, y_row);
-          else store_rows<false>(tile, LDT, 0, p.n_out, ne, lane, y_row);
-        }
-      }
-    }
-    wave_sync();
-    WSTAMP(6)   // row stores (+ residual)
-    cur = nxt;
-  }
-  if constexpr (STAMP) {
-    if (lane == 0) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) atomicAdd(&g_wide_stamps[k], wst[k]);
-    }
-  }
+#define TAIL_BID blockIdx.x
+#define TAIL_NBLK gridDim.x
+#include "tail_fwd_body.h"
+#undef TAIL_BID
+#undef TAIL_NBLK
+}
+
+// Several independent MLP tails in one launch (the static-feature embedders of a model: ten small
+// problems at the start of a Hi-LAM step, latency each): workgroup b serves problem k with
+// first[k] <= b < first[k + 1] as block b - first[k] of that share.  The same body text.
+constexpr int TAIL_MAXP = 8;   // (kernel argument block: 8 x ~390 B)
+template <int D, int NOUTB, bool HAS_LN, int TERMS>
+__global__ __launch_bounds__(256) void tail_fwd_multi_kernel(WideMulti<TailFwdParams, TAIL_MAXP> m) {
+  constexpr bool STAMP = false, PRE = false;
+  const int k_ = wide_multi_find(m, (int)blockIdx.x);
+  const TailFwdParams& p = m.p[k_];
+#define TAIL_BID (blockIdx.x - (unsigned)m.first[k_])
+#define TAIL_NBLK ((unsigned)(m.first[k_ + 1] - m.first[k_]))
+#include "tail_fwd_body.h"
+#undef TAIL_BID
+#undef TAIL_NBLK
 }
 
 static unsigned wide_grid(int64_t total_tiles) {
@@ -577,286 +357,23 @@ struct TailBwdParams {
 
 template <int D, int NOUTB, bool HAS_LN, int TERMS, bool STAMP = false>
 __global__ __launch_bounds__(256) void tail_bwd_kernel(TailBwdParams q) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int NB = D / 32, NV = D / 8, NO = 32 * NOUTB, NVG = NO / 8;
-  constexpr int NV_O = (NO + 63) / 64;
-  constexpr int LDT = D + 4;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int t = lane & 31, hh = lane >> 5;
-  float* W2s = smem;
-  float* b2s = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + b3_image_bytes(NO, D));
-  float* gs = b2s + NO;
-  float* tile = gs + NO + wave * (NLAM_TILE * LDT);
-  int* itab = reinterpret_cast<int*>(gs + NO + 4 * (NLAM_TILE * LDT)) + wave * (4 * NLAM_TILE);
-  const B3Image W2im = b3_image(W2s, NO, D);
-  // slot indices / row scales of a tile (lanes 0..31), fetched one tile ahead
-  struct Ctx { WTile w; int i1, i2, igh, rcv; float sc1; };
-  auto load_idx = [&](const WTile& w) {
-    Ctx c;
-    c.w = w;
-    c.rcv = q.tl.csr_rec ? wide_index(q.tl.csr_rec, c.w, lane) : 0;
-    c.i1 = wide_index(q.idx_g1, c.w, lane);
-    c.i2 = q.g2.ptr ? wide_index(q.idx_g2, c.w, lane) : 0;
-    c.igh = wide_index(q.idx_gh, c.w, lane);
-    c.sc1 = q.scale1 ? q.scale1[c.i1] : 1.0f;   // (dependent load, hidden by the prefetch)
-    return c;
-  };
-  auto load_ctx = [&](int64_t task, int64_t total) {
-    const int64_t tq = task < total ? task : total - 1;
-    const int64_t bq = tq / q.tl.ntiles;
-    return load_idx(wide_tile(q.tl, tq - bq * q.tl.ntiles));
-  };
-  const int64_t total = q.tl.ntiles * q.B;
-  const int64_t tstride = (int64_t)gridDim.x * 4;
-  int64_t tt = (int64_t)blockIdx.x * 4 + wave;
-  // prologue: first tile's header (scalar load), weights + vectors in flight, then the slot
-  // indices, then the LDS images (see tail_fwd_kernel)
-  Ctx cur;
-  {
-    static_assert(NO <= 256, "one vector entry per thread");
-    const int64_t tot1 = total > 0 ? total : 1;
-    const int64_t tq0 = tt < tot1 ? tt : tot1 - 1;
-    const int64_t k0 = __builtin_amdgcn_readfirstlane((int)(tq0 - (tq0 / q.tl.ntiles) * q.tl.ntiles));
-    const int4 hdr0 = wide_tile_raw(q.tl, k0);
-    __builtin_amdgcn_sched_barrier(0);
-    VecLoads<2> lv;
-    const float* const vsrc[2] = {q.b2, q.gamma};
-    float* const vdst[2] = {b2s, gs};
-    vecs_issue(lv, vsrc, q.n_out, tid);
-    WLoad16<16> lw;
-    w16_issue(lw, q.W2, q.ldW2, q.n_out, D, NO, D, tid, 256);
-    __builtin_amdgcn_sched_barrier(0);
-    cur = load_idx(wide_tile_decode(q.tl, k0, hdr0));
-    w16_commit(lw, W2im, 0, q.W2, q.ldW2, q.n_out, D, NO, D, tid, 256);
-    vecs_commit(lv, vdst, NO, tid);
-  }
-  __syncthreads();
+#define TAIL_BID blockIdx.x
+#define TAIL_NBLK gridDim.x
+#include "tail_bwd_body.h"
+#undef TAIL_BID
+#undef TAIL_NBLK
+}
 
-  // per-feature partial sums (lanes = features 64 j + lane), accumulated over the tiles
-  float dgam[NV_O], dbet[NV_O];
-#pragma unroll
-  for (int j = 0; j < NV_O; ++j) dgam[j] = dbet[j] = 0.f;
-  const B3Tile Tp = b3_tile(tile, NO);   // bf16-plane view of the tile (column sums)
-  unsigned long long wst[STAMP ? 8 : 1] = {0};
-  unsigned long long wprev = STAMP ? __builtin_amdgcn_s_memtime() : 0;
-  for (; tt < total; tt += tstride) {
-    const int64_t b = tt / q.tl.ntiles;
-    const WTile w = cur.w;
-    const int ne = w.ne;
-    const int i1 = cur.i1, i2 = cur.i2;
-    const int rcv = cur.rcv;
-    const float sc1 = cur.sc1;
-    // per-wave slot tables [g1 | g2 | gh | scale bits] -> per-lane row indices
-    stash_slot_index(itab, cur.i1, lane);
-    stash_slot_index(itab + NLAM_TILE, cur.i2, lane);
-    stash_slot_index(itab + 2 * NLAM_TILE, cur.igh, lane);
-    stash_slot_index(itab + 3 * NLAM_TILE, __float_as_int(cur.sc1), lane);
-    wave_sync();
-    const Ctx nxt = load_ctx(tt + tstride, total);
-    const float* g1b = q.g1.ptr + b * q.g1.bstride;
-    const float* g2b = q.g2.ptr ? q.g2.ptr + b * q.g2.bstride : nullptr;
-    auto g1_row = [&](int s) { return g1b + (int64_t)__shfl(i1, s, 64) * q.g1.ld; };
-    auto g2_row = [&](int s) { return g2b + (int64_t)__shfl(i2, s, 64) * q.g2.ld; };
-    // ---- h rows (contiguous) -> tile -> accumulator layout.  h is staged twice (here for
-    // s = silu(h), below for silu'(h)) instead of living in 64 registers across the whole
-    // tile: at d = 128 that is the difference between spilling and not (L2-hot re-read).
-    const float* hb = q.h + b * q.h_bstride + (int64_t)(ne > 0 ? w.p0 : (w.p0 > 0 ? w.p0 - 1 : 0)) * D;
-    const int last = ne > 0 ? ne - 1 : 0;
-    auto h_row = [&](int s) { return hb + (int64_t)(s < last ? s : last) * D; };
-    {
-      f32x4 vH[NV];
-      load_rows_v<NV>(vH, D, lane, h_row);
-      put_rows_v<NV, false>(tile, LDT, 0, D, ne, lane, vH);
-      wave_sync();
-    }
-    WSTAMP(0)   // slot tables, h rows requested + landed + staged
-    // ---- incoming gradient rows -> tile (their loads fly under the GEMM below)
-    f32x4 vG[NVG];
-    if (q.vec_g) {
-      // per-lane row indices (and row scales) straight from the tables: no shuffles
-      int ig[NVG];
-      lane_row_index<NVG>(ig, itab, NO, lane);
-      load_rows_i<NVG>(vG, g1b, q.g1.ld, ig, NO, lane);
-      if (g2b) {
-        f32x4 vO[NVG];
-        lane_row_index<NVG>(ig, itab + NLAM_TILE, NO, lane);
-        load_rows_i<NVG>(vO, g2b, q.g2.ld, ig, NO, lane);
-        if (q.scale1 != nullptr) {
-          lane_row_index<NVG>(ig, itab + 3 * NLAM_TILE, NO, lane);
-#pragma unroll
-          for (int k = 0; k < NVG; ++k) vG[k] *= __int_as_float(ig[k]);
-        }
-#pragma unroll
-        for (int k = 0; k < NVG; ++k) vG[k] += vO[k];
-      } else if (q.scale1 != nullptr) {
-        lane_row_index<NVG>(ig, itab + 3 * NLAM_TILE, NO, lane);
-#pragma unroll
-        for (int k = 0; k < NVG; ++k) vG[k] *= __int_as_float(ig[k]);
-      }
-    }
-    f32x16 z[NOUTB];
-    if (HAS_LN) {
-      f32x16 sact[NB];
-      tile_to_acc<NB>(sact, tile, LDT, lane);
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sact[nb][r] = nlam_silu(sact[nb][r]);
-      vec_to_acc<NOUTB>(z, b2s, lane);
-      gemm_acc_b3<NOUTB, NB, TERMS>(z, W2im, 0, sact, lane);
-    }
-    WSTAMP(1)   // gradient rows issued, silu, GEMM (z recomputed)
-    wave_sync();
-    if (q.vec_g) {
-      put_rows_v<NVG, false>(tile, LDT, 0, NO, ne, lane, vG);
-    } else {
-      // narrow / unaligned gradient rows (e.g. the 17-wide output map): scalar staging
-      // (uniform trip count; the index shuffles stay outside the divergent part)
-      for (int idx = lane; idx < NLAM_TILE * NO; idx += 64) {
-        const int tr = idx / NO, cc = idx - tr * NO;
-        const float* r1 = g1_row(tr);
-        const float* r2 = g2b ? g2_row(tr) : nullptr;
-        const float sc = __shfl(sc1, tr, 64);
-        float v = 0.f;
-        if (tr < ne && cc < q.n_out) {
-          v = r1[cc] * sc;
-          if (r2) v += r2[cc];
-        }
-        tile[tr * LDT + cc] = v;
-      }
-    }
-    wave_sync();
-    f32x16 g[NOUTB];
-    tile_to_acc<NOUTB>(g, tile, LDT, lane);
-    if (HAS_LN) {
-      constexpr float inv_d = 1.0f / (float)NO;
-      float mean, rstd;
-      ln_stats<NOUTB>(z, mean, rstd);
-      // dbeta: column sums of the incoming gradient, on the matrix cores from bf16 planes
-      wave_sync();
-      acc_to_tile_b3<NOUTB>(g, Tp, 0, lane);
-      wave_sync();
-      tile_colsum_b3<NV_O, TERMS>(dbet, Tp, 0, lane);
-      wave_sync();
-      float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int nb = 0; nb < NOUTB; ++nb) {
-        f32x16 prod[1];
-#pragma unroll
-        for (int qq = 0; qq < 4; ++qq) {
-          const f32x4 gm = *reinterpret_cast<const f32x4*>(gs + 32 * nb + 8 * qq + 4 * hh);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int r = 4 * qq + j;
-            const float xh = (z[nb][r] - mean) * rstd;
-            z[nb][r] = xh;
-            prod[0][r] = g[nb][r] * xh;          // gy * xhat -> dgamma
-            const float gv = g[nb][r] * gm[j];
-            g[nb][r] = gv;
-            s1 += gv;
-            s2 += gv * xh;
-          }
-        }
-        acc_to_tile_b3<1>(prod, Tp, 32 * nb, lane);
-      }
-      wave_sync();
-      tile_colsum_b3<NV_O, TERMS>(dgam, Tp, 0, lane);
-      s1 = lane_xor32_sum(s1);
-      s2 = lane_xor32_sum(s2);
-      const float m1 = s1 * inv_d, m2 = s2 * inv_d;
-#pragma unroll
-      for (int nb = 0; nb < NOUTB; ++nb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) g[nb][r] = rstd * (g[nb][r] - m1 - z[nb][r] * m2);
-    }
-    WSTAMP(2)   // gradient rows staged, LayerNorm backward, dbeta / dgamma column sums
-    // g = gz (zero on padded slots / columns): publish it for the weight-gradient pass
-    wave_sync();
-    acc_to_tile<NOUTB>(g, tile, LDT, lane);
-    wave_sync();
-    {
-      float* gzb = q.gz_out + b * q.gz_bstride + (int64_t)w.p0 * NO;
-      auto gz_row = [&](int s) { return gzb + (int64_t)s * NO; };
-      store_rows<true>(tile, LDT, 0, NO, ne, lane, gz_row);
-    }
-    WSTAMP(3)   // gz tile + row stores
-    // gh = (W2^T gz) * silu'(h)
-    f32x16 gh[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) gh[nb][r] = 0.f;
-    {
-      // h again (its loads fly under the GEMM)
-      f32x4 vH[NV];
-      load_rows_v<NV>(vH, D, lane, h_row);
-      gemm_acc_wt_b3<NB, NOUTB, TERMS>(gh, W2im, 0, g, lane);
-      wave_sync();   // (the gz rows of the tile are stored)
-      put_rows_v<NV, false>(tile, LDT, 0, D, ne, lane, vH);
-      wave_sync();
-    }
-    WSTAMP(4)   // h rows again + GEMM (W2^T gz)
-    {
-      f32x16 hpre[NB];
-      tile_to_acc<NB>(hpre, tile, LDT, lane);
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) gh[nb][r] *= nlam_silu_grad(hpre[nb][r]);
-    }
-    wave_sync();
-    acc_to_tile<NB>(gh, tile, LDT, lane);
-    wave_sync();
-    {
-      float* ghb = q.gh + b * q.gh_bstride;
-      int igh[NV];
-      lane_row_index<NV>(igh, itab + 2 * NLAM_TILE, D, lane);
-      store_rows_i<NV, false>(tile, LDT, 0, D, ne, lane, ghb, q.gh_ld, igh);
-    }
-    WSTAMP(5)   // silu', gh tile + row stores
-    if (q.gpr != nullptr) {
-      float* gb = q.gpr + b * q.gpr_bstride;
-      const int ri = w.r0 + (lane < w.nr ? lane : w.nr);
-      const int rp = q.tl.csr_rowptr[ri] - w.p0;
-      const int rpn = __shfl_down(rp, 1, 64);
-      const bool dense = __all((lane >= w.nr) || (rpn > rp));
-      if (dense) {
-        tile_segment_sums<D>(tile, LDT, ne, rcv, lane, [&](int r, int f0, float acc) {
-          gb[(int64_t)r * q.gpr_ld + f0 + lane] = acc;
-        });
-      } else {
-        for (int i = 0; i < w.nr; ++i) {
-          const int beg = __shfl(rp, i, 64), end = __shfl(rp, i + 1, 64);
-#pragma unroll
-          for (int f0 = 0; f0 < D; f0 += 64) {
-            float acc = 0.f;
-            for (int s = beg; s < end; ++s) acc += tile[s * LDT + f0 + lane];
-            gb[(int64_t)(w.r0 + i) * q.gpr_ld + f0 + lane] = acc;
-          }
-        }
-      }
-    }
-    wave_sync();
-    WSTAMP(6)   // receiver sums
-    cur = nxt;
-  }
-  (void)t;
-  if constexpr (STAMP) {
-    if (lane == 0) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) atomicAdd(&g_wide_stamps[8 + k], wst[k]);
-    }
-  }
-  if (HAS_LN) {
-    __syncthreads();
-    float* img = smem;
-    float* slab = q.slab + (int64_t)blockIdx.x * q.slab_stride;
-    fold_vec_lds<NV_O>(dgam, img, wave, lane);
-    for (int i = tid; i < NO; i += 256) slab[i] = img[i];
-    __syncthreads();
-    fold_vec_lds<NV_O>(dbet, img, wave, lane);
-    for (int i = tid; i < NO; i += 256) slab[NO + i] = img[i];
-  }
+template <int D, int NOUTB, bool HAS_LN, int TERMS>
+__global__ __launch_bounds__(256) void tail_bwd_multi_kernel(WideMulti<TailBwdParams, TAIL_MAXP> m) {
+  constexpr bool STAMP = false;
+  const int k_ = wide_multi_find(m, (int)blockIdx.x);
+  const TailBwdParams& q = m.p[k_];
+#define TAIL_BID (blockIdx.x - (unsigned)m.first[k_])
+#define TAIL_NBLK ((unsigned)(m.first[k_ + 1] - m.first[k_]))
+#include "tail_bwd_body.h"
+#undef TAIL_BID
+#undef TAIL_NBLK
 }
 
 template <int D, int NOUTB, bool HAS_LN, int TERMS>
@@ -935,6 +452,118 @@ extern "C" int nlam_tail_bwd(
   if (gamma != nullptr)
     return t3 ? launch_tail_bwd<128, 4, true, 3>(q, s) : launch_tail_bwd<128, 4, true, 1>(q, s);
   return t3 ? launch_tail_bwd<128, 1, false, 3>(q, s) : launch_tail_bwd<128, 1, false, 1>(q, s);
+}
+
+// ---- several MLP tails (row mode, LayerNorm, n_out = d = 128, no indices / residual) per launch
+// shares[k] = workgroups of problem k (= the slabs its backward writes): proportional to the tiles,
+// one round of the device in all
+extern "C" int nlam_mlp_tail_multi_shares(int n, const int64_t* B, const int64_t* rows, int32_t* shares) {
+  NLAM_REQUIRE(n >= 1 && n <= TAIL_MAXP && B && rows && shares, "nlam_mlp_tail_multi_shares: n %d out of [1, %d]",
+               n, TAIL_MAXP);
+  int64_t rounds[TAIL_MAXP], g[TAIL_MAXP];
+  for (int k = 0; k < n; ++k) {
+    NLAM_REQUIRE(B[k] >= 1 && rows[k] >= 1, "nlam_mlp_tail_multi_shares: empty problem %d", k);
+    rounds[k] = (((rows[k] + NLAM_TILE - 1) / NLAM_TILE) * B[k] + 3) / 4;
+  }
+  nlam_multi_shares(n, rounds, g, 256);
+  for (int k = 0; k < n; ++k) shares[k] = (int32_t)g[k];
+  return 0;
+}
+
+extern "C" int nlam_mlp_tail_fwd_multi(int n, int d, const float* const* h, const float* const* W2,
+                                       const int64_t* ldW2, const float* const* b2,
+                                       const float* const* gamma, const float* const* beta,
+                                       float* const* y, const int64_t* B, const int64_t* rows,
+                                       void* stream) {
+  NLAM_REQUIRE(n >= 1 && n <= TAIL_MAXP && d == 128 && nlam_mfma_terms() != 0,
+               "nlam_mlp_tail_fwd_multi: n %d out of [1, %d], hidden 128, an MFMA mode", n, TAIL_MAXP);
+  WideMulti<TailFwdParams, TAIL_MAXP> m;
+  int32_t shares[TAIL_MAXP];
+  if (nlam_mlp_tail_multi_shares(n, B, rows, shares)) return 1;
+  m.n = n;
+  m.first[0] = 0;
+  for (int k = 0; k < n; ++k) {
+    NLAM_REQUIRE(h[k] && W2[k] && b2[k] && gamma[k] && beta[k] && y[k] && nlam_aligned16(h[k]) &&
+                     nlam_aligned16(y[k]), "nlam_mlp_tail_fwd_multi: operand of problem %d", k);
+    TailFwdParams& p = m.p[k];
+    p.tl = WideTiling{nullptr, (rows[k] + NLAM_TILE - 1) / NLAM_TILE, rows[k], nullptr, nullptr};
+    p.a = RowView{h[k], rows[k] * d, d, d}; p.idx_a = nullptr;
+    p.b = RowView{nullptr, 0, 0, d}; p.idx_b = nullptr;
+    p.c = RowView{nullptr, 0, 0, d}; p.idx_c = nullptr;
+    p.W2 = W2[k]; p.ldW2 = ldW2[k]; p.b2 = b2[k]; p.gamma = gamma[k]; p.beta = beta[k]; p.n_out = d;
+    p.h_out = nullptr; p.h_bstride = 0;
+    p.y = y[k]; p.y_bstride = rows[k] * d; p.y_ld = d; p.idx_y = nullptr;
+    p.res = RowView{nullptr, 0, 0, d};
+    p.agg = nullptr; p.agg_bstride = 0; p.agg_ld = 0; p.inv_deg = nullptr;
+    p.B = (int)B[k]; p.vec_y = 1; p.stamp = 0;
+    p.pre = RowView{nullptr, 0, 0, d}; p.preW = nullptr; p.ldpreW = 0;
+    m.first[k + 1] = m.first[k] + shares[k];
+  }
+  for (int k = n; k < TAIL_MAXP; ++k) m.first[k + 1] = m.first[n];
+  const size_t lds = b3_image_bytes(128, 128) + (size_t)3 * 128 * sizeof(float) +
+                     (size_t)4 * NLAM_TILE * (128 + 4) * sizeof(float) + (size_t)4 * 4 * NLAM_TILE * sizeof(int);
+  hipStream_t s = (hipStream_t)stream;
+  if (nlam_mfma_terms() == 3) {
+    auto kern = tail_fwd_multi_kernel<128, 4, true, 3>;
+    NLAM_BIG_LDS(kern, "tail_fwd_multi_kernel");
+    kern<<<(unsigned)m.first[n], 256, lds, s>>>(m);
+  } else {
+    auto kern = tail_fwd_multi_kernel<128, 4, true, 1>;
+    NLAM_BIG_LDS(kern, "tail_fwd_multi_kernel");
+    kern<<<(unsigned)m.first[n], 256, lds, s>>>(m);
+  }
+  NLAM_CHECK_LAUNCH("tail_fwd_multi_kernel");
+  return 0;
+}
+
+// gz_out[k] (B, rows, d), gh[k] (B, rows, d) = the gradient of h; slab[k]: nslabs[k] =
+// nlam_mlp_tail_multi_shares slabs of nlam_tail_bwd_slab_stride(d) floats [dgamma | dbeta]
+extern "C" int nlam_mlp_tail_bwd_multi(int n, int d, const float* const* h, const float* const* gy,
+                                       const float* const* W2, const int64_t* ldW2,
+                                       const float* const* b2, const float* const* gamma,
+                                       float* const* gz_out, float* const* gh, float* const* slab,
+                                       const int32_t* nslabs, const int64_t* B, const int64_t* rows,
+                                       void* stream) {
+  NLAM_REQUIRE(n >= 1 && n <= TAIL_MAXP && d == 128 && nlam_mfma_terms() != 0,
+               "nlam_mlp_tail_bwd_multi: n %d out of [1, %d], hidden 128, an MFMA mode", n, TAIL_MAXP);
+  WideMulti<TailBwdParams, TAIL_MAXP> m;
+  int32_t shares[TAIL_MAXP];
+  if (nlam_mlp_tail_multi_shares(n, B, rows, shares)) return 1;
+  m.n = n;
+  m.first[0] = 0;
+  for (int k = 0; k < n; ++k) {
+    NLAM_REQUIRE(h[k] && gy[k] && W2[k] && b2[k] && gamma[k] && gz_out[k] && gh[k] && slab[k] &&
+                     nlam_aligned16(h[k]) && nlam_aligned16(gy[k]) && nlam_aligned16(gz_out[k]) &&
+                     nlam_aligned16(gh[k]) && nslabs[k] == shares[k],
+                 "nlam_mlp_tail_bwd_multi: operand / slab count of problem %d", k);
+    TailBwdParams& q = m.p[k];
+    q.tl = WideTiling{nullptr, (rows[k] + NLAM_TILE - 1) / NLAM_TILE, rows[k], nullptr, nullptr};
+    q.h = h[k]; q.h_bstride = rows[k] * d;
+    q.g1 = RowView{gy[k], rows[k] * d, d, d}; q.idx_g1 = nullptr; q.scale1 = nullptr;
+    q.g2 = RowView{nullptr, 0, 0, d}; q.idx_g2 = nullptr;
+    q.W2 = W2[k]; q.ldW2 = ldW2[k]; q.b2 = b2[k]; q.gamma = gamma[k]; q.n_out = d;
+    q.gz_out = gz_out[k]; q.gz_bstride = rows[k] * d;
+    q.gh = gh[k]; q.gh_bstride = rows[k] * d; q.gh_ld = d; q.idx_gh = nullptr;
+    q.gpr = nullptr; q.gpr_bstride = 0; q.gpr_ld = 0;
+    q.slab = slab[k]; q.slab_stride = nlam_tail_bwd_slab_stride(d); q.B = (int)B[k];
+    q.vec_g = 1; q.stamp = 0;
+    m.first[k + 1] = m.first[k] + shares[k];
+  }
+  for (int k = n; k < TAIL_MAXP; ++k) m.first[k + 1] = m.first[n];
+  const size_t lds = b3_image_bytes(128, 128) + (size_t)2 * 128 * sizeof(float) +
+                     (size_t)4 * NLAM_TILE * (128 + 4) * sizeof(float) + (size_t)4 * 4 * NLAM_TILE * sizeof(int);
+  hipStream_t s = (hipStream_t)stream;
+  if (nlam_mfma_terms() == 3) {
+    auto kern = tail_bwd_multi_kernel<128, 4, true, 3>;
+    NLAM_BIG_LDS(kern, "tail_bwd_multi_kernel");
+    kern<<<(unsigned)m.first[n], 256, lds, s>>>(m);
+  } else {
+    auto kern = tail_bwd_multi_kernel<128, 4, true, 1>;
+    NLAM_BIG_LDS(kern, "tail_bwd_multi_kernel");
+    kern<<<(unsigned)m.first[n], 256, lds, s>>>(m);
+  }
+  NLAM_CHECK_LAUNCH("tail_bwd_multi_kernel");
+  return 0;
 }
 
 // ====================================================== data gradient of a Linear ===

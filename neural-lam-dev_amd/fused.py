@@ -206,8 +206,17 @@ def embed_many(items):
     """items: [(key, HipMLP, x (rows, k))].  Returns {key: embedding}: eligible blocks in
     multi-problem launches of up to MAX_MULTI, the rest through their own forward."""
     out = {}
+    from . import wide
+
+    wide_items = [(k, m, x) for k, m, x in items if wide.embedder_multi_ok(m, x)]
+    if len(wide_items) > 1:   # hidden 128: the tails of all of them in multi-problem launches
+        out.update(wide.embed_many(wide_items))
+        items = [it for it in items if it[0] not in out]
+        if not items:
+            return out
     if not ops.mlp_multi_supported() or FORCE_GENERIC:
-        return {k: m(x) for k, m, x in items}
+        out.update({k: m(x) for k, m, x in items})
+        return out
     batch = [(k, m, x) for k, m, x in items if _embedder_ok(m, x)]
     for k, m, x in items:
         if not _embedder_ok(m, x):

@@ -590,6 +590,136 @@ class WideMLPFunction(torch.autograd.Function):
         return (gx, gres, dW1, db1, dW2, db2, dg, dbt, None, None)
 
 
+# ---- the static-feature embedders of a model as multi-problem launches (hidden 128)
+TAIL_MAXP = 8   # csrc/fused_wide.hip
+
+
+def embedder_multi_ok(seq, x):
+    """A static-feature embedder the multi-problem tails take: (rows, k) input, Linear(k, 128),
+    SiLU, Linear(128, 128), LayerNorm; fp32 rows."""
+    from .fused import FORCE_GENERIC, _mlp_parts
+
+    if FORCE_GENERIC or os.environ.get("NLAM_EMBED_MULTI", "1") == "0" or not x.is_cuda \
+            or x.dtype != torch.float32 or x.dim() != 2 or x.requires_grad:
+        return False
+    lin, ln = _mlp_parts(seq)
+    if len(lin) != 2 or ln is None:
+        return False
+    hid = lin[0].weight.shape[0]
+    return (hid == 128 and enabled(hid) and not bf16_rows(hid) and tuple(lin[1].weight.shape) == (hid, hid)
+            and lin[0].weight.shape[1] <= hid and x.shape[0] >= 1)
+
+
+def _shares(rows):
+    import ctypes
+    n = len(rows)
+    out = (ctypes.c_int32 * n)()
+    ops.check(lib.nlam_mlp_tail_multi_shares(n, _arr(ctypes.c_int64, [1] * n),
+                                             _arr(ctypes.c_int64, rows), out),
+              "nlam_mlp_tail_multi_shares")
+    return [int(v) for v in out]
+
+
+class WideMultiMLPFunction(torch.autograd.Function):
+    """n static-feature embedders y_k = LN(W2_k silu(W1_k x_k + b1_k) + b2_k): the first Linears one
+    launch each (K <= 4 mostly), the tails in launches of up to TAIL_MAXP problems, both ways."""
+
+    @staticmethod
+    def forward(ctx, n, deferred, *args):
+        import ctypes
+        xs, params = args[:n], args[n:]
+        P = [params[6 * k : 6 * k + 6] for k in range(n)]
+        dev = xs[0].device
+        d = P[0][2].shape[0]
+        xms = [mat(x.detach()) for x in xs]
+        hs = [_empty(1, xm.rows, d, device=dev) for xm in xms]
+        outs = [_empty(xm.rows, d, device=dev) for xm in xms]
+        I64 = ctypes.c_int64
+        with ops.tag("static_embedders"):
+            for k in range(n):
+                _first_linear(xms[k], P[k][0], P[k][1], mat(hs[k]))
+            for i in range(0, n, TAIL_MAXP):
+                ks = range(i, min(n, i + TAIL_MAXP))
+                _launch(
+                    "nlam_tail_fwd_multi", lib.nlam_mlp_tail_fwd_multi,
+                    (len(ks), d, _parr([hs[k].data_ptr() for k in ks]),
+                     _parr([P[k][2].data_ptr() for k in ks]), _arr(I64, [P[k][2].stride(0) for k in ks]),
+                     _parr([P[k][3].data_ptr() for k in ks]), _parr([P[k][4].data_ptr() for k in ks]),
+                     _parr([P[k][5].data_ptr() for k in ks]), _parr([outs[k].data_ptr() for k in ks]),
+                     _arr(I64, [1] * len(ks)), _arr(I64, [xms[k].rows for k in ks]), stream()),
+                    flops=sum(2.0 * xms[k].rows * d * d for k in ks),
+                    nbytes=sum(8.0 * xms[k].rows * d for k in ks))
+        ctx.save_for_backward(*params, *hs)
+        ctx.set_materialize_grads(False)
+        ctx.n, ctx.xms, ctx.deferred = n, xms, deferred
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gys):
+        import ctypes
+        n = ctx.n
+        saved = ctx.saved_tensors
+        params, hs = saved[: 6 * n], saved[6 * n :]
+        P = [params[6 * k : 6 * k + 6] for k in range(n)]
+        dev = params[0].device
+        d = P[0][2].shape[0]
+        I64, I32 = ctypes.c_int64, ctypes.c_int32
+        stride = int(lib.nlam_tail_bwd_slab_stride(d))
+        grads = []
+        with ops.tag("static_embedders"), ops.slab_batch(defer=ctx.deferred):
+            gy_c, gzs, gas, slabs, shares = [], [], [], [], []
+            for k in range(n):
+                rows = ctx.xms[k].rows
+                gy = gys[k]
+                gy = torch.zeros(rows, d, dtype=torch.float32, device=dev) if gy is None else gy.contiguous()
+                gy_c.append(gy)
+                gzs.append(_empty(1, rows, d, device=dev))
+                gas.append(_empty(1, rows, d, device=dev))
+            for i in range(0, n, TAIL_MAXP):
+                ks = list(range(i, min(n, i + TAIL_MAXP)))
+                sh = _shares([ctx.xms[k].rows for k in ks])
+                sl = [torch.empty(s_ * stride, dtype=torch.float32, device=dev) for s_ in sh]
+                shares += sh
+                slabs += sl
+                _launch(
+                    "nlam_tail_bwd_multi", lib.nlam_mlp_tail_bwd_multi,
+                    (len(ks), d, _parr([hs[k].data_ptr() for k in ks]), _parr([gy_c[k].data_ptr() for k in ks]),
+                     _parr([P[k][2].data_ptr() for k in ks]), _arr(I64, [P[k][2].stride(0) for k in ks]),
+                     _parr([P[k][3].data_ptr() for k in ks]), _parr([P[k][4].data_ptr() for k in ks]),
+                     _parr([gzs[k].data_ptr() for k in ks]), _parr([gas[k].data_ptr() for k in ks]),
+                     _parr([t.data_ptr() for t in sl]), _arr(I32, sh), _arr(I64, [1] * len(ks)),
+                     _arr(I64, [ctx.xms[k].rows for k in ks]), stream()),
+                    flops=sum(4.0 * ctx.xms[k].rows * d * d for k in ks),
+                    nbytes=sum(16.0 * ctx.xms[k].rows * d for k in ks))
+            for k in range(n):
+                W1, b1, W2, b2, gam, bet = P[k]
+                dW1, db1 = torch.empty_like(W1), _empty(W1.shape[0], device=dev)
+                dW2, db2 = torch.empty_like(W2), _empty(d, device=dev)
+                dg, dbt = _empty(d, device=dev), _empty(d, device=dev)
+                ops.reduce_segments(slabs[k], shares[k], stride, [(0, 1, d, d, dg), (d, 1, d, d, dbt)])
+                if ctx.deferred:
+                    defer_outers([(mat(gzs[k]), mat(hs[k]), dW2, db2, True)])
+                else:
+                    outer(mat(gzs[k]), mat(hs[k]), dW2, db2, silu_x=True, rows_out=d)
+                _first_linear_bwd(ctx.xms[k], mat(gas[k]), W1, False, None, dW1, db1, dev, ctx.deferred)
+                grads += [dW1, db1, dW2, db2, dg, dbt]
+        return (None, None, *([None] * n), *grads)
+
+
+def embed_many(items):
+    """items: [(key, HipMLP, x)] all embedder_multi_ok -> {key: embedding}."""
+    from .fused import _mlp_parts
+
+    params = []
+    for _, m, _x in items:
+        lin, ln = _mlp_parts(m)
+        params += [lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias, ln.weight, ln.bias]
+    prox = _proxies(params)
+    res = WideMultiMLPFunction.apply(len(items), prox is not None, *[x for _, _, x in items],
+                                     *(prox if prox is not None else params))
+    return {k: r for (k, _, _), r in zip(items, res)}
+
+
 def apply_mlp(seq, x, res=None):
     from .fused import _mlp_parts
 

@@ -390,3 +390,60 @@ def test_deferred_slab_reductions_leave_the_training_step_unchanged(ar_steps, mo
     for (k, _), a, b in zip(model.named_parameters(), g_on, g_off):
         scale = float(b.abs().max()) + 1e-30
         assert float((a - b).abs().max()) <= 2e-6 * scale, (k, float((a - b).abs().max()) / scale)
+
+
+@pytest.mark.skipif(D != 128, reason="hidden 128 only")
+def test_static_embedders_in_multi_problem_launches_match_one_launch_each(monkeypatch):
+    """wide.embed_many (the tails of all static-feature embedders of a Hi-LAM-128 model in
+    multi-problem launches, forward and backward: nlam_mlp_tail_{fwd,bwd}_multi) against one
+    launch per embedder (NLAM_EMBED_MULTI=0): embeddings bitwise equal (the same kernel body per
+    problem), loss equal, parameter gradients to fp32 summation order (dgamma / dbeta slab counts
+    follow the share of the launch), fewer launches."""
+    import tempfile
+
+    import numpy as np
+
+    from neural_lam_amd import graphgen, ops, synthetic
+    from neural_lam_amd.models import MODELS
+
+    with tempfile.TemporaryDirectory() as tmp:
+        info = graphgen.create_graph(tmp + "/graph/g", graphgen.make_xy(38, 35, 5000.0), 3, True)
+        n = info["num_grid"]
+        gen = torch.Generator().manual_seed(0)
+        ds = synthetic.SyntheticDatastore(
+            tmp, torch.randn(n, 4, generator=gen).numpy(), np.zeros(7), np.ones(7), np.zeros(7),
+            np.ones(7), (torch.rand(n, generator=gen) < 0.2).float().numpy(), n_forcing=2)
+        torch.manual_seed(1)
+        model = MODELS["hi_lam"](synthetic.model_args(graph="g", hidden_dim=128, processor_layers=2),
+                                 config=None, datastore=ds).cuda()
+    batch = synthetic.random_batch(2, 1, n, n_state=7, n_forcing_window=6, device="cuda")
+    from neural_lam_amd import fused
+
+    def run(on):
+        monkeypatch.setenv("NLAM_EMBED_MULTI", "1" if on else "0")
+        with torch.no_grad():
+            emb = fused.embed_many(model.static_embedders())
+        for p in model.parameters():
+            p.grad = None
+        ops.PROFILER = ops.KernelProfiler()
+        try:
+            loss = model.training_step(batch)
+            loss.backward()
+            stats = ops.PROFILER.collect()
+        finally:
+            ops.PROFILER = None
+        return emb, float(loss.detach()), [p.grad.clone() for p in model.parameters()], stats
+
+    e_on, l_on, g_on, s_on = run(True)
+    e_off, l_off, g_off, s_off = run(False)
+    assert any(k.startswith("nlam_tail_fwd_multi") for k in s_on) and any(
+        k.startswith("nlam_tail_bwd_multi") for k in s_on)
+    assert not any(k.startswith(("nlam_tail_fwd_multi", "nlam_tail_bwd_multi")) for k in s_off)
+    assert sum(v["calls"] for v in s_on.values()) <= sum(v["calls"] for v in s_off.values()) - 12
+    assert set(e_on) == set(e_off)
+    for k in e_on:
+        assert torch.equal(e_on[k], e_off[k]), k
+    assert l_on == l_off
+    for (k, _), a, b in zip(model.named_parameters(), g_on, g_off):
+        scale = float(b.abs().max()) + 1e-30
+        assert float((a - b).abs().max()) <= 5e-6 * scale, (k, float((a - b).abs().max()) / scale)
