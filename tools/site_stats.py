@@ -32,7 +32,7 @@ FAMILIES = [  # (kernel-name regex, family); the first match wins, template argu
     (r"^(lin_fwd(16|_b3)?|wide_lin_fwd|fs_lin_fwd)_kernel", "lin_fwd"),
     (r"^lin_bwd_data_kernel", "lin_bwd_data"), (r"^lin_bwd(16)?_kernel", "lin_bwd"),
     (r"^outer_bwd(16)?_kernel", "outer_bwd"), (r"^(wide|fs)_outer_kernel", "wide_outer"),
-    (r"^(fs_)?tail_fwd_kernel", "tail_fwd"), (r"^(fs_)?tail_bwd_kernel", "tail_bwd"),
+    (r"^(fs_)?tail_fwd(_multi)?_kernel", "tail_fwd"), (r"^(fs_)?tail_bwd(_multi)?_kernel", "tail_bwd"),
     (r"^reduce_slabs_multi_kernel", "reduce_slabs_multi"), (r"^reduce_slabs_kernel", "reduce_slabs"),
     (r"^segment_sum_", "segment_sum"), (r"^sum_batch", "sum_batch"), (r"^concat_rows", "concat_rows"),
     (r"^boundary_mix", "boundary_mix"), (r"^affine_residual", "affine_residual"),
